@@ -1,0 +1,297 @@
+/*
+ * semivl_hip.h — C-ABI of libsemivl_hip.so: the MI355X (gfx950) kernels behind the SemiVL training hot path.
+ *
+ * The reference (google-research/semivl) has no FFI layer: its boundary is Python
+ * (`model/builder.py:56-159`, `model/vlm.py:90-127`, `utils/train_utils.py:19-49`, `semivl.py:52-58,223-345`).
+ * This header is the operator boundary a maintainer would bind from Python (ctypes stub in INTEGRATION.md);
+ * `semivl_amd/` is the host-side mirror of the reference's Python surface built on top of it.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller;
+ *   - the library never allocates/frees device memory, never synchronises, enqueues only on `stream`;
+ *   - tensors are dense fp32 unless stated; token tensors are [rows, C] row-major ("NHWC"/[B,T,C]);
+ *   - returns 0 (SVL_OK) or a negative svl_status; svl_last_error() gives the message (thread-local);
+ *   - re-entrant per (device, stream); no mutable globals.
+ */
+#ifndef SEMIVL_HIP_H_
+#define SEMIVL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* svl_stream_t; /* hipStream_t */
+
+typedef enum svl_status {
+  SVL_OK = 0,
+  SVL_ERR_INVALID_ARG = -1,
+  SVL_ERR_LAUNCH = -2,
+  SVL_ERR_UNSUPPORTED = -3
+} svl_status;
+
+int svl_version(void);
+/* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
+int svl_last_error(char* buf, size_t len);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM core (fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32: exact f32 fma chain).
+ * C[z][m][n] = epilogue( alpha * sum_k A[z](m,k) * B[z](n,k) )
+ * Replaces every dense contraction of the path: F.linear / nn.MultiheadAttention in_proj+out_proj
+ * (maskclip_vit.py:110-118,141 via mmcv), FFN (maskclip_vit.py:94-100,142), PatchEmbed conv
+ * (maskclip_vit.py:266-276,495), proj 1x1 (maskclip_vit.py:338,554), the cosine-sim einsum
+ * (vlg_head.py:217), F.conv2d text classifier (vlm.py:99), all VLGHead convs (vlg_head.py:70-137,169-190),
+ * q k^T / p v bmm inside attention, and all their dgrad / wgrad counterparts (autograd in the reference).
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  SVL_A_KCONTIG = 0, /* A(m,k) = A[m*lda + k]                       (activations x, dY, Q)           */
+  SVL_A_MCONTIG = 1, /* A(m,k) = A[k*lda + m]                       (dY^T for wgrad, P^T)            */
+  SVL_A_CONV = 2,    /* A(m,k): m = NHWC pixel, k = (tap, ci): implicit im2col (see svl_conv_geom)   */
+  SVL_A_PATCH = 3    /* A(m,k): m = (img, py, px), k = (c, i, j) of an NCHW image, patch P x P       */
+};
+enum {
+  SVL_B_KCONTIG = 0, /* B(n,k) = B[n*ldb + k]   (torch Linear weight [out,in], K rows, packed conv w) */
+  SVL_B_NCONTIG = 1, /* B(n,k) = B[k*ldb + n]   (dgrad: W as [K=out][N=in]; V in P·V; X in wgrad)     */
+  SVL_B_CONVW = 2    /* B(n,k): n = (tap, ci), k = NHWC pixel: im2col^T for conv wgrad                */
+};
+enum { SVL_ACT_NONE = 0, SVL_ACT_GELU = 1, SVL_ACT_RELU = 2 };
+enum {
+  SVL_OUT_STRIDED = 0, /* C + zo*bs_outer + zi*bs_inner + m*ld_m + n*ld_n                              */
+  SVL_OUT_CONVT2X = 1, /* ConvTranspose2d k2 s2: m=(img,h,w), n=(a,b,co) -> pixel (img,2h+a,2w+b), co  */
+  SVL_OUT_PATCH = 2    /* patch tokens: row m=(img,p) -> img*(P+1)+1+p ; resid row = 1+p (pos_embed)   */
+};
+
+typedef struct svl_operand {
+  const float* ptr;
+  int64_t ld;        /* leading dimension (elements)                                   */
+  int64_t bs_outer;  /* batch stride for zo = z / batch_inner                          */
+  int64_t bs_inner;  /* batch stride for zi = z % batch_inner                          */
+} svl_operand;
+
+/* Stride-1, same-size NHWC convolution geometry used by SVL_A_CONV / SVL_B_CONVW.
+ * Logical input channel ci in [0, C1+C2): ci < C1 reads src1 (the operand ptr, pixel stride ld),
+ * otherwise src2 (pixel stride ld2) of image (img / rep) — the `repeat`+`cat` of vlg_head.py:131-134
+ * without materialising it. Tap (ti,tj) reads pixel (oh + sign*(ti*dil - pad), ow + sign*(tj*dil - pad));
+ * sign=+1 for forward/wgrad, -1 for dgrad. Out-of-range pixels read 0. */
+typedef struct svl_conv_geom {
+  int H, W;
+  int C1, C2;
+  int rep;
+  int KH, KW, dil, pad, sign;
+  const float* src2;
+  int64_t ld2;
+  int patch;  /* SVL_A_PATCH: patch size P; image is [img, C1, H, W] NCHW */
+} svl_conv_geom;
+
+typedef struct svl_gemm_desc {
+  int a_mode, b_mode;
+  int M, N, K;
+  int batch;        /* number of z slices (>=1)                                              */
+  int batch_inner;  /* z -> (zo, zi) = (z / batch_inner, z % batch_inner); >=1               */
+  int ksplit;       /* >0: split-K — z indexes K ranges [z*ksplit, min(K,(z+1)*ksplit)), operand batch strides ignored */
+  svl_operand A, B;
+  svl_conv_geom conv;
+  /* output */
+  float* C;
+  int out_mode;
+  int64_t ldc_m, ldc_n, c_bs_outer, c_bs_inner;
+  int ct_H, ct_W, ct_Cout; /* SVL_OUT_CONVT2X: input spatial size and Cout; SVL_OUT_PATCH: ct_H = patches per image */
+  /* epilogue: v = alpha*acc; v += bias[n % bias_mod]; v = act(v); v += resid; if(accumulate) v += C */
+  float alpha;
+  const float* bias;
+  int bias_mod;     /* 0: bias[n]; >0: bias[n % bias_mod] */
+  int act;
+  const float* resid; /* addressed like C for SVL_OUT_STRIDED (own strides below); see SVL_OUT_PATCH */
+  int64_t ldr_m, ldr_n, r_bs_outer, r_bs_inner;
+  int accumulate;
+} svl_gemm_desc;
+
+int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream);
+
+/* out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s*count + i]  — deterministic split-K combine. */
+int svl_reduce_slabs_f32(float* out, const float* slabs, int nslab, int64_t count, int accumulate,
+                         svl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pixel-loss family (semivl.py:232,252,267-323; utils/train_utils.py:19-49; semivl.py:52-58).
+ * logits are NCHW [B, N, H, W] fp32; label-like maps are int64 [B, H, W] (reference dtype).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* conf[b,h,w] = max_c softmax(logits)[b,c,h,w]; label = argmax (ties -> lowest index). semivl.py:232,252 */
+int svl_softmax_max_f32(const float* logits, int B, int N, int64_t HW, float* conf, int64_t* label,
+                        svl_stream_t stream);
+
+/* out = where(box == 1, b, a) elementwise over [B, HW] maps broadcast over C channels
+ * (cutmix_img_: C=3 fp32 in place when out==a; cutmix_mask: C=1). utils/train_utils.py:19-27 */
+int svl_cutmix_f32(float* out, const float* a, const float* b, const float* box, int B, int C, int64_t HW,
+                   svl_stream_t stream);
+int svl_cutmix_i64(int64_t* out, const int64_t* a, const int64_t* b, const float* box, int B, int64_t HW,
+                   svl_stream_t stream);
+
+/* Fused per-branch loss, forward + backward in one pass over the logits.
+ *   ce_t(p)  = -log_softmax(logits)[target[p]]          (target == ignore_index -> 0, if use_ignore_t)
+ *   ce_m(p)  = -log_softmax(logits)[mc_target[p]]       (mc_target == 255 -> 0)
+ * Per block (deterministic, no atomics) partials[blk] = {
+ *   sum_p w_t(p) * ce_t(p)      with w_t = 1 (supervised, conf==NULL) or
+ *                                [conf >= conf_thresh && ign != 255] (pixelwise, train_utils.py:36-38),
+ *   sum_p ce_m(p)               (mc term, semivl.py:52-58; 0 when mc_target == NULL),
+ *   sum_p conf(p) * [ign != 255]   (pixelavg bookkeeping, train_utils.py:43-46),
+ *   #(target != ignore) (supervised) or #(ign != 255) }
+ * svl_ce_finalize() reduces the partials in double, in a fixed order, to sums[4].
+ * If dlogits != NULL: dlogits = gscale_t * w_t * (softmax - onehot(target)) + gscale_m * [mc valid] * (softmax - onehot(mc))
+ * where gscale_* are read from DEVICE memory (gscale[0], gscale[1]) so no host sync is needed.
+ */
+typedef struct svl_ce_desc {
+  const float* logits;   /* [B, N, HW] */
+  int B, N;
+  int64_t HW;
+  const int64_t* target; /* [B, HW] */
+  int use_ignore_t;      /* 1: target==255 ignored (criterion_l, ignore_index=255); 0: criterion_u */
+  const float* conf;     /* [B, HW] or NULL */
+  const int64_t* ign;    /* [B, HW] or NULL */
+  float conf_thresh;
+  const int64_t* mc_target; /* [B, HW] or NULL */
+  float* partials;       /* workspace [svl_ce_num_blocks(B,N,HW)][4]: per-block {sum w*ce_t, sum ce_m, sum conf*valid, #valid} */
+  float* dlogits;        /* [B, N, HW] or NULL */
+  const float* gscale;   /* [2] device scalars, required when dlogits != NULL */
+} svl_ce_desc;
+int64_t svl_ce_num_blocks(int B, int N, int64_t HW); /* -1 if N is unsupported (N > 256) */
+int svl_ce_fused_f32(const svl_ce_desc* d, svl_stream_t stream);
+int svl_ce_finalize(const float* partials, int64_t nblocks, double* sums /* [4] device */, svl_stream_t stream);
+
+/* Loss assembly without host syncs (semivl.py:267-323, conf_mode 'pixelwise', mcc_loss_reduce 'mean_all').
+ * counts: int64[4] device = #valid of {mask_x != 255, ignore_mask_mixed1, ignore_mask_mixed2, ignore_mask} != 255.
+ * gscale out: float[4][2] device = {g_t, g_m} for the branches {x, s1, s2, fp}: the factor each per-pixel CE term
+ * carries in d(loss)/d(logits).  numel_u = B*H*W of one unlabeled branch; lam = current mcc lambda. */
+int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, float* gscale, svl_stream_t stream);
+/* sums: double[4 branches][4] device (from svl_ce_finalize); out float[8] device =
+ * {loss, loss_x, loss_s1, loss_s2, loss_fp, loss_mc_s1, loss_mc_s2, loss_mc_fp}. */
+int svl_semivl_loss(const double* sums, double numel_u, float lam, float* out, svl_stream_t stream);
+
+/* counts-only pre-pass so the normalisers of semivl.py:38/57 exist before the fused pass:
+ * counts[0] += #(map != 255) over [n] */
+int svl_count_valid_i64(const int64_t* map, int64_t n, int64_t* count, svl_stream_t stream);
+
+/* MaskCLIP guidance tail (vlm.py:100-109): dense [B, N, h, w] class scores ->
+ * bilinear(align_corners=False) to [H, W] -> softmax(100 x) -> max/argmax -> (<thr -> 255); then
+ * ign == 255 -> 255 (semivl.py:239-240). out int64 [B, H, W]. */
+int svl_maskclip_labels(const float* dense, int B, int N, int h, int w, int H, int W, float scale,
+                        float thresh, const int64_t* ign, int64_t* out, svl_stream_t stream);
+
+/* per class max over its concept channels (text_embeddings.py:188-193).
+ * concept_offsets [N+1] device int32, concepts of class c are channels [off[c], off[c+1]). */
+int svl_concept_max_f32(const float* pred, int B, int NC, int64_t HW, const int* concept_offsets, int N,
+                        float* out, svl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation / elementwise / attention helpers (maskclip_vit.py:120-144, vlg_head.py:39-137).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* LayerNorm over the last dim C of x [rows, C]; stats [rows, 2] = (mean, rstd). */
+int svl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
+                      float* y, float* stats, svl_stream_t stream);
+/* dx = LN backward (+ dx_add if non-NULL, fused residual-grad add). If dgamma_part != NULL also writes
+ * per-block partial sums dgamma_part/dbeta_part [nparts, C] (nparts = svl_layernorm_bwd_parts(rows)). */
+int svl_layernorm_bwd_parts(int64_t rows);
+int svl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int64_t rows,
+                      int C, const float* dx_add, float* dx, float* dgamma_part, float* dbeta_part,
+                      svl_stream_t stream);
+
+/* Row softmax in place over the first `cols` entries of rows with stride ld: p = softmax(scale * s).
+ * Entries [cols, ld) are zeroed. */
+int svl_softmax_rows_fwd(float* s, int64_t rows, int cols, int64_t ld, float scale, svl_stream_t stream);
+/* ds = scale * p * (dp - sum_j dp_j p_j), in place on dp. */
+int svl_softmax_rows_bwd(float* dp, const float* p, int64_t rows, int cols, int64_t ld, float scale,
+                         svl_stream_t stream);
+
+/* y = x / max(||x||_2, eps) over rows of [rows, C]; inv_norm [rows] saved. (maskclip_vit.py:555, vlg_head.py:215) */
+int svl_l2norm_fwd(const float* x, int64_t rows, int C, float eps, float* y, float* inv_norm, svl_stream_t stream);
+int svl_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, int64_t rows, int C, float* dx,
+                   svl_stream_t stream);
+
+/* out[c] (+)= sum_r x[r*ld + c]  (bias gradients). Two deterministic stages through ws
+ * (svl_colsum_ws_floats(rows, C) floats). */
+int64_t svl_colsum_ws_floats(int64_t rows, int C);
+int svl_colsum_f32(const float* x, int64_t rows, int C, int64_t ld, float* out, int accumulate, float* ws,
+                   svl_stream_t stream);
+
+/* Elementwise: mode 0: out = a + b; 1: out = a * gelu'(b) (a = dY, b = pre-activation); 2: out = a * (b > 0) (relu bwd,
+ * b = post-activation); 3: out = a * b; 4: out = a (copy). n elements. */
+int svl_eltwise_f32(int mode, const float* a, const float* b, float* out, int64_t n, svl_stream_t stream);
+/* out[r, c] = x[r, c] * mask[(r / rows_per_img) * C + c] * scale  — F.dropout2d on token layout (builder.py:79-85). */
+int svl_chanmask_f32(const float* x, const float* mask, float scale, int64_t rows, int rows_per_img, int C,
+                     float* out, svl_stream_t stream);
+int svl_fill_f32(float* p, float v, int64_t n, svl_stream_t stream);
+
+/* GroupNorm (+ optional ReLU) on NHWC class-images: x [imgs, HW, C] (pixel stride ldx), groups of C/G channels,
+ * stats [imgs, G, 2] = (mean, rstd); y pixel stride ldy (lets the result land in a concat slice). vlg_head.py:74-137 */
+int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int imgs,
+                      int64_t HW, int C, int G, int relu, float* y, int64_t ldy, float* stats, svl_stream_t stream);
+/* dy has pixel stride lddy; y (post-activation, stride ldy) is used for the ReLU mask.
+ * chan_sums [imgs, 2, C] out: per image (sum_p dy', sum_p dy' * xhat); dbeta / dgamma are their column sums
+ * over images (svl_colsum_f32 with ld = 2C). */
+int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
+                      const float* stats, const float* gamma, int imgs, int64_t HW, int C, int G, int relu,
+                      float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream);
+
+/* Small-sequence multi-head attention for the SemanticTransformer (vlg_head.py:39-67; seq = num classes).
+ * qkv rows: token (g, s) at row  (g / inner) * outer_stride + (g % inner) * inner_stride + s * seq_stride,
+ * each row = [q(E) | k(E) | v(E)], E = heads*D, D = 64. out has the same row mapping, width E. */
+typedef struct svl_seqattn_desc {
+  int groups, inner, seq, heads;
+  int64_t outer_stride, inner_stride, seq_stride; /* in rows */
+  const float* qkv;  /* [rows, 3E] */
+  float* out;        /* [rows, E] */
+  float* probs;      /* [groups, heads, seq, seq] saved for backward */
+  /* backward */
+  const float* dout; /* [rows, E] */
+  float* dqkv;       /* [rows, 3E] */
+  float* dscores;    /* workspace [groups, heads, seq, seq] */
+} svl_seqattn_desc;
+int svl_seqattn_fwd(const svl_seqattn_desc* d, svl_stream_t stream);
+int svl_seqattn_bwd(const svl_seqattn_desc* d, svl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Resampling on NHWC / NCHW maps.
+ * ---------------------------------------------------------------------------------------------- */
+/* Bilinear resize, channels-last: x [imgs, h, w, C] (pixel stride ldx) -> y [imgs*rep, H, W, :] written at channel
+ * offset 0 with pixel stride ldy; output image i reads input image i / rep (`repeat`, vlg_head.py:133).
+ * accumulate: y += . */
+int svl_bilinear_nhwc_fwd(const float* x, int64_t ldx, int imgs, int h, int w, int C, int align_corners, int rep,
+                          int H, int W, float* y, int64_t ldy, int accumulate, svl_stream_t stream);
+/* dx[imgs,h,w,C] (=|+=) sum over rep and taps of dy. Deterministic gather form. */
+int svl_bilinear_nhwc_bwd(const float* dy, int64_t lddy, int imgs, int h, int w, int C, int align_corners, int rep,
+                          int H, int W, float* dx, int64_t lddx, int accumulate, svl_stream_t stream);
+/* Bilinear resize of planes: x [planes, h, w] -> y [planes, H, W] (NCHW logits, vlg_head.py:247, builder.py:93-97). */
+int svl_bilinear_planes_fwd(const float* x, int64_t planes, int h, int w, int align_corners, int H, int W, float* y,
+                            svl_stream_t stream);
+int svl_bilinear_planes_bwd(const float* dy, int64_t planes, int h, int w, int align_corners, int H, int W,
+                            float* dx, svl_stream_t stream);
+/* AvgPool PxP (floor) on NHWC + concat of a per-class text vector: x [imgs, H, W, C] ->
+ * y [imgs, H/P, W/P, C + Ct], y[..., C:] = text[(img % nclass), :] (vlg_head.py:43-53). text may be NULL (Ct=0). */
+int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C, int P, const float* text, int Ct, int nclass,
+                        float* y, svl_stream_t stream);
+/* dx [imgs,H,W,C] = avgpool backward of dy[..., :C] (ld = C+Ct); pixels outside the floor region get 0. */
+int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int C, int P, int Ct, float* dx, svl_stream_t stream);
+/* dtext [nclass, Ct] = sum over images of class n (img % nclass == n) and pooled pixels of dy[..., C + ct]. */
+int svl_avgpool_cat_bwd_text(const float* dy, int imgs, int64_t HWp, int C, int Ct, int nclass, float* dtext,
+                             svl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser (semivl.py:123-125,328,339-345: torch AdamW, one param group per tensor, poly LR).
+ * Flat arena of `nseg` segments; seg_* arrays are DEVICE arrays of length nseg.
+ * p,g,m,v are flat fp32 arenas; segment s covers [seg_off[s], seg_off[s+1]).
+ * Update (torch.optim.AdamW, amsgrad=False):  p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *   p -= lr / (1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  gscale multiplies g first (1/world_size).
+ * If ema != NULL: ema = ema_decay*ema + (1-ema_decay)*p_new (extension).
+ * ---------------------------------------------------------------------------------------------- */
+int svl_adamw_step(float* p, const float* g, float* m, float* v, const int64_t* seg_off, const float* seg_lr,
+                   const float* seg_wd, int nseg, int64_t total, float beta1, float beta2, float eps, int step,
+                   float gscale, float* ema, float ema_decay, svl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMIVL_HIP_H_ */

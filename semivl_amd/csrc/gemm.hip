@@ -1,0 +1,473 @@
+// fp32 MFMA GEMM / implicit-GEMM core for gfx950 (CDNA4).
+//
+//   C[z](m,n) = epilogue( alpha * sum_k A[z](m,k) * B[z](n,k) )
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 — f32 in / f32 accumulate, bit-for-bit a k-ordered fmaf chain
+// (MI355X_MICROARCH.md "Matrix cores"); peak 157.3 TF = 64 FLOP/clk/SIMD.  The reference computes the
+// same contractions in fp32 through ATen (cuBLAS/cuDNN), see include/semivl_hip.h for the call sites.
+//
+// Structure: 256 threads = 4 waves; block tile BM x BN, K step 16; operands staged global -> registers ->
+// LDS as k-major panels As[k][m], Bs[k][n] (so an MFMA operand read is one conflict-free ds_read_b32 per
+// lane), double-buffered with register prefetch (one barrier per K step).  Each wave owns a
+// (BM/WR) x (BN/WC) sub-tile made of 32x32 MFMA tiles.  At the f32 MFMA rate (64 cycles per
+// instruction) one K step of a 64x64 wave tile is 8 x 4 MFMAs = 2048 cycles against 32 ds_read_b32 and
+// 4 global float4 loads per lane, so the simple 2-stage pipeline is enough to keep the matrix pipe fed
+// (cdna_hip_programming.md §3: 122 TF for the same untuned structure).
+//
+// Operand addressing modes make the same kernel an implicit-GEMM convolution (NHWC, stride 1, dilation,
+// optional second concatenated source), the patch-embedding gather, conv wgrad (im2col^T) and split-K.
+#include "svl_common.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+struct OperandP {
+  const float* p;
+  long ld;
+  int vec;  // 16-byte vector loads allowed
+};
+
+struct GemmP {
+  int M, N, K;
+  int batch_inner, ksplit;
+  OperandP A, B;
+  long a_bso, a_bsi, b_bso, b_bsi;
+  svl_conv_geom cv;
+  float* C;
+  int out_mode;
+  long ldc_m, ldc_n, c_bso, c_bsi;
+  int ct_H, ct_W, ct_Cout;
+  float alpha;
+  const float* bias;
+  int bias_mod, act;
+  const float* resid;
+  long ldr_m, ldr_n, r_bso, r_bsi;
+  int accumulate;
+  int tiles_n;
+};
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// Guarded 4-element load along the contiguous direction: elements [0, nvalid) are read.
+__device__ __forceinline__ float4 load4(const float* ptr, int nvalid, bool vec) {
+  if (nvalid >= 4 && vec) return *reinterpret_cast<const float4*>(ptr);
+  float4 r = zero4();
+  if (nvalid > 0) r.x = ptr[0];
+  if (nvalid > 1) r.y = ptr[1];
+  if (nvalid > 2) r.z = ptr[2];
+  if (nvalid > 3) r.w = ptr[3];
+  return r;
+}
+
+// Loader "shape": how the 16-deep K panel of ROWS rows is cut into per-thread float4 pieces.
+//  KMAJOR  (k contiguous in memory): piece f -> row = f / 4, k = 4 * (f % 4)        -> transposed LDS write
+//  RMAJOR  (row contiguous in memory): piece f -> k = f / (ROWS/4), row = 4*(f % (ROWS/4)) -> b128 LDS write
+enum { LS_KMAJOR = 0, LS_RMAJOR = 1 };
+
+template <int MODE_IS_A, int MODE>
+struct ModeTraits;
+template <> struct ModeTraits<1, SVL_A_KCONTIG> { static constexpr int shape = LS_KMAJOR; };
+template <> struct ModeTraits<1, SVL_A_MCONTIG> { static constexpr int shape = LS_RMAJOR; };
+template <> struct ModeTraits<1, SVL_A_CONV>    { static constexpr int shape = LS_KMAJOR; };
+template <> struct ModeTraits<1, SVL_A_PATCH>   { static constexpr int shape = LS_KMAJOR; };
+template <> struct ModeTraits<0, SVL_B_KCONTIG> { static constexpr int shape = LS_KMAJOR; };
+template <> struct ModeTraits<0, SVL_B_NCONTIG> { static constexpr int shape = LS_RMAJOR; };
+template <> struct ModeTraits<0, SVL_B_CONVW>   { static constexpr int shape = LS_RMAJOR; };
+
+// Address of logical conv input element (pixel given by (img, ih, iw) already bounds-checked, channel ci).
+__device__ __forceinline__ const float* conv_src(const OperandP& op, const svl_conv_geom& cv, int img, int ih, int iw,
+                                                 int ci) {
+  if (ci < cv.C1) return op.p + (((long)img * cv.H + ih) * cv.W + iw) * op.ld + ci;
+  return cv.src2 + (((long)(img / cv.rep) * cv.H + ih) * cv.W + iw) * cv.ld2 + (ci - cv.C1);
+}
+
+// Load one float4 piece of the (row0.., k0..) panel. `rows_total`/`kend` bound the valid region.
+template <int IS_A, int MODE, int ROWS>
+__device__ __forceinline__ float4 load_piece(const OperandP& op, const svl_conv_geom& cv, const float* base, int f,
+                                             int row0, int rows_total, int k0, int kend) {
+  constexpr int shape = ModeTraits<IS_A, MODE>::shape;
+  if constexpr (shape == LS_KMAJOR) {
+    const int row = row0 + (f >> 2);
+    const int k = k0 + ((f & 3) << 2);
+    if (row >= rows_total || k >= kend) return zero4();
+    const int nv = kend - k;
+    if constexpr (MODE == 0) {  // K-contiguous dense (SVL_A_KCONTIG / SVL_B_KCONTIG share value 0)
+      return load4(base + (long)row * op.ld + k, nv, op.vec);
+    } else if constexpr (IS_A && MODE == SVL_A_CONV) {
+      const int Ct = cv.C1 + cv.C2;
+      const int ow = row % cv.W;
+      const int t = row / cv.W;
+      const int oh = t % cv.H;
+      const int img = t / cv.H;
+      if (op.vec) {  // Ct % 4 == 0: the 4 k's share one tap
+        const int tap = k / Ct, ci = k - tap * Ct;
+        const int ti = tap / cv.KW, tj = tap - ti * cv.KW;
+        const int ih = oh + cv.sign * (ti * cv.dil - cv.pad);
+        const int iw = ow + cv.sign * (tj * cv.dil - cv.pad);
+        if (ih < 0 || ih >= cv.H || iw < 0 || iw >= cv.W) return zero4();
+        return load4(conv_src(op, cv, img, ih, iw, ci), nv, true);
+      } else {
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kk = k + j;
+          if (kk < kend) {
+            const int tap = kk / Ct, ci = kk - tap * Ct;
+            const int ti = tap / cv.KW, tj = tap - ti * cv.KW;
+            const int ih = oh + cv.sign * (ti * cv.dil - cv.pad);
+            const int iw = ow + cv.sign * (tj * cv.dil - cv.pad);
+            if (ih >= 0 && ih < cv.H && iw >= 0 && iw < cv.W) r[j] = *conv_src(op, cv, img, ih, iw, ci);
+          }
+        }
+        return make_float4(r[0], r[1], r[2], r[3]);
+      }
+    } else {  // SVL_A_PATCH: row = (img, py, px); k = (c, i, j), P = cv.patch, image NCHW [img, C1, H, W]
+      const int P = cv.patch;
+      const int npx = cv.W / P, npy = cv.H / P;
+      const int px = row % npx;
+      const int t = row / npx;
+      const int py = t % npy;
+      const int img = t / npy;
+      const int c = k / (P * P);
+      const int r2 = k - c * P * P;
+      const int i = r2 / P, j = r2 - i * P;
+      const float* ptr = base + (((long)img * cv.C1 + c) * cv.H + (py * P + i)) * cv.W + px * P + j;
+      return load4(ptr, nv, op.vec);
+    }
+  } else {  // LS_RMAJOR
+    constexpr int RP = ROWS / 4;
+    const int kk = f / RP;
+    const int row = row0 + ((f % RP) << 2);
+    const int k = k0 + kk;
+    if (k >= kend || row >= rows_total) return zero4();
+    const int nv = rows_total - row;
+    if constexpr (MODE == 1) {  // SVL_A_MCONTIG / SVL_B_NCONTIG share value 1
+      return load4(base + (long)k * op.ld + row, nv, op.vec);
+    } else {  // SVL_B_CONVW: row = (tap, ci), k = pixel
+      const int Ct = cv.C1 + cv.C2;
+      const int ow = k % cv.W;
+      const int t = k / cv.W;
+      const int oh = t % cv.H;
+      const int img = t / cv.H;
+      if (op.vec) {
+        const int tap = row / Ct, ci = row - tap * Ct;
+        const int ti = tap / cv.KW, tj = tap - ti * cv.KW;
+        const int ih = oh + cv.sign * (ti * cv.dil - cv.pad);
+        const int iw = ow + cv.sign * (tj * cv.dil - cv.pad);
+        if (ih < 0 || ih >= cv.H || iw < 0 || iw >= cv.W) return zero4();
+        return load4(conv_src(op, cv, img, ih, iw, ci), nv, true);
+      } else {
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rr = row + j;
+          if (rr < rows_total) {
+            const int tap = rr / Ct, ci = rr - tap * Ct;
+            const int ti = tap / cv.KW, tj = tap - ti * cv.KW;
+            const int ih = oh + cv.sign * (ti * cv.dil - cv.pad);
+            const int iw = ow + cv.sign * (tj * cv.dil - cv.pad);
+            if (ih >= 0 && ih < cv.H && iw >= 0 && iw < cv.W) r[j] = *conv_src(op, cv, img, ih, iw, ci);
+          }
+        }
+        return make_float4(r[0], r[1], r[2], r[3]);
+      }
+    }
+  }
+}
+
+template <int SHAPE, int ROWS, int LD>
+__device__ __forceinline__ void store_piece(float* S, int f, float4 v) {
+  if constexpr (SHAPE == LS_KMAJOR) {
+    const int row = f >> 2;
+    const int k = (f & 3) << 2;
+    S[(k + 0) * LD + row] = v.x;
+    S[(k + 1) * LD + row] = v.y;
+    S[(k + 2) * LD + row] = v.z;
+    S[(k + 3) * LD + row] = v.w;
+  } else {
+    constexpr int RP = ROWS / 4;
+    const int kk = f / RP;
+    const int row = (f % RP) << 2;
+    *reinterpret_cast<float4*>(&S[kk * LD + row]) = v;
+  }
+}
+
+template <int BM, int BN, int WR, int WC, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+  static_assert(WR * WC == 4, "4 waves per block");
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int WTM = BM / WR, WTN = BN / WC;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
+  static_assert(TM >= 1 && TN >= 1, "wave tile >= 32x32");
+  constexpr int APIECES = BM * 4, BPIECES = BN * 4;  // float4 pieces per K panel
+  constexpr int APASS = (APIECES + 255) / 256, BPASS = (BPIECES + 255) / 256;
+  constexpr int ASHAPE = ModeTraits<1, AMODE>::shape, BSHAPE = ModeTraits<0, BMODE>::shape;
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * LDA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+
+  const int tile = blockIdx.x;
+  const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
+  const int m0 = tm_i * BM, n0 = tn_i * BN;
+  const int z = blockIdx.z;
+  const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
+
+  int kbeg = 0, kend = p.K;
+  const float* Abase = p.A.p;
+  const float* Bbase = p.B.p;
+  if (p.ksplit > 0) {
+    kbeg = z * p.ksplit;
+    kend = min(p.K, kbeg + p.ksplit);
+  } else {
+    Abase += zo * p.a_bso + zi * p.a_bsi;
+    Bbase += zo * p.b_bso + zi * p.b_bsi;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[APASS], rb[BPASS];
+
+  auto g_load = [&](int k0) {
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps) {
+      const int f = tid + ps * 256;
+      if (APIECES % 256 == 0 || f < APIECES)
+        ra[ps] = load_piece<1, AMODE, BM>(p.A, p.cv, Abase, f, m0, p.M, k0, kend);
+    }
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ++ps) {
+      const int f = tid + ps * 256;
+      if (BPIECES % 256 == 0 || f < BPIECES)
+        rb[ps] = load_piece<0, BMODE, BN>(p.B, p.cv, Bbase, f, n0, p.N, k0, kend);
+    }
+  };
+  auto s_store = [&](int buf) {
+    float* Ad = As + buf * BK * LDA;
+    float* Bd = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps) {
+      const int f = tid + ps * 256;
+      if (APIECES % 256 == 0 || f < APIECES) store_piece<ASHAPE, BM, LDA>(Ad, f, ra[ps]);
+    }
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ++ps) {
+      const int f = tid + ps * 256;
+      if (BPIECES % 256 == 0 || f < BPIECES) store_piece<BSHAPE, BN, LDB>(Bd, f, rb[ps]);
+    }
+  };
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    g_load(kbeg);
+    s_store(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) g_load(kbeg + (kt + 1) * BK);
+    const float* Ac = As + buf * BK * LDA + wr * WTM + l31;
+    const float* Bc = Bs + buf * BK * LDB + wc * WTN + l31;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      const int k = 2 * s + hi;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ac[k * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bc[k * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) s_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------
+  // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  float* Cz = p.C;
+  const float* Rz = p.resid;
+  if (p.out_mode == SVL_OUT_STRIDED) {
+    Cz += zo * p.c_bso + zi * p.c_bsi;
+    if (Rz) Rz += zo * p.r_bso + zi * p.r_bsi;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wc * WTN + j * 32 + l31;
+      if (n >= p.N) continue;
+      float bv = 0.f;
+      if (p.bias) bv = p.bias[p.bias_mod > 0 ? (n % p.bias_mod) : n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] * p.alpha + bv;
+        if (p.act == SVL_ACT_GELU) v = gelu_erf(v);
+        else if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
+        long off;
+        if (p.out_mode == SVL_OUT_STRIDED) {
+          off = (long)m * p.ldc_m + (long)n * p.ldc_n;
+          if (Rz) v += Rz[(long)m * p.ldr_m + (long)n * p.ldr_n];
+        } else if (p.out_mode == SVL_OUT_CONVT2X) {
+          const int w = m % p.ct_W;
+          const int t = m / p.ct_W;
+          const int h = t % p.ct_H;
+          const int img = t / p.ct_H;
+          const int ab = n / p.ct_Cout, co = n - ab * p.ct_Cout;
+          const int a_ = ab >> 1, b_ = ab & 1;
+          off = ((((long)img * (2 * p.ct_H) + (2 * h + a_)) * (2 * p.ct_W)) + (2 * w + b_)) * p.ldc_m + co;
+        } else {  // SVL_OUT_PATCH
+          const int P = p.ct_H;
+          const int img = m / P, pp = m - img * P;
+          off = ((long)img * (P + 1) + 1 + pp) * p.ldc_m + n;
+          if (Rz) v += Rz[(long)(1 + pp) * p.ldr_m + n];
+        }
+        if (p.accumulate) v += Cz[off];
+        Cz[off] = v;
+      }
+    }
+  }
+}
+
+__global__ void reduce_slabs_kernel(float* out, const float* slabs, int nslab, long count, int accumulate) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[(long)k * count + i];
+    out[i] = s;
+  }
+}
+
+template <int BM, int BN, int WR, int WC, int AMODE, int BMODE>
+int launch_cfg(const GemmP& p, int batch, hipStream_t st) {
+  GemmP q = p;
+  q.tiles_n = (p.N + BN - 1) / BN;
+  const long tiles_m = (p.M + BM - 1) / BM;
+  const long tiles = tiles_m * q.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffL) {
+    svl_set_error("svl_gemm_f32: bad tile count %ld", tiles);
+    return SVL_ERR_INVALID_ARG;
+  }
+  dim3 grid((unsigned)tiles, 1, (unsigned)batch);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WR, WC, AMODE, BMODE>), grid, dim3(256), 0, st, q);
+  SVL_LAUNCH_CHECK("svl_gemm_f32");
+  return SVL_OK;
+}
+
+// Tile choice: wide-N problems use 128x128; narrow N gets 128x64 / 128x32; short-M (wgrad) gets 32x128 / 64x128.
+template <int AMODE, int BMODE>
+int launch_mode(const GemmP& p, int batch, hipStream_t st) {
+  if (p.M <= 32 && p.N > 32) return launch_cfg<32, 128, 1, 4, AMODE, BMODE>(p, batch, st);
+  if (p.M <= 64 && p.N > 64) return launch_cfg<64, 128, 2, 2, AMODE, BMODE>(p, batch, st);
+  if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, BMODE>(p, batch, st);
+  if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, BMODE>(p, batch, st);
+  return launch_cfg<128, 128, 2, 2, AMODE, BMODE>(p, batch, st);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
+  SVL_CHECK_ARG(d != nullptr, "svl_gemm_f32: null desc");
+  SVL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K >= 0, "svl_gemm_f32: bad sizes M=%d N=%d K=%d", d->M, d->N, d->K);
+  SVL_CHECK_ARG(d->batch >= 1 && d->batch_inner >= 1, "svl_gemm_f32: bad batch %d/%d", d->batch, d->batch_inner);
+  SVL_CHECK_ARG(d->A.ptr && d->B.ptr && d->C, "svl_gemm_f32: null operand");
+  SVL_CHECK_ARG(d->batch <= 65535, "svl_gemm_f32: batch %d > 65535", d->batch);
+  if (d->ksplit > 0)
+    SVL_CHECK_ARG((long)d->ksplit * d->batch >= d->K, "svl_gemm_f32: ksplit*batch < K");
+  hipStream_t st = (hipStream_t)stream;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.batch_inner = d->batch_inner; p.ksplit = d->ksplit;
+  p.A.p = d->A.ptr; p.A.ld = d->A.ld; p.a_bso = d->A.bs_outer; p.a_bsi = d->A.bs_inner;
+  p.B.p = d->B.ptr; p.B.ld = d->B.ld; p.b_bso = d->B.bs_outer; p.b_bsi = d->B.bs_inner;
+  p.cv = d->conv;
+  p.C = d->C; p.out_mode = d->out_mode;
+  p.ldc_m = d->ldc_m; p.ldc_n = d->ldc_n; p.c_bso = d->c_bs_outer; p.c_bsi = d->c_bs_inner;
+  p.ct_H = d->ct_H; p.ct_W = d->ct_W; p.ct_Cout = d->ct_Cout;
+  p.alpha = d->alpha; p.bias = d->bias; p.bias_mod = d->bias_mod; p.act = d->act;
+  p.resid = d->resid; p.ldr_m = d->ldr_m; p.ldr_n = d->ldr_n; p.r_bso = d->r_bs_outer; p.r_bsi = d->r_bs_inner;
+  p.accumulate = d->accumulate;
+
+  // vector-load eligibility (16-byte alignment of every piece)
+  auto dense_vec = [&](const svl_operand& o) {
+    return aligned16(o.ptr) && (o.ld % 4 == 0) && (o.bs_outer % 4 == 0) && (o.bs_inner % 4 == 0);
+  };
+  const svl_conv_geom& cv = d->conv;
+  auto conv_vec = [&](const svl_operand& o) {
+    bool ok = aligned16(o.ptr) && (o.ld % 4 == 0) && (cv.C1 % 4 == 0) && (cv.C2 % 4 == 0);
+    if (cv.C2 > 0) ok = ok && aligned16(cv.src2) && (cv.ld2 % 4 == 0);
+    return ok;
+  };
+  const bool a_conv = (d->a_mode == SVL_A_CONV), b_conv = (d->b_mode == SVL_B_CONVW);
+  if (a_conv || b_conv) {
+    SVL_CHECK_ARG(cv.H > 0 && cv.W > 0 && cv.C1 > 0 && cv.C2 >= 0 && cv.KH > 0 && cv.KW > 0 && cv.dil > 0 &&
+                      (cv.sign == 1 || cv.sign == -1),
+                  "svl_gemm_f32: bad conv geometry");
+    SVL_CHECK_ARG(cv.C2 == 0 || (cv.src2 && cv.rep >= 1), "svl_gemm_f32: conv src2/rep missing");
+    const int kk = cv.KH * cv.KW * (cv.C1 + cv.C2);
+    if (a_conv) SVL_CHECK_ARG(d->K == kk, "svl_gemm_f32: conv K=%d != taps*C=%d", d->K, kk);
+    if (b_conv) SVL_CHECK_ARG(d->N == kk, "svl_gemm_f32: convw N=%d != taps*C=%d", d->N, kk);
+    SVL_CHECK_ARG(d->batch == 1 || d->ksplit > 0, "svl_gemm_f32: conv modes are unbatched");
+  }
+  if (d->a_mode == SVL_A_PATCH) {
+    SVL_CHECK_ARG(cv.patch > 0 && cv.H % cv.patch == 0 && cv.W % cv.patch == 0 && cv.C1 > 0,
+                  "svl_gemm_f32: bad patch geometry");
+    SVL_CHECK_ARG(d->K == cv.C1 * cv.patch * cv.patch, "svl_gemm_f32: patch K mismatch");
+    p.A.vec = aligned16(d->A.ptr) && (cv.W % 4 == 0) && (cv.patch % 4 == 0);
+  } else if (a_conv) {
+    p.A.vec = conv_vec(d->A);
+  } else {
+    p.A.vec = dense_vec(d->A);
+  }
+  p.B.vec = b_conv ? conv_vec(d->B) : dense_vec(d->B);
+  if (d->out_mode == SVL_OUT_CONVT2X)
+    SVL_CHECK_ARG(d->ct_H > 0 && d->ct_W > 0 && d->ct_Cout > 0 && d->N == 4 * d->ct_Cout,
+                  "svl_gemm_f32: bad convT geometry");
+  if (d->out_mode == SVL_OUT_PATCH) SVL_CHECK_ARG(d->ct_H > 0, "svl_gemm_f32: bad patch-token geometry");
+
+  const int am = d->a_mode, bm = d->b_mode;
+#define SVL_MODE(AM, BM_) \
+  if (am == AM && bm == BM_) return launch_mode<AM, BM_>(p, d->batch, st);
+  SVL_MODE(SVL_A_KCONTIG, SVL_B_KCONTIG)
+  SVL_MODE(SVL_A_KCONTIG, SVL_B_NCONTIG)
+  SVL_MODE(SVL_A_MCONTIG, SVL_B_NCONTIG)
+  SVL_MODE(SVL_A_MCONTIG, SVL_B_KCONTIG)
+  SVL_MODE(SVL_A_CONV, SVL_B_KCONTIG)
+  SVL_MODE(SVL_A_MCONTIG, SVL_B_CONVW)
+  SVL_MODE(SVL_A_PATCH, SVL_B_KCONTIG)
+#undef SVL_MODE
+  svl_set_error("svl_gemm_f32: unsupported mode combination a=%d b=%d", am, bm);
+  return SVL_ERR_UNSUPPORTED;
+}
+
+extern "C" int svl_reduce_slabs_f32(float* out, const float* slabs, int nslab, int64_t count, int accumulate,
+                                    svl_stream_t stream) {
+  SVL_CHECK_ARG(out && slabs && nslab >= 1 && count > 0, "svl_reduce_slabs_f32: bad args");
+  const int grid = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, slabs, nslab,
+                     (long)count, accumulate);
+  SVL_LAUNCH_CHECK("svl_reduce_slabs_f32");
+  return SVL_OK;
+}

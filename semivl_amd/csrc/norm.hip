@@ -1,0 +1,565 @@
+// Normalisation / reduction / elementwise kernels (HBM-bound helpers around the GEMM core).
+// LayerNorm (maskclip_vit.py:73-75,90-92,326-334 via mmcv build_norm_layer -> nn.LayerNorm),
+// row softmax (inside nn.MultiheadAttention), L2 normalise (maskclip_vit.py:555, vlg_head.py:215-216),
+// GroupNorm+ReLU (vlg_head.py:74-137), bias-gradient column sums, F.dropout2d channel masks (builder.py:79-85).
+#include "svl_common.h"
+
+namespace {
+
+inline int grid_for(long n, int per_thread = 1) {
+  long g = (n + 256L * per_thread - 1) / (256L * per_thread);
+  if (g < 1) g = 1;
+  if (g > 256 * 16) g = 256 * 16;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, 4 rows per block. C % 4 == 0. Two-pass (mean, then centred variance)
+// like ATen's RowwiseMoments result to fp32 rounding.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, long rows, int C,
+                                                            float* __restrict__ y, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + r * C);
+    float s = 0.f;
+    for (int i = lane; i < C4; i += 64) {
+      const float4 v = xr[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+    for (int i = lane; i < C4; i += 64) {
+      const float4 v = xr[i];
+      const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float var = wave_sum(q) / C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float4* yr = reinterpret_cast<float4*>(y + r * C);
+    for (int i = lane; i < C4; i += 64) {
+      const float4 v = xr[i];
+      const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+      const float4 b = reinterpret_cast<const float4*>(beta)[i];
+      float4 o;
+      o.x = (v.x - mean) * rstd * g.x + b.x;
+      o.y = (v.y - mean) * rstd * g.y + b.y;
+      o.z = (v.z - mean) * rstd * g.z + b.z;
+      o.w = (v.w - mean) * rstd * g.w + b.w;
+      yr[i] = o;
+    }
+    if (lane == 0) {
+      stats[2 * r] = mean;
+      stats[2 * r + 1] = rstd;
+    }
+  }
+}
+
+// Backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma. Optional fused `+ dx_add`.
+// Optional per-block partial dgamma/dbeta: block b handles rows [b*rpb, (b+1)*rpb); C <= 1024.
+constexpr int LN_MAXV = 4;  // float4 per lane
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, long rows, int C,
+                                                            const float* __restrict__ dx_add, float* __restrict__ dx,
+                                                            float* __restrict__ dg_part, float* __restrict__ db_part,
+                                                            long rows_per_block) {
+  __shared__ float sh[2][4][LN_MAXV * 256];  // [dg|db][wave][column]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  float4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
+  for (long r = r0 + wave; r < r1; r += 4) {
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    const float4* xr = reinterpret_cast<const float4*>(x + r * C);
+    const float4* dr = reinterpret_cast<const float4*>(dy + r * C);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < C4) {
+        const float4 v = xr[i], d = dr[i], g = reinterpret_cast<const float4*>(gamma)[i];
+        const float h0 = (v.x - mean) * rstd, h1 = (v.y - mean) * rstd, h2 = (v.z - mean) * rstd,
+                    h3 = (v.w - mean) * rstd;
+        const float g0 = d.x * g.x, g1 = d.y * g.y, g2 = d.z * g.z, g3 = d.w * g.w;
+        s1 += (g0 + g1) + (g2 + g3);
+        s2 += (g0 * h0 + g1 * h1) + (g2 * h2 + g3 * h3);
+        if (dg_part) {
+          ag[j].x += d.x * h0; ag[j].y += d.y * h1; ag[j].z += d.z * h2; ag[j].w += d.w * h3;
+          ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+    float4* oxr = reinterpret_cast<float4*>(dx + r * C);
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < C4) {
+        const float4 v = xr[i], d = dr[i], g = reinterpret_cast<const float4*>(gamma)[i];
+        float4 o;
+        o.x = rstd * (d.x * g.x - m1 - (v.x - mean) * rstd * m2);
+        o.y = rstd * (d.y * g.y - m1 - (v.y - mean) * rstd * m2);
+        o.z = rstd * (d.z * g.z - m1 - (v.z - mean) * rstd * m2);
+        o.w = rstd * (d.w * g.w - m1 - (v.w - mean) * rstd * m2);
+        if (dx_add) {
+          const float4 a = reinterpret_cast<const float4*>(dx_add + r * C)[i];
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        oxr[i] = o;
+      }
+    }
+  }
+  if (dg_part) {
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < C4) {
+        reinterpret_cast<float4*>(&sh[0][wave][0])[i] = ag[j];
+        reinterpret_cast<float4*>(&sh[1][wave][0])[i] = ab[j];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dg_part[(long)blockIdx.x * C + c] = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+      db_part[(long)blockIdx.x * C + c] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax (materialised attention probabilities), one wave per row, re-reads hit L1/L2.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ s, long rows, int cols, long ld,
+                                                               float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    float* row = s + r * ld;
+    float m = -INFINITY;
+    for (int i = lane; i < cols; i += 64) m = fmaxf(m, row[i] * scale);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int i = lane; i < cols; i += 64) sum += expf(row[i] * scale - m);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int i = lane; i < ld; i += 64) row[i] = (i < cols) ? expf(row[i] * scale - m) * inv : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(float* __restrict__ dp, const float* __restrict__ p,
+                                                               long rows, int cols, long ld, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    float* drow = dp + r * ld;
+    const float* prow = p + r * ld;
+    float dot = 0.f;
+    for (int i = lane; i < cols; i += 64) dot += drow[i] * prow[i];
+    dot = wave_sum(dot);
+    for (int i = lane; i < ld; i += 64) drow[i] = (i < cols) ? scale * prow[i] * (drow[i] - dot) : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2 normalise rows (F.normalize / x / x.norm()).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, long rows, int C, float eps,
+                                                         float* __restrict__ y, float* __restrict__ inv_norm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const float* xr = x + r * C;
+    float q = 0.f;
+    for (int i = lane; i < C; i += 64) q += xr[i] * xr[i];
+    q = wave_sum(q);
+    const float inv = 1.f / fmaxf(sqrtf(q), eps);
+    for (int i = lane; i < C; i += 64) y[r * C + i] = xr[i] * inv;
+    if (lane == 0) inv_norm[r] = inv;
+  }
+}
+// dx = inv * (dy - y * <dy, y>)   (exact when the eps clamp is inactive, as for unit-norm CLIP features)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ inv_norm, long rows, int C,
+                                                         float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const float* dr = dy + r * C;
+    const float* yr = y + r * C;
+    float dot = 0.f;
+    for (int i = lane; i < C; i += 64) dot += dr[i] * yr[i];
+    dot = wave_sum(dot);
+    const float inv = inv_norm[r];
+    for (int i = lane; i < C; i += 64) dx[r * C + i] = inv * (dr[i] - yr[i] * dot);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums: stage 1 -> partial[chunk][C], stage 2 -> out[C]. Deterministic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x, long rows, int C, long ld,
+                                                     float* __restrict__ part, long rows_per_chunk) {
+  __shared__ float sh[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (c < C)
+    for (long r = r0 + ry; r < r1; r += 4) s += x[r * ld + c];
+  sh[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) part[(long)blockIdx.y * C + c] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+}
+__global__ void colsum_stage2(const float* __restrict__ part, int nchunk, int C, float* __restrict__ out,
+                              int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = accumulate ? out[c] : 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[(long)k * C + c];
+  out[c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Elementwise
+// ---------------------------------------------------------------------------------------------
+__global__ void eltwise_kernel(int mode, const float* __restrict__ a, const float* __restrict__ b,
+                               float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v;
+    switch (mode) {
+      case 0: v = a[i] + b[i]; break;
+      case 1: v = a[i] * gelu_erf_grad(b[i]); break;
+      case 2: v = (b[i] > 0.f) ? a[i] : 0.f; break;
+      case 3: v = a[i] * b[i]; break;
+      default: v = a[i]; break;
+    }
+    out[i] = v;
+  }
+}
+__global__ void chanmask_kernel(const float* __restrict__ x, const float* __restrict__ mask, float scale, long rows,
+                                int rows_per_img, int C, float* __restrict__ out) {
+  const long n = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    out[i] = x[i] * mask[(r / rows_per_img) * C + c] * scale;
+  }
+}
+__global__ void fill_kernel(float* p, float v, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm on NHWC class-images. One block per image; thread = (pixel lane, channel quad).
+// Statistics are accumulated in double (one image group is up to 16384 x 16 values).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __restrict__ x, long ldx, float eps, long HW,
+                                                              int C, int G, float* __restrict__ stats) {
+  __shared__ double sh_s[256], sh_q[256];
+  __shared__ double g_s[64], g_q[64];
+  const int CQ = C >> 2;             // channel quads
+  const int PR = 256 / CQ;           // pixel rows per iteration
+  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
+  const long img = blockIdx.x;
+  const float* xi = x + img * HW * ldx;
+  double s = 0.0, q = 0.0;
+  for (long p = pr; p < HW; p += PR) {
+    const float4 v = *reinterpret_cast<const float4*>(xi + p * ldx + 4 * cq);
+    s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+  sh_s[threadIdx.x] = s;
+  sh_q[threadIdx.x] = q;
+  __syncthreads();
+  const int cg4 = (C / G) >> 2;  // quads per group
+  if (threadIdx.x < G) {
+    double ts = 0.0, tq = 0.0;
+    for (int rr = 0; rr < PR; ++rr)
+      for (int k = 0; k < cg4; ++k) {
+        const int t = rr * CQ + threadIdx.x * cg4 + k;
+        ts += sh_s[t];
+        tq += sh_q[t];
+      }
+    g_s[threadIdx.x] = ts;
+    g_q[threadIdx.x] = tq;
+    const double n = (double)HW * (C / G);
+    const double mean = ts / n;
+    double var = tq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(img * G + threadIdx.x) * 2] = (float)mean;
+    stats[(img * G + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, long ldx,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, long npix, long HW, int C,
+                                                              int G, int relu, const float* __restrict__ stats,
+                                                              float* __restrict__ y, long ldy) {
+  const int CQ = C >> 2;
+  const int cg = C / G;
+  const long total = npix * CQ;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / CQ;
+    const int c = (int)(i - p * CQ) * 4;
+    const long img = p / HW;
+    const int g = c / cg;
+    const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
+    const float4 v = *reinterpret_cast<const float4*>(x + p * ldx + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = (v.x - mean) * rstd * ga.x + be.x;
+    o.y = (v.y - mean) * rstd * ga.y + be.y;
+    o.z = (v.z - mean) * rstd * ga.z + be.z;
+    o.w = (v.w - mean) * rstd * ga.w + be.w;
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(y + p * ldy + c) = o;
+  }
+}
+// chan_sums[img][0][c] = sum_p dy', chan_sums[img][1][c] = sum_p dy' * xhat   (dy' = dy masked by relu)
+__global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float* __restrict__ dy, long lddy,
+                                                                 const float* __restrict__ x, long ldx,
+                                                                 const float* __restrict__ y, long ldy,
+                                                                 const float* __restrict__ stats, long HW, int C, int G,
+                                                                 int relu, float* __restrict__ chan_sums) {
+  __shared__ double sh[2][1024];  // [a|b][pr*C + c], PR*C = 1024
+  const int CQ = C >> 2;
+  const int PR = 256 / CQ;
+  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
+  const int cg = C / G;
+  const long img = blockIdx.x;
+  const int g = (4 * cq) / cg;
+  const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
+  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  for (long p = pr; p < HW; p += PR) {
+    const long pix = img * HW + p;
+    float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + 4 * cq);
+    const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + 4 * cq);
+    if (relu) {
+      const float4 o = *reinterpret_cast<const float4*>(y + pix * ldy + 4 * cq);
+      if (!(o.x > 0.f)) d.x = 0.f;
+      if (!(o.y > 0.f)) d.y = 0.f;
+      if (!(o.z > 0.f)) d.z = 0.f;
+      if (!(o.w > 0.f)) d.w = 0.f;
+    }
+    a[0] += d.x; a[1] += d.y; a[2] += d.z; a[3] += d.w;
+    b[0] += (double)d.x * ((v.x - mean) * rstd);
+    b[1] += (double)d.y * ((v.y - mean) * rstd);
+    b[2] += (double)d.z * ((v.z - mean) * rstd);
+    b[3] += (double)d.w * ((v.w - mean) * rstd);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sh[0][pr * C + 4 * cq + j] = a[j];
+    sh[1][pr * C + 4 * cq + j] = b[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double ta = 0.0, tb = 0.0;
+    for (int rr = 0; rr < PR; ++rr) {
+      ta += sh[0][rr * C + c];
+      tb += sh[1][rr * C + c];
+    }
+    chan_sums[(img * 2 + 0) * C + c] = (float)ta;
+    chan_sums[(img * 2 + 1) * C + c] = (float)tb;
+  }
+}
+__global__ __launch_bounds__(256) void groupnorm_bwd_apply_kernel(const float* __restrict__ dy, long lddy,
+                                                                  const float* __restrict__ x, long ldx,
+                                                                  const float* __restrict__ y, long ldy,
+                                                                  const float* __restrict__ stats,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ chan_sums, long npix,
+                                                                  long HW, int C, int G, int relu,
+                                                                  float* __restrict__ dx, long lddx) {
+  const int CQ = C >> 2;
+  const int cg = C / G;
+  const long total = npix * CQ;
+  const float inv_n = 1.f / ((float)HW * cg);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / CQ;
+    const int c = (int)(i - p * CQ) * 4;
+    const long img = p / HW;
+    const int g = c / cg;
+    const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
+    // group sums S1 = sum_c gamma_c A_c, S2 = sum_c gamma_c B_c  (cg <= 64 values, L1-resident)
+    float S1 = 0.f, S2 = 0.f;
+    const float* A = chan_sums + (img * 2 + 0) * C + g * cg;
+    const float* Bc = chan_sums + (img * 2 + 1) * C + g * cg;
+    for (int k = 0; k < cg; ++k) {
+      const float gm = gamma[g * cg + k];
+      S1 += gm * A[k];
+      S2 += gm * Bc[k];
+    }
+    float4 d = *reinterpret_cast<const float4*>(dy + p * lddy + c);
+    const float4 v = *reinterpret_cast<const float4*>(x + p * ldx + c);
+    if (relu) {
+      const float4 o = *reinterpret_cast<const float4*>(y + p * ldy + c);
+      if (!(o.x > 0.f)) d.x = 0.f;
+      if (!(o.y > 0.f)) d.y = 0.f;
+      if (!(o.z > 0.f)) d.z = 0.f;
+      if (!(o.w > 0.f)) d.w = 0.f;
+    }
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    float4 o;
+    o.x = rstd * (d.x * ga.x - inv_n * (S1 + (v.x - mean) * rstd * S2));
+    o.y = rstd * (d.y * ga.y - inv_n * (S1 + (v.y - mean) * rstd * S2));
+    o.z = rstd * (d.z * ga.z - inv_n * (S1 + (v.z - mean) * rstd * S2));
+    o.w = rstd * (d.w * ga.w - inv_n * (S1 + (v.w - mean) * rstd * S2));
+    *reinterpret_cast<float4*>(dx + p * lddx + c) = o;
+  }
+}
+
+inline bool gn_shape_ok(int C, int G) {
+  if (C % 4 != 0 || G <= 0 || C % G != 0 || (C / G) % 4 != 0) return false;
+  const int CQ = C / 4;
+  return CQ <= 256 && 256 % CQ == 0 && G <= 64;
+}
+
+}  // namespace
+
+extern "C" int svl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
+                                 float* y, float* stats, svl_stream_t stream) {
+  SVL_CHECK_ARG(x && gamma && beta && y && stats && rows > 0 && C > 0 && C % 4 == 0, "svl_layernorm_fwd: bad args");
+  const int grid = (int)((rows + 3) / 4 > 4096 * 4 ? 4096 * 4 : (rows + 3) / 4);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
+                     (long)rows, C, y, stats);
+  SVL_LAUNCH_CHECK("svl_layernorm_fwd");
+  return SVL_OK;
+}
+
+extern "C" int svl_layernorm_bwd_parts(int64_t rows) {
+  long n = (rows + 63) / 64;
+  if (n > 2048) n = 2048;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+extern "C" int svl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int64_t rows,
+                                 int C, const float* dx_add, float* dx, float* dgamma_part, float* dbeta_part,
+                                 svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && x && stats && gamma && dx && rows > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+                "svl_layernorm_bwd: bad args (C=%d)", C);
+  SVL_CHECK_ARG((dgamma_part == nullptr) == (dbeta_part == nullptr), "svl_layernorm_bwd: dgamma/dbeta go together");
+  const int nparts = svl_layernorm_bwd_parts(rows);
+  const long rpb = (rows + nparts - 1) / nparts;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma,
+                     (long)rows, C, dx_add, dx, dgamma_part, dbeta_part, rpb);
+  SVL_LAUNCH_CHECK("svl_layernorm_bwd");
+  return SVL_OK;
+}
+
+extern "C" int svl_softmax_rows_fwd(float* s, int64_t rows, int cols, int64_t ld, float scale, svl_stream_t stream) {
+  SVL_CHECK_ARG(s && rows > 0 && cols > 0 && ld >= cols, "svl_softmax_rows_fwd: bad args");
+  const int grid = (int)((rows + 3) / 4 > 65536 ? 65536 : (rows + 3) / 4);
+  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, (long)rows, cols,
+                     (long)ld, scale);
+  SVL_LAUNCH_CHECK("svl_softmax_rows_fwd");
+  return SVL_OK;
+}
+extern "C" int svl_softmax_rows_bwd(float* dp, const float* p, int64_t rows, int cols, int64_t ld, float scale,
+                                    svl_stream_t stream) {
+  SVL_CHECK_ARG(dp && p && rows > 0 && cols > 0 && ld >= cols, "svl_softmax_rows_bwd: bad args");
+  const int grid = (int)((rows + 3) / 4 > 65536 ? 65536 : (rows + 3) / 4);
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dp, p, (long)rows, cols,
+                     (long)ld, scale);
+  SVL_LAUNCH_CHECK("svl_softmax_rows_bwd");
+  return SVL_OK;
+}
+
+extern "C" int svl_l2norm_fwd(const float* x, int64_t rows, int C, float eps, float* y, float* inv_norm,
+                              svl_stream_t stream) {
+  SVL_CHECK_ARG(x && y && inv_norm && rows > 0 && C > 0, "svl_l2norm_fwd: bad args");
+  const int grid = (int)((rows + 3) / 4 > 65536 ? 65536 : (rows + 3) / 4);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)rows, C, eps, y,
+                     inv_norm);
+  SVL_LAUNCH_CHECK("svl_l2norm_fwd");
+  return SVL_OK;
+}
+extern "C" int svl_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, int64_t rows, int C, float* dx,
+                              svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && y && inv_norm && dx && rows > 0 && C > 0, "svl_l2norm_bwd: bad args");
+  const int grid = (int)((rows + 3) / 4 > 65536 ? 65536 : (rows + 3) / 4);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, (long)rows, C,
+                     dx);
+  SVL_LAUNCH_CHECK("svl_l2norm_bwd");
+  return SVL_OK;
+}
+
+extern "C" int64_t svl_colsum_ws_floats(int64_t rows, int C) {
+  long nchunk = (rows + 255) / 256;
+  if (nchunk > 512) nchunk = 512;
+  if (nchunk < 1) nchunk = 1;
+  return nchunk * C;
+}
+extern "C" int svl_colsum_f32(const float* x, int64_t rows, int C, int64_t ld, float* out, int accumulate, float* ws,
+                              svl_stream_t stream) {
+  SVL_CHECK_ARG(x && out && ws && rows > 0 && C > 0 && ld >= C, "svl_colsum_f32: bad args");
+  const int nchunk = (int)(svl_colsum_ws_floats(rows, C) / C);
+  const long rpc = (rows + nchunk - 1) / nchunk;
+  hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, (hipStream_t)stream, x, (long)rows, C,
+                     (long)ld, ws, rpc);
+  SVL_LAUNCH_CHECK("svl_colsum_f32/1");
+  hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nchunk, C, out,
+                     accumulate);
+  SVL_LAUNCH_CHECK("svl_colsum_f32/2");
+  return SVL_OK;
+}
+
+extern "C" int svl_eltwise_f32(int mode, const float* a, const float* b, float* out, int64_t n, svl_stream_t stream) {
+  SVL_CHECK_ARG(a && out && n > 0 && mode >= 0 && mode <= 4 && (mode == 4 || b), "svl_eltwise_f32: bad args");
+  hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, mode, a, b, out, (long)n);
+  SVL_LAUNCH_CHECK("svl_eltwise_f32");
+  return SVL_OK;
+}
+extern "C" int svl_chanmask_f32(const float* x, const float* mask, float scale, int64_t rows, int rows_per_img, int C,
+                                float* out, svl_stream_t stream) {
+  SVL_CHECK_ARG(x && mask && out && rows > 0 && rows_per_img > 0 && C > 0, "svl_chanmask_f32: bad args");
+  hipLaunchKernelGGL(chanmask_kernel, dim3(grid_for(rows * C, 4)), dim3(256), 0, (hipStream_t)stream, x, mask, scale,
+                     (long)rows, rows_per_img, C, out);
+  SVL_LAUNCH_CHECK("svl_chanmask_f32");
+  return SVL_OK;
+}
+extern "C" int svl_fill_f32(float* p, float v, int64_t n, svl_stream_t stream) {
+  SVL_CHECK_ARG(p && n > 0, "svl_fill_f32: bad args");
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, p, v, (long)n);
+  SVL_LAUNCH_CHECK("svl_fill_f32");
+  return SVL_OK;
+}
+
+extern "C" int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int imgs,
+                                 int64_t HW, int C, int G, int relu, float* y, int64_t ldy, float* stats,
+                                 svl_stream_t stream) {
+  SVL_CHECK_ARG(x && gamma && beta && y && stats && imgs > 0 && HW > 0, "svl_groupnorm_fwd: bad args");
+  SVL_CHECK_ARG(gn_shape_ok(C, G) && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
+                "svl_groupnorm_fwd: unsupported C=%d G=%d ldx=%ld ldy=%ld", C, G, (long)ldx, (long)ldy);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(imgs), dim3(256), 0, st, x, (long)ldx, eps, (long)HW, C, G, stats);
+  SVL_LAUNCH_CHECK("svl_groupnorm_fwd/stats");
+  const long npix = (long)imgs * HW;
+  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, st, x, (long)ldx, gamma, beta,
+                     npix, (long)HW, C, G, relu, stats, y, (long)ldy);
+  SVL_LAUNCH_CHECK("svl_groupnorm_fwd/apply");
+  return SVL_OK;
+}
+
+extern "C" int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
+                                 const float* stats, const float* gamma, int imgs, int64_t HW, int C, int G, int relu,
+                                 float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && x && stats && gamma && dx && chan_sums && imgs > 0 && HW > 0 && (!relu || y),
+                "svl_groupnorm_bwd: bad args");
+  SVL_CHECK_ARG(gn_shape_ok(C, G) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || ldy % 4 == 0),
+                "svl_groupnorm_bwd: unsupported C=%d G=%d", C, G);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(groupnorm_bwd_sums_kernel, dim3(imgs), dim3(256), 0, st, dy, (long)lddy, x, (long)ldx, y, (long)ldy,
+                     stats, (long)HW, C, G, relu, chan_sums);
+  SVL_LAUNCH_CHECK("svl_groupnorm_bwd/sums");
+  const long npix = (long)imgs * HW;
+  hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, st, dy, (long)lddy, x,
+                     (long)ldx, y, (long)ldy, stats, gamma, chan_sums, npix, (long)HW, C, G, relu, dx, (long)lddx);
+  SVL_LAUNCH_CHECK("svl_groupnorm_bwd/apply");
+  return SVL_OK;
+}

@@ -1,0 +1,442 @@
+// Pixel-loss family for the SemiVL step (HBM-bound, one pass over the logits per kernel).
+// Reference math: semivl.py:232,252 (softmax-max), utils/train_utils.py:19-49 (cutmix, confidence weighting),
+// semivl.py:52-58 (mc loss), semivl.py:267-323 (loss assembly), vlm.py:100-109 (MaskCLIP label tail).
+#include "svl_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// softmax-max: conf = 1 / sum_c exp(x_c - max), label = argmax (first max wins, like torch.max).
+// One thread = 4 consecutive pixels; class planes are read as float4 -> 1 KiB per wave per class.
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void softmax_max_kernel(const float* __restrict__ logits, int B, int N, long HW,
+                                                          float* __restrict__ conf, int64_t* __restrict__ label) {
+  constexpr int PX = VEC ? 4 : 1;
+  const long quads = (HW + PX - 1) / PX;
+  const long total = (long)B * quads;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const long b = q / quads;
+    const long p = (q - b * quads) * PX;
+    const float* base = logits + (long)b * N * HW + p;
+    float m[PX], s[PX];
+    int idx[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) { m[j] = -INFINITY; s[j] = 0.f; idx[j] = 0; }
+    for (int c = 0; c < N; ++c) {
+      float x[PX];
+      if constexpr (VEC) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (long)c * HW);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+      } else {
+        x[0] = base[(long)c * HW];
+      }
+#pragma unroll
+      for (int j = 0; j < PX; ++j) {
+        if (x[j] > m[j]) {
+          s[j] = s[j] * expf(m[j] - x[j]) + 1.f;
+          m[j] = x[j];
+          idx[j] = c;
+        } else {
+          s[j] += expf(x[j] - m[j]);
+        }
+      }
+    }
+    const long o = b * HW + p;
+    if constexpr (VEC) {
+      *reinterpret_cast<float4*>(conf + o) = make_float4(1.f / s[0], 1.f / s[1], 1.f / s[2], 1.f / s[3]);
+      long long* lp = reinterpret_cast<long long*>(label + o);
+      *reinterpret_cast<longlong2*>(lp) = make_longlong2(idx[0], idx[1]);
+      *reinterpret_cast<longlong2*>(lp + 2) = make_longlong2(idx[2], idx[3]);
+    } else {
+      conf[o] = 1.f / s[0];
+      label[o] = idx[0];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cutmix select
+// ------------------------------------------------------------------------------------------------
+__global__ void cutmix_f32_kernel(float* out, const float* a, const float* b, const float* box, int B, int C,
+                                  long HW) {
+  const long total = (long)B * C * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % HW;
+    const long bi = i / (HW * C);
+    out[i] = (box[bi * HW + p] == 1.f) ? b[i] : a[i];
+  }
+}
+__global__ void cutmix_i64_kernel(int64_t* out, const int64_t* a, const int64_t* b, const float* box, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    out[i] = (box[i] == 1.f) ? b[i] : a[i];
+}
+
+__global__ void count_valid_kernel(const int64_t* map, long n, unsigned long long* count) {
+  __shared__ float red[4];
+  float c = 0.f;  // per-thread count stays far below 2^24
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    c += (map[i] != 255) ? 1.f : 0.f;
+  const float tot = block_sum_256(c, red);
+  if (threadIdx.x == 0) atomicAdd(count, (unsigned long long)(tot + 0.5f));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused CE forward + backward.  A block stages a [N][P] logits tile in LDS (read from HBM once), each
+// thread owns one pixel column: log-sum-exp, the two NLL terms, then the tile is overwritten with
+// dlogits and streamed back coalesced.  HBM traffic: 4N read + 4N write + 28 B of maps per pixel,
+// below the (12N+40) B/px "API boundary" accounting of SURVEY §8(d).
+// partials[block] = { sum w_t*ce_t, sum ce_m, sum conf*valid, #valid }.
+// ------------------------------------------------------------------------------------------------
+struct CeP {
+  const float* logits;
+  int B, N;
+  long HW;
+  const int64_t* target;
+  int use_ignore_t;
+  const float* conf;
+  const int64_t* ign;
+  float conf_thresh;
+  const int64_t* mc;
+  float* partials;
+  float* dlogits;
+  const float* gscale;
+  int P;             // pixels per block
+  long blocks_per_img;
+};
+
+__global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [N][P]
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const long blk = blockIdx.x;
+  const long b = blk / p.blocks_per_img;
+  const long p0 = (blk - b * p.blocks_per_img) * p.P;
+  const int np = (int)min((long)p.P, p.HW - p0);
+  const float* src = p.logits + (long)b * p.N * p.HW + p0;
+  const int P = p.P;
+  const bool vec = ((p.HW & 3) == 0) && ((np & 3) == 0);
+  if (vec) {
+    const int q4 = np >> 2;
+    for (int i = tid; i < p.N * q4; i += 256) {
+      const int c = i / q4, q = i - c * q4;
+      *reinterpret_cast<float4*>(&tile[c * P + 4 * q]) = *reinterpret_cast<const float4*>(src + (long)c * p.HW + 4 * q);
+    }
+  } else {
+    for (int i = tid; i < p.N * np; i += 256) {
+      const int c = i / np, q = i - c * np;
+      tile[c * P + q] = src[(long)c * p.HW + q];
+    }
+  }
+  __syncthreads();
+
+  float s_t = 0.f, s_m = 0.f, s_c = 0.f, n_v = 0.f;
+  if (tid < np) {
+    const long o = b * p.HW + p0 + tid;
+    float m = -INFINITY;
+    for (int c = 0; c < p.N; ++c) m = fmaxf(m, tile[c * P + tid]);
+    float s = 0.f;
+    for (int c = 0; c < p.N; ++c) s += expf(tile[c * P + tid] - m);
+    const float lse = m + logf(s);
+    const long t = p.target[o];
+    const bool t_ok = !(p.use_ignore_t && t == 255);
+    float w = 1.f;
+    bool valid = t_ok;
+    if (p.conf) {
+      const bool v = p.ign[o] != 255;
+      const float cf = p.conf[o];
+      w = (cf >= p.conf_thresh && v) ? 1.f : 0.f;
+      valid = v;
+      s_c = v ? cf : 0.f;
+    }
+    n_v = valid ? 1.f : 0.f;
+    float ce_t = 0.f;
+    int ti = -1;
+    if (t_ok) {
+      ti = (int)t;
+      ce_t = lse - tile[ti * P + tid];
+    }
+    s_t = w * ce_t;
+    int mi = -1;
+    if (p.mc) {
+      const long mm = p.mc[o];
+      if (mm != 255) {
+        mi = (int)mm;
+        s_m = lse - tile[mi * P + tid];
+      }
+    }
+    if (p.dlogits) {
+      const float gt = t_ok ? p.gscale[0] * w : 0.f;
+      const float gm = (mi >= 0) ? p.gscale[1] : 0.f;
+      const float gsum = gt + gm;
+      const float inv = 1.f / s;
+      for (int c = 0; c < p.N; ++c) {
+        const float pr = expf(tile[c * P + tid] - m) * inv;
+        float d = gsum * pr;
+        if (c == ti) d -= gt;
+        if (c == mi) d -= gm;
+        tile[c * P + tid] = d;
+      }
+    }
+  }
+  // block partial sums (deterministic order: fixed tree, one slot per block)
+  const float r0 = block_sum_256(s_t, red);
+  const float r1 = block_sum_256(s_m, red);
+  const float r2 = block_sum_256(s_c, red);
+  const float r3 = block_sum_256(n_v, red);
+  if (tid == 0) {
+    float* pp = p.partials + blk * 4;
+    pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3;
+  }
+  if (p.dlogits) {
+    __syncthreads();
+    float* dst = p.dlogits + (long)b * p.N * p.HW + p0;
+    if (vec) {
+      const int q4 = np >> 2;
+      for (int i = tid; i < p.N * q4; i += 256) {
+        const int c = i / q4, q = i - c * q4;
+        *reinterpret_cast<float4*>(dst + (long)c * p.HW + 4 * q) = *reinterpret_cast<const float4*>(&tile[c * P + 4 * q]);
+      }
+    } else {
+      for (int i = tid; i < p.N * np; i += 256) {
+        const int c = i / np, q = i - c * np;
+        dst[(long)c * p.HW + q] = tile[c * P + q];
+      }
+    }
+  }
+}
+
+// sums[k] = sum over blocks of partials[blk][k] in double, fixed order (one block, tree over 256 lanes).
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* partials, long nblocks, double* sums) {
+  __shared__ double sh[4][256];
+  double a[4] = {0, 0, 0, 0};
+  for (long i = threadIdx.x; i < nblocks; i += 256)
+    for (int k = 0; k < 4; ++k) a[k] += (double)partials[i * 4 + k];
+  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = a[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) sums[threadIdx.x] = sh[threadIdx.x][0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loss assembly (semivl.py:267-323, train_utils.py:30-49 'pixelwise').  Single-thread scalar kernels:
+// they exist only so the step has no host sync (.item()) on the normalisers.
+// counts: int64 [4] = #valid for {x (mask_x != 255), s1, s2, fp (ignore maps != 255)}.
+// gscale out: float [4][2] = {g_t, g_m} per branch {x, s1, s2, fp}.
+// ------------------------------------------------------------------------------------------------
+__global__ void semivl_gscale_kernel(const unsigned long long* counts, double numel_u, float lam, float* gscale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double c0 = (double)counts[0], c1 = (double)counts[1], c2 = (double)counts[2], c3 = (double)counts[3];
+  gscale[0] = (float)(0.5 / c0);          gscale[1] = 0.f;
+  gscale[2] = (float)(0.125 / c1);        gscale[3] = (float)(0.25 * lam / numel_u);
+  gscale[4] = (float)(0.125 / c2);        gscale[5] = (float)(0.25 * lam / numel_u);
+  gscale[6] = (float)(0.25 / c3);         gscale[7] = (float)(0.5 * lam / numel_u);
+}
+// sums: double [4 branches][4]; out: float[8] = {loss, loss_x, loss_s1, loss_s2, loss_fp, mc_s1, mc_s2, mc_fp}
+__global__ void semivl_loss_kernel(const double* sums, double numel_u, float lam, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float lx = (float)(sums[0] / sums[3]);
+  const float l1 = (float)(sums[4] / sums[7]);
+  const float l2 = (float)(sums[8] / sums[11]);
+  const float lf = (float)(sums[12] / sums[15]);
+  const float m1 = (float)(sums[5] / numel_u);
+  const float m2 = (float)(sums[9] / numel_u);
+  const float mf = (float)(sums[13] / numel_u);
+  float loss = (lx + l1 * 0.25f + l2 * 0.25f + lf * 0.5f) / 2.0f;
+  loss = loss + m1 * 0.25f * lam;
+  loss = loss + m2 * 0.25f * lam;
+  loss = loss + mf * 0.5f * lam;
+  out[0] = loss; out[1] = lx; out[2] = l1; out[3] = l2; out[4] = lf; out[5] = m1; out[6] = m2; out[7] = mf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaskCLIP label tail: upsample (align_corners=False) -> softmax(scale*x) -> max -> threshold -> ignore.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, bool align, int& i0, int& i1, float& l0,
+                                          float& l1) {
+  float s = align ? scale * dst : scale * (dst + 0.5f) - 0.5f;
+  if (!align && s < 0.f) s = 0.f;
+  i0 = min((int)s, in_size - 1);
+  i1 = min(i0 + 1, in_size - 1);
+  l1 = fminf(fmaxf(s - i0, 0.f), 1.f);
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void maskclip_labels_kernel(const float* __restrict__ dense, int B, int N, int h,
+                                                              int w, int H, int W, float lscale, float thresh,
+                                                              const int64_t* __restrict__ ign,
+                                                              int64_t* __restrict__ out) {
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const long total = (long)B * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % W);
+    const long t = i / W;
+    const int oy = (int)(t % H);
+    const int b = (int)(t / H);
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(oy, sh, h, false, y0, y1, ly0, ly1);
+    src_index(ox, sw, w, false, x0, x1, lx0, lx1);
+    const float* base = dense + (long)b * N * h * w;
+    float m = -INFINITY, s = 0.f;
+    int idx = 0;
+    for (int c = 0; c < N; ++c) {
+      const float* pl = base + (long)c * h * w;
+      const float v = ly0 * (lx0 * pl[y0 * w + x0] + lx1 * pl[y0 * w + x1]) +
+                      ly1 * (lx0 * pl[y1 * w + x0] + lx1 * pl[y1 * w + x1]);
+      const float x = lscale * v;
+      if (x > m) {
+        s = s * expf(m - x) + 1.f;
+        m = x;
+        idx = c;
+      } else {
+        s += expf(x - m);
+      }
+    }
+    const float conf = 1.f / s;
+    int64_t lab = (conf < thresh) ? 255 : idx;
+    if (ign && ign[i] == 255) lab = 255;
+    out[i] = lab;
+  }
+}
+
+__global__ void concept_max_kernel(const float* pred, int B, int NC, long HW, const int* off, int N, float* out) {
+  const long total = (long)B * N * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % HW;
+    const long t = i / HW;
+    const int c = (int)(t % N);
+    const long b = t / N;
+    float m = -INFINITY;
+    for (int k = off[c]; k < off[c + 1]; ++k) m = fmaxf(m, pred[(b * NC + k) * HW + p]);
+    out[i] = m;
+  }
+}
+
+inline int grid_for(long n, int per_thread = 1) {
+  long g = (n + 256L * per_thread - 1) / (256L * per_thread);
+  if (g < 1) g = 1;
+  if (g > 256 * 16) g = 256 * 16;
+  return (int)g;
+}
+inline int ce_tile_pixels(int N) {
+  int P = (64 * 1024) / (4 * N);
+  if (P > 256) P = 256;
+  P &= ~63;
+  return P;
+}
+
+}  // namespace
+
+extern "C" int svl_softmax_max_f32(const float* logits, int B, int N, int64_t HW, float* conf, int64_t* label,
+                                   svl_stream_t stream) {
+  SVL_CHECK_ARG(logits && conf && label && B > 0 && N > 0 && HW > 0, "svl_softmax_max_f32: bad args");
+  const bool vec = (HW % 4 == 0) && (((uintptr_t)logits | (uintptr_t)conf | (uintptr_t)label) % 16 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL(softmax_max_kernel<true>, dim3(grid_for((long)B * HW / 4)), dim3(256), 0, st, logits, B, N,
+                       (long)HW, conf, label);
+  else
+    hipLaunchKernelGGL(softmax_max_kernel<false>, dim3(grid_for((long)B * HW)), dim3(256), 0, st, logits, B, N,
+                       (long)HW, conf, label);
+  SVL_LAUNCH_CHECK("svl_softmax_max_f32");
+  return SVL_OK;
+}
+
+extern "C" int svl_cutmix_f32(float* out, const float* a, const float* b, const float* box, int B, int C, int64_t HW,
+                              svl_stream_t stream) {
+  SVL_CHECK_ARG(out && a && b && box && B > 0 && C > 0 && HW > 0, "svl_cutmix_f32: bad args");
+  hipLaunchKernelGGL(cutmix_f32_kernel, dim3(grid_for((long)B * C * HW, 4)), dim3(256), 0, (hipStream_t)stream, out,
+                     a, b, box, B, C, (long)HW);
+  SVL_LAUNCH_CHECK("svl_cutmix_f32");
+  return SVL_OK;
+}
+
+extern "C" int svl_cutmix_i64(int64_t* out, const int64_t* a, const int64_t* b, const float* box, int B, int64_t HW,
+                              svl_stream_t stream) {
+  SVL_CHECK_ARG(out && a && b && box && B > 0 && HW > 0, "svl_cutmix_i64: bad args");
+  hipLaunchKernelGGL(cutmix_i64_kernel, dim3(grid_for((long)B * HW, 4)), dim3(256), 0, (hipStream_t)stream, out, a, b,
+                     box, (long)B * HW);
+  SVL_LAUNCH_CHECK("svl_cutmix_i64");
+  return SVL_OK;
+}
+
+extern "C" int svl_count_valid_i64(const int64_t* map, int64_t n, int64_t* count, svl_stream_t stream) {
+  SVL_CHECK_ARG(map && count && n > 0, "svl_count_valid_i64: bad args");
+  hipLaunchKernelGGL(count_valid_kernel, dim3(grid_for(n, 8)), dim3(256), 0, (hipStream_t)stream, map, (long)n,
+                     (unsigned long long*)count);
+  SVL_LAUNCH_CHECK("svl_count_valid_i64");
+  return SVL_OK;
+}
+
+extern "C" int64_t svl_ce_num_blocks(int B, int N, int64_t HW) {
+  if (B <= 0 || N <= 0 || HW <= 0 || 4 * N > 64 * 1024 / 64) return -1;
+  const int P = ce_tile_pixels(N);
+  return (int64_t)B * ((HW + P - 1) / P);
+}
+
+extern "C" int svl_ce_fused_f32(const svl_ce_desc* d, svl_stream_t stream) {
+  SVL_CHECK_ARG(d && d->logits && d->target && d->partials, "svl_ce_fused_f32: null args");
+  SVL_CHECK_ARG(d->B > 0 && d->N > 0 && d->HW > 0, "svl_ce_fused_f32: bad sizes");
+  SVL_CHECK_ARG((d->conf == nullptr) == (d->ign == nullptr), "svl_ce_fused_f32: conf and ign go together");
+  SVL_CHECK_ARG(d->dlogits == nullptr || d->gscale != nullptr, "svl_ce_fused_f32: gscale required with dlogits");
+  const int P = ce_tile_pixels(d->N);
+  SVL_CHECK_ARG(P >= 64, "svl_ce_fused_f32: N=%d too large for the LDS tile", d->N);
+  CeP p;
+  p.logits = d->logits; p.B = d->B; p.N = d->N; p.HW = d->HW;
+  p.target = d->target; p.use_ignore_t = d->use_ignore_t;
+  p.conf = d->conf; p.ign = d->ign; p.conf_thresh = d->conf_thresh;
+  p.mc = d->mc_target; p.partials = d->partials; p.dlogits = d->dlogits; p.gscale = d->gscale;
+  p.P = P;
+  p.blocks_per_img = (d->HW + P - 1) / P;
+  const long nblk = (long)d->B * p.blocks_per_img;
+  const size_t lds = (size_t)d->N * P * sizeof(float);
+  hipLaunchKernelGGL(ce_fused_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, p);
+  SVL_LAUNCH_CHECK("svl_ce_fused_f32");
+  return SVL_OK;
+}
+
+extern "C" int svl_ce_finalize(const float* partials, int64_t nblocks, double* sums, svl_stream_t stream) {
+  SVL_CHECK_ARG(partials && sums && nblocks > 0, "svl_ce_finalize: bad args");
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (long)nblocks, sums);
+  SVL_LAUNCH_CHECK("svl_ce_finalize");
+  return SVL_OK;
+}
+
+extern "C" int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, float* gscale,
+                                 svl_stream_t stream) {
+  SVL_CHECK_ARG(counts && gscale && numel_u > 0, "svl_semivl_gscale: bad args");
+  hipLaunchKernelGGL(semivl_gscale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     (const unsigned long long*)counts, numel_u, lam, gscale);
+  SVL_LAUNCH_CHECK("svl_semivl_gscale");
+  return SVL_OK;
+}
+
+extern "C" int svl_semivl_loss(const double* sums, double numel_u, float lam, float* out, svl_stream_t stream) {
+  SVL_CHECK_ARG(sums && out && numel_u > 0, "svl_semivl_loss: bad args");
+  hipLaunchKernelGGL(semivl_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, numel_u, lam, out);
+  SVL_LAUNCH_CHECK("svl_semivl_loss");
+  return SVL_OK;
+}
+
+extern "C" int svl_maskclip_labels(const float* dense, int B, int N, int h, int w, int H, int W, float scale,
+                                   float thresh, const int64_t* ign, int64_t* out, svl_stream_t stream) {
+  SVL_CHECK_ARG(dense && out && B > 0 && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "svl_maskclip_labels: bad args");
+  hipLaunchKernelGGL(maskclip_labels_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, dense,
+                     B, N, h, w, H, W, scale, thresh, ign, out);
+  SVL_LAUNCH_CHECK("svl_maskclip_labels");
+  return SVL_OK;
+}
+
+extern "C" int svl_concept_max_f32(const float* pred, int B, int NC, int64_t HW, const int* concept_offsets, int N,
+                                   float* out, svl_stream_t stream) {
+  SVL_CHECK_ARG(pred && concept_offsets && out && B > 0 && NC > 0 && N > 0 && HW > 0, "svl_concept_max_f32: bad args");
+  hipLaunchKernelGGL(concept_max_kernel, dim3(grid_for((long)B * N * HW)), dim3(256), 0, (hipStream_t)stream, pred, B,
+                     NC, (long)HW, concept_offsets, N, out);
+  SVL_LAUNCH_CHECK("svl_concept_max_f32");
+  return SVL_OK;
+}

@@ -1,0 +1,307 @@
+// Resampling kernels: bilinear resize (both corner conventions) on channels-last class-images and on NCHW logit
+// planes, AvgPool + text concat for the SemanticTransformer.  Index math follows ATen's upsample_bilinear2d
+// (area_pixel_compute_source_index + guard_index_and_lambda), which is what F.interpolate / mmseg.ops.resize call
+// in the reference (vlg_head.py:61,81,132,247; builder.py:93-97; vlm.py:103).
+#include "svl_common.h"
+
+namespace {
+
+inline int grid_for(long n) {
+  long g = (n + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 256 * 32) g = 256 * 32;
+  return (int)g;
+}
+
+__device__ __forceinline__ float area_scale(int in, int out, bool align) {
+  if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, bool align, int& i0, int& i1, float& l0,
+                                          float& l1) {
+  float s = align ? scale * dst : scale * (dst + 0.5f) - 0.5f;
+  if (!align && s < 0.f) s = 0.f;
+  i0 = min((int)s, in_size - 1);
+  i1 = min(i0 + 1, in_size - 1);
+  l1 = fminf(fmaxf(s - i0, 0.f), 1.f);
+  l0 = 1.f - l1;
+}
+// Conservative range of destination indices whose taps can touch source index `i`.
+__device__ __forceinline__ void dst_range(int i, float scale, int out_size, bool align, int& lo, int& hi) {
+  if (scale <= 0.f) {
+    lo = 0;
+    hi = out_size - 1;
+    return;
+  }
+  const float off = align ? 0.f : 0.5f;
+  lo = (int)floorf((i - 1 + off) / scale - off) - 1;
+  hi = (int)ceilf((i + 1 + off) / scale - off) + 1;
+  lo = max(lo, 0);
+  hi = min(hi, out_size - 1);
+}
+
+__global__ __launch_bounds__(256) void bilinear_nhwc_fwd_kernel(const float* __restrict__ x, long ldx, int imgs, int h,
+                                                                int w, int C, int align, int rep, int H, int W,
+                                                                float* __restrict__ y, long ldy, int accumulate) {
+  const int CQ = C >> 2;
+  const float sh = area_scale(h, H, align), sw = area_scale(w, W, align);
+  const long total = (long)imgs * rep * H * W * CQ;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CQ) * 4;
+    long t = i / CQ;
+    const int ox = (int)(t % W);
+    t /= W;
+    const int oy = (int)(t % H);
+    const long oimg = t / H;
+    const long iimg = oimg / rep;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(oy, sh, h, align, y0, y1, ly0, ly1);
+    src_index(ox, sw, w, align, x0, x1, lx0, lx1);
+    const float* b = x + iimg * h * w * ldx + c;
+    const float4 v00 = *reinterpret_cast<const float4*>(b + ((long)y0 * w + x0) * ldx);
+    const float4 v01 = *reinterpret_cast<const float4*>(b + ((long)y0 * w + x1) * ldx);
+    const float4 v10 = *reinterpret_cast<const float4*>(b + ((long)y1 * w + x0) * ldx);
+    const float4 v11 = *reinterpret_cast<const float4*>(b + ((long)y1 * w + x1) * ldx);
+    float4 o;
+    o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+    o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+    o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+    o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    float4* dst = reinterpret_cast<float4*>(y + ((oimg * H + oy) * W + ox) * ldy + c);
+    if (accumulate) {
+      const float4 a = *dst;
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    *dst = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void bilinear_nhwc_bwd_kernel(const float* __restrict__ dy, long lddy, int imgs, int h,
+                                                                int w, int C, int align, int rep, int H, int W,
+                                                                float* __restrict__ dx, long lddx, int accumulate) {
+  const int CQ = C >> 2;
+  const float sh = area_scale(h, H, align), sw = area_scale(w, W, align);
+  const long total = (long)imgs * h * w * CQ;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CQ) * 4;
+    long t = i / CQ;
+    const int ix = (int)(t % w);
+    t /= w;
+    const int iy = (int)(t % h);
+    const long iimg = t / h;
+    int ylo, yhi, xlo, xhi;
+    dst_range(iy, sh, H, align, ylo, yhi);
+    dst_range(ix, sw, W, align, xlo, xhi);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      src_index(oy, sh, h, align, y0, y1, ly0, ly1);
+      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        src_index(ox, sw, w, align, x0, x1, lx0, lx1);
+        const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+        if (wx == 0.f) continue;
+        const float wgt = wy * wx;
+        for (int r = 0; r < rep; ++r) {
+          const long oimg = iimg * rep + r;
+          const float4 d = *reinterpret_cast<const float4*>(dy + ((oimg * H + oy) * W + ox) * lddy + c);
+          acc.x += wgt * d.x; acc.y += wgt * d.y; acc.z += wgt * d.z; acc.w += wgt * d.w;
+        }
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(dx + ((iimg * h + iy) * w + ix) * lddx + c);
+    if (accumulate) {
+      const float4 a = *dst;
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    *dst = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void bilinear_planes_fwd_kernel(const float* __restrict__ x, long planes, int h, int w,
+                                                                  int align, int H, int W, float* __restrict__ y) {
+  const float sh = area_scale(h, H, align), sw = area_scale(w, W, align);
+  const long total = planes * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % W);
+    const long t = i / W;
+    const int oy = (int)(t % H);
+    const long pl = t / H;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(oy, sh, h, align, y0, y1, ly0, ly1);
+    src_index(ox, sw, w, align, x0, x1, lx0, lx1);
+    const float* b = x + pl * h * w;
+    y[i] = ly0 * (lx0 * b[y0 * w + x0] + lx1 * b[y0 * w + x1]) + ly1 * (lx0 * b[y1 * w + x0] + lx1 * b[y1 * w + x1]);
+  }
+}
+__global__ __launch_bounds__(256) void bilinear_planes_bwd_kernel(const float* __restrict__ dy, long planes, int h, int w,
+                                                                  int align, int H, int W, float* __restrict__ dx) {
+  const float sh = area_scale(h, H, align), sw = area_scale(w, W, align);
+  const long total = planes * h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % w);
+    const long t = i / w;
+    const int iy = (int)(t % h);
+    const long pl = t / h;
+    int ylo, yhi, xlo, xhi;
+    dst_range(iy, sh, H, align, ylo, yhi);
+    dst_range(ix, sw, W, align, xlo, xhi);
+    const float* d = dy + pl * H * W;
+    float acc = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      src_index(oy, sh, h, align, y0, y1, ly0, ly1);
+      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        src_index(ox, sw, w, align, x0, x1, lx0, lx1);
+        const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+        if (wx != 0.f) acc += wy * wx * d[(long)oy * W + ox];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool_cat_fwd_kernel(const float* __restrict__ x, int imgs, int H, int W, int C,
+                                                              int P, const float* __restrict__ text, int Ct, int nclass,
+                                                              float* __restrict__ y) {
+  const int Hp = H / P, Wp = W / P, Co = C + Ct;
+  const long total = (long)imgs * Hp * Wp * Co;
+  const float inv = 1.f / (float)(P * P);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Co);
+    long t = i / Co;
+    const int px = (int)(t % Wp);
+    t /= Wp;
+    const int py = (int)(t % Hp);
+    const long img = t / Hp;
+    float v;
+    if (c < C) {
+      float s = 0.f;
+      for (int a = 0; a < P; ++a)
+        for (int b = 0; b < P; ++b) s += x[((img * H + py * P + a) * W + px * P + b) * C + c];
+      v = s * inv;
+    } else {
+      v = text[(img % nclass) * Ct + (c - C)];
+    }
+    y[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void avgpool_cat_bwd_kernel(const float* __restrict__ dy, int imgs, int H, int W, int C,
+                                                              int P, int Ct, float* __restrict__ dx) {
+  const int Hp = H / P, Wp = W / P, Co = C + Ct;
+  const long total = (long)imgs * H * W * C;
+  const float inv = 1.f / (float)(P * P);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int xx = (int)(t % W);
+    t /= W;
+    const int yy = (int)(t % H);
+    const long img = t / H;
+    const int py = yy / P, px = xx / P;
+    dx[i] = (py < Hp && px < Wp) ? dy[((img * Hp + py) * Wp + px) * Co + c] * inv : 0.f;
+  }
+}
+
+// dtext[n][ct] = sum over images of class n and pooled pixels of dy[..., C + ct]  (grad of the broadcast text concat)
+__global__ __launch_bounds__(256) void text_grad_kernel(const float* __restrict__ dy, int imgs, long HWp, int C, int Ct,
+                                                        int nclass, float* __restrict__ dtext) {
+  __shared__ float sh[256];
+  const int n = blockIdx.x;
+  const int lanes_r = 256 / Ct;  // row lanes (Ct <= 256, 256 % Ct == 0)
+  const int ct = threadIdx.x % Ct, rl = threadIdx.x / Ct;
+  const int Co = C + Ct;
+  float s = 0.f;
+  for (long img = n; img < imgs; img += nclass)
+    for (long p = rl; p < HWp; p += lanes_r) s += dy[(img * HWp + p) * Co + C + ct];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0) {
+    float t = 0.f;
+    for (int r = 0; r < lanes_r; ++r) t += sh[r * Ct + ct];
+    dtext[n * Ct + ct] = t;
+  }
+}
+
+}  // namespace
+
+extern "C" int svl_bilinear_nhwc_fwd(const float* x, int64_t ldx, int imgs, int h, int w, int C, int align_corners,
+                                     int rep, int H, int W, float* y, int64_t ldy, int accumulate, svl_stream_t stream) {
+  SVL_CHECK_ARG(x && y && imgs > 0 && h > 0 && w > 0 && H > 0 && W > 0 && rep >= 1 && C > 0 && C % 4 == 0 &&
+                    ldx % 4 == 0 && ldy % 4 == 0,
+                "svl_bilinear_nhwc_fwd: bad args");
+  const long total = (long)imgs * rep * H * W * (C / 4);
+  hipLaunchKernelGGL(bilinear_nhwc_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                     imgs, h, w, C, align_corners, rep, H, W, y, (long)ldy, accumulate);
+  SVL_LAUNCH_CHECK("svl_bilinear_nhwc_fwd");
+  return SVL_OK;
+}
+extern "C" int svl_bilinear_nhwc_bwd(const float* dy, int64_t lddy, int imgs, int h, int w, int C, int align_corners,
+                                     int rep, int H, int W, float* dx, int64_t lddx, int accumulate,
+                                     svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && dx && imgs > 0 && h > 0 && w > 0 && H > 0 && W > 0 && rep >= 1 && C > 0 && C % 4 == 0 &&
+                    lddy % 4 == 0 && lddx % 4 == 0,
+                "svl_bilinear_nhwc_bwd: bad args");
+  const long total = (long)imgs * h * w * (C / 4);
+  hipLaunchKernelGGL(bilinear_nhwc_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy,
+                     imgs, h, w, C, align_corners, rep, H, W, dx, (long)lddx, accumulate);
+  SVL_LAUNCH_CHECK("svl_bilinear_nhwc_bwd");
+  return SVL_OK;
+}
+extern "C" int svl_bilinear_planes_fwd(const float* x, int64_t planes, int h, int w, int align_corners, int H, int W,
+                                       float* y, svl_stream_t stream) {
+  SVL_CHECK_ARG(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "svl_bilinear_planes_fwd: bad args");
+  hipLaunchKernelGGL(bilinear_planes_fwd_kernel, dim3(grid_for(planes * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)planes, h, w, align_corners, H, W, y);
+  SVL_LAUNCH_CHECK("svl_bilinear_planes_fwd");
+  return SVL_OK;
+}
+extern "C" int svl_bilinear_planes_bwd(const float* dy, int64_t planes, int h, int w, int align_corners, int H, int W,
+                                       float* dx, svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && dx && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "svl_bilinear_planes_bwd: bad args");
+  hipLaunchKernelGGL(bilinear_planes_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0, (hipStream_t)stream, dy,
+                     (long)planes, h, w, align_corners, H, W, dx);
+  SVL_LAUNCH_CHECK("svl_bilinear_planes_bwd");
+  return SVL_OK;
+}
+extern "C" int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C, int P, const float* text, int Ct,
+                                   int nclass, float* y, svl_stream_t stream) {
+  SVL_CHECK_ARG(x && y && imgs > 0 && H >= P && W >= P && C > 0 && P > 0 && (Ct == 0 || (text && nclass > 0)),
+                "svl_avgpool_cat_fwd: bad args");
+  const long total = (long)imgs * (H / P) * (W / P) * (C + Ct);
+  hipLaunchKernelGGL(avgpool_cat_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, imgs, H, W, C,
+                     P, text, Ct, nclass > 0 ? nclass : 1, y);
+  SVL_LAUNCH_CHECK("svl_avgpool_cat_fwd");
+  return SVL_OK;
+}
+extern "C" int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int C, int P, int Ct, float* dx,
+                                   svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && dx && imgs > 0 && H >= P && W >= P && C > 0 && P > 0 && Ct >= 0, "svl_avgpool_cat_bwd: bad args");
+  const long total = (long)imgs * H * W * C;
+  hipLaunchKernelGGL(avgpool_cat_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, imgs, H, W,
+                     C, P, Ct, dx);
+  SVL_LAUNCH_CHECK("svl_avgpool_cat_bwd");
+  return SVL_OK;
+}
+
+extern "C" int svl_avgpool_cat_bwd_text(const float* dy, int imgs, int64_t HWp, int C, int Ct, int nclass, float* dtext,
+                                        svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && dtext && imgs > 0 && HWp > 0 && C > 0 && Ct > 0 && Ct <= 256 && 256 % Ct == 0 && nclass > 0 &&
+                    imgs % nclass == 0,
+                "svl_avgpool_cat_bwd_text: bad args");
+  hipLaunchKernelGGL(text_grad_kernel, dim3(nclass), dim3(256), 0, (hipStream_t)stream, dy, imgs, (long)HWp, C, Ct,
+                     nclass, dtext);
+  SVL_LAUNCH_CHECK("svl_avgpool_cat_bwd_text");
+  return SVL_OK;
+}

@@ -1,0 +1,496 @@
+"""Thin tensor-level wrappers over the C-ABI (include/semivl_hip.h).
+
+torch is used here for device memory (torch.empty), views and the current HIP stream only; every FLOP of the hot
+path is issued through libsemivl_hip.so.  All tensors are fp32 CUDA(HIP) tensors unless stated.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+A_KC, A_MC, A_CONV, A_PATCH = 0, 1, 2, 3
+B_KC, B_NC, B_CONVW = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+OUT_STRIDED, OUT_CONVT2X, OUT_PATCH = 0, 1, 2
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype, (t.device, t.dtype)
+    return t
+
+
+def empty(*shape, dtype=torch.float32, device=None):
+    return torch.empty(*shape, dtype=dtype, device=device if device is not None else torch.cuda.current_device())
+
+
+def zeros(*shape, dtype=torch.float32, device=None):
+    return torch.zeros(*shape, dtype=dtype, device=device if device is not None else torch.cuda.current_device())
+
+
+class Op:
+    """Operand description: tensor (+ element offset), leading dim, batch strides."""
+    __slots__ = ("t", "off", "ld", "bso", "bsi")
+
+    def __init__(self, t, ld, off=0, bso=0, bsi=0):
+        self.t, self.off, self.ld, self.bso, self.bsi = t, off, ld, bso, bsi
+
+    def c(self):
+        return L.Operand(C.c_void_p(self.t.data_ptr() + 4 * self.off), self.ld, self.bso, self.bsi)
+
+
+def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batch=1, batch_inner=1, ksplit=0,
+         c_bso=0, c_bsi=0, alpha=1.0, bias=None, bias_mod=0, act=ACT_NONE, resid=None, r_off=0, ldr_m=None, ldr_n=1,
+         r_bso=0, r_bsi=0, accumulate=False, out_mode=OUT_STRIDED, conv=None, ct=(0, 0, 0)):
+    d = L.GemmDesc()
+    d.a_mode, d.b_mode, d.M, d.N, d.K = a_mode, b_mode, M, N, K
+    d.batch, d.batch_inner, d.ksplit = batch, batch_inner, ksplit
+    d.A, d.B = A.c(), B.c()
+    if conv is not None:
+        d.conv = conv
+    d.C = C.c_void_p(Cout.data_ptr() + 4 * c_off)
+    d.out_mode = out_mode
+    d.ldc_m = ldc_m if ldc_m is not None else N
+    d.ldc_n, d.c_bs_outer, d.c_bs_inner = ldc_n, c_bso, c_bsi
+    d.ct_H, d.ct_W, d.ct_Cout = ct
+    d.alpha = alpha
+    d.bias = _p(bias)
+    d.bias_mod, d.act = bias_mod, act
+    if resid is not None:
+        d.resid = C.c_void_p(resid.data_ptr() + 4 * r_off)
+        d.ldr_m = ldr_m if ldr_m is not None else d.ldc_m
+        d.ldr_n, d.r_bs_outer, d.r_bs_inner = ldr_n, r_bso, r_bsi
+    d.accumulate = 1 if accumulate else 0
+    L.check(L.load().svl_gemm_f32(C.byref(d), _st()), "svl_gemm_f32")
+
+
+def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld2=0, patch=0):
+    g = L.ConvGeom()
+    g.H, g.W, g.C1, g.C2, g.rep = H, W, C1, C2, rep
+    g.KH, g.KW, g.dil, g.pad, g.sign = KH, KW, dil, pad, sign
+    g.src2 = _p(src2)
+    g.ld2, g.patch = ld2, patch
+    return g
+
+
+# ------------------------------------------------------------------------------------------------ dense helpers
+def linear(x, W, bias=None, act=ACT_NONE, resid=None, out=None, accumulate=False):
+    """out[M,N] = act(x[M,K] @ W[N,K]^T + bias) + resid   (torch F.linear layout)."""
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and x.stride(1) == 1 and W.is_contiguous()
+    if out is None:
+        out = empty(M, N, device=x.device)
+    gemm(A_KC, B_KC, M, N, K, Op(x, x.stride(0)), Op(W, K), out, ldc_m=out.stride(0), bias=bias, act=act,
+         resid=resid, ldr_m=resid.stride(0) if resid is not None else None, accumulate=accumulate)
+    return out
+
+
+def matmul_nn(a, b, out=None, accumulate=False):
+    """out[M,N] = a[M,K] @ b[K,N]  (dgrad: dY @ W with W [out,in])."""
+    M, K = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = empty(M, N, device=a.device)
+    gemm(A_KC, B_NC, M, N, K, Op(a, a.stride(0)), Op(b, b.stride(0)), out, ldc_m=out.stride(0), accumulate=accumulate)
+    return out
+
+
+def _ksplit_plan(M, N, K):
+    bm = 32 if M <= 32 else (64 if M <= 64 else 128)
+    bn = 128 if (M <= 64 and N > 64) else (32 if N <= 32 else (64 if N <= 64 else 128))
+    tiles = math.ceil(M / bm) * math.ceil(N / bn)
+    s = max(1, min(math.ceil(1024 / tiles), K // 512 if K >= 1024 else 1, 512))
+    ks = math.ceil(math.ceil(K / s) / 16) * 16
+    s = math.ceil(K / ks)
+    return s, ks
+
+
+def matmul_tn(a, b, out=None, accumulate=False):
+    """out[M,N] = a[K,M]^T @ b[K,N] with deterministic split-K (wgrad: dY^T @ X)."""
+    K, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = empty(M, N, device=a.device)
+        accumulate = False
+    assert out.is_contiguous()
+    s, ks = _ksplit_plan(M, N, K)
+    if s == 1:
+        gemm(A_MC, B_NC, M, N, K, Op(a, a.stride(0)), Op(b, b.stride(0)), out, accumulate=accumulate)
+        return out
+    slabs = empty(s, M, N, device=a.device)
+    gemm(A_MC, B_NC, M, N, K, Op(a, a.stride(0)), Op(b, b.stride(0)), slabs, batch=s, ksplit=ks, c_bso=M * N)
+    reduce_slabs(out, slabs, accumulate)
+    return out
+
+
+def reduce_slabs(out, slabs, accumulate=False):
+    L.check(L.load().svl_reduce_slabs_f32(_p(out), _p(slabs), slabs.shape[0], out.numel(), 1 if accumulate else 0,
+                                          _st()), "svl_reduce_slabs_f32")
+
+
+def colsum(x2d, out=None, accumulate=False, C_=None, ld=None):
+    rows = x2d.shape[0]
+    Cc = C_ if C_ is not None else x2d.shape[1]
+    ldd = ld if ld is not None else x2d.stride(0)
+    if out is None:
+        out = empty(Cc, device=x2d.device)
+        accumulate = False
+    lib = L.load()
+    ws = empty(int(lib.svl_colsum_ws_floats(rows, Cc)), device=x2d.device)
+    L.check(lib.svl_colsum_f32(_p(x2d), rows, Cc, ldd, _p(out), 1 if accumulate else 0, _p(ws), _st()),
+            "svl_colsum_f32")
+    return out
+
+
+def eltwise(mode, a, b=None, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(L.load().svl_eltwise_f32(mode, _p(a), _p(b), _p(out), a.numel(), _st()), "svl_eltwise_f32")
+    return out
+
+
+def add(a, b, out=None):
+    return eltwise(0, a, b, out)
+
+
+def fill(t, v):
+    L.check(L.load().svl_fill_f32(_p(t), float(v), t.numel(), _st()), "svl_fill_f32")
+    return t
+
+
+def chanmask(x, mask, scale, rows_per_img, out=None):
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.load().svl_chanmask_f32(_p(x), _p(mask), float(scale), rows, rows_per_img, Cc, _p(out), _st()),
+            "svl_chanmask_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ normalisation
+def layernorm_fwd(x, gamma, beta, eps):
+    rows, Cc = x.shape
+    y = torch.empty_like(x)
+    stats = empty(rows, 2, device=x.device)
+    L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),
+            "svl_layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(dy, x, stats, gamma, dx_add=None, want_wgrad=False):
+    rows, Cc = x.shape
+    dx = torch.empty_like(x)
+    lib = L.load()
+    dgp = dbp = None
+    if want_wgrad:
+        nparts = lib.svl_layernorm_bwd_parts(rows)
+        dgp = empty(nparts, Cc, device=x.device)
+        dbp = empty(nparts, Cc, device=x.device)
+    L.check(lib.svl_layernorm_bwd(_p(dy), _p(x), _p(stats), _p(gamma), rows, Cc, _p(dx_add), _p(dx), _p(dgp), _p(dbp),
+                                  _st()), "svl_layernorm_bwd")
+    if want_wgrad:
+        return dx, colsum(dgp), colsum(dbp)
+    return dx
+
+
+def softmax_rows_fwd(s, rows, cols, ld, scale):
+    L.check(L.load().svl_softmax_rows_fwd(_p(s), rows, cols, ld, float(scale), _st()), "svl_softmax_rows_fwd")
+
+
+def softmax_rows_bwd(dp, p, rows, cols, ld, scale):
+    L.check(L.load().svl_softmax_rows_bwd(_p(dp), _p(p), rows, cols, ld, float(scale), _st()), "svl_softmax_rows_bwd")
+
+
+def l2norm_fwd(x, eps=0.0):
+    rows, Cc = x.shape
+    y = torch.empty_like(x)
+    inv = empty(rows, device=x.device)
+    L.check(L.load().svl_l2norm_fwd(_p(x), rows, Cc, float(eps), _p(y), _p(inv), _st()), "svl_l2norm_fwd")
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    rows, Cc = y.shape
+    dx = torch.empty_like(y)
+    L.check(L.load().svl_l2norm_bwd(_p(dy), _p(y), _p(inv), rows, Cc, _p(dx), _st()), "svl_l2norm_bwd")
+    return dx
+
+
+def groupnorm_fwd(x, ldx, gamma, beta, eps, imgs, HW, Cc, G, relu, y, ldy):
+    """x/y are flat tensors viewed as [imgs*HW, ld]; y may be a channel slice of a wider buffer (pass data offset via
+    a narrowed view: y.data_ptr() is used)."""
+    stats = empty(imgs, G, 2, device=x.device)
+    L.check(L.load().svl_groupnorm_fwd(_p(x), ldx, _p(gamma), _p(beta), float(eps), imgs, HW, Cc, G, 1 if relu else 0,
+                                       _p(y), ldy, _p(stats), _st()), "svl_groupnorm_fwd")
+    return stats
+
+
+def groupnorm_bwd(dy, lddy, x, ldx, y, ldy, stats, gamma, imgs, HW, Cc, G, relu, dx, lddx):
+    cs = empty(imgs, 2, Cc, device=x.device)
+    L.check(L.load().svl_groupnorm_bwd(_p(dy), lddy, _p(x), ldx, _p(y), ldy, _p(stats), _p(gamma), imgs, HW, Cc, G,
+                                       1 if relu else 0, _p(dx), lddx, _p(cs), _st()), "svl_groupnorm_bwd")
+    flat = cs.view(imgs, 2 * Cc)
+    dbeta = colsum(flat, C_=Cc, ld=2 * Cc)
+    dgamma = colsum(flat[:, Cc:], C_=Cc, ld=2 * Cc)
+    return dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------ ViT attention (v0: materialised)
+def vit_attention_fwd(qkv, Bn, T, H, D):
+    """qkv [Bn*T, 3E] -> (out [Bn*T, E], probs [Bn*H, T, Tp]).  q is scaled by D^-0.5 (a power of two here) inside
+    the softmax, identical to nn.MultiheadAttention's q-scaling."""
+    E = H * D
+    Tp = (T + 3) // 4 * 4
+    dev = qkv.device
+    P = empty(Bn * H, T, Tp, device=dev)
+    gemm(A_KC, B_KC, T, T, D, Op(qkv, 3 * E, 0, T * 3 * E, D), Op(qkv, 3 * E, E, T * 3 * E, D), P, ldc_m=Tp,
+         batch=Bn * H, batch_inner=H, c_bso=H * T * Tp, c_bsi=T * Tp)
+    softmax_rows_fwd(P, Bn * H * T, T, Tp, 1.0 / math.sqrt(D))
+    out = empty(Bn * T, E, device=dev)
+    gemm(A_KC, B_NC, T, D, T, Op(P, Tp, 0, H * T * Tp, T * Tp), Op(qkv, 3 * E, 2 * E, T * 3 * E, D), out, ldc_m=E,
+         batch=Bn * H, batch_inner=H, c_bso=T * E, c_bsi=D)
+    return out, P
+
+
+def vit_attention_bwd(dout, qkv, P, Bn, T, H, D):
+    E = H * D
+    Tp = P.shape[2]
+    dev = qkv.device
+    dqkv = empty(Bn * T, 3 * E, device=dev)
+    bh = dict(batch=Bn * H, batch_inner=H)
+    p_op = Op(P, Tp, 0, H * T * Tp, T * Tp)
+    do_op = Op(dout, E, 0, T * E, D)
+    # dV = P^T dO
+    gemm(A_MC, B_NC, T, D, T, p_op, do_op, dqkv, c_off=2 * E, ldc_m=3 * E, c_bso=T * 3 * E, c_bsi=D, **bh)
+    # dP = dO V^T
+    dP = empty(Bn * H, T, Tp, device=dev)
+    gemm(A_KC, B_KC, T, T, D, do_op, Op(qkv, 3 * E, 2 * E, T * 3 * E, D), dP, ldc_m=Tp, c_bso=H * T * Tp,
+         c_bsi=T * Tp, **bh)
+    softmax_rows_bwd(dP, P, Bn * H * T, T, Tp, 1.0 / math.sqrt(D))
+    ds_op = Op(dP, Tp, 0, H * T * Tp, T * Tp)
+    # dQ = dS K ; dK = dS^T Q
+    gemm(A_KC, B_NC, T, D, T, ds_op, Op(qkv, 3 * E, E, T * 3 * E, D), dqkv, c_off=0, ldc_m=3 * E, c_bso=T * 3 * E,
+         c_bsi=D, **bh)
+    gemm(A_MC, B_NC, T, D, T, ds_op, Op(qkv, 3 * E, 0, T * 3 * E, D), dqkv, c_off=E, ldc_m=3 * E, c_bso=T * 3 * E,
+         c_bsi=D, **bh)
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------ SemanticTransformer attention
+def seqattn_fwd(qkv, groups, inner, seq, heads, outer_stride, inner_stride, seq_stride):
+    rows, E3 = qkv.shape
+    E = E3 // 3
+    out = empty(rows, E, device=qkv.device)
+    probs = empty(groups, heads, seq, seq, device=qkv.device)
+    d = L.SeqAttnDesc(groups, inner, seq, heads, outer_stride, inner_stride, seq_stride, _p(qkv), _p(out), _p(probs),
+                      None, None, None)
+    L.check(L.load().svl_seqattn_fwd(C.byref(d), _st()), "svl_seqattn_fwd")
+    return out, probs
+
+
+def seqattn_bwd(dout, qkv, probs, groups, inner, seq, heads, outer_stride, inner_stride, seq_stride):
+    dqkv = torch.empty_like(qkv)
+    ds = torch.empty_like(probs)
+    d = L.SeqAttnDesc(groups, inner, seq, heads, outer_stride, inner_stride, seq_stride, _p(qkv), None, _p(probs),
+                      _p(dout), _p(dqkv), _p(ds))
+    L.check(L.load().svl_seqattn_bwd(C.byref(d), _st()), "svl_seqattn_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------ convolutions (NHWC, stride 1)
+def pack_conv_w(W):
+    """[Co, Ci, kh, kw] -> forward pack [Co, (kh kw) Ci] and dgrad pack [Ci, (kh kw) Co] (weight-sized permutes)."""
+    Co, Ci, kh, kw = W.shape
+    wf = W.permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci).contiguous()
+    wd = W.permute(1, 2, 3, 0).reshape(Ci, kh * kw * Co).contiguous()
+    return wf, wd
+
+
+def unpack_conv_wgrad(dwf, Co, Ci, kh, kw):
+    return dwf.view(Co, kh, kw, Ci).permute(0, 3, 1, 2).contiguous()
+
+
+def conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, KH, KW, dil, pad, bias=None, act=ACT_NONE, out=None, ldo=None, src2=None,
+             ld2=0, C2=0, rep=1, resid=None, ldr=None):
+    """y[pix, Co] = conv(x) with packed weight wf [Co, KH*KW*(C1+C2)]."""
+    M = imgs * H * W
+    K = KH * KW * (C1 + C2)
+    if out is None:
+        out = empty(M, Co, device=x.device)
+        ldo = Co
+    g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2)
+    gemm(A_CONV, B_KC, M, Co, K, Op(x, ldx), Op(wf, K), out, ldc_m=ldo, bias=bias, act=act, conv=g, resid=resid,
+         ldr_m=ldr)
+    return out
+
+
+def conv_dgrad(dy, lddy, imgs, H, W, Co, wd, Ci, KH, KW, dil, pad, out=None, ldo=None, accumulate=False):
+    """dx[pix, Ci] from dy[pix, Co] with the dgrad pack wd [Ci, KH*KW*Co] (taps mirrored via sign=-1)."""
+    M = imgs * H * W
+    K = KH * KW * Co
+    if out is None:
+        out = empty(M, Ci, device=dy.device)
+        ldo = Ci
+    g = conv_geom(H, W, Co, KH, KW, dil, pad, -1)
+    gemm(A_CONV, B_KC, M, Ci, K, Op(dy, lddy), Op(wd, K), out, ldc_m=ldo, conv=g, accumulate=accumulate)
+    return out
+
+
+def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None, ld2=0, C2=0, rep=1):
+    """dWf[Co, KH*KW*(C1+C2)] = dy^T im2col(x), deterministic split-K over pixels."""
+    Kpix = imgs * H * W
+    N = KH * KW * (C1 + C2)
+    g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2)
+    s, ks = _ksplit_plan(Co, N, Kpix)
+    out = empty(Co, N, device=dy.device)
+    if s == 1:
+        gemm(A_MC, B_CONVW, Co, N, Kpix, Op(dy, lddy), Op(x, ldx), out, conv=g)
+        return out
+    slabs = empty(s, Co, N, device=dy.device)
+    gemm(A_MC, B_CONVW, Co, N, Kpix, Op(dy, lddy), Op(x, ldx), slabs, batch=s, ksplit=ks, c_bso=Co * N, conv=g)
+    reduce_slabs(out, slabs)
+    return out
+
+
+def convT2x_fwd(x, ldx, imgs, H, W, Ci, wp, Co, bias, out, ldo):
+    """ConvTranspose2d(k=2,s=2): wp [4*Co, Ci] packed as n=(a,b,co); out [imgs,2H,2W,:] pixel stride ldo."""
+    M = imgs * H * W
+    gemm(A_KC, B_KC, M, 4 * Co, Ci, Op(x, ldx), Op(wp, Ci), out, ldc_m=ldo, bias=bias, bias_mod=Co,
+         out_mode=OUT_CONVT2X, ct=(H, W, Co))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ resampling
+def bilinear_nhwc_fwd(x, ldx, imgs, h, w, Cc, align, rep, H, W, y, ldy, accumulate=False):
+    L.check(L.load().svl_bilinear_nhwc_fwd(_p(x), ldx, imgs, h, w, Cc, 1 if align else 0, rep, H, W, _p(y), ldy,
+                                           1 if accumulate else 0, _st()), "svl_bilinear_nhwc_fwd")
+
+
+def bilinear_nhwc_bwd(dy, lddy, imgs, h, w, Cc, align, rep, H, W, dx, lddx, accumulate=False):
+    L.check(L.load().svl_bilinear_nhwc_bwd(_p(dy), lddy, imgs, h, w, Cc, 1 if align else 0, rep, H, W, _p(dx), lddx,
+                                           1 if accumulate else 0, _st()), "svl_bilinear_nhwc_bwd")
+
+
+def bilinear_planes_fwd(x, h, w, align, H, W):
+    planes = x.numel() // (h * w)
+    y = empty(*x.shape[:-2], H, W, device=x.device)
+    L.check(L.load().svl_bilinear_planes_fwd(_p(x), planes, h, w, 1 if align else 0, H, W, _p(y), _st()),
+            "svl_bilinear_planes_fwd")
+    return y
+
+
+def bilinear_planes_bwd(dy, h, w, align, H, W):
+    planes = dy.numel() // (H * W)
+    dx = empty(*dy.shape[:-2], h, w, device=dy.device)
+    L.check(L.load().svl_bilinear_planes_bwd(_p(dy), planes, h, w, 1 if align else 0, H, W, _p(dx), _st()),
+            "svl_bilinear_planes_bwd")
+    return dx
+
+
+def avgpool_cat_fwd(x, imgs, H, W, Cc, P, text, nclass):
+    Ct = text.shape[1] if text is not None else 0
+    y = empty(imgs * (H // P) * (W // P), Cc + Ct, device=x.device)
+    L.check(L.load().svl_avgpool_cat_fwd(_p(x), imgs, H, W, Cc, P, _p(text), Ct, nclass, _p(y), _st()),
+            "svl_avgpool_cat_fwd")
+    return y
+
+
+def avgpool_cat_bwd(dy, imgs, H, W, Cc, P, Ct, nclass):
+    dx = empty(imgs * H * W, Cc, device=dy.device)
+    lib = L.load()
+    L.check(lib.svl_avgpool_cat_bwd(_p(dy), imgs, H, W, Cc, P, Ct, _p(dx), _st()), "svl_avgpool_cat_bwd")
+    dtext = None
+    if Ct > 0:
+        dtext = empty(nclass, Ct, device=dy.device)
+        L.check(lib.svl_avgpool_cat_bwd_text(_p(dy), imgs, (H // P) * (W // P), Cc, Ct, nclass, _p(dtext), _st()),
+                "svl_avgpool_cat_bwd_text")
+    return dx, dtext
+
+
+# ------------------------------------------------------------------------------------------------ pixel losses
+def softmax_max(logits):
+    Bn, N = logits.shape[:2]
+    HW = logits[0, 0].numel()
+    conf = empty(Bn, *logits.shape[2:], device=logits.device)
+    label = empty(Bn, *logits.shape[2:], dtype=torch.int64, device=logits.device)
+    L.check(L.load().svl_softmax_max_f32(_p(logits), Bn, N, HW, _p(conf), _p(label), _st()), "svl_softmax_max_f32")
+    return conf, label
+
+
+def cutmix_f32(a, b, box, out=None):
+    """where(box==1, b, a); a,b [B,(C,)H,W] fp32, box [B,H,W] fp32."""
+    Bn = a.shape[0]
+    HW = box[0].numel()
+    Cc = a[0].numel() // HW
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(L.load().svl_cutmix_f32(_p(out), _p(a), _p(b), _p(box), Bn, Cc, HW, _st()), "svl_cutmix_f32")
+    return out
+
+
+def cutmix_i64(a, b, box):
+    out = torch.empty_like(a)
+    L.check(L.load().svl_cutmix_i64(_p(out), _p(a), _p(b), _p(box), a.shape[0], box[0].numel(), _st()),
+            "svl_cutmix_i64")
+    return out
+
+
+def count_valid(map_i64, out_count):
+    """out_count (int64[1] view, pre-zeroed) += #(map != 255)."""
+    L.check(L.load().svl_count_valid_i64(_p(map_i64), map_i64.numel(), _p(out_count), _st()), "svl_count_valid_i64")
+
+
+def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0, mc=None, dlogits=None, gscale=None,
+             sums_out=None):
+    """Returns sums (double[4] device): {sum w*ce_t, sum ce_m, sum conf*valid, #valid}."""
+    Bn, N = logits.shape[:2]
+    HW = logits[0, 0].numel()
+    lib = L.load()
+    nblk = lib.svl_ce_num_blocks(Bn, N, HW)
+    if nblk <= 0:
+        raise RuntimeError(f"svl_ce_fused: unsupported N={N}")
+    partials = empty(nblk, 4, device=logits.device)
+    d = L.CeDesc(_p(logits), Bn, N, HW, _p(target), 1 if use_ignore_t else 0, _p(conf), _p(ign), float(conf_thresh),
+                 _p(mc), _p(partials), _p(dlogits), _p(gscale))
+    L.check(lib.svl_ce_fused_f32(C.byref(d), _st()), "svl_ce_fused_f32")
+    if sums_out is None:
+        sums_out = empty(4, dtype=torch.float64, device=logits.device)
+    L.check(lib.svl_ce_finalize(_p(partials), nblk, _p(sums_out), _st()), "svl_ce_finalize")
+    return sums_out
+
+
+def maskclip_labels(dense, H, W, scale, thresh, ign=None):
+    Bn, N, h, w = dense.shape
+    out = empty(Bn, H, W, dtype=torch.int64, device=dense.device)
+    L.check(L.load().svl_maskclip_labels(_p(dense), Bn, N, h, w, H, W, float(scale), float(thresh), _p(ign), _p(out),
+                                         _st()), "svl_maskclip_labels")
+    return out
+
+
+def concept_max(pred, offsets_i32, N):
+    Bn, NC = pred.shape[:2]
+    HW = pred[0, 0].numel()
+    out = empty(Bn, N, *pred.shape[2:], device=pred.device)
+    L.check(L.load().svl_concept_max_f32(_p(pred), Bn, NC, HW, _p(offsets_i32), N, _p(out), _st()),
+            "svl_concept_max_f32")
+    return out
+
+
+def adamw_step(p, g, m, v, seg_off, seg_lr, seg_wd, nseg, beta1, beta2, eps, step, gscale=1.0, ema=None, ema_decay=0.0):
+    L.check(L.load().svl_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(seg_off), _p(seg_lr), _p(seg_wd), nseg, p.numel(),
+                                    float(beta1), float(beta2), float(eps), int(step), float(gscale), _p(ema),
+                                    float(ema_decay), _st()), "svl_adamw_step")

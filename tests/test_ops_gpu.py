@@ -1,0 +1,440 @@
+"""Per-kernel parity of the HIP C-ABI against plain PyTorch fp32 ops on the same device (ATen is only the checker
+here).  Everything goes through semivl_amd.ops -> ctypes -> libsemivl_hip.so."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, dev, scale=1.0, seed=None):
+    if seed is not None:
+        torch.manual_seed(seed)
+    return (torch.randn(*shape, device=dev) * scale).contiguous()
+
+
+def close(a, b, atol=1e-4, rtol=1e-4, what=""):
+    a, b = a.float(), b.float()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), f"{what}: max abs err {err:.3e} (ref max {ref:.3e})"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def test_mfma_layout_identity(dev):
+    """A = I with an ASYMMETRIC B catches row/col swaps of the MFMA C/D layout."""
+    from semivl_amd import ops
+    n = 160
+    a = torch.eye(n, device=dev)
+    b = (torch.arange(n, device=dev)[:, None] * 1000.0 + torch.arange(n, device=dev)[None, :]).contiguous()  # [N,K]
+    out = ops.linear(a, b)
+    assert torch.equal(out, b.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 21, 49), (128, 128, 16), (257, 130, 70), (1025, 768, 768),
+                                   (300, 64, 512), (300, 32, 100), (20, 300, 64), (50, 200, 96)])
+def test_linear(dev, M, N, K):
+    from semivl_amd import ops
+    x, w, b, r = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev), rnd(N, dev=dev), rnd(M, N, dev=dev)
+    close(ops.linear(x, w), x @ w.t(), what="plain", atol=1e-4 * math.sqrt(K))
+    close(ops.linear(x, w, b, act=ops.ACT_GELU, resid=r), F.gelu(x @ w.t() + b) + r, what="gelu+res",
+          atol=1e-4 * math.sqrt(K))
+    close(ops.linear(x, w, b, act=ops.ACT_RELU), F.relu(x @ w.t() + b), what="relu", atol=1e-4 * math.sqrt(K))
+    acc = r.clone()
+    ops.linear(x, w, out=acc, accumulate=True)
+    close(acc, r + x @ w.t(), what="accumulate", atol=1e-4 * math.sqrt(K))
+
+
+def test_linear_bitexact_fma_order(dev):
+    """f32 MFMA is a k-ordered fma chain: result must be reproducible run to run."""
+    from semivl_amd import ops
+    x, w = rnd(500, 768, dev=dev, seed=3), rnd(300, 768, dev=dev)
+    assert torch.equal(ops.linear(x, w), ops.linear(x, w))
+
+
+@pytest.mark.parametrize("M,N,K", [(257, 130, 70), (1025, 768, 3072), (64, 21, 5), (31, 1, 288)])
+def test_matmul_nn(dev, M, N, K):
+    from semivl_amd import ops
+    a, b = rnd(M, K, dev=dev, seed=2), rnd(K, N, dev=dev)
+    close(ops.matmul_nn(a, b), a @ b, atol=1e-4 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 70, 257), (768, 768, 4100), (2304, 768, 1025), (32, 576, 40000),
+                                   (1, 288, 5000), (16, 6912, 2048)])
+def test_matmul_tn_splitk(dev, M, N, K):
+    from semivl_amd import ops
+    a, b = rnd(K, M, dev=dev, seed=4), rnd(K, N, dev=dev)
+    ref = (a.double().t() @ b.double()).float()
+    close(ops.matmul_tn(a, b), ref, atol=2e-4 * math.sqrt(K))
+    o1, o2 = ops.matmul_tn(a, b), ops.matmul_tn(a, b)
+    assert torch.equal(o1, o2), "split-K must be deterministic"
+
+
+@pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (3, 17, 4), (1, 64, 2)])
+def test_vit_attention(dev, Bn, T, H):
+    from semivl_amd import ops
+    D, E = 64, 64 * H
+    qkv = rnd(Bn * T, 3 * E, dev=dev, seed=5).requires_grad_(True)
+    q, k, v = [t.reshape(Bn, T, H, D).transpose(1, 2) for t in qkv.view(Bn, T, 3 * E).split(E, dim=2)]
+    p = ((q * D ** -0.5) @ k.transpose(-1, -2)).softmax(-1)
+    ref = (p @ v).transpose(1, 2).reshape(Bn * T, E)
+    out, P = ops.vit_attention_fwd(qkv.detach(), Bn, T, H, D)
+    close(out, ref, atol=2e-5, what="attn fwd")
+    do = rnd(Bn * T, E, dev=dev)
+    (gref,) = torch.autograd.grad(ref, qkv, do)
+    dqkv = ops.vit_attention_bwd(do, qkv.detach(), P, Bn, T, H, D)
+    close(dqkv, gref, atol=5e-5, what="attn bwd")
+
+
+# ------------------------------------------------------------------------------------------------ conv family
+def nhwc(x):  # NCHW -> [N*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def nchw(x2d, n, h, w):
+    return x2d.view(n, h, w, -1).permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("Ci,Co,k,dil,H", [(128, 128, 3, 1, 16), (128, 128, 3, 6, 32), (128, 128, 3, 18, 32),
+                                           (128, 128, 1, 1, 8), (1, 128, 7, 1, 32), (32, 1, 3, 1, 24),
+                                           (768, 32, 3, 1, 8), (64, 32, 3, 1, 20), (768, 16, 3, 1, 8)])
+def test_conv_fwd_dgrad_wgrad(dev, Ci, Co, k, dil, H):
+    from semivl_amd import ops
+    n, W = 3, H
+    pad = dil * (k - 1) // 2
+    x = rnd(n, Ci, H, W, dev=dev, seed=6).requires_grad_(True)
+    w = rnd(Co, Ci, k, k, dev=dev, scale=0.1).requires_grad_(True)
+    b = rnd(Co, dev=dev)
+    ref = F.conv2d(x, w, b, padding=pad, dilation=dil)
+    wf, wd = ops.pack_conv_w(w.detach())
+    xs = nhwc(x.detach())
+    y = ops.conv_fwd(xs, Ci, n, H, W, Ci, wf, Co, k, k, dil, pad, bias=b)
+    tol = 2e-5 * math.sqrt(Ci * k * k) + 1e-5
+    close(nchw(y, n, H, W), ref, atol=tol, what="conv fwd")
+    dy = rnd(n, Co, H, W, dev=dev)
+    gx, gw = torch.autograd.grad(ref, (x, w), dy)
+    dys = nhwc(dy)
+    dx = ops.conv_dgrad(dys, Co, n, H, W, Co, wd, Ci, k, k, dil, pad)
+    close(nchw(dx, n, H, W), gx, atol=2e-5 * math.sqrt(Co * k * k) + 1e-5, what="conv dgrad")
+    dwf = ops.conv_wgrad(dys, Co, xs, Ci, n, H, W, Ci, Co, k, k, dil, pad)
+    close(ops.unpack_conv_wgrad(dwf, Co, Ci, k, k), gw, atol=3e-5 * math.sqrt(n * H * W), what="conv wgrad")
+
+
+def test_conv_two_source_concat(dev):
+    """cat([x, repeat(skip)]) -> conv3x3 without materialising the concat (vlg_head.py:131-135)."""
+    from semivl_amd import ops
+    b, N, C1, C2, Co, H = 2, 5, 96, 32, 64, 12
+    x = rnd(b * N, C1, H, H, dev=dev, seed=7)
+    skip = rnd(b, C2, H, H, dev=dev)
+    w = rnd(Co, C1 + C2, 3, 3, dev=dev, scale=0.1)
+    ref = F.conv2d(torch.cat([x, skip.repeat_interleave(N, dim=0)], 1), w, padding=1)
+    wf, _ = ops.pack_conv_w(w)
+    y = ops.conv_fwd(nhwc(x), C1, b * N, H, H, C1, wf, Co, 3, 3, 1, 1, src2=nhwc(skip), ld2=C2, C2=C2, rep=N)
+    close(nchw(y, b * N, H, H), ref, atol=5e-4, what="2-source conv")
+    dy = rnd(b * N, Co, H, H, dev=dev)
+    dwf = ops.conv_wgrad(nhwc(dy), Co, nhwc(x), C1, b * N, H, H, C1, Co, 3, 3, 1, 1, src2=nhwc(skip), ld2=C2, C2=C2,
+                         rep=N)
+    wref = torch.nn.grad.conv2d_weight(torch.cat([x, skip.repeat_interleave(N, dim=0)], 1), w.shape, dy, padding=1)
+    close(ops.unpack_conv_wgrad(dwf, Co, C1 + C2, 3, 3), wref, atol=2e-3, what="2-source wgrad")
+
+
+def test_convT2x(dev):
+    from semivl_amd import ops
+    n, Ci, Co, H = 4, 128, 96, 8
+    x = rnd(n, Ci, H, H, dev=dev, seed=8)
+    w = rnd(Ci, Co, 2, 2, dev=dev, scale=0.1)
+    b = rnd(Co, dev=dev)
+    ref = F.conv_transpose2d(x, w, b, stride=2)
+    wp = w.permute(2, 3, 1, 0).reshape(4 * Co, Ci).contiguous()  # n = (a, b, co)
+    out = torch.zeros(n * 4 * H * H, Co + 32, device=dev)
+    ops.convT2x_fwd(nhwc(x), Ci, n, H, H, Ci, wp, Co, b, out, Co + 32)
+    close(nchw(out, n, 2 * H, 2 * H)[:, :Co], ref, atol=5e-4, what="convT")
+    assert (out[:, Co:] == 0).all()
+
+
+def test_patch_embed(dev):
+    from semivl_amd import ops
+    n, S, P, E = 2, 64, 16, 768
+    img = rnd(n, 3, S, S, dev=dev, seed=9)
+    w = rnd(E, 3, P, P, dev=dev, scale=0.05)
+    pos = rnd((S // P) ** 2 + 1, E, dev=dev)
+    ref = F.conv2d(img, w, stride=P).flatten(2).transpose(1, 2) + pos[1:]
+    np_ = (S // P) ** 2
+    out = torch.zeros(n * (np_ + 1), E, device=dev)
+    g = ops.conv_geom(S, S, 3, P, P, patch=P)
+    ops.gemm(ops.A_PATCH, ops.B_KC, n * np_, E, 3 * P * P, ops.Op(img, 0), ops.Op(w.view(E, -1), 3 * P * P), out,
+             ldc_m=E, out_mode=ops.OUT_PATCH, ct=(np_, 0, 0), conv=g, resid=pos, ldr_m=E)
+    close(out.view(n, np_ + 1, E)[:, 1:], ref, atol=5e-4, what="patch embed")
+    assert (out.view(n, np_ + 1, E)[:, 0] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("rows,C,eps", [(1025, 768, 1e-6), (77, 256, 1e-5), (4, 1024, 1e-5)])
+def test_layernorm(dev, rows, C, eps):
+    from semivl_amd import ops
+    x = rnd(rows, C, dev=dev, seed=10).requires_grad_(True)
+    g = (1 + 0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    b = (0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    ref = F.layer_norm(x, (C,), g, b, eps)
+    y, st = ops.layernorm_fwd(x.detach(), g.detach(), b.detach(), eps)
+    close(y, ref, atol=2e-5)
+    dy, extra = rnd(rows, C, dev=dev), rnd(rows, C, dev=dev)
+    gx, gg, gb = torch.autograd.grad(ref, (x, g, b), dy)
+    dx, dg, db = ops.layernorm_bwd(dy, x.detach(), st, g.detach(), dx_add=extra, want_wgrad=True)
+    close(dx, gx + extra, atol=5e-5, what="ln dx")
+    close(dg, gg, atol=1e-3, what="ln dgamma")
+    close(db, gb, atol=1e-3, what="ln dbeta")
+    close(ops.layernorm_bwd(dy, x.detach(), st, g.detach()), gx, atol=5e-5, what="ln dx only")
+
+
+def test_softmax_rows(dev):
+    from semivl_amd import ops
+    rows, cols, ld = 100, 1025, 1028
+    s = rnd(rows, ld, dev=dev, seed=11, scale=3)
+    ref_in = s[:, :cols].clone().requires_grad_(True)
+    ref = (ref_in * 0.125).softmax(-1)
+    p = s.clone()
+    ops.softmax_rows_fwd(p, rows, cols, ld, 0.125)
+    close(p[:, :cols], ref, atol=1e-6)
+    assert (p[:, cols:] == 0).all()
+    dp = rnd(rows, ld, dev=dev)
+    (g,) = torch.autograd.grad(ref, ref_in, dp[:, :cols])
+    d = dp.clone()
+    ops.softmax_rows_bwd(d, p, rows, cols, ld, 0.125)
+    close(d[:, :cols], g, atol=1e-6)
+
+
+def test_l2norm_colsum_eltwise(dev):
+    from semivl_amd import ops
+    x = rnd(1000, 512, dev=dev, seed=12).requires_grad_(True)
+    ref = x / x.norm(dim=1, keepdim=True)
+    y, inv = ops.l2norm_fwd(x.detach())
+    close(y, ref, atol=1e-6)
+    dy = rnd(1000, 512, dev=dev)
+    (g,) = torch.autograd.grad(ref, x, dy)
+    close(ops.l2norm_bwd(dy, y, inv), g, atol=1e-5)
+    big = rnd(70001, 96, dev=dev)
+    close(ops.colsum(big), big.double().sum(0).float(), atol=2e-2, rtol=1e-4)
+    a, b = rnd(5000, dev=dev), rnd(5000, dev=dev)
+    close(ops.add(a, b), a + b, atol=0)
+    bb = b.clone().requires_grad_(True)
+    (gg,) = torch.autograd.grad(F.gelu(bb), bb, a)
+    close(ops.eltwise(1, a, b), gg, atol=1e-6)
+    close(ops.eltwise(2, a, b), a * (b > 0), atol=0)
+    m = (torch.rand(3, 64, device=dev) > 0.5).float()
+    xx = rnd(3 * 10, 64, dev=dev)
+    close(ops.chanmask(xx, m, 2.0, 10), xx * m.repeat_interleave(10, 0) * 2.0, atol=0)
+
+
+@pytest.mark.parametrize("imgs,HW,C,G,relu", [(5, 1024, 128, 8, True), (3, 4096, 64, 4, True), (7, 1, 128, 8, True),
+                                              (2, 900, 32, 2, False)])
+def test_groupnorm(dev, imgs, HW, C, G, relu):
+    from semivl_amd import ops
+    h = int(math.sqrt(HW))
+    x = (rnd(imgs, C, h, HW // h, dev=dev, seed=13) + 0.5).requires_grad_(True)
+    g = (1 + 0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    b = (0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    ref = F.group_norm(x, G, g, b, 1e-5)
+    if relu:
+        ref = F.relu(ref)
+    xs = nhwc(x.detach())
+    ybuf = torch.zeros(imgs * HW, C + 8, device=dev)
+    st = ops.groupnorm_fwd(xs, C, g.detach(), b.detach(), 1e-5, imgs, HW, C, G, relu, ybuf, C + 8)
+    close(nchw(ybuf, imgs, h, HW // h)[:, :C], ref, atol=3e-5, what="gn fwd")
+    dy = rnd(imgs, C, h, HW // h, dev=dev)
+    gx, gg, gb = torch.autograd.grad(ref, (x, g, b), dy)
+    dx = torch.empty(imgs * HW, C, device=dev)
+    dg, db = ops.groupnorm_bwd(nhwc(dy), C, xs, C, ybuf, C + 8, st, g.detach(), imgs, HW, C, G, relu, dx, C)
+    close(nchw(dx, imgs, h, HW // h), gx, atol=1e-4, what="gn dx")
+    close(dg, gg, atol=2e-3, what="gn dgamma")
+    close(db, gb, atol=2e-3, what="gn dbeta")
+
+
+# ------------------------------------------------------------------------------------------------ seq attention
+@pytest.mark.parametrize("b,N,hw", [(2, 21, 16), (1, 150, 4), (1, 81, 3), (3, 19, 9)])
+def test_seqattn(dev, b, N, hw):
+    from semivl_amd import ops
+    heads, D = 4, 64
+    E = heads * D
+    # rows laid out as [(b n), hw]
+    qkv = rnd(b * N * hw, 3 * E, dev=dev, seed=14).requires_grad_(True)
+    t = qkv.view(b, N, hw, 3, heads, D).permute(3, 0, 2, 4, 1, 5)  # [3, b, hw, heads, N, D]
+    q, k, v = t[0], t[1], t[2]
+    p = ((q * D ** -0.5) @ k.transpose(-1, -2)).softmax(-1)
+    o = (p @ v)  # [b, hw, heads, N, D]
+    ref = o.permute(0, 3, 1, 2, 4).reshape(b * N * hw, E)
+    out, probs = ops.seqattn_fwd(qkv.detach(), b * hw, hw, N, heads, N * hw, 1, hw)
+    close(out, ref, atol=2e-5, what="seqattn fwd")
+    do = rnd(b * N * hw, E, dev=dev)
+    (g,) = torch.autograd.grad(ref, qkv, do)
+    dqkv = ops.seqattn_bwd(do, qkv.detach(), probs, b * hw, hw, N, heads, N * hw, 1, hw)
+    close(dqkv, g, atol=5e-5, what="seqattn bwd")
+
+
+# ------------------------------------------------------------------------------------------------ resampling
+@pytest.mark.parametrize("h,H,align,rep", [(8, 32, True, 1), (32, 64, True, 3), (12, 51, True, 1), (1, 16, True, 1),
+                                           (16, 64, False, 1), (7, 20, False, 2)])
+def test_bilinear_nhwc(dev, h, H, align, rep):
+    from semivl_amd import ops
+    n, C = 2, 32
+    x = rnd(n, C, h, h, dev=dev, seed=15).requires_grad_(True)
+    ref = F.interpolate(x, size=(H, H), mode="bilinear", align_corners=align).repeat_interleave(rep, dim=0)
+    y = torch.zeros(n * rep * H * H, C + 4, device=dev)
+    ops.bilinear_nhwc_fwd(nhwc(x.detach()), C, n, h, h, C, align, rep, H, H, y, C + 4)
+    close(nchw(y, n * rep, H, H)[:, :C], ref, atol=1e-5, what="bilinear fwd")
+    dy = rnd(n * rep, C, H, H, dev=dev)
+    (g,) = torch.autograd.grad(ref, x, dy)
+    dx = torch.empty(n * h * h, C, device=dev)
+    ops.bilinear_nhwc_bwd(nhwc(dy), C, n, h, h, C, align, rep, H, H, dx, C)
+    close(nchw(dx, n, h, h), g, atol=1e-4, what="bilinear bwd")
+
+
+@pytest.mark.parametrize("h,H,align", [(128, 512, False), (32, 512, False), (204, 801, False), (16, 64, True)])
+def test_bilinear_planes(dev, h, H, align):
+    from semivl_amd import ops
+    x = rnd(2, 3, h, h, dev=dev, seed=16).requires_grad_(True)
+    ref = F.interpolate(x, size=(H, H), mode="bilinear", align_corners=align)
+    close(ops.bilinear_planes_fwd(x.detach(), h, h, align, H, H), ref, atol=1e-5)
+    dy = rnd(2, 3, H, H, dev=dev)
+    (g,) = torch.autograd.grad(ref, x, dy)
+    close(ops.bilinear_planes_bwd(dy, h, h, align, H, H), g, atol=1e-4)
+
+
+@pytest.mark.parametrize("H,P", [(32, 4), (51, 4)])
+def test_avgpool_cat(dev, H, P):
+    from semivl_amd import ops
+    b, N, C, Ct = 2, 5, 128, 128
+    x = rnd(b * N, C, H, H, dev=dev, seed=17).requires_grad_(True)
+    text = rnd(N, Ct, dev=dev).requires_grad_(True)
+    pooled = F.avg_pool2d(x, P)
+    Hp = pooled.shape[-1]
+    ref = torch.cat([pooled, text.repeat(b, 1)[:, :, None, None].expand(-1, -1, Hp, Hp)], 1)
+    y = ops.avgpool_cat_fwd(nhwc(x.detach()), b * N, H, H, C, P, text.detach(), N)
+    close(nchw(y, b * N, Hp, Hp), ref, atol=1e-6)
+    dy = rnd(b * N, C + Ct, Hp, Hp, dev=dev)
+    gx, gt = torch.autograd.grad(ref, (x, text), dy)
+    dx, dt = ops.avgpool_cat_bwd(nhwc(dy), b * N, H, H, C, P, Ct, N)
+    close(nchw(dx, b * N, H, H), gx, atol=1e-6)
+    close(dt, gt, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ pixel losses
+@pytest.mark.parametrize("N,HW", [(21, 512 * 512), (150, 4096), (19, 801 * 801), (81, 1000)])
+def test_softmax_max(dev, N, HW):
+    from semivl_amd import ops
+    B = 2
+    logits = rnd(B, N, HW, dev=dev, seed=18, scale=3)
+    conf, lab = ops.softmax_max(logits)
+    rc, rl = logits.softmax(1).max(1)
+    assert torch.equal(lab, rl), "labels must be bit-exact"
+    close(conf, rc, atol=1e-6)
+    # ties -> lowest index
+    t = torch.zeros(1, N, 64, device=dev)
+    _, l2 = ops.softmax_max(t)
+    assert (l2 == 0).all()
+
+
+def test_cutmix(dev):
+    from semivl_amd import ops
+    B, H = 3, 40
+    box = (torch.rand(B, H, H, device=dev) > 0.6).float()
+    a, b = rnd(B, 3, H, H, dev=dev, seed=19), rnd(B, 3, H, H, dev=dev)
+    ref = a.clone()
+    ref[box.unsqueeze(1).expand(a.shape) == 1] = b[box.unsqueeze(1).expand(a.shape) == 1]
+    out = a.clone()
+    ops.cutmix_f32(out, b, box, out=out)
+    assert torch.equal(out, ref)
+    la, lb = torch.randint(0, 21, (B, H, H), device=dev), torch.randint(0, 21, (B, H, H), device=dev)
+    r2 = la.clone()
+    r2[box == 1] = lb[box == 1]
+    assert torch.equal(ops.cutmix_i64(la, lb, box), r2)
+
+
+@pytest.mark.parametrize("N,H", [(21, 128), (150, 32), (19, 51), (81, 40)])
+def test_ce_fused(dev, N, H):
+    from semivl_amd import ops
+    B = 3
+    logits = rnd(B, N, H, H, dev=dev, seed=20, scale=2).requires_grad_(True)
+    # supervised branch: CE(ignore_index=255, mean)
+    tgt = torch.randint(0, N, (B, H, H), device=dev)
+    tgt[torch.rand(B, H, H, device=dev) < 0.1] = 255
+    ref = F.cross_entropy(logits, tgt, ignore_index=255)
+    (g,) = torch.autograd.grad(ref, logits)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ops.count_valid(tgt, cnt)
+    assert cnt.item() == (tgt != 255).sum().item()
+    gs = torch.tensor([1.0 / cnt.item(), 0.0], device=dev)
+    dl = torch.empty_like(logits)
+    sums = ops.ce_fused(logits.detach(), tgt, True, dlogits=dl, gscale=gs)
+    close((sums[0] / sums[3]).float(), ref, atol=1e-5, what="sup loss")
+    close(dl, g, atol=1e-8, rtol=1e-4, what="sup dlogits")
+    # unsupervised branch: pixelwise confidence weighting + mc loss (semivl.py:274-284)
+    lab = torch.randint(0, N, (B, H, H), device=dev)
+    conf = torch.rand(B, H, H, device=dev)
+    ign = torch.zeros(B, H, H, dtype=torch.int64, device=dev)
+    ign[:, -5:] = 255
+    mc = torch.randint(0, N, (B, H, H), device=dev)
+    mc[torch.rand(B, H, H, device=dev) < 0.5] = 255
+    valid = ign != 255
+    lu = F.cross_entropy(logits, lab, reduction="none")
+    lu = (lu * ((conf >= 0.7) & valid)).sum() / valid.sum().item()
+    lm = F.cross_entropy(logits, mc, ignore_index=255, reduction="none").sum() / ign.numel()
+    tot = 0.125 * lu + 0.03 * lm
+    (g2,) = torch.autograd.grad(tot, logits)
+    gs2 = torch.tensor([0.125 / valid.sum().item(), 0.03 / ign.numel()], device=dev)
+    sums2 = ops.ce_fused(logits.detach(), lab, False, conf=conf, ign=ign, conf_thresh=0.7, mc=mc, dlogits=dl, gscale=gs2)
+    close((sums2[0] / sums2[3]).float(), lu, atol=1e-5, what="unsup loss")
+    close((sums2[1] / ign.numel()).float(), lm, atol=1e-5, what="mc loss")
+    close(sums2[2].float(), (conf * valid).sum(), rtol=1e-5, atol=1e-2, what="conf sum")
+    close(dl, g2, atol=1e-9, rtol=1e-4, what="unsup dlogits")
+    s3 = ops.ce_fused(logits.detach(), lab, False, conf=conf, ign=ign, conf_thresh=0.7, mc=mc)
+    assert torch.equal(s3, sums2), "deterministic partial sums"
+
+
+def test_maskclip_labels_and_concept_max(dev):
+    from semivl_amd import ops
+    B, NC, h, S = 2, 30, 32, 512
+    emb = F.normalize(rnd(B, 64, h, h, dev=dev, seed=21), dim=1)
+    text = F.normalize(rnd(NC, 64, dev=dev), dim=1)
+    dense = F.conv2d(emb, text[:, :, None, None])
+    offs = [0, 10, 13, 20, 30]
+    agg_ref = torch.stack([dense[:, offs[i]:offs[i + 1]].max(1).values for i in range(4)], 1)
+    agg = ops.concept_max(dense, torch.tensor(offs, dtype=torch.int32, device=dev), 4)
+    assert torch.equal(agg, agg_ref)
+    up = F.interpolate(agg_ref, size=(S, S), mode="bilinear", align_corners=False)
+    prob = (100.0 * up).softmax(1)
+    cert, pred = prob.max(1)
+    ref = pred.clone()
+    ref[cert < 0.9] = 255
+    ign = torch.zeros(B, S, S, dtype=torch.int64, device=dev)
+    ign[1, -64:] = 255
+    ref[ign == 255] = 255
+    out = ops.maskclip_labels(agg, S, S, 100.0, 0.9, ign)
+    mism = (out != ref)
+    # allow flips only where the decision sits on the threshold / a near-tie
+    near = ((cert - 0.9).abs() < 1e-4) | ((prob.topk(2, 1).values[:, 0] - prob.topk(2, 1).values[:, 1]) < 1e-4)
+    assert not (mism & ~near).any(), f"{mism.sum().item()} label mismatches away from the threshold"
+    assert mism.float().mean().item() < 1e-4
+
+
+def test_adamw(dev):
+    from semivl_amd import ops
+    torch.manual_seed(22)
+    sizes = [5, 1000, 77, 4096]
+    params = [torch.randn(s, device=dev).requires_grad_(True) for s in sizes]
+    lrs, wds = [1e-3, 1e-4, 1e-2, 1e-3], [0.01, 0.0, 0.01, 0.05]
+    opt = torch.optim.AdamW([dict(params=[p], lr=lr, weight_decay=wd) for p, lr, wd in zip(params, lrs, wds)],
+                            betas=(0.9, 0.999), eps=1e-8)
+    flat = torch.cat([p.detach() for p in params]).contiguous()
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int64, device=dev)
+    for step in range(1, 4):
+        grads = [torch.randn(s, device=dev) for s in sizes]
+        for p, g in zip(params, grads):
+            p.grad = g.clone()
+        opt.step()
+        ops.adamw_step(flat, torch.cat(grads), m, v, off, torch.tensor(lrs, device=dev), torch.tensor(wds, device=dev),
+                       len(sizes), 0.9, 0.999, 1e-8, step)
+        close(flat, torch.cat([p.detach() for p in params]), atol=1e-6, rtol=1e-5, what=f"adamw step {step}")
