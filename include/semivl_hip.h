@@ -73,10 +73,12 @@ typedef struct svl_operand {
 /* Stride-1, same-size NHWC convolution geometry used by SVL_A_CONV / SVL_B_CONVW.
  * Logical input channel ci in [0, C1+C2): ci < C1 reads src1 (the operand ptr, pixel stride ld),
  * otherwise src2 (pixel stride ld2) of image (img / rep) — the `repeat`+`cat` of vlg_head.py:131-134
- * without materialising it. Tap (ti,tj) reads pixel (oh + sign*(ti*dil - pad), ow + sign*(tj*dil - pad));
+ * without materialising it. Tap (ti,tj) reads pixel (oh*stride + sign*(ti*dil - pad), ow*stride + sign*(tj*dil - pad));
  * sign=+1 for forward/wgrad, -1 for dgrad. Out-of-range pixels read 0. */
 typedef struct svl_conv_geom {
-  int H, W;
+  int H, W;          /* INPUT spatial size (bounds + addressing)                                  */
+  int Ho, Wo;        /* OUTPUT spatial size used to decompose the pixel index (0 -> same as H, W) */
+  int stride;        /* output -> input pixel stride (0/1 -> 1); >1 only with sign=+1 (ConvT k2s2 backward = conv k2 s2) */
   int C1, C2;
   int rep;
   int KH, KW, dil, pad, sign;
@@ -103,6 +105,7 @@ typedef struct svl_gemm_desc {
   const float* bias;
   int bias_mod;     /* 0: bias[n]; >0: bias[n % bias_mod] */
   int act;
+  float* preact;    /* optional: value BEFORE act is also stored here (same addressing as C, SVL_OUT_STRIDED only) */
   const float* resid; /* addressed like C for SVL_OUT_STRIDED (own strides below); see SVL_OUT_PATCH */
   int64_t ldr_m, ldr_n, r_bs_outer, r_bs_inner;
   int accumulate;
@@ -218,12 +221,17 @@ int svl_colsum_f32(const float* x, int64_t rows, int C, int64_t ld, float* out, 
                    svl_stream_t stream);
 
 /* Elementwise: mode 0: out = a + b; 1: out = a * gelu'(b) (a = dY, b = pre-activation); 2: out = a * (b > 0) (relu bwd,
- * b = post-activation); 3: out = a * b; 4: out = a (copy). n elements. */
+ * b = post-activation); 3: out = a * b; 4: out = a (copy); 5: out = gelu(a); 6: out = relu(a). n elements. */
 int svl_eltwise_f32(int mode, const float* a, const float* b, float* out, int64_t n, svl_stream_t stream);
 /* out[r, c] = x[r, c] * mask[(r / rows_per_img) * C + c] * scale  — F.dropout2d on token layout (builder.py:79-85). */
 int svl_chanmask_f32(const float* x, const float* mask, float scale, int64_t rows, int rows_per_img, int C,
                      float* out, svl_stream_t stream);
 int svl_fill_f32(float* p, float v, int64_t n, svl_stream_t stream);
+/* Strided row copy / gather / scatter / broadcast of `rows` rows of C floats:
+ *   dst[(i / dgrp)*dst_go + (i % dgrp)*dst_ld + c] (=|+=) src[(i / sgrp)*src_go + (i % sgrp)*src_ld + c]
+ * (token slicing x[:, 1:], cls-row scatter, torch.cat into channel slices, batch broadcast, strided grad adds). */
+int svl_copy2d_f32(const float* src, int64_t sgrp, int64_t src_go, int64_t src_ld, float* dst, int64_t dgrp,
+                   int64_t dst_go, int64_t dst_ld, int64_t rows, int C, int accumulate, svl_stream_t stream);
 
 /* GroupNorm (+ optional ReLU) on NHWC class-images: x [imgs, HW, C] (pixel stride ldx), groups of C/G channels,
  * stats [imgs, G, 2] = (mean, rstd); y pixel stride ldy (lets the result land in a concat slice). vlg_head.py:74-137 */

@@ -1,0 +1,515 @@
+"""ORACLE — test infrastructure only.  A plain-PyTorch fp32 restatement of the SemiVL hot path.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module; the product
+(`semivl_amd/`) never does.  It restates, op for op, what the reference computes on its hot path, free of the
+un-vendored mmcv / mmseg / timm / clip imports, with the SAME `state_dict` key schema so weights captured from the
+reference load with `strict=True`:
+
+  * CLIP ViT-B/16 dense encoder in MaskCLIP form ........ third_party/maskclip/models/backbones/maskclip_vit.py:110-144,492-596
+    (mmcv MultiheadAttention / FFN / build_norm_layer / mmseg PatchEmbed semantics: SURVEY §8(c), App. A, App. D)
+  * VLG decode head ...................................... model/decode_heads/vlg_head.py:27-251
+  * VLM wrapper, feature perturbation, MaskCLIP guidance . model/vlm.py:90-127, model/builder.py:56-102
+  * loss helpers + the two-branch step ................... utils/train_utils.py:19-49, semivl.py:52-58,223-328
+  * optimizer grouping + poly LR ......................... semivl.py:123-125,339-345 (mmcv DefaultOptimizerConstructor, recalled)
+
+Pinning: the reference ships no tests or golden vectors.  This restatement is pinned against the
+reference's own modules imported in the build container (tests/golden/gen_golden.py, through a shim for the
+un-vendored deps) and against the fixtures that script committed under tests/golden/.  The un-vendored mmcv/mmseg
+semantics themselves remain "parity unpinned" by reference tests.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------ ViT
+class _MHA(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names (in_proj_weight, in_proj_bias, out_proj.*)."""
+
+    def __init__(self, dims, heads):
+        super().__init__()
+        self.embed_dim, self.num_heads = dims, heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * dims, dims))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * dims))
+        self.out_proj = nn.Linear(dims, dims)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+    def forward(self, x):  # x [B, L, C] batch-first; q scaled by d^-0.5, fp32 softmax, no mask, no dropout
+        B, L, Cc = x.shape
+        H = self.num_heads
+        D = Cc // H
+        qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias)
+        q, k, v = qkv.view(B, L, 3, H, D).permute(2, 0, 3, 1, 4)
+        attn = ((q * (D ** -0.5)) @ k.transpose(-1, -2)).softmax(dim=-1)
+        out = (attn @ v).transpose(1, 2).reshape(B, L, Cc)
+        return self.out_proj(out)
+
+
+class _AttnWrap(nn.Module):  # mmcv MultiheadAttention: self.attn = nn.MultiheadAttention; identity + out
+    def __init__(self, dims, heads):
+        super().__init__()
+        self.attn = _MHA(dims, heads)
+
+    def forward(self, x, identity):
+        return identity + self.attn(x)
+
+
+class _FFN(nn.Module):  # mmcv FFN: layers = Sequential(Sequential(Linear, GELU, Dropout), Linear, Dropout)
+    def __init__(self, dims, hidden):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Sequential(nn.Linear(dims, hidden), nn.GELU(), nn.Dropout(0.0)),
+                                    nn.Linear(hidden, dims), nn.Dropout(0.0))
+
+    def forward(self, x, identity):
+        return identity + self.layers(x)
+
+
+class TransformerEncoderLayer(nn.Module):
+    """maskclip_vit.py:29-144 (LoRA off).  LN eps: 1e-6 in the ViT cfg, nn.LayerNorm default 1e-5 in the decoder."""
+
+    def __init__(self, embed_dims, num_heads, feedforward_channels, eps=1e-5):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(embed_dims, eps=eps)
+        self.attn = _AttnWrap(embed_dims, num_heads)
+        self.ln2 = nn.LayerNorm(embed_dims, eps=eps)
+        self.ffn = _FFN(embed_dims, feedforward_channels)
+
+    def forward_qkv(self, x):  # maskclip_vit.py:110-118
+        y = self.ln1(x)
+        y = F.linear(y, self.attn.attn.in_proj_weight, self.attn.attn.in_proj_bias)
+        N, L, Cc = y.shape
+        y = y.view(N, L, 3, Cc // 3).permute(2, 0, 1, 3).reshape(3 * N, L, Cc // 3)
+        y = F.linear(y, self.attn.attn.out_proj.weight, self.attn.attn.out_proj.bias)
+        q, k, v = y.tensor_split(3, dim=0)
+        v = v + x
+        return q, k, v
+
+    def forward(self, x, return_qkv=False):  # maskclip_vit.py:120-144
+        q = k = v = None
+        if return_qkv:
+            q, k, v = self.forward_qkv(x)
+            v = self.ffn(self.ln2(v), identity=v)
+        x = self.attn(self.ln1(x), identity=x)
+        x = self.ffn(self.ln2(x), identity=x)
+        return x, q, k, v
+
+
+class _PatchEmbed(nn.Module):  # mmseg PatchEmbed(conv_type='Conv2d', padding='corner'), maskclip_vit.py:266-276
+    def __init__(self, in_channels, embed_dims, patch, bias):
+        super().__init__()
+        self.patch = patch
+        self.projection = nn.Conv2d(in_channels, embed_dims, patch, stride=patch, bias=bias)
+
+    def forward(self, x):
+        H, W = x.shape[-2:]
+        ph, pw = (-H) % self.patch, (-W) % self.patch
+        if ph or pw:
+            x = F.pad(x, (0, pw, 0, ph))  # 'corner': pad bottom/right
+        x = self.projection(x)
+        hw = x.shape[-2:]
+        return x.flatten(2).transpose(1, 2), (hw[0], hw[1])
+
+
+class MaskClipVisionTransformer(nn.Module):
+    """maskclip_vit.py:147-603 for the cfgs of the path (pre_norm, final_norm, return_clip_embed, return_qkv=True)."""
+
+    def __init__(self, img_size=(512, 512), patch_size=16, patch_bias=False, in_channels=3, embed_dims=768,
+                 num_layers=12, num_heads=12, mlp_ratio=4, out_indices=(0, 4, 12), eps=1e-6, proj_dims=512):
+        super().__init__()
+        if isinstance(img_size, int):
+            img_size = (img_size, img_size)
+        self.img_size, self.patch_size, self.num_layers = tuple(img_size), patch_size, num_layers
+        self.patch_embed = _PatchEmbed(in_channels, embed_dims, patch_size, patch_bias)
+        num_patches = (img_size[0] // patch_size) * (img_size[1] // patch_size)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dims))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dims))
+        self.out_indices = [num_layers] if out_indices is None else list(out_indices)
+        self.layers = nn.ModuleList(
+            [TransformerEncoderLayer(embed_dims, num_heads, mlp_ratio * embed_dims, eps) for _ in range(num_layers)])
+        self.ln0 = nn.LayerNorm(embed_dims, eps=eps)
+        self.ln1 = nn.LayerNorm(embed_dims, eps=eps)
+        self.proj = nn.Conv2d(embed_dims, proj_dims, 1, bias=False)
+        self.return_qkv = [False] * num_layers
+        for o in self.out_indices:
+            if o < num_layers:
+                self.return_qkv[o] = True
+        self.return_qkv[num_layers - 1] = True  # return_clip_embed
+
+    def init_weights_(self, gen=None):
+        """Deterministic stand-in for CLIP weights (maskclip_vit.py:416-429: trunc-normal 0.02, ffn bias 1e-6)."""
+        for n, p in self.named_parameters():
+            with torch.no_grad():
+                if n.endswith("ln0.weight") or n.endswith("ln1.weight") or n.endswith("ln2.weight"):
+                    p.fill_(1.0)
+                elif "ln" in n.split(".")[-2:][0] and n.endswith("bias"):
+                    p.zero_()
+                elif p.dim() >= 2 or n in ("cls_token", "pos_embed"):
+                    nn.init.trunc_normal_(p, std=0.02, generator=gen)
+                elif n.endswith("bias"):
+                    p.zero_()
+        return self
+
+    def resize_pos_embed(self, pos_embed, hw, pos_hw):  # maskclip_vit.py:460-490
+        ph, pw = pos_hw
+        cls_w = pos_embed[:, 0:1]
+        w = pos_embed[:, -ph * pw:].reshape(1, ph, pw, pos_embed.shape[2]).permute(0, 3, 1, 2)
+        w = F.interpolate(w, size=hw, mode="bicubic", align_corners=False)
+        return torch.cat((cls_w, w.flatten(2).transpose(1, 2)), dim=1)
+
+    def forward(self, inputs):
+        B = inputs.shape[0]
+        x, hw = self.patch_embed(inputs)
+        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
+        pos = self.pos_embed
+        if x.shape[1] != pos.shape[1]:
+            pos = self.resize_pos_embed(pos, hw, (self.img_size[0] // self.patch_size, self.img_size[1] // self.patch_size))
+        x = self.ln0(x + pos)
+        feats = []
+        emb = None
+        for i, layer in enumerate(self.layers):
+            x, q, k, v = layer(x, self.return_qkv[i])
+            if i == self.num_layers - 1:
+                x = self.ln1(x)
+                v = self.ln1(v)
+                ve = v[:, 1:].reshape(B, hw[0], hw[1], -1).permute(0, 3, 1, 2).contiguous()
+                ve = self.proj(ve)
+                emb = ve / ve.norm(dim=1, keepdim=True)
+            if i in self.out_indices:
+                feats.append(v[:, 1:].reshape(B, hw[0], hw[1], -1).permute(0, 3, 1, 2).contiguous())
+        if self.num_layers in self.out_indices:
+            feats.append(emb)
+        g = self.proj(x[:, 0][:, :, None, None])[:, :, 0, 0]
+        g = g / g.norm(dim=1, keepdim=True)
+        return [tuple(feats), g]
+
+
+# ------------------------------------------------------------------------------------------------ VLG head
+class SemanticTransformer(nn.Module):  # vlg_head.py:27-67
+    def __init__(self, channels, text_channels, num_heads, pool_size):
+        super().__init__()
+        self.pool = nn.AvgPool2d(pool_size) if pool_size is not None else None
+        self.transformer = TransformerEncoderLayer(channels + text_channels, num_heads, 4 * channels)
+
+    def forward(self, x, text_feats):
+        B, Cc, N, H, W = x.shape
+        xp = x.permute(0, 2, 1, 3, 4).reshape(B * N, Cc, H, W)
+        if self.pool is not None:
+            xp = self.pool(xp)
+        Hp, Wp = xp.shape[-2:]
+        xp = xp.view(B, N, Cc, Hp, Wp).permute(0, 3, 4, 1, 2).reshape(B * Hp * Wp, N, Cc)
+        if text_feats is not None:
+            t = text_feats[:, None, None].expand(B, Hp, Wp, N, text_feats.shape[-1]).reshape(B * Hp * Wp, N, -1)
+            xp = torch.cat([xp, t], dim=-1)
+        xp, _, _, _ = self.transformer(xp)
+        xp = xp[..., :Cc]
+        xp = xp.view(B, Hp, Wp, N, Cc).permute(0, 3, 4, 1, 2).reshape(B * N, Cc, Hp, Wp)
+        if self.pool is not None:
+            xp = F.interpolate(xp, size=(H, W), mode="bilinear", align_corners=True)
+        xp = xp.view(B, N, Cc, H, W).permute(0, 2, 1, 3, 4)
+        return x + xp
+
+
+class ASPPPooling(nn.Module):  # vlg_head.py:70-81
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.gap = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False),
+                                 nn.GroupNorm(cout // 16, cout), nn.ReLU(True))
+
+    def forward(self, x):
+        return F.interpolate(self.gap(x), x.shape[-2:], mode="bilinear", align_corners=True)
+
+
+class ASPPModule(nn.Module):  # vlg_head.py:84-113
+    def __init__(self, cin, rates=(1, 6, 12, 18)):
+        super().__init__()
+        cout = cin
+        self.aspp_convs = nn.ModuleList()
+        for d in rates:
+            k, pad = (1, 0) if d == 1 else (3, d)
+            self.aspp_convs.append(nn.Sequential(nn.Conv2d(cin, cout, k, padding=pad, dilation=d, bias=False),
+                                                 nn.GroupNorm(cout // 16, cout), nn.ReLU(True)))
+        self.aspp_convs.append(ASPPPooling(cin, cout))
+        self.project = nn.Sequential(nn.Conv2d(5 * cout, cout, 1, bias=False), nn.GroupNorm(cout // 16, cout),
+                                     nn.ReLU(True))
+
+    def forward(self, x):
+        return x + self.project(torch.cat([c(x) for c in self.aspp_convs], 1))
+
+
+class Up(nn.Module):  # vlg_head.py:116-137
+    def __init__(self, cin, cout, cskip):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(cin, cin - cskip, kernel_size=2, stride=2)
+        self.conv = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), nn.GroupNorm(cout // 16, cout),
+                                  nn.ReLU(inplace=True),
+                                  nn.Conv2d(cout, cout, 3, padding=1, bias=False), nn.GroupNorm(cout // 16, cout),
+                                  nn.ReLU(inplace=True))
+
+    def forward(self, x, skip):
+        x = self.up(x)
+        n = x.size(0) // skip.size(0)
+        skip = F.interpolate(skip, size=x.shape[-2:], mode="bilinear", align_corners=True)
+        skip = skip.repeat_interleave(n, dim=0)  # einops 'b c h w -> (b n) c h w'
+        return self.conv(torch.cat([x, skip], dim=1))
+
+
+class VLGHead(nn.Module):  # vlg_head.py:140-251
+    def __init__(self, img_size=512, num_classes=21, text_in_channels=512, text_channels=128, up_channels=(64, 32),
+                 skip_in_channels=(768, 768), skip_channels=(32, 16), num_layers=2, num_heads=4, channels=128,
+                 pool_size=(4, 4), conv1_ksize=7, align_corners=False):
+        super().__init__()
+        self.image_size, self.num_classes, self.align_corners = img_size, num_classes, align_corners
+        self.conv1 = nn.Conv2d(1, channels, conv1_ksize, padding=(conv1_ksize - 1) // 2)
+        self.aspp = ASPPModule(channels)
+        self.layers = nn.ModuleList([SemanticTransformer(channels, text_channels, num_heads, pool_size)
+                                     for _ in range(num_layers)])
+        self.text_proj = nn.Sequential(nn.Linear(text_in_channels, text_channels), nn.ReLU())
+        self.skip_proj = nn.ModuleList([nn.Sequential(nn.Conv2d(sic, sc, 3, padding=1), nn.ReLU())
+                                        for sic, sc in zip(skip_in_channels, skip_channels)])
+        self.up1 = Up(channels, up_channels[0], skip_channels[0])
+        self.up2 = Up(up_channels[0], up_channels[1], skip_channels[1])
+        self.head = nn.Conv2d(up_channels[1], 1, 3, padding=1)
+        self.cls2con = None  # concept aggregation map when the text embedding has more rows than classes
+
+    def forward(self, inputs):
+        pyramid = inputs[0][0]
+        img_feats = pyramid[-1]
+        skip_feats = list(pyramid[:-1][::-1])
+        text = inputs[1]
+        B, Cc, H, W = img_feats.shape
+        text = text.repeat(B, 1, 1).float()
+        img_feats = F.normalize(img_feats, dim=1)
+        text = F.normalize(text, dim=-1)
+        x = torch.einsum("bchw,bnc->bnhw", img_feats, text)
+        N = x.shape[1]
+        x = x.reshape(B * N, 1, H, W)
+        x = self.aspp(self.conv1(x))
+        x = x.view(B, N, -1, H, W).permute(0, 2, 1, 3, 4)
+        text = self.text_proj(text)
+        for layer in self.layers:
+            x = layer(x, text)
+        skips = [proj(f) for proj, f in zip(self.skip_proj, skip_feats)]
+        x = x.permute(0, 2, 1, 3, 4).reshape(B * N, -1, H, W)
+        x = self.up2(self.up1(x, skips[0]), skips[1])
+        x = self.head(x).view(B, N, x.shape[-2], x.shape[-1])
+        if x.shape[1] != self.num_classes:
+            x = aggregate_concept_predictions(x, self.cls2con)
+        return F.interpolate(x, size=(self.image_size, self.image_size), mode="bilinear",
+                             align_corners=self.align_corners)
+
+
+def aggregate_concept_predictions(pred, class_to_concept_idxs):  # text_embeddings.py:188-193
+    B, _, H, W = pred.shape
+    agg = torch.zeros(B, len(class_to_concept_idxs), H, W, device=pred.device)
+    for ci, idxs in class_to_concept_idxs.items():
+        agg[:, ci] = pred[:, idxs].max(dim=1).values
+    return agg
+
+
+# ------------------------------------------------------------------------------------------------ VLM
+class VLM(nn.Module):
+    """model/vlm.py + model/builder.py:56-102 (forward_wrapper) for the VLG configs (no conv_encoder, no renorm)."""
+
+    def __init__(self, backbone, decode_head, clip_encoder, text_feat, mcc_text_feat, mcc_cls2con=None, fp_rate=0.5,
+                 exclude_keys=("attn", "pos_embed")):
+        super().__init__()
+        self.backbone, self.decode_head, self.clip_encoder = backbone, decode_head, clip_encoder
+        self.register_buffer("text_feat", text_feat.clone(), persistent=False)  # fp16 on disk (vlm.py:116-117)
+        self.register_buffer("mcc_text_feat", mcc_text_feat.float().clone(), persistent=False)  # vlm.py:61-62
+        self.mcc_cls2con = mcc_cls2con
+        self.num_classes, self.align_corners, self.fp_rate = decode_head.num_classes, decode_head.align_corners, fp_rate
+        for n, p in self.backbone.named_parameters():  # vlm.py:80-88
+            p.requires_grad = any(k in n for k in exclude_keys)
+
+    def forward_maskclip(self, img, conf_tresh):  # vlm.py:90-110
+        with torch.no_grad():
+            feats, _ = self.clip_encoder(img)
+            dense = F.conv2d(feats[-1], self.mcc_text_feat[:, :, None, None])
+            if dense.shape[1] != self.num_classes:
+                dense = aggregate_concept_predictions(dense, self.mcc_cls2con)
+            dense = F.interpolate(dense, size=img.shape[-2:], mode="bilinear", align_corners=self.align_corners)
+            dense = (100.0 * dense).softmax(dim=1)
+            cert, pred = dense.max(dim=1)
+            out = pred.clone()
+            out[cert < conf_tresh] = 255
+        return out
+
+    def forward(self, img, need_fp=False, fp_masks=None):
+        """fp_masks: optional list of 3 {0,1} masks [b, C_i] replacing F.dropout2d's RNG (builder.py:79-85)."""
+        feats, g = self.backbone(img)
+        feats = list(feats)
+        if need_fp:
+            out = []
+            for i, f in enumerate(feats):
+                if fp_masks is None:
+                    d = F.dropout2d(f, self.fp_rate)
+                else:
+                    d = f * fp_masks[i][:, :, None, None] / (1.0 - self.fp_rate)
+                out.append(torch.cat((f, d)))
+            feats = out
+        logits = self.decode_head([[feats, g], self.text_feat])
+        logits = F.interpolate(logits, size=img.shape[2:], mode="bilinear", align_corners=self.align_corners)
+        return logits.chunk(2) if need_fp else logits
+
+
+# ------------------------------------------------------------------------------------------------ losses / step
+def cutmix_img_(img, img_mix, box):  # train_utils.py:19-21
+    m = box.unsqueeze(1).expand(img.shape) == 1
+    img[m] = img_mix[m]
+
+
+def cutmix_mask(mask, mask_mix, box):  # train_utils.py:24-27
+    out = mask.clone()
+    out[box == 1] = mask_mix[box == 1]
+    return out
+
+
+def confidence_weighted_loss(loss, conf_map, ignore_mask, conf_mode, conf_thresh):  # train_utils.py:30-49
+    valid = ignore_mask != 255
+    sp = dict(dim=(1, 2), keepdim=True)
+    if conf_mode == "pixelwise":
+        loss = loss * ((conf_map >= conf_thresh) & valid)
+        return loss.sum() / valid.sum().item()
+    if conf_mode == "pixelratio":
+        r = ((conf_map >= conf_thresh) & valid).sum(**sp) / valid.sum(**sp)
+        return (loss * r).sum() / valid.sum().item()
+    if conf_mode == "pixelavg":
+        avg = (conf_map * valid).sum(**sp) / valid.sum(**sp)
+        return (loss.sum() * avg).sum() / valid.sum().item()
+    raise ValueError(conf_mode)
+
+
+def compute_mc_loss(pred, mask, ign):  # semivl.py:52-58 with mcc_loss_reduce == 'mean_all'
+    return F.cross_entropy(pred, mask, ignore_index=255, reduction="none").sum() / ign.numel()
+
+
+def semivl_step(model, batch, iters, total_iters, conf_thresh=0.95, conf_mode="pixelwise", mcc_lambda=(0.1, 0.0),
+                mcc_conf_thresh=0.9, fp_masks=None):
+    """semivl.py:223-323 for method='semivl', criterion CELoss(ignore 255), criterion_u CELoss, mean_all mc loss.
+    `batch` holds the 12 step tensors.  Returns (loss, dict of intermediates)."""
+    b = {k: v.clone() for k, v in batch.items()}
+    cutmix_img_(b["img_s1"], b["img_s1_other"], b["mix1"])
+    cutmix_img_(b["img_s2"], b["img_s2_other"], b["mix2"])
+    with torch.no_grad():
+        model.eval()
+        pred_w_other = model(b["img_w_other"]).detach()
+        conf_w_other, mask_w_other = pred_w_other.softmax(dim=1).max(dim=1)
+        mclip = model.forward_maskclip(torch.cat((b["img_w"], b["img_w_other"])), mcc_conf_thresh)
+        nb = b["img_w"].shape[0]
+        mclip, mclip_other = mclip.split([nb, nb])
+        mclip[b["ignore_mask"] == 255] = 255
+        mclip_other[b["ignore_mask_other"] == 255] = 255
+    model.train()
+    preds, preds_fp = model(torch.cat((b["img_x"], b["img_w"])), need_fp=True, fp_masks=fp_masks)
+    pred_x, pred_w = preds.chunk(2)
+    _, pred_w_fp = preds_fp.chunk(2)
+    pred_s1, pred_s2 = model(torch.cat((b["img_s1"], b["img_s2"]))).chunk(2)
+    pred_w = pred_w.detach()
+    conf_w, mask_w = pred_w.softmax(dim=1).max(dim=1)
+    mw1, mw2 = cutmix_mask(mask_w, mask_w_other, b["mix1"]), cutmix_mask(mask_w, mask_w_other, b["mix2"])
+    cw1, cw2 = cutmix_mask(conf_w, conf_w_other, b["mix1"]), cutmix_mask(conf_w, conf_w_other, b["mix2"])
+    ig1 = cutmix_mask(b["ignore_mask"], b["ignore_mask_other"], b["mix1"])
+    ig2 = cutmix_mask(b["ignore_mask"], b["ignore_mask_other"], b["mix2"])
+    mc1, mc2 = cutmix_mask(mclip, mclip_other, b["mix1"]), cutmix_mask(mclip, mclip_other, b["mix2"])
+    ce_none = lambda p, t: F.cross_entropy(p, t, reduction="none")
+    loss_x = F.cross_entropy(pred_x, b["mask_x"], ignore_index=255)
+    loss_s1 = confidence_weighted_loss(ce_none(pred_s1, mw1), cw1, ig1, conf_mode, conf_thresh)
+    loss_s2 = confidence_weighted_loss(ce_none(pred_s2, mw2), cw2, ig2, conf_mode, conf_thresh)
+    loss_fp = confidence_weighted_loss(ce_none(pred_w_fp, mask_w), conf_w, b["ignore_mask"], conf_mode, conf_thresh)
+    loss_mc_s1 = compute_mc_loss(pred_s1, mc1, ig1)
+    loss_mc_s2 = compute_mc_loss(pred_s2, mc2, ig2)
+    loss_mc_fp = compute_mc_loss(pred_w_fp, mclip, b["ignore_mask"])
+    prog = iters / total_iters
+    lam = mcc_lambda[0] * (1 - prog) + mcc_lambda[1] * prog
+    loss = (loss_x + loss_s1 * 0.25 + loss_s2 * 0.25 + loss_fp * 0.5) / 2.0
+    loss = loss + loss_mc_s1 * 0.25 * lam
+    loss = loss + loss_mc_s2 * 0.25 * lam
+    loss = loss + loss_mc_fp * 0.5 * lam
+    aux = dict(loss_x=loss_x, loss_s1=loss_s1, loss_s2=loss_s2, loss_fp=loss_fp, loss_mc_s1=loss_mc_s1,
+               loss_mc_s2=loss_mc_s2, loss_mc_fp=loss_mc_fp, mask_w=mask_w, mask_w_other=mask_w_other, mclip=mclip,
+               mclip_other=mclip_other, conf_w=conf_w, pred_x=pred_x, pred_s1=pred_s1)
+    return loss, aux
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def param_groups(model, lr, weight_decay, custom_keys):
+    """mmcv DefaultOptimizerConstructor (1.4.4, recalled — SURVEY O1): one group per parameter; custom keys are tried
+    in (alphabetical, then longest-first) order and the FIRST one contained in the parameter name sets lr_mult /
+    decay_mult.  Parameters with requires_grad=False are still listed by mmcv (they simply never get a grad)."""
+    keys = sorted(sorted(custom_keys.keys()), key=len, reverse=True)
+    groups = []
+    for name, p in model.named_parameters():
+        g = dict(params=[p], name=name, lr=lr, weight_decay=weight_decay)
+        for k in keys:
+            if k in name:
+                g["lr"] = lr * custom_keys[k].get("lr_mult", 1.0)
+                g["weight_decay"] = weight_decay * custom_keys[k].get("decay_mult", 1.0)
+                break
+        groups.append(g)
+    return groups
+
+
+def poly_lr(initial_lr, iters, max_iters):  # semivl.py:343-345
+    return initial_lr * (1 - iters / max_iters) ** 0.9
+
+
+# ------------------------------------------------------------------------------------------------ builders
+VOC_CFG = dict(nclass=21, crop=512, embed=768, layers=12, heads=12, out_indices=(0, 4, 12), proj=512,
+               text_in=512, channels=128, text_channels=128, up=(64, 32), skip_in=(768, 768), skip=(32, 16))
+
+
+def build_vlm(cfg, text_feat, mcc_text_feat, mcc_cls2con=None, clip_img_size=None):
+    """Assemble the VLG model of configs/_base_/models/vlm-vlg-aspp-s2p4-sk04-ftap-mcvitb.py + mcvit16.py."""
+    c = dict(VOC_CFG)
+    c.update(cfg)
+    S = c["crop"]
+    bb = MaskClipVisionTransformer((S, S), 16, False, 3, c["embed"], c["layers"], c["heads"], 4,
+                                   c["out_indices"], 1e-6, c["proj"])
+    cs = clip_img_size or S
+    ce = MaskClipVisionTransformer((cs, cs), 16, False, 3, c["embed"], c["layers"], c["heads"], 4, None, 1e-6,
+                                   c["proj"])
+    head = VLGHead(S, c["nclass"], c["text_in"], c["text_channels"], c["up"], c["skip_in"], c["skip"], 2, 4,
+                   c["channels"], (4, 4), 7, False)
+    return VLM(bb, head, ce, text_feat, mcc_text_feat, mcc_cls2con)
+
+
+def synthetic_batch(B, S, nclass, seed=1234, device="cpu"):
+    """SURVEY §8(d) synthetic step inputs (seed = 1234 + rank)."""
+    g = torch.Generator().manual_seed(seed)
+    img = lambda: torch.randn(B, 3, S, S, generator=g)
+    blk = max(S // 16, 1)
+    nb = (S + blk - 1) // blk
+    lab = torch.randint(0, nclass, (B, nb, nb), generator=g)
+    lab[torch.rand(B, nb, nb, generator=g) < 0.05] = 255
+    mask_x = lab.repeat_interleave(blk, 1).repeat_interleave(blk, 2)[:, :S, :S].contiguous()
+
+    def ign():
+        m = torch.zeros(B, S, S, dtype=torch.int64)
+        m[1::2, S - S // 8:] = 255
+        return m
+
+    def box():
+        m = torch.zeros(B, S, S)
+        for i in range(B):
+            if torch.rand(1, generator=g).item() < 0.5:
+                area = (0.02 + 0.38 * torch.rand(1, generator=g).item()) * S * S
+                ratio = 0.3 + (1 / 0.3 - 0.3) * torch.rand(1, generator=g).item()
+                w, h = int(math.sqrt(area / ratio)), int(math.sqrt(area * ratio))
+                w, h = min(w, S), min(h, S)
+                x = int(torch.randint(0, S - w + 1, (1,), generator=g).item())
+                y = int(torch.randint(0, S - h + 1, (1,), generator=g).item())
+                m[i, y:y + h, x:x + w] = 1
+        return m
+
+    b = dict(img_x=img(), mask_x=mask_x, img_w=img(), img_s1=img(), img_s2=img(), ignore_mask=ign(), mix1=box(),
+             mix2=box(), img_w_other=img(), img_s1_other=img(), img_s2_other=img(), ignore_mask_other=ign())
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def synthetic_text(n, dim=512, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    t = F.normalize(torch.randn(n, dim, generator=g), dim=-1)
+    return t.half()

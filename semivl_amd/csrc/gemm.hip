@@ -41,6 +41,7 @@ struct GemmP {
   float alpha;
   const float* bias;
   int bias_mod, act;
+  float* preact;
   const float* resid;
   long ldr_m, ldr_n, r_bso, r_bsi;
   int accumulate;
@@ -96,10 +97,10 @@ __device__ __forceinline__ float4 load_piece(const OperandP& op, const svl_conv_
       return load4(base + (long)row * op.ld + k, nv, op.vec);
     } else if constexpr (IS_A && MODE == SVL_A_CONV) {
       const int Ct = cv.C1 + cv.C2;
-      const int ow = row % cv.W;
-      const int t = row / cv.W;
-      const int oh = t % cv.H;
-      const int img = t / cv.H;
+      const int ow = (row % cv.Wo) * cv.stride;
+      const int t = row / cv.Wo;
+      const int oh = (t % cv.Ho) * cv.stride;
+      const int img = t / cv.Ho;
       if (op.vec) {  // Ct % 4 == 0: the 4 k's share one tap
         const int tap = k / Ct, ci = k - tap * Ct;
         const int ti = tap / cv.KW, tj = tap - ti * cv.KW;
@@ -146,10 +147,10 @@ __device__ __forceinline__ float4 load_piece(const OperandP& op, const svl_conv_
       return load4(base + (long)k * op.ld + row, nv, op.vec);
     } else {  // SVL_B_CONVW: row = (tap, ci), k = pixel
       const int Ct = cv.C1 + cv.C2;
-      const int ow = k % cv.W;
-      const int t = k / cv.W;
-      const int oh = t % cv.H;
-      const int img = t / cv.H;
+      const int ow = (k % cv.Wo) * cv.stride;
+      const int t = k / cv.Wo;
+      const int oh = (t % cv.Ho) * cv.stride;
+      const int img = t / cv.Ho;
       if (op.vec) {
         const int tap = row / Ct, ci = row - tap * Ct;
         const int ti = tap / cv.KW, tj = tap - ti * cv.KW;
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         const int m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (m >= p.M) continue;
         float v = acc[i][j][r] * p.alpha + bv;
+        if (p.preact) p.preact[(zo * p.c_bso + zi * p.c_bsi) + (long)m * p.ldc_m + (long)n * p.ldc_n] = v;
         if (p.act == SVL_ACT_GELU) v = gelu_erf(v);
         else if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
         long off;
@@ -407,6 +409,11 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   p.ldc_m = d->ldc_m; p.ldc_n = d->ldc_n; p.c_bso = d->c_bs_outer; p.c_bsi = d->c_bs_inner;
   p.ct_H = d->ct_H; p.ct_W = d->ct_W; p.ct_Cout = d->ct_Cout;
   p.alpha = d->alpha; p.bias = d->bias; p.bias_mod = d->bias_mod; p.act = d->act;
+  p.preact = d->preact;
+  SVL_CHECK_ARG(d->preact == nullptr || d->out_mode == SVL_OUT_STRIDED, "svl_gemm_f32: preact needs SVL_OUT_STRIDED");
+  if (p.cv.stride <= 0) p.cv.stride = 1;
+  if (p.cv.Ho <= 0) p.cv.Ho = p.cv.H;
+  if (p.cv.Wo <= 0) p.cv.Wo = p.cv.W;
   p.resid = d->resid; p.ldr_m = d->ldr_m; p.ldr_n = d->ldr_n; p.r_bso = d->r_bs_outer; p.r_bsi = d->r_bs_inner;
   p.accumulate = d->accumulate;
 
@@ -426,6 +433,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
                       (cv.sign == 1 || cv.sign == -1),
                   "svl_gemm_f32: bad conv geometry");
     SVL_CHECK_ARG(cv.C2 == 0 || (cv.src2 && cv.rep >= 1), "svl_gemm_f32: conv src2/rep missing");
+    SVL_CHECK_ARG(p.cv.stride == 1 || cv.sign == 1, "svl_gemm_f32: strided conv needs sign=+1");
     const int kk = cv.KH * cv.KW * (cv.C1 + cv.C2);
     if (a_conv) SVL_CHECK_ARG(d->K == kk, "svl_gemm_f32: conv K=%d != taps*C=%d", d->K, kk);
     if (b_conv) SVL_CHECK_ARG(d->N == kk, "svl_gemm_f32: convw N=%d != taps*C=%d", d->N, kk);

@@ -232,6 +232,8 @@ __global__ void eltwise_kernel(int mode, const float* __restrict__ a, const floa
       case 1: v = a[i] * gelu_erf_grad(b[i]); break;
       case 2: v = (b[i] > 0.f) ? a[i] : 0.f; break;
       case 3: v = a[i] * b[i]; break;
+      case 5: v = gelu_erf(a[i]); break;
+      case 6: v = fmaxf(a[i], 0.f); break;
       default: v = a[i]; break;
     }
     out[i] = v;
@@ -244,6 +246,18 @@ __global__ void chanmask_kernel(const float* __restrict__ x, const float* __rest
     const long r = i / C;
     const int c = (int)(i - r * C);
     out[i] = x[i] * mask[(r / rows_per_img) * C + c] * scale;
+  }
+}
+__global__ void copy2d_kernel(const float* __restrict__ src, long sgrp, long src_go, long src_ld,
+                              float* __restrict__ dst, long dgrp, long dst_go, long dst_ld, long rows, int C,
+                              int accumulate) {
+  const long n = rows * C;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const long i = t / C;
+    const int c = (int)(t - i * C);
+    const float v = src[(i / sgrp) * src_go + (i % sgrp) * src_ld + c];
+    float* d = dst + (i / dgrp) * dst_go + (i % dgrp) * dst_ld + c;
+    *d = accumulate ? (*d + v) : v;
   }
 }
 __global__ void fill_kernel(float* p, float v, long n) {
@@ -510,7 +524,7 @@ extern "C" int svl_colsum_f32(const float* x, int64_t rows, int C, int64_t ld, f
 }
 
 extern "C" int svl_eltwise_f32(int mode, const float* a, const float* b, float* out, int64_t n, svl_stream_t stream) {
-  SVL_CHECK_ARG(a && out && n > 0 && mode >= 0 && mode <= 4 && (mode == 4 || b), "svl_eltwise_f32: bad args");
+  SVL_CHECK_ARG(a && out && n > 0 && mode >= 0 && mode <= 6 && (mode >= 4 || b), "svl_eltwise_f32: bad args");
   hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, mode, a, b, out, (long)n);
   SVL_LAUNCH_CHECK("svl_eltwise_f32");
   return SVL_OK;
@@ -561,5 +575,14 @@ extern "C" int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, 
   hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, st, dy, (long)lddy, x,
                      (long)ldx, y, (long)ldy, stats, gamma, chan_sums, npix, (long)HW, C, G, relu, dx, (long)lddx);
   SVL_LAUNCH_CHECK("svl_groupnorm_bwd/apply");
+  return SVL_OK;
+}
+
+extern "C" int svl_copy2d_f32(const float* src, int64_t sgrp, int64_t src_go, int64_t src_ld, float* dst, int64_t dgrp,
+                              int64_t dst_go, int64_t dst_ld, int64_t rows, int C, int accumulate, svl_stream_t stream) {
+  SVL_CHECK_ARG(src && dst && sgrp >= 1 && dgrp >= 1 && rows > 0 && C > 0, "svl_copy2d_f32: bad args");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * C, 4)), dim3(256), 0, (hipStream_t)stream, src, (long)sgrp,
+                     (long)src_go, (long)src_ld, dst, (long)dgrp, (long)dst_go, (long)dst_ld, (long)rows, C, accumulate);
+  SVL_LAUNCH_CHECK("svl_copy2d_f32");
   return SVL_OK;
 }

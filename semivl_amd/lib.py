@@ -20,7 +20,8 @@ class Operand(C.Structure):
 
 
 class ConvGeom(C.Structure):
-    _fields_ = [("H", C.c_int), ("W", C.c_int), ("C1", C.c_int), ("C2", C.c_int), ("rep", C.c_int),
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("stride", C.c_int),
+                ("C1", C.c_int), ("C2", C.c_int), ("rep", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("dil", C.c_int), ("pad", C.c_int), ("sign", C.c_int),
                 ("src2", C.c_void_p), ("ld2", C.c_int64), ("patch", C.c_int)]
 
@@ -33,7 +34,7 @@ class GemmDesc(C.Structure):
                 ("ldc_m", C.c_int64), ("ldc_n", C.c_int64), ("c_bs_outer", C.c_int64), ("c_bs_inner", C.c_int64),
                 ("ct_H", C.c_int), ("ct_W", C.c_int), ("ct_Cout", C.c_int),
                 ("alpha", C.c_float), ("bias", C.c_void_p), ("bias_mod", C.c_int), ("act", C.c_int),
-                ("resid", C.c_void_p),
+                ("preact", C.c_void_p), ("resid", C.c_void_p),
                 ("ldr_m", C.c_int64), ("ldr_n", C.c_int64), ("r_bs_outer", C.c_int64), ("r_bs_inner", C.c_int64),
                 ("accumulate", C.c_int)]
 
@@ -82,6 +83,7 @@ SIGNATURES = {
     "svl_eltwise_f32": (_I, [_I, _P, _P, _P, _L, _P]),
     "svl_chanmask_f32": (_I, [_P, _P, _F, _L, _I, _I, _P, _P]),
     "svl_fill_f32": (_I, [_P, _F, _L, _P]),
+    "svl_copy2d_f32": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _P]),
     "svl_groupnorm_fwd": (_I, [_P, _L, _P, _P, _F, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_seqattn_fwd": (_I, [C.POINTER(SeqAttnDesc), _P]),

@@ -1,0 +1,239 @@
+"""`build_model(cfg)` and the `VLM` segmentor — the drop-in model API of the reference
+(/root/reference model/builder.py:56-159, model/vlm.py:27-127) on the HIP kernel library.
+
+`build_model` consumes the SAME flat experiment dict the reference's `experiments.py` generates:
+`model`, `nclass`, `crop_size`, `dataset`, `text_embedding_variant`, `mcc_text`, `pl_text`, `clip_encoder`,
+`model_args`, `disable_dropout`, `fp_rate`.  Model hyper-parameter files `configs/_base_/models/<name>.py` are read
+from the working directory when present (the reference resolves them relative to cwd, builder.py:110), otherwise the
+package's own restatement of the VLG configs is used.
+"""
+import copy
+import os
+import runpy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .text_embeddings import aggregate_concept_predictions, get_class_to_concept_idxs
+from .vit import MaskClipVisionTransformer
+from .vlg_head import VLGHead
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BACKBONES = {"MaskClipVisionTransformer": MaskClipVisionTransformer}
+HEADS = {"VLGHead": VLGHead}
+SEGMENTORS = {}
+
+
+def _resolve(path):
+    """cwd-relative first (reference behaviour), then the package copy of configs/_base_/..."""
+    if os.path.exists(path):
+        return path
+    alt = os.path.join(_PKG, path)
+    if os.path.exists(alt):
+        return alt
+    raise FileNotFoundError(path)
+
+
+def _vit_cfg(img_size, out_indices):
+    return dict(type="MaskClipVisionTransformer", img_size=(img_size, img_size), patch_size=16, patch_bias=False,
+                in_channels=3, embed_dims=768, num_layers=12, num_heads=12, mlp_ratio=4, out_indices=out_indices,
+                qkv_bias=True, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, with_cls_token=True,
+                output_cls_token=False, norm_cfg=dict(type="LN", eps=1e-6), act_cfg=dict(type="GELU"),
+                patch_norm=False, pre_norm=True, final_norm=True, return_clip_embed=True, return_qkv=True,
+                interpolate_mode="bicubic", num_fcs=2, norm_eval=False)
+
+
+def builtin_model_cfg(name):
+    """Own restatement of the hyper-parameters of configs/_base_/models/{vlm-vlg-aspp-s2p4-sk04-ftap-mcvitb,mcvit16}.py."""
+    if name == "vlm-vlg-aspp-s2p4-sk04-ftap-mcvitb":
+        return dict(img_size=512, model=dict(
+            type="VLM", pretrained="pretrained/clip2mmseg_ViT16_clip_backbone.pth",
+            backbone=_vit_cfg(512, [0, 4, 12]),
+            decode_head=dict(type="VLGHead", img_size=512, num_classes=19, text_in_channels=512, text_channels=128,
+                             up_channels=(64, 32), skip_in_channels=(768, 768), skip_channels=(32, 16),
+                             skip_from_conv_feat=False, num_layers=2, num_heads=4, channels=128, pool_size=(4, 4),
+                             conv1_ksize=7, align_corners=False, loss_decode=None),
+            freeze_backbone=True, exclude_keys=["attn", "pos_embed"]))
+    if name == "mcvit16":
+        bb = _vit_cfg(512, None)
+        bb["pretrained"] = "pretrained/clip2mmseg_ViT16_clip_backbone.pth"
+        return dict(img_size=512, backbone=bb)
+    raise ValueError(f"no built-in model config '{name}' (SURVEY §8(f): skr04 / dlv3p / zegclip variants are next-row or out of scope)")
+
+
+def load_model_cfg(name):
+    path = f"configs/_base_/models/{name}.py"
+    if os.path.exists(path):
+        ns = runpy.run_path(path)
+        return {k: v for k, v in ns.items() if not k.startswith("_")}
+    return builtin_model_cfg(name)
+
+
+def build_backbone(cfg):
+    cfg = dict(cfg)
+    return BACKBONES[cfg.pop("type")](**cfg)
+
+
+def build_head(cfg):
+    cfg = dict(cfg)
+    return HEADS[cfg.pop("type")](**cfg)
+
+
+class VLM(nn.Module):
+    """model/vlm.py:27-127 (+ mmseg EncoderDecoder's attribute surface: backbone, decode_head, align_corners, num_classes)."""
+
+    def __init__(self, backbone, decode_head, freeze_backbone=False, exclude_keys=None, load_text_embedding=None,
+                 load_mcc_text_embedding=None, load_pl_text_embedding=None, clip_encoder=None, conv_encoder=None,
+                 maskclip_class_filter=None, maskclip_trust_head=None, renorm_clip_img=False, pretrained=None,
+                 train_cfg=None, test_cfg=None, neck=None, auxiliary_head=None, init_cfg=None, type=None):
+        super().__init__()
+        assert load_text_embedding == load_pl_text_embedding
+        assert maskclip_class_filter is None and maskclip_trust_head is None
+        if conv_encoder is not None or renorm_clip_img:
+            raise NotImplementedError("conv_encoder / renorm_clip_img (Cityscapes cfg, SURVEY N2) are next-row items")
+        backbone = dict(backbone)
+        if pretrained is not None and backbone.get("pretrained") is None:
+            backbone["pretrained"] = pretrained  # EncoderDecoder forwards `pretrained` to the backbone cfg
+        self.backbone = build_backbone(backbone)
+        self.decode_head = build_head(decode_head)
+        self.align_corners = self.decode_head.align_corners
+        self.num_classes = self.decode_head.num_classes
+        self.local_iter = 0
+        self.clip_encoder = build_backbone(clip_encoder) if clip_encoder is not None else None
+        self.conv_encoder = None
+        self.load_text_embedding = load_text_embedding
+        self.decode_head.load_text_embedding = load_text_embedding
+        self.load_mcc_text_embedding = load_mcc_text_embedding
+        self.renorm_clip_img = renorm_clip_img
+        if not self.load_mcc_text_embedding:
+            raise NotImplementedError
+        self.loaded_mcc_text_feat = torch.from_numpy(np.load(_resolve(self.load_mcc_text_embedding))).float()
+        # the reference re-reads the .npy on every extract_feat (vlm.py:116): cached, same values
+        self._text_feat = torch.from_numpy(np.load(_resolve(self.load_text_embedding)))
+        self._dev_cache = {}
+        self.disable_dropout, self.fp_rate = True, 0.5
+        if freeze_backbone:
+            self.freeze(self.backbone, exclude_keys=exclude_keys)
+
+    def freeze(self, model, exclude_keys=None):  # vlm.py:80-88
+        for n, m in model.named_parameters():
+            m.requires_grad = False
+            if exclude_keys is not None:
+                assert isinstance(exclude_keys, list)
+                for k in exclude_keys:
+                    if str(k) in n:
+                        m.requires_grad = True
+
+    def init_weights(self):
+        pass  # sub-modules initialise themselves at construction (pretrained file when present)
+
+    def _on(self, name, t, device):
+        key = (name, str(device))
+        if key not in self._dev_cache:
+            self._dev_cache[key] = t.to(device)
+        return self._dev_cache[key]
+
+    def text_feat(self, device):
+        return self._on("text", self._text_feat, device)
+
+    # -- MaskCLIP guidance (vlm.py:90-110) ---------------------------------------------------------------------
+    def forward_maskclip(self, img, conf_tresh, ignore_mask=None):
+        """int64 [b, H, W] in {0..N-1, 255}.  `ignore_mask` (optional, fused form of semivl.py:239-240): pixels where
+        it equals 255 are set to 255."""
+        with torch.no_grad():
+            feats, _ = self.clip_encoder.forward_tokens(img, need_global=False)
+            emb = feats[-1]  # [b, hw, 512]
+            b, HW, Ce = emb.shape
+            hp = img.shape[2] // self.clip_encoder.patch_size
+            wp = img.shape[3] // self.clip_encoder.patch_size
+            text = self._on("mcc", self.loaded_mcc_text_feat, img.device)
+            NC = text.shape[0]
+            dense = ops.empty(b, NC, hp, wp, device=img.device)  # F.conv2d(visual_feat, text[:, :, None, None])
+            ops.gemm(ops.A_KC, ops.B_KC, HW, NC, Ce, ops.Op(emb, Ce, 0, HW * Ce, 0), ops.Op(text, Ce), dense, ldc_m=1,
+                     ldc_n=HW, batch=b, c_bso=NC * HW)
+            if NC != self.num_classes:
+                dense = aggregate_concept_predictions(dense, get_class_to_concept_idxs(self.load_mcc_text_embedding))
+            assert dense.shape[1] == self.num_classes
+            return ops.maskclip_labels(dense, img.shape[2], img.shape[3], 100.0, conf_tresh, ignore_mask)
+
+    # -- features ------------------------------------------------------------------------------------------------
+    def extract_feat(self, img):  # vlm.py:112-123 (reference return format)
+        visual_feat = self.backbone(img)
+        self.decode_head.load_text_embedding = self.load_text_embedding
+        return [visual_feat, self.text_feat(img.device), None]
+
+    def _decode_head_forward_test(self, x, img_metas=None):  # vlm.py:125-127
+        return self.decode_head.forward(x, force_output_pred_masks=True)["pred_masks"]
+
+    # -- forward_wrapper (builder.py:56-102) ---------------------------------------------------------------------
+    def forward(self, img, gt=None, need_fp=False, only_fp=False, forward_mode="default", fp_masks=None,
+                split_fp=True):
+        """Logits [b, N, H, W] at input resolution; with need_fp a 2-tuple (plain, feature-perturbed) halves.
+        `fp_masks` (list of three {0,1} tensors [b, C_i]) injects the F.dropout2d channel masks for parity tests;
+        `split_fp=False` returns the un-chunked [2b, ...] tensor."""
+        if forward_mode != "default":
+            raise ValueError(forward_mode)
+        if only_fp:
+            raise NotImplementedError("only_fp is not used by semivl.py (SURVEY §8(a) V4)")
+        if tuple(img.shape[2:]) != (self.decode_head.image_size, self.decode_head.image_size):
+            raise NotImplementedError("input size != decode_head.img_size (second resize, builder.py:93-97)")
+        feats, _ = self.backbone.forward_tokens(img, need_global=False)
+        hp, wp = img.shape[2] // self.backbone.patch_size, img.shape[3] // self.backbone.patch_size
+        masks = None
+        if need_fp:
+            masks = fp_masks
+            if masks is None:  # F.dropout2d: one Bernoulli(1-p) draw per (sample, channel); always stochastic (App. E.7)
+                masks = [torch.bernoulli(torch.full((f.shape[0], f.shape[2]), 1.0 - self.fp_rate, device=img.device))
+                         for f in feats]
+        out = self.decode_head.forward_tokens(feats, self.text_feat(img.device), (hp, wp), masks, self.fp_rate,
+                                              out_size=tuple(img.shape[2:]))
+        if need_fp and split_fp:
+            return out.chunk(2)
+        return out
+
+
+SEGMENTORS["VLM"] = VLM
+
+
+def nested_set(dic, key, value):
+    keys = key.split(".")
+    for k in keys[:-1]:
+        dic = dic.setdefault(k, {})
+    dic[keys[-1]] = value
+
+
+def build_model(cfg):
+    """builder.py:104-159."""
+    model_type = cfg["model"]
+    if "mmseg." not in model_type:
+        raise ValueError(model_type)  # 'deeplabv3plus' (UniMatch CNN baseline) is out of scope
+    model_type = model_type.replace("mmseg.", "")
+    mcfg = copy.deepcopy(load_model_cfg(model_type))
+    mcfg["model"]["decode_head"]["num_classes"] = cfg["nclass"]
+    if "zegclip" in model_type or "vlm" in model_type:
+        if mcfg["img_size"] != cfg["crop_size"]:
+            nested_set(mcfg, "img_size", cfg["crop_size"])
+            nested_set(mcfg, "model.backbone.img_size", (cfg["crop_size"], cfg["crop_size"]))
+            nested_set(mcfg, "model.decode_head.img_size", cfg["crop_size"])
+        prefix = {"pascal": "voc12_wbg", "cityscapes": "cityscapes", "coco": "coco", "ade": "ade"}[cfg["dataset"]]
+        base = "configs/_base_/datasets/text_embedding/"
+        nested_set(mcfg, "model.load_text_embedding", f"{base}{prefix}_{cfg['text_embedding_variant']}.npy")
+        nested_set(mcfg, "model.load_mcc_text_embedding", f"{base}{prefix}_{cfg['mcc_text']}.npy")
+        nested_set(mcfg, "model.load_pl_text_embedding", f"{base}{prefix}_{cfg['pl_text']}.npy")
+    if cfg.get("clip_encoder") is not None:
+        ccfg = copy.deepcopy(load_model_cfg(cfg["clip_encoder"]))
+        ccfg["img_size"] = mcfg["img_size"]
+        if cfg.get("mcc_fix_resize_pos"):
+            ccfg["backbone"]["img_size"] = mcfg["img_size"]
+        mcfg["model"]["clip_encoder"] = ccfg["backbone"]
+    if "model_args" in cfg:
+        mcfg["model"].update(cfg["model_args"])
+    mdict = dict(mcfg["model"])
+    model = SEGMENTORS[mdict.pop("type")](**mdict)
+    model.disable_dropout = cfg["disable_dropout"]
+    model.fp_rate = cfg["fp_rate"]
+    model.init_weights()
+    return model

@@ -1,0 +1,455 @@
+"""Language-guided decode head (VLGHead) on the HIP kernel library.
+
+Mirror of /root/reference model/decode_heads/vlg_head.py:27-251 (SemanticTransformer, ASPPModule, ASPPPooling, Up,
+VLGHead): same constructor kwargs, same parameter names / shapes, same math.  The B x num_classes
+"class-images" live channels-last ([(b n), h, w, C] row-major) so every conv is an implicit GEMM of the fp32-MFMA core
+(K = taps x channels contiguous), the einops permutes of the reference become stride arithmetic, `repeat`+`cat` of the
+skip features is a two-source operand, and ConvTranspose2d is a GEMM with a pixel-shuffle epilogue.
+Forward and backward of the whole head are explicit kernel sequences inside one autograd.Function.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .vit import TransformerEncoderLayer, sink_grad
+
+
+# ------------------------------------------------------------------------------------------------ parameter containers
+class SemanticTransformer(nn.Module):
+    def __init__(self, channels, text_channels, num_heads, pool_size):
+        super().__init__()
+        assert pool_size is not None and pool_size[0] == pool_size[1]
+        self.pool_size = pool_size[0]
+        self.pool = nn.AvgPool2d(pool_size)  # parameter-free; kept for module-tree parity
+        self.transformer = TransformerEncoderLayer(channels + text_channels, num_heads, 4 * channels)
+
+
+class ASPPPooling(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.gap = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False),
+                                 nn.GroupNorm(cout // 16, cout), nn.ReLU(True))
+
+
+class ASPPModule(nn.Module):
+    def __init__(self, cin, atrous_rates=(1, 6, 12, 18)):
+        super().__init__()
+        cout = cin
+        self.rates = tuple(atrous_rates)
+        self.aspp_convs = nn.ModuleList()
+        for d in atrous_rates:
+            k, pad = (1, 0) if d == 1 else (3, d)
+            self.aspp_convs.append(nn.Sequential(nn.Conv2d(cin, cout, k, padding=pad, dilation=d, bias=False),
+                                                 nn.GroupNorm(cout // 16, cout), nn.ReLU(True)))
+        self.aspp_convs.append(ASPPPooling(cin, cout))
+        self.project = nn.Sequential(nn.Conv2d(5 * cout, cout, 1, bias=False), nn.GroupNorm(cout // 16, cout),
+                                     nn.ReLU(True))
+
+
+class Up(nn.Module):
+    def __init__(self, cin, cout, cskip):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(cin, cin - cskip, kernel_size=2, stride=2)
+        self.conv = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), nn.GroupNorm(cout // 16, cout),
+                                  nn.ReLU(inplace=True),
+                                  nn.Conv2d(cout, cout, 3, padding=1, bias=False), nn.GroupNorm(cout // 16, cout),
+                                  nn.ReLU(inplace=True))
+
+
+class _GradCollector:
+    """Collects parameter gradients produced inside the head's backward; routes them to main_grad or to autograd."""
+
+    def __init__(self):
+        self.out = {}
+
+    def put(self, param, fn):
+        """fn(dst, accumulate) writes the gradient."""
+        prev = self.out.get(id(param))
+        if getattr(param, "main_grad", None) is not None:
+            fn(param.main_grad, True)
+            self.out[id(param)] = None
+        elif isinstance(prev, torch.Tensor):
+            fn(prev, True)
+        else:
+            t = ops.empty(*param.shape, device=param.device)
+            fn(t, False)
+            self.out[id(param)] = t
+
+    def put_tensor(self, param, t):
+        self.put(param, lambda dst, acc: (ops.add(dst.view(-1), t.reshape(-1), out=dst.view(-1)) if acc
+                                          else ops.eltwise(4, t.reshape(-1), None, out=dst.view(-1))))
+
+
+# ------------------------------------------------------------------------------------------------ conv + GN (+ReLU) unit
+def _conv_gn_fwd(x, ldx, imgs, H, W, C1, conv, gn, k, dil, sv, src2=None, ld2=0, C2=0, rep=1, y=None, ldy=None):
+    Co = conv.weight.shape[0]
+    wf, wd = ops.pack_conv_w(conv.weight)
+    pad = dil * (k - 1) // 2
+    pre = ops.conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, k, k, dil, pad, src2=src2, ld2=ld2, C2=C2, rep=rep)
+    if y is None:
+        y = ops.empty(imgs * H * W, Co, device=x.device)
+        ldy = Co
+    st = ops.groupnorm_fwd(pre, Co, gn.weight, gn.bias, gn.eps, imgs, H * W, Co, gn.num_groups, True, y, ldy)
+    if sv is not None:
+        sv.update(x=x, ldx=ldx, pre=pre, y=y, ldy=ldy, st=st, wd=wd, geom=(imgs, H, W, C1, Co, k, dil, pad),
+                  src2=src2, ld2=ld2, C2=C2, rep=rep)
+    return y
+
+
+def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True):
+    imgs, H, W, C1, Co, k, dil, pad = sv["geom"]
+    dpre = ops.empty(imgs * H * W, Co, device=dy.device)
+    dg, db = ops.groupnorm_bwd(dy, lddy, sv["pre"], Co, sv["y"], sv["ldy"], sv["st"], gn.weight, imgs, H * W, Co,
+                               gn.num_groups, True, dpre, Co)
+    gc.put_tensor(gn.weight, dg)
+    gc.put_tensor(gn.bias, db)
+    C2 = sv["C2"]
+    dwf = ops.conv_wgrad(dpre, Co, sv["x"], sv["ldx"], imgs, H, W, C1, Co, k, k, dil, pad, src2=sv["src2"],
+                         ld2=sv["ld2"], C2=C2, rep=sv["rep"])
+    gc.put_tensor(conv.weight, ops.unpack_conv_wgrad(dwf, Co, C1 + C2, k, k))
+    if not need_dx:
+        return None
+    return ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad)  # [pix, C1+C2]
+
+
+# ------------------------------------------------------------------------------------------------ head
+class VLGHead(nn.Module):
+    def __init__(self, img_size, num_classes, text_in_channels, text_channels, up_channels, skip_in_channels,
+                 skip_channels, skip_from_conv_feat, num_layers, num_heads, channels, pool_size, conv1_ksize,
+                 loss_decode, align_corners, type=None):
+        super().__init__()
+        assert loss_decode is None
+        if skip_from_conv_feat:
+            raise NotImplementedError("skip_from_conv_feat (Cityscapes conv_encoder, SURVEY N2) is a next-row item")
+        self.image_size, self.num_classes, self.align_corners = img_size, num_classes, align_corners
+        self.text_in_channels, self.num_layers, self.channels = text_in_channels, num_layers, channels
+        self.skip_from_conv_feat = skip_from_conv_feat
+        self.num_heads, self.text_channels = num_heads, text_channels
+        self.conv1_ksize = conv1_ksize
+        self.conv1 = nn.Conv2d(1, channels, kernel_size=conv1_ksize, stride=1, padding=(conv1_ksize - 1) // 2)
+        self.aspp = ASPPModule(channels)
+        self.layers = nn.ModuleList([SemanticTransformer(channels, text_channels, num_heads, pool_size)
+                                     for _ in range(num_layers)])
+        self.text_proj = nn.Sequential(nn.Linear(text_in_channels, text_channels), nn.ReLU())
+        self.skip_proj = nn.ModuleList([nn.Sequential(nn.Conv2d(sic, sc, kernel_size=3, stride=1, padding=1), nn.ReLU())
+                                        for sic, sc in zip(skip_in_channels, skip_channels)])
+        self.up1 = Up(channels, up_channels[0], skip_channels[0])
+        self.up2 = Up(up_channels[0], up_channels[1], skip_channels[1])
+        self.head = nn.Conv2d(up_channels[1], 1, kernel_size=3, stride=1, padding=1)
+        self.load_text_embedding = None
+        if (channels + text_channels) % num_heads or (channels + text_channels) // num_heads != 64:
+            raise NotImplementedError("SemanticTransformer head dim must be 64")
+
+    # ---------------------------------------------------------------------------------------------------
+    def forward_tokens(self, feats, text, hw, fp_masks=None, fp_rate=0.5, out_size=None):
+        """feats: [v0, v4, emb] token tensors [b, hw, C]; text [N, 512] (any float dtype).
+        fp_masks: None, or list of three {0,1} masks [b, C_i]: the batch is doubled with the channel-dropped copy
+        (builder.py:78-89).  Returns logits [b', N, S, S]."""
+        params = [p for p in self.parameters() if p.requires_grad]
+        need_grad = torch.is_grad_enabled() and (bool(params) or any(f.requires_grad for f in feats))
+        out_size = out_size or (self.image_size, self.image_size)
+        if need_grad:
+            return _HeadFn.apply(self, hw, fp_masks, fp_rate, out_size, text, feats[0], feats[1], feats[2], *params)
+        return _head_forward(self, hw, fp_masks, fp_rate, out_size, text, feats, None)
+
+    def forward(self, inputs, force_output_pred_masks=False):
+        """Reference signature (vlg_head.py:192-251): inputs = [[feature_pyramid, global], text_feats, conv_feats]."""
+        pyramid = inputs[0][0]
+        toks, hw = [], None
+        for f in pyramid:  # NCHW (possibly channels-last views) -> tokens
+            b, c, h, w = f.shape
+            hw = (h, w)
+            toks.append(f.permute(0, 2, 3, 1).contiguous().view(b, h * w, c))
+        size = (self.image_size, self.image_size) if force_output_pred_masks else (4 * hw[0], 4 * hw[1])
+        x = self.forward_tokens(toks, inputs[1], hw, out_size=size)
+        return {"pred_masks": x} if force_output_pred_masks else x
+
+
+def _head_forward(m, hw, fp_masks, fp_rate, out_size, text, feats, sv):
+    h, w = hw
+    HW = h * w
+    v0, v4, emb = [f.contiguous() for f in feats]
+    b0 = emb.shape[0]
+    dev = emb.device
+    N = text.shape[0]
+    if N != m.num_classes:
+        raise NotImplementedError("concept-level text embeddings inside VLGHead are off the BASELINE configs")
+    Ch, Ct = m.channels, m.text_channels
+    Ce, Cv = emb.shape[2], v0.shape[2]
+    # ---- feature perturbation: cat(f, dropout2d(f)) ------------------------------------------------------
+    if fp_masks is not None:
+        b = 2 * b0
+        sc = 1.0 / (1.0 - fp_rate)
+
+        def dbl(f, mk, Cc):
+            out = ops.empty(b * HW, Cc, device=dev)
+            ops.eltwise(4, f.view(-1), None, out=out.view(-1)[:b0 * HW * Cc])
+            ops.chanmask(f.view(b0 * HW, Cc), mk.contiguous(), sc, HW, out=out[b0 * HW:])
+            return out
+        v0, v4, emb = dbl(v0, fp_masks[0], Cv), dbl(v4, fp_masks[1], Cv), dbl(emb, fp_masks[2], Ce)
+    else:
+        b = b0
+        v0, v4, emb = v0.view(b * HW, Cv), v4.view(b * HW, Cv), emb.view(b * HW, Ce)
+    imgs = b * N
+    # ---- cosine similarity map (vlg_head.py:214-217) ------------------------------------------------------
+    embn, inv_e = ops.l2norm_fwd(emb, 1e-12)
+    textf = text.float().contiguous()
+    textn, _ = ops.l2norm_fwd(textf, 1e-12)
+    sim = ops.empty(imgs * HW, 1, device=dev)  # [(b n), h, w, 1]
+    ops.gemm(ops.A_KC, ops.B_KC, HW, N, Ce, ops.Op(embn, Ce, 0, HW * Ce, 0), ops.Op(textn, Ce), sim, ldc_m=1, ldc_n=HW,
+             batch=b, c_bso=N * HW)
+    S = {} if sv is not None else None
+    # ---- conv1 7x7 -----------------------------------------------------------------------------------------
+    k1 = m.conv1_ksize
+    w1f, w1d = ops.pack_conv_w(m.conv1.weight)
+    x1 = ops.conv_fwd(sim, 1, imgs, h, w, 1, w1f, Ch, k1, k1, 1, (k1 - 1) // 2, bias=m.conv1.bias)
+    # ---- ASPP ----------------------------------------------------------------------------------------------
+    cat = ops.empty(imgs * HW, 5 * Ch, device=dev)
+    aspp_sv = []
+    for j, d in enumerate(m.aspp.rates):
+        seq = m.aspp.aspp_convs[j]
+        s_ = {} if sv is not None else None
+        _conv_gn_fwd(x1, Ch, imgs, h, w, Ch, seq[0], seq[1], 1 if d == 1 else 3, d, s_, y=cat[:, j * Ch:], ldy=5 * Ch)
+        aspp_sv.append(s_)
+    gap = m.aspp.aspp_convs[4].gap
+    pooled = ops.avgpool_cat_fwd(x1, imgs, h, w, Ch, h, None, 1) if h == w else None
+    if pooled is None:
+        raise NotImplementedError("non-square feature maps")
+    s_gap = {} if sv is not None else None
+    gy = _conv_gn_fwd(pooled, Ch, imgs, 1, 1, Ch, gap[1], gap[2], 1, 1, s_gap)
+    ops.bilinear_nhwc_fwd(gy, Ch, imgs, 1, 1, Ch, True, 1, h, w, cat[:, 4 * Ch:], 5 * Ch)
+    s_proj = {} if sv is not None else None
+    x2 = _conv_gn_fwd(cat, 5 * Ch, imgs, h, w, 5 * Ch, m.aspp.project[0], m.aspp.project[1], 1, 1, s_proj)
+    x = ops.add(x2, x1)  # y = x + project(cat); new buffer: x2 stays intact as the ReLU mask of the project GN
+    # ---- semantic reasoning ----------------------------------------------------------------------------------
+    tp = ops.linear(textn, m.text_proj[0].weight, m.text_proj[0].bias, act=ops.ACT_RELU)
+    tr_sv = []
+    for lyr in m.layers:
+        s_ = {} if sv is not None else None
+        x = _semtr_forward(lyr, x, tp, imgs, b, N, h, w, Ch, Ct, s_)
+        tr_sv.append(s_)
+    # ---- skip projections (order [v4, v0], vlg_head.py:207) ----------------------------------------------------
+    skips, skip_sv = [], []
+    for proj, f in zip(m.skip_proj, (v4, v0)):
+        wf, wd = ops.pack_conv_w(proj[0].weight)
+        Cs = proj[0].weight.shape[0]
+        sk = ops.conv_fwd(f, Cv, b, h, w, Cv, wf, Cs, 3, 3, 1, 1, bias=proj[0].bias, act=ops.ACT_RELU)
+        skips.append(sk)
+        skip_sv.append(dict(x=f, wd=wd, y=sk, Cs=Cs))
+    # ---- upsampling ------------------------------------------------------------------------------------------
+    s_up1 = {} if sv is not None else None
+    g2 = _up_forward(m.up1, x, imgs, h, w, skips[0], b, N, s_up1)
+    s_up2 = {} if sv is not None else None
+    g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], b, N, s_up2)
+    C4 = g4.shape[1]
+    whf, whd = ops.pack_conv_w(m.head.weight)
+    lg = ops.conv_fwd(g4, C4, imgs, 4 * h, 4 * w, C4, whf, 1, 3, 3, 1, 1, bias=m.head.bias)  # [(b n), 4h, 4w, 1]
+    lg = lg.view(b, N, 4 * h, 4 * w)
+    if out_size != (4 * h, 4 * w):
+        logits = ops.bilinear_planes_fwd(lg, 4 * h, 4 * w, m.align_corners, out_size[0], out_size[1])
+    else:
+        logits = lg
+    if sv is not None:
+        sv.update(dims=(b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv), fp=(fp_masks, fp_rate), emb=emb, embn=embn,
+                  inv_e=inv_e, textn=textn, sim=sim, w1d=w1d, x1=x1, aspp=aspp_sv, gap=s_gap, pooled=pooled, proj=s_proj,
+                  cat=cat, tp=tp, tr=tr_sv, skip=skip_sv, up1=s_up1, up2=s_up2, g4=g4, whd=whd,
+                  out_size=out_size, v0=v0, v4=v4)
+    return logits
+
+
+def _semtr_forward(lyr, x, tp, imgs, b, N, h, w, Ch, Ct, sv):
+    """vlg_head.py:39-67.  x [(b n) h w, Ch] is updated in place (x += upsample(transformer(pool(x) ++ text)))."""
+    P = lyr.pool_size
+    hp, wp = h // P, w // P
+    t = lyr.transformer
+    p = t.plist()
+    E = Ch + Ct
+    tok = ops.avgpool_cat_fwd(x, imgs, h, w, Ch, P, tp, N)  # rows [(b n), hp, wp], E channels
+    y1, st1 = ops.layernorm_fwd(tok, p["ln1w"], p["ln1b"], t.eps)
+    qkv = ops.linear(y1, p["win"], p["bin"])
+    G = hp * wp
+    o, probs = ops.seqattn_fwd(qkv, b * G, G, N, t.num_heads, N * G, 1, G)
+    t2 = ops.linear(o, p["wout"], p["bout"], resid=tok)
+    y2, st2 = ops.layernorm_fwd(t2, p["ln2w"], p["ln2b"], t.eps)
+    h_pre = ops.empty(y2.shape[0], p["w1"].shape[0], device=x.device) if sv is not None else None
+    hh = ops.linear(y2, p["w1"], p["b1"], act=ops.ACT_GELU, preact=h_pre)
+    t3 = ops.linear(hh, p["w2"], p["b2"], resid=t2)
+    # keep the image half (first Ch channels), bilinear up (align_corners=True), residual add
+    ops.bilinear_nhwc_fwd(t3, E, imgs, hp, wp, Ch, True, 1, h, w, x, Ch, accumulate=True)
+    if sv is not None:
+        sv.update(tok=tok, y1=y1, st1=st1, qkv=qkv, o=o, probs=probs, t2=t2, y2=y2, st2=st2, h_pre=h_pre, hh=hh,
+                  dims=(hp, wp, G, E))
+    return x
+
+
+def _semtr_backward(lyr, dx, dtp_acc, imgs, b, N, h, w, Ch, Ct, sv, gc):
+    """dx [(b n) h w, Ch] grad wrt the block output; returns grad wrt its input, accumulates dtext into dtp_acc."""
+    hp, wp, G, E = sv["dims"]
+    t = lyr.transformer
+    p = t.plist()
+    a, f = t.attn.attn, t.ffn.layers
+    rows = imgs * G
+    dev = dx.device
+    dt3 = ops.zeros(rows, E, device=dev)
+    ops.bilinear_nhwc_bwd(dx, Ch, imgs, hp, wp, Ch, True, 1, h, w, dt3, E)
+    # t3 = t2 + W2 hh + b2
+    gc.put(f[1].weight, lambda d, acc: ops.matmul_tn(dt3, sv["hh"], out=d, accumulate=acc))
+    gc.put(f[1].bias, lambda d, acc: ops.colsum(dt3, out=d, accumulate=acc))
+    dh = ops.matmul_nn(dt3, p["w2"])
+    dhp = ops.eltwise(1, dh, sv["h_pre"], out=dh)
+    gc.put(f[0][0].weight, lambda d, acc: ops.matmul_tn(dhp, sv["y2"], out=d, accumulate=acc))
+    gc.put(f[0][0].bias, lambda d, acc: ops.colsum(dhp, out=d, accumulate=acc))
+    dy2 = ops.matmul_nn(dhp, p["w1"])
+    dt2, dg2, db2 = ops.layernorm_bwd(dy2, sv["t2"], sv["st2"], p["ln2w"], dx_add=dt3, want_wgrad=True)
+    gc.put_tensor(t.ln2.weight, dg2)
+    gc.put_tensor(t.ln2.bias, db2)
+    # t2 = tok + Wout o + bout
+    gc.put(a.out_proj.weight, lambda d, acc: ops.matmul_tn(dt2, sv["o"], out=d, accumulate=acc))
+    gc.put(a.out_proj.bias, lambda d, acc: ops.colsum(dt2, out=d, accumulate=acc))
+    do = ops.matmul_nn(dt2, p["wout"])
+    dqkv = ops.seqattn_bwd(do, sv["qkv"], sv["probs"], b * G, G, N, t.num_heads, N * G, 1, G)
+    gc.put(a.in_proj_weight, lambda d, acc: ops.matmul_tn(dqkv, sv["y1"], out=d, accumulate=acc))
+    gc.put(a.in_proj_bias, lambda d, acc: ops.colsum(dqkv, out=d, accumulate=acc))
+    dy1 = ops.matmul_nn(dqkv, p["win"])
+    dtok, dg1, db1 = ops.layernorm_bwd(dy1, sv["tok"], sv["st1"], p["ln1w"], dx_add=dt2, want_wgrad=True)
+    gc.put_tensor(t.ln1.weight, dg1)
+    gc.put_tensor(t.ln1.bias, db1)
+    dxin_pool, dtext = ops.avgpool_cat_bwd(dtok, imgs, h, w, Ch, lyr.pool_size, Ct, N)
+    ops.add(dtp_acc, dtext, out=dtp_acc)
+    return ops.add(dx, dxin_pool, out=dxin_pool)
+
+
+def _up_forward(up, x, imgs, h, w, skip, b, N, sv):
+    """vlg_head.py:129-137.  x [(b n) h w, Cin]; skip [b h w, Cs] -> [(b n) 2h 2w, Cout]."""
+    Cin = up.up.weight.shape[0]
+    Cu = up.up.weight.shape[1]
+    Cs = skip.shape[1]
+    dev = x.device
+    wp_ = up.up.weight.permute(2, 3, 1, 0).reshape(4 * Cu, Cin).contiguous()  # n = (a, b, co)
+    u = ops.empty(imgs * 4 * h * w, Cu, device=dev)
+    ops.convT2x_fwd(x, Cin, imgs, h, w, Cin, wp_, Cu, up.up.bias, u, Cu)
+    sup = ops.empty(b * 4 * h * w, Cs, device=dev)
+    ops.bilinear_nhwc_fwd(skip, Cs, b, h, w, Cs, True, 1, 2 * h, 2 * w, sup, Cs)
+    sa = {} if sv is not None else None
+    g1 = _conv_gn_fwd(u, Cu, imgs, 2 * h, 2 * w, Cu, up.conv[0], up.conv[1], 3, 1, sa, src2=sup, ld2=Cs, C2=Cs, rep=N)
+    sb = {} if sv is not None else None
+    g2 = _conv_gn_fwd(g1, g1.shape[1], imgs, 2 * h, 2 * w, g1.shape[1], up.conv[3], up.conv[4], 3, 1, sb)
+    if sv is not None:
+        sv.update(x=x, wp=wp_, a=sa, b=sb, dims=(Cin, Cu, Cs))
+    return g2
+
+
+def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
+    """Returns (dx [(b n) h w, Cin], dskip [b h w, Cs])."""
+    Cin, Cu, Cs = sv["dims"]
+    dev = dg2.device
+    dg1 = _conv_gn_bwd(dg2, dg2.shape[1], up.conv[3], up.conv[4], sv["b"], gc)
+    dcat = _conv_gn_bwd(dg1, dg1.shape[1], up.conv[0], up.conv[1], sv["a"], gc)  # [pix, Cu + Cs]
+    ld = Cu + Cs
+    # skip half: sum over the N repeats, then bilinear backward
+    dskip = ops.empty(b * h * w, Cs, device=dev)
+    ops.bilinear_nhwc_bwd(dcat[:, Cu:], ld, b, h, w, Cs, True, N, 2 * h, 2 * w, dskip, Cs)
+    # ConvTranspose half
+    gc.put(up.up.bias, lambda d, acc: ops.colsum(dcat, out=d, accumulate=acc, C_=Cu, ld=ld))
+    dwb = ops.convT2x_wgrad(sv["x"], Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
+    gc.put_tensor(up.up.weight, dwb.view(Cin, 2, 2, Cu).permute(0, 3, 1, 2).contiguous())
+    wb = up.up.weight.permute(0, 2, 3, 1).reshape(Cin, 4 * Cu).contiguous()
+    dx = ops.convT2x_dgrad(dcat, ld, imgs, h, w, Cu, wb, Cin)
+    return dx, dskip
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m, hw, fp_masks, fp_rate, out_size, text, v0, v4, emb, *params):
+        sv = {}
+        out = _head_forward(m, hw, fp_masks, fp_rate, out_size, text, [v0, v4, emb], sv)
+        ctx.m, ctx.sv, ctx.params, ctx.hw = m, sv, params, hw
+        ctx.feat_req = (v0.requires_grad, v4.requires_grad, emb.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m, sv = ctx.m, ctx.sv
+        b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv = sv["dims"]
+        dev = dlogits.device
+        gc = _GradCollector()
+        dlogits = dlogits.contiguous()
+        if sv["out_size"] != (4 * h, 4 * w):
+            dlg = ops.bilinear_planes_bwd(dlogits, 4 * h, 4 * w, m.align_corners, sv["out_size"][0], sv["out_size"][1])
+        else:
+            dlg = dlogits
+        dlg = dlg.view(imgs * 16 * HW, 1)
+        # ---- head conv
+        g4 = sv["g4"]
+        C4 = g4.shape[1]
+        gc.put(m.head.bias, lambda d, acc: ops.colsum(dlg, out=d, accumulate=acc))
+        dwh = ops.conv_wgrad(dlg, 1, g4, C4, imgs, 4 * h, 4 * w, C4, 1, 3, 3, 1, 1)
+        gc.put_tensor(m.head.weight, ops.unpack_conv_wgrad(dwh, 1, C4, 3, 3))
+        dg4 = ops.conv_dgrad(dlg, 1, imgs, 4 * h, 4 * w, 1, sv["whd"], C4, 3, 3, 1, 1)
+        # ---- up2, up1
+        dg2, dskip0 = _up_backward(m.up2, dg4, imgs, 2 * h, 2 * w, b, N, sv["up2"], gc)
+        sv["up2"] = sv["g4"] = None
+        dx, dskip4 = _up_backward(m.up1, dg2, imgs, h, w, b, N, sv["up1"], gc)
+        sv["up1"] = None
+        # ---- skip projections -> grads for v4 / v0
+        dfe = []
+        for proj, ss, dsk in zip(m.skip_proj, sv["skip"], (dskip4, dskip0)):
+            Cs = ss["Cs"]
+            dpre = ops.eltwise(2, dsk, ss["y"], out=dsk)  # relu backward (post-activation mask)
+            gc.put(proj[0].bias, lambda d, acc, dpre=dpre: ops.colsum(dpre, out=d, accumulate=acc))
+            dwf = ops.conv_wgrad(dpre, Cs, ss["x"], Cv, b, h, w, Cv, Cs, 3, 3, 1, 1)
+            gc.put_tensor(proj[0].weight, ops.unpack_conv_wgrad(dwf, Cs, Cv, 3, 3))
+            dfe.append(ops.conv_dgrad(dpre, Cs, b, h, w, Cs, ss["wd"], Cv, 3, 3, 1, 1))
+        dv4, dv0 = dfe
+        # ---- semantic transformers (reverse)
+        dtp = ops.zeros(N, Ct, device=dev)
+        for lyr, s_ in zip(reversed(list(m.layers)), reversed(sv["tr"])):
+            dx = _semtr_backward(lyr, dx, dtp, imgs, b, N, h, w, Ch, Ct, s_, gc)
+        sv["tr"] = None
+        dtp_pre = ops.eltwise(2, dtp, sv["tp"], out=dtp)
+        gc.put(m.text_proj[0].weight, lambda d, acc: ops.matmul_tn(dtp_pre, sv["textn"], out=d, accumulate=acc))
+        gc.put(m.text_proj[0].bias, lambda d, acc: ops.colsum(dtp_pre, out=d, accumulate=acc))
+        # ---- ASPP: x2 = x1 + project(cat)
+        dcat = _conv_gn_bwd(dx, Ch, m.aspp.project[0], m.aspp.project[1], sv["proj"], gc)  # [pix, 5Ch]
+        dx1 = dx  # residual branch (dx is not used afterwards; accumulate into it)
+        for j, d in enumerate(m.aspp.rates):
+            seq = m.aspp.aspp_convs[j]
+            dbr = _conv_gn_bwd(dcat[:, j * Ch:], 5 * Ch, seq[0], seq[1], sv["aspp"][j], gc)
+            ops.add(dx1, dbr, out=dx1)
+        gap = m.aspp.aspp_convs[4].gap
+        dgy = ops.empty(imgs, Ch, device=dev)
+        ops.bilinear_nhwc_bwd(dcat[:, 4 * Ch:], 5 * Ch, imgs, 1, 1, Ch, True, 1, h, w, dgy, Ch)
+        dpooled = _conv_gn_bwd(dgy, Ch, gap[1], gap[2], sv["gap"], gc)  # [imgs, Ch]
+        # avgpool over the whole map: every pixel gets dpooled / HW
+        dgap, _ = ops.avgpool_cat_bwd(dpooled, imgs, h, w, Ch, h, 0, 1)
+        ops.add(dx1, dgap, out=dx1)
+        sv["aspp"] = sv["cat"] = sv["proj"] = None
+        # ---- conv1
+        k1 = m.conv1_ksize
+        gc.put(m.conv1.bias, lambda d, acc: ops.colsum(dx1, out=d, accumulate=acc))
+        dw1 = ops.conv_wgrad(dx1, Ch, sv["sim"], 1, imgs, h, w, 1, Ch, k1, k1, 1, (k1 - 1) // 2)
+        gc.put_tensor(m.conv1.weight, ops.unpack_conv_wgrad(dw1, Ch, 1, k1, k1))
+        dsim = ops.conv_dgrad(dx1, Ch, imgs, h, w, Ch, sv["w1d"], 1, k1, k1, 1, (k1 - 1) // 2)  # [(b n) hw, 1]
+        # ---- cosine sim: demb_n[b,p,c] = sum_n dsim[b,n,p] textn[n,c]
+        dembn = ops.empty(b * HW, Ce, device=dev)
+        ops.gemm(ops.A_MC, ops.B_NC, HW, Ce, N, ops.Op(dsim, HW, 0, N * HW, 0), ops.Op(sv["textn"], Ce), dembn,
+                 ldc_m=Ce, batch=b, c_bso=HW * Ce)
+        demb = ops.l2norm_bwd(dembn, sv["embn"], sv["inv_e"])
+        # ---- undo the feature-perturbation doubling
+        fp_masks, fp_rate = sv["fp"]
+
+        def undbl(dfull, mk, Cc):
+            if fp_masks is None:
+                return dfull.view(b0, HW, Cc)
+            sc = 1.0 / (1.0 - fp_rate)
+            second = ops.chanmask(dfull[b0 * HW:], mk.contiguous(), sc, HW)
+            first = dfull[:b0 * HW]
+            return ops.add(first, second, out=second).view(b0, HW, Cc)
+        mk = fp_masks if fp_masks is not None else (None, None, None)
+        dv0 = undbl(dv0, mk[0], Cv)
+        dv4 = undbl(dv4, mk[1], Cv)
+        demb = undbl(demb, mk[2], Ce)
+        ctx.sv = None
+        req = ctx.feat_req
+        return (None, None, None, None, None, None, dv0 if req[0] else None, dv4 if req[1] else None,
+                demb if req[2] else None) + tuple(gc.out.get(id(p)) for p in ctx.params)

@@ -52,7 +52,7 @@ class Op:
 
 def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batch=1, batch_inner=1, ksplit=0,
          c_bso=0, c_bsi=0, alpha=1.0, bias=None, bias_mod=0, act=ACT_NONE, resid=None, r_off=0, ldr_m=None, ldr_n=1,
-         r_bso=0, r_bsi=0, accumulate=False, out_mode=OUT_STRIDED, conv=None, ct=(0, 0, 0)):
+         r_bso=0, r_bsi=0, accumulate=False, out_mode=OUT_STRIDED, conv=None, ct=(0, 0, 0), preact=None):
     d = L.GemmDesc()
     d.a_mode, d.b_mode, d.M, d.N, d.K = a_mode, b_mode, M, N, K
     d.batch, d.batch_inner, d.ksplit = batch, batch_inner, ksplit
@@ -67,6 +67,7 @@ def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batc
     d.alpha = alpha
     d.bias = _p(bias)
     d.bias_mod, d.act = bias_mod, act
+    d.preact = _p(preact)
     if resid is not None:
         d.resid = C.c_void_p(resid.data_ptr() + 4 * r_off)
         d.ldr_m = ldr_m if ldr_m is not None else d.ldc_m
@@ -75,9 +76,10 @@ def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batc
     L.check(L.load().svl_gemm_f32(C.byref(d), _st()), "svl_gemm_f32")
 
 
-def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld2=0, patch=0):
+def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld2=0, patch=0, stride=1, Ho=0, Wo=0):
     g = L.ConvGeom()
     g.H, g.W, g.C1, g.C2, g.rep = H, W, C1, C2, rep
+    g.stride, g.Ho, g.Wo = stride, Ho, Wo
     g.KH, g.KW, g.dil, g.pad, g.sign = KH, KW, dil, pad, sign
     g.src2 = _p(src2)
     g.ld2, g.patch = ld2, patch
@@ -85,7 +87,7 @@ def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld
 
 
 # ------------------------------------------------------------------------------------------------ dense helpers
-def linear(x, W, bias=None, act=ACT_NONE, resid=None, out=None, accumulate=False):
+def linear(x, W, bias=None, act=ACT_NONE, resid=None, out=None, accumulate=False, preact=None):
     """out[M,N] = act(x[M,K] @ W[N,K]^T + bias) + resid   (torch F.linear layout)."""
     M, K = x.shape
     N = W.shape[0]
@@ -93,8 +95,15 @@ def linear(x, W, bias=None, act=ACT_NONE, resid=None, out=None, accumulate=False
     if out is None:
         out = empty(M, N, device=x.device)
     gemm(A_KC, B_KC, M, N, K, Op(x, x.stride(0)), Op(W, K), out, ldc_m=out.stride(0), bias=bias, act=act,
-         resid=resid, ldr_m=resid.stride(0) if resid is not None else None, accumulate=accumulate)
+         resid=resid, ldr_m=resid.stride(0) if resid is not None else None, accumulate=accumulate, preact=preact)
     return out
+
+
+def copy2d(src, s_off, sgrp, src_go, src_ld, dst, d_off, dgrp, dst_go, dst_ld, rows, Cc, accumulate=False):
+    """Strided row copy; offsets in elements."""
+    L.check(L.load().svl_copy2d_f32(C.c_void_p(src.data_ptr() + 4 * s_off), sgrp, src_go, src_ld,
+                                    C.c_void_p(dst.data_ptr() + 4 * d_off), dgrp, dst_go, dst_ld, rows, Cc,
+                                    1 if accumulate else 0, _st()), "svl_copy2d_f32")
 
 
 def matmul_nn(a, b, out=None, accumulate=False):
@@ -165,6 +174,10 @@ def eltwise(mode, a, b=None, out=None):
 
 def add(a, b, out=None):
     return eltwise(0, a, b, out)
+
+
+def gelu(a, out=None):
+    return eltwise(5, a, None, out)
 
 
 def fill(t, v):
@@ -374,6 +387,31 @@ def convT2x_fwd(x, ldx, imgs, H, W, Ci, wp, Co, bias, out, ldo):
     return out
 
 
+def convT2x_dgrad(du, lddu, imgs, H, W, Co, wb, Ci):
+    """dx[imgs*H*W, Ci] of ConvTranspose2d(k2,s2) = conv(k2, s2) of du [imgs,2H,2W,Co] with wb [Ci, 4*Co] (n=(a,b,co))."""
+    M = imgs * H * W
+    g = conv_geom(2 * H, 2 * W, Co, 2, 2, 1, 0, 1, stride=2, Ho=H, Wo=W)
+    out = empty(M, Ci, device=du.device)
+    gemm(A_CONV, B_KC, M, Ci, 4 * Co, Op(du, lddu), Op(wb, 4 * Co), out, conv=g)
+    return out
+
+
+def convT2x_wgrad(x, ldx, du, lddu, imgs, H, W, Ci, Co):
+    """dWb[Ci, (a,b,co)] = sum_m x[m,ci] * du[pix(m;a,b), co]."""
+    Kpix = imgs * H * W
+    N = 4 * Co
+    g = conv_geom(2 * H, 2 * W, Co, 2, 2, 1, 0, 1, stride=2, Ho=H, Wo=W)
+    s, ks = _ksplit_plan(Ci, N, Kpix)
+    out = empty(Ci, N, device=x.device)
+    if s == 1:
+        gemm(A_MC, B_CONVW, Ci, N, Kpix, Op(x, ldx), Op(du, lddu), out, conv=g)
+        return out
+    slabs = empty(s, Ci, N, device=x.device)
+    gemm(A_MC, B_CONVW, Ci, N, Kpix, Op(x, ldx), Op(du, lddu), slabs, batch=s, ksplit=ks, c_bso=Ci * N, conv=g)
+    reduce_slabs(out, slabs)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ resampling
 def bilinear_nhwc_fwd(x, ldx, imgs, h, w, Cc, align, rep, H, W, y, ldy, accumulate=False):
     L.check(L.load().svl_bilinear_nhwc_fwd(_p(x), ldx, imgs, h, w, Cc, 1 if align else 0, rep, H, W, _p(y), ldy,
@@ -494,3 +532,12 @@ def adamw_step(p, g, m, v, seg_off, seg_lr, seg_wd, nseg, beta1, beta2, eps, ste
     L.check(L.load().svl_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(seg_off), _p(seg_lr), _p(seg_wd), nseg, p.numel(),
                                     float(beta1), float(beta2), float(eps), int(step), float(gscale), _p(ema),
                                     float(ema_decay), _st()), "svl_adamw_step")
+
+
+def semivl_gscale(counts_i64, numel_u, lam, gscale_out):
+    L.check(L.load().svl_semivl_gscale(_p(counts_i64), float(numel_u), float(lam), _p(gscale_out), _st()),
+            "svl_semivl_gscale")
+
+
+def semivl_loss(sums_f64, numel_u, lam, out8):
+    L.check(L.load().svl_semivl_loss(_p(sums_f64), float(numel_u), float(lam), _p(out8), _st()), "svl_semivl_loss")

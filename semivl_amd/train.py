@@ -1,0 +1,282 @@
+"""The SemiVL training step on MI355X: loss helpers, the two-branch step, fused AdamW and the gradient all-reduce.
+
+Mirrors (same names / argument meaning):
+  utils/train_utils.py:19-49   cutmix_img_, cutmix_mask, confidence_weighted_loss
+  semivl.py:52-58              compute_mc_loss
+  semivl.py:223-345            the loop body  -> semivl_train_step()
+  semivl.py:123-125,339-345    mmcv param-wise AdamW + poly LR -> FusedAdamW
+  semivl.py:139-140            DistributedDataParallel -> GradAllReducer (RCCL all-reduce of the flat grad arena)
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------ reference-named helpers
+def cutmix_img_(img, img_mix, cutmix_box):
+    """In place: img[box == 1] = img_mix[box == 1] (train_utils.py:19-21), one select kernel, no host sync."""
+    ops.cutmix_f32(img, img_mix, cutmix_box, out=img)
+
+
+def cutmix_mask(mask, mask_mix, cutmix_box):
+    """train_utils.py:24-27 for int64 label-like maps and fp32 confidence maps."""
+    if mask.dtype == torch.int64:
+        return ops.cutmix_i64(mask, mask_mix, cutmix_box)
+    return ops.cutmix_f32(mask, mask_mix, cutmix_box)
+
+
+def confidence_weighted_loss(loss, conf_map, ignore_mask, cfg):
+    """train_utils.py:30-49 on an autograd-tracked per-pixel loss map.  API-compatibility helper for callers that
+    compute the per-pixel CE themselves; `semivl_train_step` uses the fused CE kernel instead."""
+    assert loss.dim() == 3 and conf_map.dim() == 3 and ignore_mask.dim() == 3
+    valid_mask = ignore_mask != 255
+    sum_pixels = dict(dim=(1, 2), keepdim=True)
+    if cfg["conf_mode"] == "pixelwise":
+        loss = loss * ((conf_map >= cfg["conf_thresh"]) & valid_mask)
+        return loss.sum() / valid_mask.sum().item()
+    if cfg["conf_mode"] == "pixelratio":
+        r = ((conf_map >= cfg["conf_thresh"]) & valid_mask).sum(**sum_pixels) / valid_mask.sum(**sum_pixels)
+        return (loss * r).sum() / valid_mask.sum().item()
+    if cfg["conf_mode"] == "pixelavg":
+        avg_conf = (conf_map * valid_mask).sum(**sum_pixels) / valid_mask.sum(**sum_pixels)
+        return (loss.sum() * avg_conf).sum() / valid_mask.sum().item()
+    raise ValueError(cfg["conf_mode"])
+
+
+def _cat2(a, b):
+    """torch.cat((a, b)) along dim 0 with the library's copy kernel."""
+    out = ops.empty(a.shape[0] + b.shape[0], *a.shape[1:], device=a.device)
+    flat = out.view(-1)
+    ops.eltwise(4, a.contiguous().view(-1), None, out=flat[:a.numel()])
+    ops.eltwise(4, b.contiguous().view(-1), None, out=flat[a.numel():])
+    return out
+
+
+LOSS_NAMES = ("loss", "loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "loss_mc_s2", "loss_mc_fp")
+
+
+def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, reducer=None, fp_masks=None,
+                      return_aux=False):
+    """One iteration of semivl.py:223-328 (method 'semivl', CELoss(ignore 255) / CELoss, conf_mode 'pixelwise',
+    mcc_loss_reduce 'mean_all').  `batch`: the 12 step tensors on the GPU.  No host syncs: the
+    returned `losses` is a device float[8] (LOSS_NAMES order).
+    """
+    if cfg.get("conf_mode", "pixelwise") != "pixelwise" or cfg.get("mcc_loss_reduce", "mean_all") != "mean_all":
+        raise NotImplementedError("only conf_mode='pixelwise' / mcc_loss_reduce='mean_all' (VOC/COCO/ADE recipes); "
+                                  "'pixelavg' is the Cityscapes next-row item (SURVEY N2)")
+    lam_cfg = cfg.get("maskclip_consistency_lambda", [0.1, 0])
+    if isinstance(lam_cfg, (list, tuple)):
+        prog = iters / total_iters
+        lam = lam_cfg[0] * (1 - prog) + lam_cfg[1] * prog
+    else:
+        lam = lam_cfg
+    b = batch
+    img_x, mask_x = b["img_x"], b["mask_x"]
+    img_w, img_s1, img_s2 = b["img_w"], b["img_s1"], b["img_s2"]
+    ign, mix1, mix2 = b["ignore_mask"], b["mix1"], b["mix2"]
+    ign_o = b["ignore_mask_other"]
+    B = img_x.shape[0]
+    dev = img_x.device
+    # CutMix images (in place, like the reference)
+    cutmix_img_(img_s1, b["img_s1_other"], mix1)
+    cutmix_img_(img_s2, b["img_s2_other"], mix2)
+    # pseudo labels + MaskCLIP guidance
+    with torch.no_grad():
+        pred_w_other = model(b["img_w_other"])
+        conf_w_other, mask_w_other = ops.softmax_max(pred_w_other)
+        del pred_w_other
+        mclip_all = model.forward_maskclip(_cat2(img_w, b["img_w_other"]), cfg.get("mcc_conf_thresh", 0.9),
+                                           ignore_mask=_cat2i(ign, ign_o))
+        mclip, mclip_other = mclip_all[:B], mclip_all[B:]
+    # predictions
+    preds4 = model(_cat2(img_x, img_w), need_fp=True, fp_masks=fp_masks, split_fp=False)  # [x, w, x_fp, w_fp]
+    preds_s = model(_cat2(img_s1, img_s2))                                                 # [s1, s2]
+    pred_x, pred_w, pred_w_fp = preds4[:B], preds4[B:2 * B], preds4[3 * B:]
+    pred_s1, pred_s2 = preds_s[:B], preds_s[B:]
+    conf_w, mask_w = ops.softmax_max(pred_w.detach())
+    # CutMix labels
+    mw1, mw2 = cutmix_mask(mask_w, mask_w_other, mix1), cutmix_mask(mask_w, mask_w_other, mix2)
+    cw1, cw2 = cutmix_mask(conf_w, conf_w_other, mix1), cutmix_mask(conf_w, conf_w_other, mix2)
+    ig1, ig2 = cutmix_mask(ign, ign_o, mix1), cutmix_mask(ign, ign_o, mix2)
+    mc1, mc2 = cutmix_mask(mclip, mclip_other, mix1), cutmix_mask(mclip, mclip_other, mix2)
+    # normalisers -> per-branch gradient scales, on the device
+    counts = ops.zeros(4, dtype=torch.int64, device=dev)
+    for i, m_ in enumerate((mask_x, ig1, ig2, ign)):
+        ops.count_valid(m_, counts[i:i + 1])
+    numel_u = float(ign.numel())
+    gscale = ops.empty(4, 2, device=dev)
+    ops.semivl_gscale(counts, numel_u, lam, gscale)
+    # fused CE forward + backward per branch
+    thr = cfg["conf_thresh"]
+    dl4 = torch.empty_like(preds4)
+    dls = torch.empty_like(preds_s)
+    ops.fill(dl4[B:3 * B], 0.0)  # pred_w is detached, pred_x_fp is unused (semivl.py:247,251)
+    sums = ops.empty(4, 4, dtype=torch.float64, device=dev)
+    ops.ce_fused(pred_x.detach(), mask_x, True, dlogits=dl4[:B], gscale=gscale[0], sums_out=sums[0])
+    ops.ce_fused(pred_s1.detach(), mw1, False, conf=cw1, ign=ig1, conf_thresh=thr, mc=mc1, dlogits=dls[:B],
+                 gscale=gscale[1], sums_out=sums[1])
+    ops.ce_fused(pred_s2.detach(), mw2, False, conf=cw2, ign=ig2, conf_thresh=thr, mc=mc2, dlogits=dls[B:],
+                 gscale=gscale[2], sums_out=sums[2])
+    ops.ce_fused(pred_w_fp.detach(), mask_w, False, conf=conf_w, ign=ign, conf_thresh=thr, mc=mclip,
+                 dlogits=dl4[3 * B:], gscale=gscale[3], sums_out=sums[3])
+    losses = ops.empty(8, device=dev)
+    ops.semivl_loss(sums, numel_u, lam, losses)
+    # backward (+ all-reduce) + optimizer
+    if optimizer is not None:
+        optimizer.zero_grad()
+    torch.autograd.backward([preds4, preds_s], [dl4, dls])
+    if reducer is not None:
+        reducer.reduce()
+    if optimizer is not None:
+        optimizer.step()
+        optimizer.poly_lr(iters, cfg.get("scheduler_max_iters", total_iters))
+    if return_aux:
+        aux = dict(mask_w=mask_w, mask_w_other=mask_w_other, mclip=mclip, mclip_other=mclip_other, conf_w=conf_w,
+                   pred_x=pred_x.detach(), pred_s1=pred_s1.detach(), dl4=dl4, dls=dls)
+        return losses, aux
+    return losses
+
+
+def _cat2i(a, b):
+    out = ops.empty(a.shape[0] + b.shape[0], *a.shape[1:], dtype=torch.int64, device=a.device)
+    # int64 maps: copy as pairs of fp32 words with the fp32 copy kernel
+    fa, fb = a.contiguous().view(torch.float32), b.contiguous().view(torch.float32)
+    fo = out.view(torch.float32).view(-1)
+    ops.eltwise(4, fa.view(-1), None, out=fo[:fa.numel()])
+    ops.eltwise(4, fb.view(-1), None, out=fo[fa.numel():])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def mmcv_param_groups(named_params, lr, weight_decay, custom_keys):
+    """mmcv 1.4.4 DefaultOptimizerConstructor semantics (recalled): one group per parameter; custom keys
+    sorted alphabetically then longest-first; the FIRST key contained in the parameter name sets lr_mult/decay_mult."""
+    keys = sorted(sorted(custom_keys.keys()), key=len, reverse=True)
+    out = []
+    for name, p in named_params:
+        g = dict(name=name, param=p, lr=lr, weight_decay=weight_decay)
+        for k in keys:
+            if k in name:
+                g["lr"] = lr * custom_keys[k].get("lr_mult", 1.0)
+                g["weight_decay"] = weight_decay * custom_keys[k].get("decay_mult", 1.0)
+                break
+        out.append(g)
+    return out
+
+
+class FusedAdamW:
+    """torch.optim.AdamW semantics over ONE flat fp32 arena: parameters, gradients (`main_grad` views the model's
+    backward writes into), exp_avg, exp_avg_sq; one svl_adamw_step launch per step (28 B/param of HBM traffic).
+
+    Only parameters that can receive a gradient are placed in the arena: `clip_encoder.*` (registered with
+    requires_grad=True in the reference, never given a grad — SURVEY App. E.2) and frozen backbone tensors are left
+    untouched, which is also what torch's AdamW does for params whose .grad is None.
+    """
+
+    def __init__(self, model, optimizer_cfg, ema_decay=None):
+        assert optimizer_cfg.get("type", "AdamW") == "AdamW"
+        self.lr, self.wd = optimizer_cfg["lr"], optimizer_cfg.get("weight_decay", 0.01)
+        self.betas, self.eps = optimizer_cfg.get("betas", (0.9, 0.999)), optimizer_cfg.get("eps", 1e-8)
+        ck = optimizer_cfg.get("paramwise_cfg", {}).get("custom_keys", {})
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.startswith("clip_encoder.")]
+        self.groups = mmcv_param_groups(named, self.lr, self.wd, ck)
+        dev = named[0][1].device
+        sizes = [g["param"].numel() for g in self.groups]
+        # 16-byte aligned segments
+        offs, o = [], 0
+        for s in sizes:
+            offs.append(o)
+            o += (s + 3) // 4 * 4
+        self.total = o
+        self.p = ops.zeros(self.total, device=dev)
+        self.g = ops.zeros(self.total, device=dev)
+        self.m = ops.zeros(self.total, device=dev)
+        self.v = ops.zeros(self.total, device=dev)
+        self.ema = None
+        for g_, off, s in zip(self.groups, offs, sizes):
+            prm = g_["param"]
+            view = self.p[off:off + s].view(prm.shape)
+            ops.eltwise(4, prm.data.contiguous().view(-1), None, out=view.view(-1))
+            prm.data = view
+            prm.main_grad = self.g[off:off + s].view(prm.shape)
+            g_["initial_lr"] = g_["lr"]
+        if ema_decay is not None:
+            self.ema = self.p.clone()
+        self.ema_decay = ema_decay or 0.0
+        self.seg_off = torch.tensor(offs + [self.total], dtype=torch.int64, device=dev)
+        self.seg_wd = torch.tensor([g_["weight_decay"] for g_ in self.groups], dtype=torch.float32, device=dev)
+        self._lr_host = torch.tensor([g_["lr"] for g_ in self.groups], dtype=torch.float32).pin_memory() \
+            if torch.cuda.is_available() else torch.tensor([g_["lr"] for g_ in self.groups], dtype=torch.float32)
+        self.seg_lr = self._lr_host.to(dev)
+        self.step_count = 0
+        self.grad_scale = 1.0
+
+    @property
+    def param_groups(self):
+        return self.groups
+
+    def zero_grad(self):
+        ops.fill(self.g, 0.0)
+
+    def step(self):
+        self.step_count += 1
+        ops.adamw_step(self.p, self.g, self.m, self.v, self.seg_off, self.seg_lr, self.seg_wd, len(self.groups),
+                       self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale, self.ema,
+                       self.ema_decay)
+
+    def poly_lr(self, iters, max_iters, power=0.9):
+        """semivl.py:343-345: applied after the step, for the next one."""
+        f = (1 - iters / max_iters) ** power
+        for i, g_ in enumerate(self.groups):
+            g_["lr"] = g_["initial_lr"] * f
+            self._lr_host[i] = g_["lr"]
+        self.seg_lr.copy_(self._lr_host, non_blocking=True)
+
+
+def build_optimizer(model, optimizer_cfg):
+    return FusedAdamW(model, optimizer_cfg)
+
+
+# ------------------------------------------------------------------------------------------------ data parallel
+class GradAllReducer:
+    """Data-parallel gradient mean over the flat grad arena (replaces DDP's reducer, semivl.py:139-140).
+
+    One process per GPU, `torch.distributed` backend 'nccl' (= RCCL over xGMI on ROCm; 'gloo' for the CPU tests).
+    The arena holds only the 31.4 M live gradients (125 MB) — the reference's DDP also reduces the 86.8 M
+    never-updated clip_encoder gradients.  The arena is cut into buckets and each bucket's all-reduce
+    is enqueued on a side stream as soon as it is issued, so bucket k+1's SUM overlaps bucket k's; the optimizer
+    divides by world_size inside its kernel (grad_scale) instead of a separate pass.
+    Loss normalisers stay per-rank as in the reference.
+    """
+
+    def __init__(self, optimizer, bucket_mb=32, group=None):
+        self.opt, self.group = optimizer, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        optimizer.grad_scale = 1.0 / self.world
+        n = optimizer.g.numel()
+        per = max(1, int(bucket_mb * 1024 * 1024 // 4))
+        self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
+        self.stream = torch.cuda.Stream() if optimizer.g.is_cuda else None
+
+    def broadcast_params(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.opt.p, src, group=self.group)
+
+    def reduce(self):
+        if self.world == 1:
+            return
+        g = self.opt.g
+        if self.stream is None:
+            for s, e in self.buckets:
+                dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            works = [dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                     for s, e in self.buckets]
+        for w in works:
+            w.wait()
+        torch.cuda.current_stream().wait_stream(self.stream)

@@ -1,0 +1,229 @@
+"""Golden-vector generator.  Runs ONLY in the build container: it imports the real reference modules from
+/root/reference (through tests/golden/_ref_shim.py for the un-vendored deps), drives them with a restatement of the
+semivl.py:223-328 loop body, checks the oracle restatement (oracle/semivl_oracle.py) against them, and writes small
+fixtures (inputs + expected outputs, never reference source) to tests/golden/*.npz.
+
+    python tests/golden/gen_golden.py            # regenerates fixtures, prints oracle-vs-reference deltas
+
+Fixture 'tiny'  : everything small; weights, inputs and all outputs are stored.
+Fixture 'vlgdim': real VLG decoder dims (channels 128, 4 heads of 64) on a tiny ViT; weights/inputs are regenerated
+                  from seeds (checksums stored), outputs stored.
+"""
+import os
+import runpy
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+TEXT = "configs/_base_/datasets/text_embedding/voc12_wbg_single.npy"
+MCC_TEXT = "configs/_base_/datasets/text_embedding/voc12_wbg_concept4_single.npy"
+
+CONFIGS = {
+    "tiny": dict(S=128, B=1, embed=64, layers=3, heads=4, out_indices=[0, 1, 3], channels=32, text_channels=32,
+                 dec_heads=1, up=(32, 16), skip=(16, 16), seed=11, conf_thresh=0.95),
+    "vlgdim": dict(S=128, B=1, embed=64, layers=3, heads=1, out_indices=[0, 1, 3], channels=128, text_channels=128,
+                   dec_heads=4, up=(64, 32), skip=(32, 16), seed=12, conf_thresh=0.058),
+}
+
+
+def seeded_state(named_shapes, seed):
+    """Deterministic non-trivial parameters: LN/GN gains 1+0.1n, biases 0.02n, cls/pos/weights 0.05n (conv/linear
+    fan-in scaled so activations stay O(1))."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shape in named_shapes:
+        r = torch.randn(*shape, generator=g)
+        leaf = name.split(".")[-1]
+        parent = name.split(".")[-2] if "." in name else ""
+        is_norm = parent.startswith("ln") or (leaf in ("weight", "bias") and len(shape) == 1 and
+                                              any(s in name for s in (".1.weight", ".1.bias", ".2.weight", ".2.bias",
+                                                                      ".4.weight", ".4.bias")))
+        if is_norm and leaf == "weight":
+            out[name] = 1.0 + 0.1 * r
+        elif leaf == "bias" or name.endswith("in_proj_bias"):
+            out[name] = 0.02 * r
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            out[name] = r * (1.0 / np.sqrt(fan_in))
+        else:
+            out[name] = 0.05 * r
+    return out
+
+
+def build_reference(c):
+    import model.vlm as ref_vlm  # noqa: registers VLM
+    import model.decode_heads.vlg_head  # noqa: registers VLGHead
+    import third_party.maskclip.models.backbones.maskclip_vit  # noqa: registers the ViT
+    from model.builder import forward_wrapper
+    import types
+    mcfg = runpy.run_path("configs/_base_/models/vlm-vlg-aspp-s2p4-sk04-ftap-mcvitb.py")["model"]
+    ccfg = runpy.run_path("configs/_base_/models/mcvit16.py")["backbone"]
+    S = c["S"]
+    for bb in (mcfg["backbone"], ccfg):
+        bb.update(img_size=(S, S), embed_dims=c["embed"], num_layers=c["layers"], num_heads=c["heads"])
+        bb.pop("pretrained", None)
+    mcfg["backbone"]["out_indices"] = c["out_indices"]
+    mcfg["decode_head"].update(img_size=S, num_classes=21, text_channels=c["text_channels"], up_channels=c["up"],
+                               skip_in_channels=(c["embed"], c["embed"]), skip_channels=c["skip"],
+                               num_heads=c["dec_heads"], channels=c["channels"])
+    mcfg.pop("type")
+    mcfg.pop("pretrained", None)
+    for bb in (mcfg["backbone"], ccfg):
+        bb.pop("type", None)
+    mcfg["backbone"]["type"] = "MaskClipVisionTransformer"
+    ccfg["type"] = "MaskClipVisionTransformer"
+    mcfg["decode_head"]["type"] = "VLGHead"
+    m = ref_vlm.VLM(load_text_embedding=TEXT, load_mcc_text_embedding=MCC_TEXT, load_pl_text_embedding=TEXT,
+                    clip_encoder=ccfg, maskclip_class_filter=None, **mcfg)
+    m.disable_dropout, m.fp_rate = True, 0.5
+    m.forward = types.MethodType(forward_wrapper, m)
+    return m
+
+
+class MaskFeeder:
+    """Replaces F.dropout2d's RNG by injected {0,1} channel masks (same scaling 1/(1-p))."""
+
+    def __init__(self, masks):
+        self.masks, self.i = masks, 0
+
+    def __call__(self, f, p=0.5, training=True, inplace=False):
+        m = self.masks[self.i % len(self.masks)]
+        self.i += 1
+        return f * m[:, :, None, None] / (1.0 - p)
+
+
+def main():
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    import _ref_shim
+    _ref_shim.install()
+    from oracle import semivl_oracle as O
+    from model.text_embeddings import get_class_to_concept_idxs
+    cls2con = get_class_to_concept_idxs(MCC_TEXT)
+    text = torch.from_numpy(np.load(TEXT))
+    mcc = torch.from_numpy(np.load(MCC_TEXT))
+
+    for name, c in CONFIGS.items():
+        torch.manual_seed(c["seed"])
+        ref = build_reference(c)
+        shapes = [(k, tuple(v.shape)) for k, v in ref.state_dict().items()]
+        sd = seeded_state(shapes, c["seed"])
+        ref.load_state_dict(sd, strict=True)
+
+        orc = O.build_vlm(dict(nclass=21, crop=c["S"], embed=c["embed"], layers=c["layers"], heads=c["heads"],
+                               out_indices=tuple(c["out_indices"]), channels=c["channels"],
+                               text_channels=c["text_channels"], up=c["up"], skip_in=(c["embed"], c["embed"]),
+                               skip=c["skip"]), text, mcc, cls2con)
+        if c["dec_heads"] != 4:
+            for lyr in orc.decode_head.layers:
+                lyr.transformer.attn.attn.num_heads = c["dec_heads"]
+        missing = orc.load_state_dict(sd, strict=True)
+
+        B, S = c["B"], c["S"]
+        batch = O.synthetic_batch(B, S, 21, seed=1234 + c["seed"])
+        g = torch.Generator().manual_seed(c["seed"] + 100)
+        fp_masks = [(torch.rand(2 * B, ch, generator=g) > 0.5).float() for ch in (c["embed"], c["embed"], 512)]
+        total_iters, iters = 100, 10
+
+        # ---- reference run (its modules, the restated loop) ---------------------------------------------
+        def run(model, is_ref):
+            model.zero_grad()
+            if is_ref:
+                feeder = MaskFeeder(fp_masks)
+                orig = F.dropout2d
+                F.dropout2d = feeder
+                try:
+                    class Adapter:
+                        def __init__(s, m):
+                            s.m = m
+                        def eval(s):
+                            s.m.eval()
+                        def train(s):
+                            s.m.train()
+                        def __call__(s, img, need_fp=False, fp_masks=None):
+                            return s.m(img, need_fp=need_fp)
+                        def forward_maskclip(s, img, t):
+                            return s.m.forward_maskclip(img, t)
+                    loss, aux = O.semivl_step(Adapter(model), batch, iters, total_iters, conf_thresh=c["conf_thresh"],
+                                              fp_masks=fp_masks)
+                finally:
+                    F.dropout2d = orig
+            else:
+                loss, aux = O.semivl_step(model, batch, iters, total_iters, conf_thresh=c["conf_thresh"], fp_masks=fp_masks)
+            loss.backward()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            return loss.detach(), aux, grads
+
+        rl, raux, rg = run(ref, True)
+        ol, oaux, og = run(orc, False)
+        print(f"[{name}] loss ref {rl.item():.8f} oracle {ol.item():.8f}  |d| {abs(rl.item() - ol.item()):.2e}")
+        for k in ("loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "loss_mc_s2", "loss_mc_fp"):
+            print(f"    {k:11s} ref {raux[k].item():.8f}  |d| {abs(raux[k].item() - oaux[k].item()):.2e}")
+        for k in ("mask_w", "mask_w_other", "mclip", "mclip_other"):
+            assert torch.equal(raux[k], oaux[k]), f"{k} differs"
+        print("    frac conf_w >= thr:", (raux["conf_w"] >= c["conf_thresh"]).float().mean().item())
+        print("    label maps bit-exact; conf_w |d|", (raux["conf_w"] - oaux["conf_w"]).abs().max().item(),
+              " pred_x |d|", (raux["pred_x"] - oaux["pred_x"]).abs().max().item())
+        assert set(rg) == set(og), (set(rg) ^ set(og))
+        worst = max(((rg[k] - og[k]).abs().max() / (rg[k].abs().max() + 1e-12)).item() for k in rg)
+        print(f"    {len(rg)} grads, worst rel max-err {worst:.2e}; trainable ref={sum(p.requires_grad for p in ref.parameters())}")
+        assert worst < 1e-4
+
+        # eval forward + maskclip on img_x for completeness
+        ref.eval()
+        with torch.no_grad():
+            logits_eval = ref(batch["img_x"])
+            mclip_x = ref.forward_maskclip(batch["img_x"], 0.9)
+
+        # one AdamW step with the reference hyper-parameters (exp 40): lr 1e-4, wd 0.01, backbone x0.01, head x10
+        ck = dict(backbone=dict(lr_mult=0.01), text_encoder=dict(lr_mult=0.0), conv_encoder=dict(lr_mult=1.0),
+                  norm=dict(decay_mult=0.0), ln=dict(decay_mult=0.0), head=dict(lr_mult=10.0))
+        groups = [gr for gr in O.param_groups(ref, 1e-4, 0.01, ck) if gr["params"][0].grad is not None]
+        names = [gr.pop("name") for gr in groups]
+        opt = torch.optim.AdamW(groups, lr=1e-4, weight_decay=0.01)
+        opt.step()
+        after = {k: v.detach().clone() for k, v in ref.state_dict().items() if k in rg}
+
+        out = dict(
+            cfg=np.array(repr(c)), iters=np.array([iters, total_iters]),
+            loss=rl.numpy(), **{k: raux[k].detach().numpy() for k in ("loss_x", "loss_s1", "loss_s2", "loss_fp",
+                                                                       "loss_mc_s1", "loss_mc_s2", "loss_mc_fp")},
+            mask_w=raux["mask_w"].numpy().astype(np.uint8), mask_w_other=raux["mask_w_other"].numpy().astype(np.uint8),
+            mclip=raux["mclip"].numpy().astype(np.uint8), mclip_other=raux["mclip_other"].numpy().astype(np.uint8),
+            conf_w=raux["conf_w"].numpy().astype(np.float32),
+            pred_x_s4=raux["pred_x"].detach()[:, :, ::4, ::4].numpy(), logits_eval_s4=logits_eval[:, :, ::4, ::4].numpy(),
+            mclip_x=mclip_x.numpy().astype(np.uint8),
+            fp_masks=np.concatenate([m.numpy().ravel() for m in fp_masks]).astype(np.uint8),
+            grad_names=np.array(sorted(rg)), opt_group_lr=np.array([gr["lr"] for gr in groups]),
+            opt_group_wd=np.array([gr["weight_decay"] for gr in groups]), opt_group_names=np.array(names),
+        )
+        for k in sorted(rg):
+            out["gnorm/" + k] = np.array([rg[k].norm().item(), rg[k].flatten()[0].item(), rg[k].flatten()[-1].item()])
+            out["after/" + k] = np.array([after[k].double().sum().item(), after[k].flatten()[0].item(),
+                                          after[k].flatten()[-1].item()])
+        if name == "tiny":
+            for k, v in sd.items():
+                out["w/" + k] = v.numpy()
+            for k, v in batch.items():
+                out["in/" + k] = v.numpy() if v.dtype != torch.int64 else v.numpy().astype(np.uint8)
+            for k in sorted(rg):
+                out["grad/" + k] = rg[k].numpy()
+        else:
+            out["w_checksum"] = np.array([sum(v.double().sum().item() for v in sd.values()),
+                                          sum(v.double().abs().sum().item() for v in sd.values())])
+            out["in_checksum"] = np.array([sum(v.double().sum().item() for v in batch.values())])
+        path = os.path.join(HERE, f"semivl_{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"    wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+if __name__ == "__main__":
+    main()

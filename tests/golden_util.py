@@ -1,0 +1,113 @@
+"""Shared helpers for the golden-fixture tests (no reference access: fixtures + seeds only)."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TEXT = "configs/_base_/datasets/text_embedding/voc12_wbg_single.npy"
+MCC_TEXT = "configs/_base_/datasets/text_embedding/voc12_wbg_concept4_single.npy"
+PKG = os.path.join(os.path.dirname(HERE), "semivl_amd")
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(HERE, "golden", f"semivl_{name}.npz"), allow_pickle=False)
+    cfg = ast.literal_eval(str(z["cfg"]))
+    return z, cfg
+
+
+def seeded_state(named_shapes, seed):
+    """Must stay in lock-step with tests/golden/gen_golden.py::seeded_state."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shape in named_shapes:
+        r = torch.randn(*shape, generator=g)
+        leaf = name.split(".")[-1]
+        parent = name.split(".")[-2] if "." in name else ""
+        is_norm = parent.startswith("ln") or (leaf in ("weight", "bias") and len(shape) == 1 and
+                                              any(s in name for s in (".1.weight", ".1.bias", ".2.weight", ".2.bias",
+                                                                      ".4.weight", ".4.bias")))
+        if is_norm and leaf == "weight":
+            out[name] = 1.0 + 0.1 * r
+        elif leaf == "bias" or name.endswith("in_proj_bias"):
+            out[name] = 0.02 * r
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            out[name] = r * (1.0 / np.sqrt(fan_in))
+        else:
+            out[name] = 0.05 * r
+    return out
+
+
+def text_feats():
+    t = torch.from_numpy(np.load(os.path.join(PKG, TEXT)))
+    m = torch.from_numpy(np.load(os.path.join(PKG, MCC_TEXT)))
+    return t, m
+
+
+def build_oracle(c):
+    from oracle import semivl_oracle as O
+    from semivl_amd.model.text_embeddings import get_class_to_concept_idxs
+    t, m = text_feats()
+    orc = O.build_vlm(dict(nclass=21, crop=c["S"], embed=c["embed"], layers=c["layers"], heads=c["heads"],
+                           out_indices=tuple(c["out_indices"]), channels=c["channels"],
+                           text_channels=c["text_channels"], up=c["up"], skip_in=(c["embed"], c["embed"]),
+                           skip=c["skip"]), t, m, get_class_to_concept_idxs(MCC_TEXT))
+    for lyr in orc.decode_head.layers:
+        lyr.transformer.attn.attn.num_heads = c["dec_heads"]
+    return orc
+
+
+def build_hip(c):
+    """The product model with the fixture's (tiny) dimensions, built through the same cfg-dict constructors."""
+    from semivl_amd.model.builder import VLM, builtin_model_cfg
+    import copy
+    mcfg = copy.deepcopy(builtin_model_cfg("vlm-vlg-aspp-s2p4-sk04-ftap-mcvitb"))["model"]
+    ccfg = copy.deepcopy(builtin_model_cfg("mcvit16"))["backbone"]
+    S = c["S"]
+    for bb in (mcfg["backbone"], ccfg):
+        bb.update(img_size=(S, S), embed_dims=c["embed"], num_layers=c["layers"], num_heads=c["heads"])
+        bb.pop("pretrained", None)
+    mcfg["backbone"]["out_indices"] = c["out_indices"]
+    mcfg["decode_head"].update(img_size=S, num_classes=21, text_channels=c["text_channels"], up_channels=c["up"],
+                               skip_in_channels=(c["embed"], c["embed"]), skip_channels=c["skip"],
+                               num_heads=c["dec_heads"], channels=c["channels"])
+    mcfg.pop("type")
+    mcfg.pop("pretrained", None)
+    return VLM(load_text_embedding=TEXT, load_mcc_text_embedding=MCC_TEXT, load_pl_text_embedding=TEXT,
+               clip_encoder=ccfg, maskclip_class_filter=None, **mcfg)
+
+
+def fixture_state(z, c, model):
+    if "w_checksum" in z.files:
+        shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        sd = seeded_state(shapes, c["seed"])
+        chk = np.array([sum(v.double().sum().item() for v in sd.values()),
+                        sum(v.double().abs().sum().item() for v in sd.values())])
+        assert np.allclose(chk, z["w_checksum"], rtol=0, atol=1e-6), "seeded weight stream differs from the fixture's"
+        return sd
+    return {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}
+
+
+def fixture_batch(z, c):
+    from oracle import semivl_oracle as O
+    if "in_checksum" in z.files:
+        batch = O.synthetic_batch(c["B"], c["S"], 21, seed=1234 + c["seed"])
+        chk = sum(v.double().sum().item() for v in batch.values())
+        assert abs(chk - float(z["in_checksum"][0])) < 1e-6, "seeded input stream differs from the fixture's"
+        return batch
+    out = {}
+    for k in z.files:
+        if k.startswith("in/"):
+            v = torch.from_numpy(z[k])
+            out[k[3:]] = v.long() if v.dtype == torch.uint8 else v
+    return out
+
+
+def fixture_fp_masks(z, c):
+    flat = torch.from_numpy(z["fp_masks"]).float()
+    B = c["B"]
+    sizes = [2 * B * c["embed"], 2 * B * c["embed"], 2 * B * 512]
+    parts = flat.split(sizes)
+    return [p.view(2 * B, -1) for p in parts]
