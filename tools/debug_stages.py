@@ -62,3 +62,18 @@ with torch.no_grad():
     cmp('final logits', out, fin)
     full = hip(img.to(dev))
     cmp('hip(img) vs oracle(img)', full, orc(img))
+    # ---- inside up2
+    U = H.up2
+    uu = U.up(u1)
+    a = sv['up2']['a']; bq = sv['up2']['b']
+    cmp('up2.convT', nhwc(a['x'], B*N, 4*hp), uu)
+    sk = F.interpolate(skips[1], size=uu.shape[-2:], mode='bilinear', align_corners=True)
+    cmp('up2.skip_up', nhwc(a['src2'], B, 4*hp), sk)
+    catu = torch.cat([uu, sk.repeat_interleave(N, 0)], 1)
+    pre = U.conv[0](catu)
+    cmp('up2.conv0 pre-GN', nhwc(a['pre'], B*N, 4*hp), pre)
+    y0 = U.conv[2](U.conv[1](pre))
+    cmp('up2.gn0+relu', nhwc(a['y'], B*N, 4*hp), y0)
+    pre1 = U.conv[3](y0)
+    cmp('up2.conv1 pre-GN', nhwc(bq['pre'], B*N, 4*hp), pre1)
+    cmp('up2.gn1+relu', nhwc(bq['y'], B*N, 4*hp), U.conv[5](U.conv[4](pre1)))
