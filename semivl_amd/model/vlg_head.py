@@ -238,9 +238,9 @@ def _head_forward(m, hw, fp_masks, fp_rate, out_size, text, feats, sv):
         skip_sv.append(dict(x=f, wd=wd, y=sk, Cs=Cs))
     # ---- upsampling ------------------------------------------------------------------------------------------
     s_up1 = {} if sv is not None else None
-    g2 = _up_forward(m.up1, x, imgs, h, w, skips[0], b, N, s_up1)
+    g2 = _up_forward(m.up1, x, imgs, h, w, skips[0], h, w, b, N, s_up1)
     s_up2 = {} if sv is not None else None
-    g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], b, N, s_up2)
+    g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], h, w, b, N, s_up2)
     C4 = g4.shape[1]
     whf, whd = ops.pack_conv_w(m.head.weight)
     lg = ops.conv_fwd(g4, C4, imgs, 4 * h, 4 * w, C4, whf, 1, 3, 3, 1, 1, bias=m.head.bias)  # [(b n), 4h, 4w, 1]
@@ -319,8 +319,8 @@ def _semtr_backward(lyr, dx, dtp_acc, imgs, b, N, h, w, Ch, Ct, sv, gc):
     return ops.add(dx, dxin_pool, out=dxin_pool)
 
 
-def _up_forward(up, x, imgs, h, w, skip, b, N, sv):
-    """vlg_head.py:129-137.  x [(b n) h w, Cin]; skip [b h w, Cs] -> [(b n) 2h 2w, Cout]."""
+def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv):
+    """vlg_head.py:129-137.  x [(b n) h w, Cin]; skip [b sh sw, Cs] -> [(b n) 2h 2w, Cout]."""
     Cin = up.up.weight.shape[0]
     Cu = up.up.weight.shape[1]
     Cs = skip.shape[1]
@@ -329,26 +329,26 @@ def _up_forward(up, x, imgs, h, w, skip, b, N, sv):
     u = ops.empty(imgs * 4 * h * w, Cu, device=dev)
     ops.convT2x_fwd(x, Cin, imgs, h, w, Cin, wp_, Cu, up.up.bias, u, Cu)
     sup = ops.empty(b * 4 * h * w, Cs, device=dev)
-    ops.bilinear_nhwc_fwd(skip, Cs, b, h, w, Cs, True, 1, 2 * h, 2 * w, sup, Cs)
+    ops.bilinear_nhwc_fwd(skip, Cs, b, sh, sw, Cs, True, 1, 2 * h, 2 * w, sup, Cs)
     sa = {} if sv is not None else None
     g1 = _conv_gn_fwd(u, Cu, imgs, 2 * h, 2 * w, Cu, up.conv[0], up.conv[1], 3, 1, sa, src2=sup, ld2=Cs, C2=Cs, rep=N)
     sb = {} if sv is not None else None
     g2 = _conv_gn_fwd(g1, g1.shape[1], imgs, 2 * h, 2 * w, g1.shape[1], up.conv[3], up.conv[4], 3, 1, sb)
     if sv is not None:
-        sv.update(x=x, wp=wp_, a=sa, b=sb, dims=(Cin, Cu, Cs))
+        sv.update(x=x, wp=wp_, a=sa, b=sb, dims=(Cin, Cu, Cs, sh, sw))
     return g2
 
 
 def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
     """Returns (dx [(b n) h w, Cin], dskip [b h w, Cs])."""
-    Cin, Cu, Cs = sv["dims"]
+    Cin, Cu, Cs, sh, sw = sv["dims"]
     dev = dg2.device
     dg1 = _conv_gn_bwd(dg2, dg2.shape[1], up.conv[3], up.conv[4], sv["b"], gc)
     dcat = _conv_gn_bwd(dg1, dg1.shape[1], up.conv[0], up.conv[1], sv["a"], gc)  # [pix, Cu + Cs]
     ld = Cu + Cs
     # skip half: sum over the N repeats, then bilinear backward
-    dskip = ops.empty(b * h * w, Cs, device=dev)
-    ops.bilinear_nhwc_bwd(dcat[:, Cu:], ld, b, h, w, Cs, True, N, 2 * h, 2 * w, dskip, Cs)
+    dskip = ops.empty(b * sh * sw, Cs, device=dev)
+    ops.bilinear_nhwc_bwd(dcat[:, Cu:], ld, b, sh, sw, Cs, True, N, 2 * h, 2 * w, dskip, Cs)
     # ConvTranspose half
     gc.put(up.up.bias, lambda d, acc: ops.colsum(dcat, out=d, accumulate=acc, C_=Cu, ld=ld))
     dwb = ops.convT2x_wgrad(sv["x"], Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
