@@ -81,8 +81,10 @@ def test_train_step_matches_reference_fixture(dev, name):
     for k, g in grads.items():
         ref = z["gnorm/" + k]
         rel = abs(g.norm().item() - ref[0]) / max(ref[0], 1e-8)
-        worst = max(worst, rel)
-        assert rel < 2e-3, f"grad norm of {k}: {g.norm().item()} vs {ref[0]}"
+        # (head.bias' gradient is sum(softmax - onehot) ~ 0: pure cancellation noise, hence the absolute floor)
+        if ref[0] > 1e-6:
+            worst = max(worst, rel)
+        assert abs(g.norm().item() - ref[0]) < 2e-3 * ref[0] + 1e-7, f"grad norm of {k}: {g.norm().item()} vs {ref[0]}"
         if ("grad/" + k) in z.files:
             full = z["grad/" + k]
             e = np.abs(g.cpu().numpy() - full).max() / max(np.abs(full).max(), 1e-6)
