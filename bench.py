@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""SemiVL training-step benchmark on MI355X (BASELINE.json metric: train images/sec, 512^2, ViT-B/16).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full iteration of semivl.py:223-345 on one synthetic batch per rank: CutMix, pseudo-label
+forward, MaskCLIP guidance on the frozen CLIP encoder, the two grad-carrying forwards (need_fp + strong), the fused
+per-pixel losses, backward through the VLG head and the ViT, gradient all-reduce (RCCL) and the fused AdamW step.
+images/s := (B_labeled + B_unlabeled) * world / t_step = 2*B*W / t_step, inputs resident in HBM.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per step per unit batch, VOC N=21, 512^2
+VIT_GF_PER_UNIT_B = 2866.6      # 5 ViT fwd (231.0) + 2 frozen fwd (209.2) + 4 bwd (323.3) GFLOP
+DEC_GF_PER_UNIT_B = 1322.0      # 7 decoder fwd + 6 x 2 fwd-equivalents bwd, 69.6 GFLOP/img
+PEAK_F32_MFMA_TF = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="labeled (= unlabeled) images per GPU per step")
+    ap.add_argument("--crop", type=int, default=512)
+    ap.add_argument("--nclass", type=int, default=21)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(crop, nclass):
+    """The oracle restatement (kind 'port') on the host cores, bounded sample: ONE step at bs=1 of the same workload."""
+    from oracle import semivl_oracle as O
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    text, mcc = O.synthetic_text(nclass), O.synthetic_text(nclass, seed=8)
+    model = O.build_vlm(dict(nclass=nclass, crop=crop), text, mcc)
+    model.backbone.init_weights_()
+    model.clip_encoder.init_weights_()
+    batch = O.synthetic_batch(1, crop, nclass, seed=1234)
+    params = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith("clip_encoder")]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
+    t0 = time.time()
+    loss, _ = O.semivl_step(model, batch, 0, 100)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    dt = time.time() - t0
+    return dict(value=2.0 / dt, unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 full SemiVL step of oracle/semivl_oracle.py (PyTorch CPU fp32) at VOC N={nclass}, {crop}x{crop}, "
+                       f"bs=1 (2 images/step), {dt:.1f} s")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X; the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from semivl_amd import ops
+    from semivl_amd.model.builder import build_model
+    from semivl_amd.synthetic import exp40_cfg, synthetic_batch
+    from semivl_amd.train import FusedAdamW, GradAllReducer, semivl_train_step
+
+    dataset = {21: "pascal", 81: "coco", 150: "ade", 19: "cityscapes"}.get(a.nclass, "pascal")
+    cfg = exp40_cfg(a.batch, a.crop, a.nclass, dataset)
+    torch.manual_seed(1234)  # identical random init on every rank (no pretrained CLIP offline)
+    model = build_model(cfg).to(dev)
+    opt = FusedAdamW(model, cfg["optimizer"])
+    red = GradAllReducer(opt)
+    red.broadcast_params()
+    batch = synthetic_batch(a.batch, a.crop, a.nclass, seed=1234 + rank, device=dev)
+    total_iters = 10000
+
+    def step(i):
+        return semivl_train_step(model, batch, i, total_iters, cfg, optimizer=opt, reducer=red)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        losses = step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_val = float(losses[0].item())
+    ms = dt / a.steps * 1e3
+    ips = 2.0 * a.batch * world / (dt / a.steps)
+
+    out = dict(metric="train images/sec (512^2, ViT-B/16)", value=round(ips, 3), unit="images/s", n_gpus=world,
+               steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 2), higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=f"SemiVL step, VOC12-style N={a.nclass}, ViT-B/16 + VLG head, {a.crop}x{a.crop}, "
+                                    f"bs={a.batch}/GPU labeled + {a.batch}/GPU unlabeled (BASELINE configs[1])",
+                           global_batch=2 * a.batch * world, parallelism=f"dp{world}", loss=round(loss_val, 5),
+                           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)))
+
+    # ---- roofline of the dominant kernel family (fp32-MFMA GEMM / implicit-GEMM), measured live with HIP events ----
+    if rank == 0 and not a.no_profile:
+        ops.PROFILE = {}
+        step(a.warmup + a.steps)
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        g = prof.get("gemm", [])
+        t_gemm = sum(e0.elapsed_time(e1) for e0, e1, _, _ in g) * 1e-3
+        executed = sum(w for _, _, w, _ in g)
+        algo = (VIT_GF_PER_UNIT_B + DEC_GF_PER_UNIT_B) * 1e9 * a.batch if (a.nclass == 21 and a.crop == 512) else executed
+        ach = algo / t_gemm / 1e12
+        out["roofline"] = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
+                               frac=round(ach / PEAK_F32_MFMA_TF, 4), traffic=None,
+                               kernel="gemm_kernel (svl_gemm_f32, v_mfma_f32_32x32x2_f32)", launches=len(g),
+                               kernel_time_ms=round(t_gemm * 1e3, 2),
+                               executed_tflops=round(executed / t_gemm / 1e12, 2),
+                               note="achieved = algorithmic FLOPs of one step (SURVEY §8(d): (2866.6+1322.0) GF x B) / "
+                                    "summed duration of all svl_gemm_f32 launches of one step (HIP events on the launch stream)")
+        # largest single launch shapes
+        by = {}
+        for e0, e1, w, tag in g:
+            r = by.setdefault(tag, [0.0, 0.0, 0])
+            r[0] += e0.elapsed_time(e1) * 1e-3
+            r[1] += w
+            r[2] += 1
+        top = sorted(by.items(), key=lambda kv: -kv[1][0])[:6]
+        out["roofline"]["top_shapes"] = [dict(mode_MNKb=list(k), ms=round(v[0] * 1e3, 2), n=v[2],
+                                              tflops=round(v[1] / v[0] / 1e12, 1)) for k, v in top]
+        c = prof.get("ce_fused", [])
+        if c:
+            t_ce = sum(e0.elapsed_time(e1) for e0, e1, _, _ in c) * 1e-3
+            by_ce = sum(w for _, _, w, _ in c)
+            out["roofline_hbm"] = dict(bound="hbm", kernel="ce_fused_kernel (svl_ce_fused_f32)",
+                                       achieved=round(by_ce / t_ce / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                                       frac=round(by_ce / t_ce / 1e9 / PEAK_HBM_GBS, 4), traffic=None, launches=len(c),
+                                       note="algorithmic bytes (12N+40) B/px per fwd+bwd branch (SURVEY §8(d))")
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(a.crop, a.nclass)
+        except Exception as e:  # the baseline leg must never take the GPU number down with it
+            out["cpu_baseline"] = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port",
+                                       sample=f"failed: {type(e).__name__}: {e}")
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

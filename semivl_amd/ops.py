@@ -20,6 +20,27 @@ def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional live kernel timing (bench.py): PROFILE = {} enables HIP-event brackets around the launches of the kernel
+# families we report rooflines for.  Events are recorded on the launch stream (torch's current stream).
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(name, e0, work, tag=None):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.setdefault(name, []).append((e0, e1, work, tag))
+
+
 def _p(t):
     if t is None:
         return None
@@ -73,7 +94,9 @@ def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batc
         d.ldr_m = ldr_m if ldr_m is not None else d.ldc_m
         d.ldr_n, d.r_bs_outer, d.r_bs_inner = ldr_n, r_bso, r_bsi
     d.accumulate = 1 if accumulate else 0
+    e0 = _prof_begin()
     L.check(L.load().svl_gemm_f32(C.byref(d), _st()), "svl_gemm_f32")
+    _prof_end("gemm", e0, 2.0 * M * N * K * (1 if ksplit > 0 else batch), (a_mode, b_mode, M, N, K, batch))
 
 
 def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld2=0, patch=0, stride=1, Ho=0, Wo=0):
@@ -465,7 +488,9 @@ def softmax_max(logits):
     HW = logits[0, 0].numel()
     conf = empty(Bn, *logits.shape[2:], device=logits.device)
     label = empty(Bn, *logits.shape[2:], dtype=torch.int64, device=logits.device)
+    e0 = _prof_begin()
     L.check(L.load().svl_softmax_max_f32(_p(logits), Bn, N, HW, _p(conf), _p(label), _st()), "svl_softmax_max_f32")
+    _prof_end("softmax_max", e0, float(Bn * HW) * (4 * N + 12), (Bn, N, HW))
     return conf, label
 
 
@@ -504,7 +529,10 @@ def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0,
     partials = empty(nblk, 4, device=logits.device)
     d = L.CeDesc(_p(logits), Bn, N, HW, _p(target), 1 if use_ignore_t else 0, _p(conf), _p(ign), float(conf_thresh),
                  _p(mc), _p(partials), _p(dlogits), _p(gscale))
+    e0 = _prof_begin()
     L.check(lib.svl_ce_fused_f32(C.byref(d), _st()), "svl_ce_fused_f32")
+    # algorithmic bytes: fwd (4N+20) + bwd (8N+20) B/px when dlogits is produced, else fwd only
+    _prof_end("ce_fused", e0, float(Bn * HW) * ((12 * N + 40) if dlogits is not None else (4 * N + 20)), (Bn, N, HW))
     if sums_out is None:
         sums_out = empty(4, dtype=torch.float64, device=logits.device)
     L.check(lib.svl_ce_finalize(_p(partials), nblk, _p(sums_out), _st()), "svl_ce_finalize")
