@@ -7,6 +7,8 @@ import ctypes as C
 import os
 import subprocess
 
+import torch  # noqa: F401  (must be imported BEFORE the .so so that both share torch's HIP runtime, not /opt/rocm's copy)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsemivl_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
