@@ -45,7 +45,7 @@ def cpu_baseline(crop, nclass):
     """The oracle restatement (kind 'port') on the host cores, bounded sample: ONE step at bs=1 of the same workload."""
     from oracle import semivl_oracle as O
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)  # the CPU path stops scaling (and oversubscribes) beyond ~16 threads at bs=1
     torch.set_num_threads(cores)
     text, mcc = O.synthetic_text(nclass), O.synthetic_text(nclass, seed=8)
     model = O.build_vlm(dict(nclass=nclass, crop=crop), text, mcc)

@@ -17,6 +17,7 @@
 // Operand addressing modes make the same kernel an implicit-GEMM convolution (NHWC, stride 1, dilation,
 // optional second concatenated source), the patch-embedding gather, conv wgrad (im2col^T) and split-K.
 #include "svl_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -49,6 +50,14 @@ struct GemmP {
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int I, int N_, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N_) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N_>(f);
+  }
+}
 
 // Guarded 4-element load along the contiguous direction: elements [0, nvalid) are read.
 __device__ __forceinline__ float4 load4(const float* ptr, int nvalid, bool vec) {
@@ -177,6 +186,64 @@ __device__ __forceinline__ float4 load_piece(const OperandP& op, const svl_conv_
   }
 }
 
+// Interior-tile fast path: every row of the panel is in range, the K panel is a full BK, and 16-byte vector loads
+// are legal -> no per-element guards (conv taps still mask their halo with ONE predicated float4 load).
+template <int IS_A, int MODE, int ROWS>
+__device__ __forceinline__ float4 load_piece_fast(const OperandP& op, const svl_conv_geom& cv, const float* base, int f,
+                                                  int row0, int k0) {
+  constexpr int shape = ModeTraits<IS_A, MODE>::shape;
+  if constexpr (shape == LS_KMAJOR) {
+    const int row = row0 + (f >> 2);
+    const int k = k0 + ((f & 3) << 2);
+    if constexpr (MODE == 0) {
+      return *reinterpret_cast<const float4*>(base + (long)row * op.ld + k);
+    } else if constexpr (IS_A && MODE == SVL_A_CONV) {
+      const int Ct = cv.C1 + cv.C2;
+      const int ow = (row % cv.Wo) * cv.stride;
+      const int t = row / cv.Wo;
+      const int oh = (t % cv.Ho) * cv.stride;
+      const int img = t / cv.Ho;
+      const int tap = k / Ct, ci = k - tap * Ct;
+      const int ti = tap / cv.KW, tj = tap - ti * cv.KW;
+      const int ih = oh + cv.sign * (ti * cv.dil - cv.pad);
+      const int iw = ow + cv.sign * (tj * cv.dil - cv.pad);
+      if (ih < 0 || ih >= cv.H || iw < 0 || iw >= cv.W) return zero4();
+      return *reinterpret_cast<const float4*>(conv_src(op, cv, img, ih, iw, ci));
+    } else {
+      const int P = cv.patch;
+      const int npx = cv.W / P, npy = cv.H / P;
+      const int px = row % npx;
+      const int t = row / npx;
+      const int py = t % npy;
+      const int img = t / npy;
+      const int c = k / (P * P);
+      const int r2 = k - c * P * P;
+      const int i = r2 / P, j = r2 - i * P;
+      return *reinterpret_cast<const float4*>(base + (((long)img * cv.C1 + c) * cv.H + (py * P + i)) * cv.W + px * P + j);
+    }
+  } else {
+    constexpr int RP = ROWS / 4;
+    const int kk = f / RP;
+    const int row = row0 + ((f % RP) << 2);
+    const int k = k0 + kk;
+    if constexpr (MODE == 1) {
+      return *reinterpret_cast<const float4*>(base + (long)k * op.ld + row);
+    } else {
+      const int Ct = cv.C1 + cv.C2;
+      const int ow = (k % cv.Wo) * cv.stride;
+      const int t = k / cv.Wo;
+      const int oh = (t % cv.Ho) * cv.stride;
+      const int img = t / cv.Ho;
+      const int tap = row / Ct, ci = row - tap * Ct;
+      const int ti = tap / cv.KW, tj = tap - ti * cv.KW;
+      const int ih = oh + cv.sign * (ti * cv.dil - cv.pad);
+      const int iw = ow + cv.sign * (tj * cv.dil - cv.pad);
+      if (ih < 0 || ih >= cv.H || iw < 0 || iw >= cv.W) return zero4();
+      return *reinterpret_cast<const float4*>(conv_src(op, cv, img, ih, iw, ci));
+    }
+  }
+}
+
 template <int SHAPE, int ROWS, int LD>
 __device__ __forceinline__ void store_piece(float* S, int f, float4 v) {
   if constexpr (SHAPE == LS_KMAJOR) {
@@ -214,7 +281,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const int l31 = lane & 31, hi = lane >> 5;
   const int wr = wave / WC, wc = wave % WC;
 
-  const int tile = blockIdx.x;
+  // XCD-aware tile map (bijective): workgroup b runs on XCD b % 8; give every XCD a CONTIGUOUS range of tiles so the
+  // tiles that share an A row-panel (n-fastest order) hit the same 4 MiB L2 (cdna_hip_programming.md T1).
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, xcd = tile & 7, q = nt >> 3, r = nt & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
+  }
   const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
   const int m0 = tm_i * BM, n0 = tn_i * BN;
   const int z = blockIdx.z;
@@ -241,18 +314,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 
   float4 ra[APASS], rb[BPASS];
 
+  // A's "rows" are m (or, for the RMAJOR shapes, the contiguous direction); interior tiles take the unguarded path.
+  const bool a_int = p.A.vec && (m0 + BM <= p.M);
+  const bool b_int = p.B.vec && (n0 + BN <= p.N);
   auto g_load = [&](int k0) {
+    const bool kfull = (k0 + BK <= kend);
+    if (a_int && kfull) {
 #pragma unroll
-    for (int ps = 0; ps < APASS; ++ps) {
-      const int f = tid + ps * 256;
-      if (APIECES % 256 == 0 || f < APIECES)
-        ra[ps] = load_piece<1, AMODE, BM>(p.A, p.cv, Abase, f, m0, p.M, k0, kend);
+      for (int ps = 0; ps < APASS; ++ps) {
+        const int f = tid + ps * 256;
+        if (APIECES % 256 == 0 || f < APIECES) ra[ps] = load_piece_fast<1, AMODE, BM>(p.A, p.cv, Abase, f, m0, k0);
+      }
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < APASS; ++ps) {
+        const int f = tid + ps * 256;
+        if (APIECES % 256 == 0 || f < APIECES)
+          ra[ps] = load_piece<1, AMODE, BM>(p.A, p.cv, Abase, f, m0, p.M, k0, kend);
+      }
     }
+    if (b_int && kfull) {
 #pragma unroll
-    for (int ps = 0; ps < BPASS; ++ps) {
-      const int f = tid + ps * 256;
-      if (BPIECES % 256 == 0 || f < BPIECES)
-        rb[ps] = load_piece<0, BMODE, BN>(p.B, p.cv, Bbase, f, n0, p.N, k0, kend);
+      for (int ps = 0; ps < BPASS; ++ps) {
+        const int f = tid + ps * 256;
+        if (BPIECES % 256 == 0 || f < BPIECES) rb[ps] = load_piece_fast<0, BMODE, BN>(p.B, p.cv, Bbase, f, n0, k0);
+      }
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < BPASS; ++ps) {
+        const int f = tid + ps * 256;
+        if (BPIECES % 256 == 0 || f < BPIECES)
+          rb[ps] = load_piece<0, BMODE, BN>(p.B, p.cv, Bbase, f, n0, p.N, k0, kend);
+      }
     }
   };
   auto s_store = [&](int buf) {
@@ -282,19 +375,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     if (kt + 1 < nk) g_load(kbeg + (kt + 1) * BK);
     const float* Ac = As + buf * BK * LDA + wr * WTM + l31;
     const float* Bc = Bs + buf * BK * LDB + wc * WTN + l31;
+    // fragment reads run one k-pair ahead of the MFMAs (register double buffer)
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = Ac[hi * LDA + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = Bc[hi * LDB + j * 32];
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
-      const int k = 2 * s + hi;
-      float a[TM], b[TN];
+      if (s + 1 < BK / 2) {
+        const int k = 2 * (s + 1) + hi;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = Ac[k * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) a[(s + 1) & 1][i] = Ac[k * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bc[k * LDB + j * 32];
+        for (int j = 0; j < TN; ++j) b[(s + 1) & 1][j] = Bc[k * LDB + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) s_store(buf ^ 1);
     __syncthreads();
@@ -308,45 +408,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     Cz += zo * p.c_bso + zi * p.c_bsi;
     if (Rz) Rz += zo * p.r_bso + zi * p.r_bsi;
   }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
+  // Compile-time indices only: a runtime index into acc[][] would demote the accumulators to scratch memory.
+  static_for<0, TM>([&](auto I) {
+    static_for<0, TN>([&](auto J) {
+      constexpr int i = decltype(I)::value, j = decltype(J)::value;
       const int n = n0 + wc * WTN + j * 32 + l31;
-      if (n >= p.N) continue;
+      const bool n_ok = n < p.N;
       float bv = 0.f;
-      if (p.bias) bv = p.bias[p.bias_mod > 0 ? (n % p.bias_mod) : n];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      if (p.bias && n_ok) bv = p.bias[p.bias_mod > 0 ? (n % p.bias_mod) : n];
+      static_for<0, 16>([&](auto R) {
+        constexpr int r = decltype(R)::value;
         const int m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] * p.alpha + bv;
-        if (p.preact) p.preact[(zo * p.c_bso + zi * p.c_bsi) + (long)m * p.ldc_m + (long)n * p.ldc_n] = v;
-        if (p.act == SVL_ACT_GELU) v = gelu_erf(v);
-        else if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
-        long off;
-        if (p.out_mode == SVL_OUT_STRIDED) {
-          off = (long)m * p.ldc_m + (long)n * p.ldc_n;
-          if (Rz) v += Rz[(long)m * p.ldr_m + (long)n * p.ldr_n];
-        } else if (p.out_mode == SVL_OUT_CONVT2X) {
-          const int w = m % p.ct_W;
-          const int t = m / p.ct_W;
-          const int h = t % p.ct_H;
-          const int img = t / p.ct_H;
-          const int ab = n / p.ct_Cout, co = n - ab * p.ct_Cout;
-          const int a_ = ab >> 1, b_ = ab & 1;
-          off = ((((long)img * (2 * p.ct_H) + (2 * h + a_)) * (2 * p.ct_W)) + (2 * w + b_)) * p.ldc_m + co;
-        } else {  // SVL_OUT_PATCH
-          const int P = p.ct_H;
-          const int img = m / P, pp = m - img * P;
-          off = ((long)img * (P + 1) + 1 + pp) * p.ldc_m + n;
-          if (Rz) v += Rz[(long)(1 + pp) * p.ldr_m + n];
+        if (n_ok && m < p.M) {
+          float v = acc[i][j][r] * p.alpha + bv;
+          if (p.preact) p.preact[(zo * p.c_bso + zi * p.c_bsi) + (long)m * p.ldc_m + (long)n * p.ldc_n] = v;
+          if (p.act == SVL_ACT_GELU) v = gelu_erf(v);
+          else if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
+          long off;
+          if (p.out_mode == SVL_OUT_STRIDED) {
+            off = (long)m * p.ldc_m + (long)n * p.ldc_n;
+            if (Rz) v += Rz[(long)m * p.ldr_m + (long)n * p.ldr_n];
+          } else if (p.out_mode == SVL_OUT_CONVT2X) {
+            const int w = m % p.ct_W;
+            const int t = m / p.ct_W;
+            const int h = t % p.ct_H;
+            const int img = t / p.ct_H;
+            const int ab = n / p.ct_Cout, co = n - ab * p.ct_Cout;
+            const int a_ = ab >> 1, b_ = ab & 1;
+            off = ((((long)img * (2 * p.ct_H) + (2 * h + a_)) * (2 * p.ct_W)) + (2 * w + b_)) * p.ldc_m + co;
+          } else {  // SVL_OUT_PATCH
+            const int P = p.ct_H;
+            const int img = m / P, pp = m - img * P;
+            off = ((long)img * (P + 1) + 1 + pp) * p.ldc_m + n;
+            if (Rz) v += Rz[(long)(1 + pp) * p.ldr_m + n];
+          }
+          if (p.accumulate) v += Cz[off];
+          Cz[off] = v;
         }
-        if (p.accumulate) v += Cz[off];
-        Cz[off] = v;
-      }
-    }
-  }
+      });
+    });
+  });
 }
 
 __global__ void reduce_slabs_kernel(float* out, const float* slabs, int nslab, long count, int accumulate) {

@@ -122,16 +122,21 @@ def test_train_step_matches_oracle_with_fused_optimizer(dev):
                                fp_masks=[m.to(dev) for m in masks])
     assert abs(losses[0].item() - loss.item()) < 1e-3
     assert [g["name"] for g in opt.groups] == names
-    hsd, osd = hip.state_dict(), orc.state_dict()
     ograd = dict((n, p.grad) for n, p in orc.named_parameters() if p.grad is not None)
-    for k in names:
-        d = (hsd[k].cpu() - osd[k]).abs()
-        step = (osd[k] - sd[k]).abs().max().item()
-        # Adam's first step is lr * g / (|g| + eps): for |g| ~ eps the update direction is rounding noise, so the
-        # tight comparison is made where the gradient is significant; elsewhere the update is bounded by one step.
-        sig = ograd[k].abs() > 1e-5 * ograd[k].abs().max().clamp_min(1e-12)
-        assert d[sig].max().item() < 0.05 * step + 1e-7, f"{k}: post-step diff {d[sig].max().item()} vs step {step}"
-        assert d.max().item() <= 2.0 * step + 1e-7, f"{k}: post-step diff {d.max().item()} vs step {step}"
+    hsd = hip.state_dict()
+    hp = dict(hip.named_parameters())
+    for gcfg, k in zip(groups, names):
+        # (1) gradients in the flat arena == oracle gradients
+        hg = hp[k].main_grad.cpu()
+        assert (hg - ograd[k]).abs().max().item() < 5e-3 * ograd[k].abs().max().item() + 1e-9, k
+        # (2) arena update == torch.optim.AdamW applied to the SAME gradient (the gradients of this tiny random model are
+        # ~1e-8..1e-6, i.e. around Adam's eps, so the oracle's own update is rounding-noise sensitive; the kernel
+        # math itself is checked here and in test_ops_gpu.py::test_adamw)
+        pr = sd[k].clone().requires_grad_(True)
+        pr.grad = hg.clone()
+        torch.optim.AdamW([dict(params=[pr], lr=gcfg["lr"], weight_decay=gcfg["weight_decay"])]).step()
+        d = (hsd[k].cpu() - pr.detach()).abs().max().item()
+        assert d < 1e-6 * sd[k].abs().max().item() + 1e-9, f"{k}: post-step diff {d}"
     # lr schedule rewritten for the next step (semivl.py:343-345)
     assert abs(opt.groups[0]["lr"] - opt.groups[0]["initial_lr"] * (1 - 3 / 50) ** 0.9) < 1e-12
 
