@@ -1,0 +1,96 @@
+"""CPU: host-side logic of the product path (no kernels run): model construction / state_dict schema / freeze policy,
+optimizer param grouping + poly LR, concept maps, synthetic inputs, loud failure without a GPU."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from semivl_amd.synthetic import exp40_cfg, synthetic_batch
+
+
+def test_build_model_schema_and_freeze_policy():
+    from semivl_amd.model.builder import build_model
+    m = build_model(exp40_cfg())
+    sd = m.state_dict()
+    assert len(sd) == 372
+    total = sum(p.numel() for p in m.parameters())
+    assert abs(total / 1e6 - 175.87) < 0.01
+    bb_tr = [n for n, p in m.backbone.named_parameters() if p.requires_grad]
+    assert len(bb_tr) == 49 and all(("attn" in n) or ("pos_embed" in n) for n in bb_tr)   # vlm.py:66-67,80-88
+    assert sum(p.numel() for n, p in m.backbone.named_parameters() if p.requires_grad) == 29_135_616
+    assert sum(p.numel() for p in m.decode_head.parameters()) == 2_217_185
+    for k in ("backbone.cls_token", "backbone.pos_embed", "backbone.patch_embed.projection.weight", "backbone.ln0.weight",
+              "backbone.proj.weight", "backbone.layers.11.attn.attn.in_proj_weight",
+              "backbone.layers.0.ffn.layers.0.0.weight", "backbone.layers.0.ffn.layers.1.bias",
+              "clip_encoder.layers.3.ln2.bias", "decode_head.conv1.weight", "decode_head.aspp.aspp_convs.4.gap.1.weight",
+              "decode_head.aspp.project.0.weight", "decode_head.layers.1.transformer.attn.attn.out_proj.weight",
+              "decode_head.text_proj.0.weight", "decode_head.skip_proj.1.0.weight", "decode_head.up1.up.weight",
+              "decode_head.up2.conv.4.bias", "decode_head.head.weight"):
+        assert k in sd, k
+    assert sd["backbone.pos_embed"].shape == (1, 1025, 768) and sd["backbone.proj.weight"].shape == (512, 768, 1, 1)
+    assert sd["decode_head.up1.up.weight"].shape == (128, 96, 2, 2) and sd["decode_head.conv1.weight"].shape == (128, 1, 7, 7)
+    assert m.num_classes == 21 and m.align_corners is False and m.fp_rate == 0.5
+    assert tuple(m.loaded_mcc_text_feat.shape) == (98, 512)
+
+
+def test_unsupported_configs_fail_loudly():
+    from semivl_amd.model.builder import build_model
+    cfg = exp40_cfg()
+    cfg["model"] = "mmseg.vlm-vlg-aspp-s2p4-skr04-ftap-mcvitb"
+    with pytest.raises((ValueError, NotImplementedError)):
+        build_model(cfg)
+    cfg["model"] = "deeplabv3plus"
+    with pytest.raises(ValueError):
+        build_model(cfg)
+
+
+def test_no_cpu_fallback():
+    """The product path refuses to run without the GPU/extension instead of silently computing on the CPU."""
+    from semivl_amd.model.builder import build_model
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = build_model(exp40_cfg(crop=64))
+    with pytest.raises((AssertionError, RuntimeError)):
+        m(torch.randn(1, 3, 64, 64))
+
+
+def test_param_groups_and_poly_lr():
+    from semivl_amd.train import mmcv_param_groups
+    ck = exp40_cfg()["optimizer"]["paramwise_cfg"]["custom_keys"]
+    names = ["backbone.pos_embed", "backbone.layers.0.attn.attn.in_proj_weight", "decode_head.conv1.weight",
+             "decode_head.layers.0.transformer.ln1.weight", "decode_head.aspp.aspp_convs.0.1.bias", "conv_encoder.x",
+             "something.norm.weight", "plain.weight"]
+    g = {d["name"]: d for d in mmcv_param_groups([(n, None) for n in names], 1e-4, 0.01, ck)}
+    assert math.isclose(g["backbone.pos_embed"]["lr"], 1e-6) and g["backbone.pos_embed"]["weight_decay"] == 0.01
+    assert math.isclose(g["decode_head.conv1.weight"]["lr"], 1e-3)
+    # 'head' outranks 'ln' (longest key first): decoder LN gets lr x10 AND keeps weight decay
+    assert math.isclose(g["decode_head.layers.0.transformer.ln1.weight"]["lr"], 1e-3)
+    assert g["decode_head.layers.0.transformer.ln1.weight"]["weight_decay"] == 0.01
+    assert math.isclose(g["conv_encoder.x"]["lr"], 1e-4)
+    assert g["something.norm.weight"]["weight_decay"] == 0.0 and g["plain.weight"]["lr"] == 1e-4
+    from oracle import semivl_oracle as O
+    assert math.isclose(O.poly_lr(1e-3, 10, 100), 1e-3 * 0.9 ** 0.9)
+
+
+def test_concept_maps():
+    from semivl_amd.model.text_embeddings import concept_offsets, get_class_to_concept_idxs
+    voc = get_class_to_concept_idxs("configs/_base_/datasets/text_embedding/voc12_wbg_concept4_single.npy")
+    assert len(voc) == 21 and len(voc[0]) == 45 and voc[20][-1] == 97
+    cs = get_class_to_concept_idxs("x/cityscapes_concept3_single.npy")
+    assert len(cs) == 19 and sum(len(v) for v in cs.values()) == 54
+    assert concept_offsets(voc, "cpu").tolist()[-1] == 98
+    with pytest.raises(ValueError):
+        get_class_to_concept_idxs("voc12_wbg_single.npy")
+
+
+def test_synthetic_batch_spec():
+    b = synthetic_batch(4, 64, 21, seed=1)
+    assert set(b) == {"img_x", "mask_x", "img_w", "img_s1", "img_s2", "ignore_mask", "mix1", "mix2", "img_w_other",
+                      "img_s1_other", "img_s2_other", "ignore_mask_other"}
+    assert b["mask_x"].dtype == torch.int64 and set(b["mask_x"].unique().tolist()) <= set(range(21)) | {255}
+    assert (b["ignore_mask"][1, -8:] == 255).all() and (b["ignore_mask"][0] == 0).all()
+    assert set(b["mix1"].unique().tolist()) <= {0.0, 1.0}
+    from oracle import semivl_oracle as O
+    o = O.synthetic_batch(4, 64, 21, seed=1)
+    assert all(torch.equal(b[k], o[k]) for k in b)   # product and oracle feed the same synthetic stream
