@@ -244,6 +244,14 @@ int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx
                       const float* stats, const float* gamma, int imgs, int64_t HW, int C, int G, int relu,
                       float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream);
 
+/* Fused (flash-style) multi-head self-attention of the ViT blocks, head dim 64, softmax scale 64^-0.5, fp32 MFMA
+ * (nn.MultiheadAttention inside mmcv's wrapper, maskclip_vit.py:77-84,141).  qkv [B*T, 3E] = in-proj output
+ * (q | k | v, E = 64*H); out [B*T, E]; lse [B*H*T] (log-sum-exp per query, saved for backward; may be NULL).
+ * Backward: dqkv [B*T, 3E] fully written; dsum_ws is a [B*H*T] float workspace.  Deterministic. */
+int svl_attention_fwd(const float* qkv, int B, int T, int H, float* out, float* lse, svl_stream_t stream);
+int svl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int H,
+                      float* dsum_ws, float* dqkv, svl_stream_t stream);
+
 /* Small-sequence multi-head attention for the SemanticTransformer (vlg_head.py:39-67; seq = num classes).
  * qkv rows: token (g, s) at row  (g / inner) * outer_stride + (g % inner) * inner_stride + s * seq_stride,
  * each row = [q(E) | k(E) | v(E)], E = heads*D, D = 64. out has the same row mapping, width E. */

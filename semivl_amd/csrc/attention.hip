@@ -1,0 +1,406 @@
+// Fused multi-head self-attention for the ViT encoder (head dim 64, no mask, no dropout), fp32 on
+// v_mfma_f32_32x32x2_f32.  Replaces nn.MultiheadAttention's bmm / softmax / bmm (maskclip_vit.py:141 via mmcv)
+// and their autograd without materialising the [B*heads, T, T] probabilities (T = 1025 at 512^2, 2602 at 801^2).
+//
+// Layout trick (fp32 MFMA): an MFMA's k index is (lane >> 5) and any k ORDER is a valid dot product, so a C-layout
+// tile  X[row = (r&3)+8(r>>2)+4(lane>>5)][col = lane&31]  can be fed back as the B (or A) operand of the next MFMA
+// with "k = row", register r at a time, WITHOUT moving data between lanes: the partner operand is simply read from
+// LDS at row (r, lane>>5).  So S^T = K Q^T -> softmax -> O^T = V^T P^T chain entirely in registers.
+//
+//   forward : block = 128 queries (4 waves x 32), K/V tiles of 64 keys through LDS, online softmax,
+//             saves LSE = m + log(l) per (b, head, query).
+//   backward: D = rowsum(dO * O);   dK,dV kernel (block = 128 keys, loops query tiles);
+//             dQ kernel (block = 128 queries, loops key tiles).  Deterministic (no atomics).
+// qkv is the in-proj output [B*T, 3E] (q | k | v, heads contiguous 64-wide), out / dout are [B*T, E].
+#include "svl_common.h"
+
+namespace {
+
+constexpr int D = 64;
+constexpr int LDP = D + 1;  // padded LDS row for row-varying (A-operand style) reads
+
+struct AttnP {
+  const float* qkv;
+  float* out;
+  float* lse;
+  const float* dout;
+  const float* dsum;
+  float* dqkv;
+  int B, T, H;
+  long ld;  // 3E
+  long E;
+  float scale;
+};
+
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// Cooperative load of a [64 rows x 64 floats] tile (rows row0.. of one head slice) into registers: 4 float4 per thread.
+__device__ __forceinline__ void tile_gload(float4 (&rg)[4], const float* base, long ld, int row0, int T, int tid) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int f = tid + 256 * p;
+    const int row = row0 + (f >> 4), c4 = (f & 15) << 2;
+    rg[p] = (row < T) ? *reinterpret_cast<const float4*>(base + (long)row * ld + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int LD>
+__device__ __forceinline__ void tile_sstore(float* S, const float4 (&rg)[4], int tid, float mul) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int f = tid + 256 * p;
+    const int row = f >> 4, c = (f & 15) << 2;
+    float* d = S + row * LD + c;
+    d[0] = rg[p].x * mul; d[1] = rg[p].y * mul; d[2] = rg[p].z * mul; d[3] = rg[p].w * mul;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) float Ks[64 * LDP];
+  __shared__ __attribute__((aligned(16))) float Vs[64 * D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int z = blockIdx.y, b = z / p.H, h = z - b * p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qi = q0 + l31;
+  const bool wave_active = q0 < p.T;
+  const float* head = p.qkv + (long)b * p.T * p.ld + h * D;  // q slice; k at +E, v at +2E
+  float q[32];
+  {
+    const float* qr = head + (long)min(qi, p.T - 1) * p.ld + hi;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) q[s] = qr[2 * s] * p.scale;
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  const int nkt = (p.T + 63) >> 6;
+  float4 rk[4], rv[4];
+  tile_gload(rk, head + p.E, p.ld, 0, p.T, tid);
+  tile_gload(rv, head + 2 * p.E, p.ld, 0, p.T, tid);
+  tile_sstore<LDP>(Ks, rk, tid, 1.f);
+#pragma unroll
+  for (int pz = 0; pz < 4; ++pz) {
+    const int f = tid + 256 * pz;
+    *reinterpret_cast<float4*>(&Vs[(f >> 4) * D + ((f & 15) << 2)]) = rv[pz];
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) {
+      tile_gload(rk, head + p.E, p.ld, (kt + 1) * 64, p.T, tid);
+      tile_gload(rv, head + 2 * p.E, p.ld, (kt + 1) * 64, p.T, tid);
+    }
+    if (wave_active) {
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      const float* ka = Ks + l31 * LDP + hi;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const float a0 = ka[2 * s], a1 = ka[32 * LDP + 2 * s];
+        s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q[s], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q[s], s1, 0, 0, 0);
+      }
+      const int j0 = kt * 64;
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j0 + crow(r, hi);
+        if (key >= p.T) s0[r] = -INFINITY;
+        if (key + 32 >= p.T) s1[r] = -INFINITY;
+        mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float mnew = fmaxf(m, mloc);
+      const float alpha = expf(m - mnew);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = expf(s0[r] - mnew);
+        s1[r] = expf(s1[r] - mnew);
+        sum += s0[r] + s1[r];
+      }
+      l = l * alpha + sum;
+      m = mnew;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* va = Vs + crow(r, hi) * D + l31;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s0[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s0[r], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32 * D], s1[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32 * D + 32], s1[r], o1, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_sstore<LDP>(Ks, rk, tid, 1.f);
+#pragma unroll
+      for (int pz = 0; pz < 4; ++pz) {
+        const int f = tid + 256 * pz;
+        *reinterpret_cast<float4*>(&Vs[(f >> 4) * D + ((f & 15) << 2)]) = rv[pz];
+      }
+      __syncthreads();
+    }
+  }
+  if (wave_active && qi < p.T) {
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = 1.f / lt;
+    float* orow = p.out + ((long)b * p.T + qi) * p.E + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = 8 * g + 4 * hi;
+      *reinterpret_cast<float4*>(orow + d0) =
+          make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      *reinterpret_cast<float4*>(orow + 32 + d0) =
+          make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+    if (p.lse && hi == 0) p.lse[(long)z * p.T + qi] = m + logf(lt);
+  } else if (wave_active) {
+    (void)__shfl_xor(l, 32, 64);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ D = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                        float* __restrict__ dsum, int B, int T, int H, long E) {
+  // one 16-lane group per (b, t, h): 64 floats = 16 float4
+  const long total = (long)B * T * H;
+  const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  if (g >= total) return;
+  const int h = (int)(g % H);
+  const long bt = g / H;
+  const long off = bt * E + h * D + sub * 4;
+  const float4 a = *reinterpret_cast<const float4*>(dout + off), c = *reinterpret_cast<const float4*>(out + off);
+  float s = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (sub == 0) {
+    const long b = bt / T, t = bt - b * T;
+    dsum[((long)b * H + h) * T + t] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) float Qs[64 * LDP];
+  __shared__ __attribute__((aligned(16))) float Os[64 * LDP];
+  __shared__ float Ls[64], Ds[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int z = blockIdx.y, b = z / p.H, h = z - b * p.H;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int kj = k0 + l31;
+  const bool wave_active = k0 < p.T;
+  const bool key_ok = kj < p.T;
+  const float* head = p.qkv + (long)b * p.T * p.ld + h * D;
+  const float* dhead = p.dout + (long)b * p.T * p.E + h * D;
+  float kreg[32], vreg[32];
+  {
+    const float* kr = head + p.E + (long)min(kj, p.T - 1) * p.ld + hi;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) { kreg[s] = kr[2 * s]; vreg[s] = kr[p.E + 2 * s]; }
+  }
+  f32x16 dv0, dv1, dk0, dk1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dv0[r] = 0.f; dv1[r] = 0.f; dk0[r] = 0.f; dk1[r] = 0.f; }
+  const int nqt = (p.T + 63) >> 6;
+  float4 rq[4], ro[4];
+  float ln = 0.f, dn = 0.f;
+  auto gload = [&](int qt) {
+    tile_gload(rq, head, p.ld, qt * 64, p.T, tid);
+    tile_gload(ro, dhead, p.E, qt * 64, p.T, tid);
+    if (tid < 64) {
+      const int qi = qt * 64 + tid;
+      ln = (qi < p.T) ? p.lse[(long)z * p.T + qi] : INFINITY;  // exp(s - inf) = 0 for padded queries
+      dn = (qi < p.T) ? p.dsum[(long)z * p.T + qi] : 0.f;
+    }
+  };
+  auto sstore = [&]() {
+    tile_sstore<LDP>(Qs, rq, tid, p.scale);
+    tile_sstore<LDP>(Os, ro, tid, 1.f);
+    if (tid < 64) { Ls[tid] = ln; Ds[tid] = dn; }
+  };
+  gload(0);
+  sstore();
+  __syncthreads();
+  for (int qt = 0; qt < nqt; ++qt) {
+    if (qt + 1 < nqt) gload(qt + 1);
+    if (wave_active) {
+#pragma unroll 1
+      for (int it = 0; it < 2; ++it) {
+        f32x16 sa, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+        const float* qa = Qs + (it * 32 + l31) * LDP + hi;
+        const float* oa = Os + (it * 32 + l31) * LDP + hi;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * s], kreg[s], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[2 * s], vreg[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qi = it * 32 + crow(r, hi);
+          const float pv = key_ok ? expf(sa[r] - Ls[qi]) : 0.f;
+          sa[r] = pv;
+          dp[r] = pv * (dp[r] - Ds[qi]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qi = it * 32 + crow(r, hi);
+          const float* ob = Os + qi * LDP + l31;
+          const float* qb = Qs + qi * LDP + l31;
+          dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[r], ob[0], dv0, 0, 0, 0);
+          dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[r], ob[32], dv1, 0, 0, 0);
+          dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[r], qb[0], dk0, 0, 0, 0);
+          dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[r], qb[32], dk1, 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (qt + 1 < nqt) {
+      sstore();
+      __syncthreads();
+    }
+  }
+  if (wave_active) {
+    // C layout: row = key (k0 + crow(r, hi)), col = d (l31 / 32 + l31); Qs was pre-scaled so dk already carries `scale`
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + crow(r, hi);
+      if (key < p.T) {
+        float* row = p.dqkv + ((long)b * p.T + key) * p.ld + h * D;
+        row[p.E + l31] = dk0[r];
+        row[p.E + 32 + l31] = dk1[r];
+        row[2 * p.E + l31] = dv0[r];
+        row[2 * p.E + 32 + l31] = dv1[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) float Ks[64 * LDP];
+  __shared__ __attribute__((aligned(16))) float Vs[64 * LDP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int z = blockIdx.y, b = z / p.H, h = z - b * p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qi = q0 + l31;
+  const bool wave_active = q0 < p.T;
+  const float* head = p.qkv + (long)b * p.T * p.ld + h * D;
+  const float* dhead = p.dout + (long)b * p.T * p.E + h * D;
+  float qreg[32], oreg[32];
+  {
+    const int qc = min(qi, p.T - 1);
+    const float* qr = head + (long)qc * p.ld + hi;
+    const float* orr = dhead + (long)qc * p.E + hi;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) { qreg[s] = qr[2 * s] * p.scale; oreg[s] = orr[2 * s]; }
+  }
+  const float lse_i = p.lse[(long)z * p.T + min(qi, p.T - 1)];
+  const float d_i = p.dsum[(long)z * p.T + min(qi, p.T - 1)];
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+  const int nkt = (p.T + 63) >> 6;
+  float4 rk[4], rv[4];
+  tile_gload(rk, head + p.E, p.ld, 0, p.T, tid);
+  tile_gload(rv, head + 2 * p.E, p.ld, 0, p.T, tid);
+  tile_sstore<LDP>(Ks, rk, tid, 1.f);
+  tile_sstore<LDP>(Vs, rv, tid, 1.f);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) {
+      tile_gload(rk, head + p.E, p.ld, (kt + 1) * 64, p.T, tid);
+      tile_gload(rv, head + 2 * p.E, p.ld, (kt + 1) * 64, p.T, tid);
+    }
+    if (wave_active) {
+#pragma unroll 1
+      for (int jt = 0; jt < 2; ++jt) {
+        f32x16 sa, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+        const float* ka = Ks + (jt * 32 + l31) * LDP + hi;
+        const float* va = Vs + (jt * 32 + l31) * LDP + hi;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qreg[s], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * s], oreg[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 64 + jt * 32 + crow(r, hi);
+          const float pv = (key < p.T) ? expf(sa[r] - lse_i) : 0.f;
+          dp[r] = pv * (dp[r] - d_i);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* kb = Ks + (jt * 32 + crow(r, hi)) * LDP + l31;
+          dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[0], dp[r], dq0, 0, 0, 0);
+          dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[32], dp[r], dq1, 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_sstore<LDP>(Ks, rk, tid, 1.f);
+      tile_sstore<LDP>(Vs, rv, tid, 1.f);
+      __syncthreads();
+    }
+  }
+  if (wave_active && qi < p.T) {
+    float* row = p.dqkv + ((long)b * p.T + qi) * p.ld + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = 8 * g + 4 * hi;
+      *reinterpret_cast<float4*>(row + d0) = make_float4(dq0[4 * g] * p.scale, dq0[4 * g + 1] * p.scale,
+                                                         dq0[4 * g + 2] * p.scale, dq0[4 * g + 3] * p.scale);
+      *reinterpret_cast<float4*>(row + 32 + d0) = make_float4(dq1[4 * g] * p.scale, dq1[4 * g + 1] * p.scale,
+                                                              dq1[4 * g + 2] * p.scale, dq1[4 * g + 3] * p.scale);
+    }
+  }
+}
+
+int check(const float* qkv, int B, int T, int H, const char* who) {
+  SVL_CHECK_ARG(qkv && B > 0 && T > 0 && H > 0 && (long)B * H <= 65535, "%s: bad args", who);
+  SVL_CHECK_ARG(((uintptr_t)qkv & 15) == 0, "%s: qkv must be 16-byte aligned", who);
+  return SVL_OK;
+}
+
+}  // namespace
+
+extern "C" int svl_attention_fwd(const float* qkv, int B, int T, int H, float* out, float* lse, svl_stream_t stream) {
+  int rc = check(qkv, B, T, H, "svl_attention_fwd");
+  if (rc) return rc;
+  SVL_CHECK_ARG(out, "svl_attention_fwd: out missing");
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.qkv = qkv; p.out = out; p.lse = lse; p.B = B; p.T = T; p.H = H; p.E = (long)H * D; p.ld = 3 * p.E; p.scale = 0.125f;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + 127) / 128, B * H), dim3(256), 0, (hipStream_t)stream, p);
+  SVL_LAUNCH_CHECK("svl_attention_fwd");
+  return SVL_OK;
+}
+
+extern "C" int svl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T,
+                                 int H, float* dsum_ws, float* dqkv, svl_stream_t stream) {
+  int rc = check(qkv, B, T, H, "svl_attention_bwd");
+  if (rc) return rc;
+  SVL_CHECK_ARG(out && dout && lse && dsum_ws && dqkv, "svl_attention_bwd: null args");
+  hipStream_t st = (hipStream_t)stream;
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.qkv = qkv; p.dout = dout; p.lse = const_cast<float*>(lse); p.dsum = dsum_ws; p.dqkv = dqkv;
+  p.B = B; p.T = T; p.H = H; p.E = (long)H * D; p.ld = 3 * p.E; p.scale = 0.125f;
+  const long groups = (long)B * T * H;
+  hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, st, dout, out, dsum_ws,
+                     B, T, H, p.E);
+  SVL_LAUNCH_CHECK("svl_attention_bwd/dsum");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((T + 127) / 128, B * H), dim3(256), 0, st, p);
+  SVL_LAUNCH_CHECK("svl_attention_bwd/dkv");
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, B * H), dim3(256), 0, st, p);
+  SVL_LAUNCH_CHECK("svl_attention_bwd/dq");
+  return SVL_OK;
+}

@@ -88,6 +88,8 @@ SIGNATURES = {
     "svl_copy2d_f32": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _P]),
     "svl_groupnorm_fwd": (_I, [_P, _L, _P, _P, _F, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
+    "svl_attention_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "svl_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "svl_seqattn_fwd": (_I, [C.POINTER(SeqAttnDesc), _P]),
     "svl_seqattn_bwd": (_I, [C.POINTER(SeqAttnDesc), _P]),
     "svl_bilinear_nhwc_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P]),

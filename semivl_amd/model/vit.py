@@ -105,7 +105,10 @@ def block_forward(x, p, heads, eps, Bn, T, want_v, skip_x, save):
             save.update(vo=vo, st2v=st2v, hv_pre=hv_pre)
     xo = None
     if not skip_x:
-        o, P = ops.vit_attention_fwd(qkv, Bn, T, heads, D)
+        if D == 64:
+            o, P = ops.attention_fwd(qkv, Bn, T, heads, want_lse=save is not None)  # P := log-sum-exp rows
+        else:  # generic head dim: batched-GEMM attention with materialised probabilities
+            o, P = ops.vit_attention_fwd(qkv, Bn, T, heads, D)
         x2 = ops.linear(o, p["wout"], p["bout"], resid=x)
         y2, st2 = ops.layernorm_fwd(x2, p["ln2w"], p["ln2b"], eps)
         h_pre = ops.empty(y2.shape[0], p["w1"].shape[0], device=x.device) if save is not None else None
@@ -149,7 +152,10 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False):
         dx2 = ffn_ln_bwd(dxo, s["x2"], s["st2"], s["h_pre"], "x")
         do = ops.matmul_nn(dx2, p["wout"])
         wout_parts.append((dx2, s["o"]))
-        dqkv = ops.vit_attention_bwd(do, s["qkv"], s["P"], Bn, T, heads, D) if "P" in s else None
+        if D == 64:
+            dqkv = ops.attention_bwd(do, s["qkv"], s["o"], s["P"], Bn, T, heads)
+        else:
+            dqkv = ops.vit_attention_bwd(do, s["qkv"], s["P"], Bn, T, heads, D)
         dx_res = dx2
     dvproj = None
     if s["want_v"] and dv is not None:

@@ -285,7 +285,29 @@ def groupnorm_bwd(dy, lddy, x, ldx, y, ldy, stats, gamma, imgs, HW, Cc, G, relu,
     return dgamma, dbeta
 
 
-# ------------------------------------------------------------------------------------------------ ViT attention (v0: materialised)
+# ------------------------------------------------------------------------------------------------ ViT attention (fused, D = 64)
+def attention_fwd(qkv, Bn, T, H, want_lse=True):
+    """Flash-style fused attention: qkv [Bn*T, 3E] -> (out [Bn*T, E], lse [Bn*H*T] or None)."""
+    E = H * 64
+    out = empty(Bn * T, E, device=qkv.device)
+    lse = empty(Bn * H * T, device=qkv.device) if want_lse else None
+    e0 = _prof_begin()
+    L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _st()), "svl_attention_fwd")
+    _prof_end("attention", e0, 4.0 * Bn * H * T * T * 64, ("fwd", Bn, T, H))
+    return out, lse
+
+
+def attention_bwd(dout, qkv, out, lse, Bn, T, H):
+    dqkv = torch.empty_like(qkv)
+    ws = empty(Bn * H * T, device=qkv.device)
+    e0 = _prof_begin()
+    L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv), _st()),
+            "svl_attention_bwd")
+    _prof_end("attention", e0, 14.0 * Bn * H * T * T * 64, ("bwd", Bn, T, H))
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------ ViT attention (materialised probabilities; head dims != 64)
 def vit_attention_fwd(qkv, Bn, T, H, D):
     """qkv [Bn*T, 3E] -> (out [Bn*T, E], probs [Bn*H, T, Tp]).  q is scaled by D^-0.5 (a power of two here) inside
     the softmax, identical to nn.MultiheadAttention's q-scaling."""

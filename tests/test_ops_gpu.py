@@ -88,6 +88,32 @@ def test_vit_attention(dev, Bn, T, H):
     close(dqkv, gref, atol=5e-5, what="attn bwd")
 
 
+@pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 17, 4), (1, 64, 1), (2, 129, 3), (1, 128, 2)])
+def test_fused_attention(dev, Bn, T, H):
+    """Flash-style kernel vs explicit softmax(q k^T / 8) v and its autograd; ragged T, spiky logits (forces rescales)."""
+    from semivl_amd import ops
+    D, E = 64, 64 * H
+    qkv = rnd(Bn * T, 3 * E, dev=dev, seed=50)
+    qkv[:, :2 * E] *= 2.0
+    if T > 40:  # one key that dominates late in the sequence -> the running max jumps at a later tile
+        qkv.view(Bn, T, 3 * E)[0, T - 3, E:E + 64] = 6.0 * qkv.view(Bn, T, 3 * E)[0, 5, 0:64]
+    qkv = qkv.requires_grad_(True)
+    q, k, v = [t.reshape(Bn, T, H, D).transpose(1, 2) for t in qkv.view(Bn, T, 3 * E).split(E, dim=2)]
+    sc = (q.double() * D ** -0.5) @ k.double().transpose(-1, -2)
+    ref = (sc.softmax(-1) @ v.double()).transpose(1, 2).reshape(Bn * T, E)
+    out, lse = ops.attention_fwd(qkv.detach(), Bn, T, H)
+    close(out, ref.float(), atol=3e-5, what="flash fwd")
+    close(lse.view(Bn, H, T), torch.logsumexp(sc, -1).float(), atol=2e-5, what="lse")
+    do = rnd(Bn * T, E, dev=dev)
+    (g,) = torch.autograd.grad(ref, qkv, do.double())
+    dqkv = ops.attention_bwd(do, qkv.detach(), out, lse, Bn, T, H)
+    close(dqkv[:, 2 * E:], g[:, 2 * E:].float(), atol=1e-4, what="flash dV")
+    close(dqkv[:, E:2 * E], g[:, E:2 * E].float(), atol=1e-4, what="flash dK")
+    close(dqkv[:, :E], g[:, :E].float(), atol=1e-4, what="flash dQ")
+    o2, _ = ops.attention_fwd(qkv.detach(), Bn, T, H)
+    assert torch.equal(out, o2) and torch.equal(dqkv, ops.attention_bwd(do, qkv.detach(), out, lse, Bn, T, H))
+
+
 # ------------------------------------------------------------------------------------------------ conv family
 def nhwc(x):  # NCHW -> [N*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()

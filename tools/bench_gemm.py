@@ -42,3 +42,7 @@ for (C, Co, Hh, dil) in [(128, 128, 32, 6), (128, 64, 64, 1), (64, 64, 64, 1), (
     dy = torch.randn(imgs * Hh * Hh, Co, device=dev)
     timeit(lambda: ops.conv_dgrad(dy, Co, imgs, Hh, Hh, Co, wd, C, 3, 3, dil, dil), fl, f"conv3x3 dgrad")
     timeit(lambda: ops.conv_wgrad(dy, Co, x, C, imgs, Hh, Hh, C, Co, 3, 3, dil, dil), fl, f"conv3x3 wgrad")
+timeit(lambda: ops.attention_fwd(qkv, Bn, T, H), 4.0 * Bn * H * T * T * D, "FUSED attention fwd b=32")
+o_, lse_ = ops.attention_fwd(qkv, Bn, T, H)
+do_ = torch.randn_like(o_)
+timeit(lambda: ops.attention_bwd(do_, qkv, o_, lse_, Bn, T, H), 8.0 * Bn * H * T * T * D, "FUSED attention bwd b=32 (alg. 8*B*H*T^2*D)")
