@@ -134,18 +134,18 @@ def main():
         step(a.warmup + a.steps)
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
-        g = prof.get("gemm", [])
+        g = prof.get("gemm", []) + prof.get("attention", [])   # the two fp32-MFMA kernel families
         t_gemm = sum(e0.elapsed_time(e1) for e0, e1, _, _ in g) * 1e-3
         executed = sum(w for _, _, w, _ in g)
         algo = (VIT_GF_PER_UNIT_B + DEC_GF_PER_UNIT_B) * 1e9 * a.batch if (a.nclass == 21 and a.crop == 512) else executed
         ach = algo / t_gemm / 1e12
         out["roofline"] = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
                                frac=round(ach / PEAK_F32_MFMA_TF, 4), traffic=None,
-                               kernel="gemm_kernel (svl_gemm_f32, v_mfma_f32_32x32x2_f32)", launches=len(g),
+                               kernel="gemm_kernel + attn_{fwd,bwd}_kernel (svl_gemm_f32, svl_attention_*; v_mfma_f32_32x32x2_f32)", launches=len(g),
                                kernel_time_ms=round(t_gemm * 1e3, 2),
                                executed_tflops=round(executed / t_gemm / 1e12, 2),
                                note="achieved = algorithmic FLOPs of one step (SURVEY §8(d): (2866.6+1322.0) GF x B) / "
-                                    "summed duration of all svl_gemm_f32 launches of one step (HIP events on the launch stream)")
+                                    "summed duration of all svl_gemm_f32 + svl_attention_* launches of one step (HIP events on the launch stream)")
         # largest single launch shapes
         by = {}
         for e0, e1, w, tag in g:
