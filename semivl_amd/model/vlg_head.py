@@ -374,6 +374,70 @@ class _HeadFn(torch.autograd.Function):
         dev = dlogits.device
         gc = _GradCollector()
         dlogits = dlogits.contiguous()
+        # Samples whose dlogits are identically zero (pred_w is detached, pred_x_fp unused: semivl.py:247,251) contribute
+        # exactly nothing to any gradient: every op of the head is per-sample.  The step announces the live sample
+        # ranges and the backward runs on those contiguous sub-batches only.
+        ranges = (getattr(m, "_bwd_ranges", None) or {}).get(b)
+        if ranges is None:
+            dv0, dv4, demb = _head_backward_core(m, sv, dlogits, gc)
+        else:
+            dv0, dv4, demb = (ops.zeros(b * HW, Cv, device=dev), ops.zeros(b * HW, Cv, device=dev),
+                              ops.zeros(b * HW, Ce, device=dev))
+            for s0, s1 in ranges:
+                a0, a4, ae = _head_backward_core(m, _slice_saved(sv, b, s0, s1), dlogits[s0:s1], gc)
+                for full, part in ((dv0, a0), (dv4, a4), (demb, ae)):
+                    ops.eltwise(4, part.view(-1), None, out=full[s0 * HW:s1 * HW].view(-1))
+        # ---- undo the feature-perturbation doubling
+        fp_masks, fp_rate = sv["fp"]
+
+        def undbl(dfull, mk, Cc):
+            if fp_masks is None:
+                return dfull.view(b0, HW, Cc)
+            sc = 1.0 / (1.0 - fp_rate)
+            second = ops.chanmask(dfull[b0 * HW:], mk.contiguous(), sc, HW)
+            first = dfull[:b0 * HW]
+            return ops.add(first, second, out=second).view(b0, HW, Cc)
+        mk = fp_masks if fp_masks is not None else (None, None, None)
+        dv0 = undbl(dv0, mk[0], Cv)
+        dv4 = undbl(dv4, mk[1], Cv)
+        demb = undbl(demb, mk[2], Ce)
+        ctx.sv = None
+        req = ctx.feat_req
+        return (None, None, None, None, None, None, dv0 if req[0] else None, dv4 if req[1] else None,
+                demb if req[2] else None) + tuple(gc.out.get(id(p)) for p in ctx.params)
+
+
+_SHARED_KEYS = {"textn", "tp", "w1d", "whd", "wd", "wp"}  # saved tensors that are NOT per-sample
+
+
+def _slice_saved(sv, b, s0, s1):
+    """View of the saved activations restricted to samples [s0, s1) (all per-sample tensors are batch-major)."""
+    def sl(k, v):
+        if isinstance(v, torch.Tensor):
+            if k in _SHARED_KEYS or v.dim() == 0:
+                return v
+            assert v.shape[0] % b == 0, (k, tuple(v.shape), b)
+            r = v.shape[0] // b
+            return v[s0 * r:s1 * r]
+        if isinstance(v, dict):
+            return {kk: sl(kk, vv) for kk, vv in v.items()}
+        if isinstance(v, list):
+            return [sl(k, vv) for vv in v]
+        if k == "geom":
+            return (v[0] // b * (s1 - s0),) + tuple(v[1:])
+        return v
+    out = {k: sl(k, v) for k, v in sv.items() if k not in ("dims", "fp")}
+    d = sv["dims"]
+    out["dims"] = (d[0], s1 - s0, d[2], d[3], d[4], d[5], d[6] // b * (s1 - s0)) + tuple(d[7:])
+    out["fp"] = sv["fp"]
+    return out
+
+
+def _head_backward_core(m, sv, dlogits, gc):
+    """Backward of the head for the (sub-)batch described by `sv`; returns grads wrt the (doubled) v0, v4, emb tokens."""
+    if True:
+        b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv = sv["dims"]
+        dev = dlogits.device
         if sv["out_size"] != (4 * h, 4 * w):
             dlg = ops.bilinear_planes_bwd(dlogits, 4 * h, 4 * w, m.align_corners, sv["out_size"][0], sv["out_size"][1])
         else:
@@ -435,21 +499,4 @@ class _HeadFn(torch.autograd.Function):
         ops.gemm(ops.A_MC, ops.B_NC, HW, Ce, N, ops.Op(dsim, HW, 0, N * HW, 0), ops.Op(sv["textn"], Ce), dembn,
                  ldc_m=Ce, batch=b, c_bso=HW * Ce)
         demb = ops.l2norm_bwd(dembn, sv["embn"], sv["inv_e"])
-        # ---- undo the feature-perturbation doubling
-        fp_masks, fp_rate = sv["fp"]
-
-        def undbl(dfull, mk, Cc):
-            if fp_masks is None:
-                return dfull.view(b0, HW, Cc)
-            sc = 1.0 / (1.0 - fp_rate)
-            second = ops.chanmask(dfull[b0 * HW:], mk.contiguous(), sc, HW)
-            first = dfull[:b0 * HW]
-            return ops.add(first, second, out=second).view(b0, HW, Cc)
-        mk = fp_masks if fp_masks is not None else (None, None, None)
-        dv0 = undbl(dv0, mk[0], Cv)
-        dv4 = undbl(dv4, mk[1], Cv)
-        demb = undbl(demb, mk[2], Ce)
-        ctx.sv = None
-        req = ctx.feat_req
-        return (None, None, None, None, None, None, dv0 if req[0] else None, dv4 if req[1] else None,
-                demb if req[2] else None) + tuple(gc.out.get(id(p)) for p in ctx.params)
+        return dv0, dv4, demb

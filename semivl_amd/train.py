@@ -127,7 +127,15 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     # backward (+ all-reduce) + optimizer
     if optimizer is not None:
         optimizer.zero_grad()
-    torch.autograd.backward([preds4, preds_s], [dl4, dls])
+    # pred_w / pred_x_fp carry exactly-zero dlogits: let the head's backward skip those samples (results identical)
+    head = getattr(model, "decode_head", None)
+    if head is not None:
+        head._bwd_ranges = {4 * B: [(0, B), (3 * B, 4 * B)]}
+    try:
+        torch.autograd.backward([preds4, preds_s], [dl4, dls])
+    finally:
+        if head is not None:
+            head._bwd_ranges = None
     if reducer is not None:
         reducer.reduce()
     if optimizer is not None:
