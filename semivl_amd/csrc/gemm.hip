@@ -18,10 +18,10 @@
 // optional second concatenated source), the patch-embedding gather, conv wgrad (im2col^T) and split-K.
 #include "svl_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BK = 16;
 
 struct OperandP {
   const float* p;
@@ -93,13 +93,13 @@ __device__ __forceinline__ const float* conv_src(const OperandP& op, const svl_c
 }
 
 // Load one float4 piece of the (row0.., k0..) panel. `rows_total`/`kend` bound the valid region.
-template <int IS_A, int MODE, int ROWS>
+template <int IS_A, int MODE, int ROWS, int BK>
 __device__ __forceinline__ float4 load_piece(const OperandP& op, const svl_conv_geom& cv, const float* base, int f,
                                              int row0, int rows_total, int k0, int kend) {
   constexpr int shape = ModeTraits<IS_A, MODE>::shape;
   if constexpr (shape == LS_KMAJOR) {
-    const int row = row0 + (f >> 2);
-    const int k = k0 + ((f & 3) << 2);
+    const int row = row0 + f / (BK / 4);
+    const int k = k0 + ((f % (BK / 4)) << 2);
     if (row >= rows_total || k >= kend) return zero4();
     const int nv = kend - k;
     if constexpr (MODE == 0) {  // K-contiguous dense (SVL_A_KCONTIG / SVL_B_KCONTIG share value 0)
@@ -188,13 +188,13 @@ __device__ __forceinline__ float4 load_piece(const OperandP& op, const svl_conv_
 
 // Interior-tile fast path: every row of the panel is in range, the K panel is a full BK, and 16-byte vector loads
 // are legal -> no per-element guards (conv taps still mask their halo with ONE predicated float4 load).
-template <int IS_A, int MODE, int ROWS>
+template <int IS_A, int MODE, int ROWS, int BK>
 __device__ __forceinline__ float4 load_piece_fast(const OperandP& op, const svl_conv_geom& cv, const float* base, int f,
                                                   int row0, int k0) {
   constexpr int shape = ModeTraits<IS_A, MODE>::shape;
   if constexpr (shape == LS_KMAJOR) {
-    const int row = row0 + (f >> 2);
-    const int k = k0 + ((f & 3) << 2);
+    const int row = row0 + f / (BK / 4);
+    const int k = k0 + ((f % (BK / 4)) << 2);
     if constexpr (MODE == 0) {
       return *reinterpret_cast<const float4*>(base + (long)row * op.ld + k);
     } else if constexpr (IS_A && MODE == SVL_A_CONV) {
@@ -244,11 +244,11 @@ __device__ __forceinline__ float4 load_piece_fast(const OperandP& op, const svl_
   }
 }
 
-template <int SHAPE, int ROWS, int LD>
+template <int SHAPE, int ROWS, int LD, int BK>
 __device__ __forceinline__ void store_piece(float* S, int f, float4 v) {
   if constexpr (SHAPE == LS_KMAJOR) {
-    const int row = f >> 2;
-    const int k = (f & 3) << 2;
+    const int row = f / (BK / 4);
+    const int k = (f % (BK / 4)) << 2;
     S[(k + 0) * LD + row] = v.x;
     S[(k + 1) * LD + row] = v.y;
     S[(k + 2) * LD + row] = v.z;
@@ -261,14 +261,14 @@ __device__ __forceinline__ void store_piece(float* S, int f, float4 v) {
   }
 }
 
-template <int BM, int BN, int WR, int WC, int AMODE, int BMODE>
+template <int BM, int BN, int WR, int WC, int AMODE, int BMODE, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   static_assert(WR * WC == 4, "4 waves per block");
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int WTM = BM / WR, WTN = BN / WC;  // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
   static_assert(TM >= 1 && TN >= 1, "wave tile >= 32x32");
-  constexpr int APIECES = BM * 4, BPIECES = BN * 4;  // float4 pieces per K panel
+  constexpr int APIECES = BM * BK / 4, BPIECES = BN * BK / 4;  // float4 pieces per K panel
   constexpr int APASS = (APIECES + 255) / 256, BPASS = (BPIECES + 255) / 256;
   constexpr int ASHAPE = ModeTraits<1, AMODE>::shape, BSHAPE = ModeTraits<0, BMODE>::shape;
 
@@ -323,28 +323,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int ps = 0; ps < APASS; ++ps) {
         const int f = tid + ps * 256;
-        if (APIECES % 256 == 0 || f < APIECES) ra[ps] = load_piece_fast<1, AMODE, BM>(p.A, p.cv, Abase, f, m0, k0);
+        if (APIECES % 256 == 0 || f < APIECES) ra[ps] = load_piece_fast<1, AMODE, BM, BK>(p.A, p.cv, Abase, f, m0, k0);
       }
     } else {
 #pragma unroll
       for (int ps = 0; ps < APASS; ++ps) {
         const int f = tid + ps * 256;
         if (APIECES % 256 == 0 || f < APIECES)
-          ra[ps] = load_piece<1, AMODE, BM>(p.A, p.cv, Abase, f, m0, p.M, k0, kend);
+          ra[ps] = load_piece<1, AMODE, BM, BK>(p.A, p.cv, Abase, f, m0, p.M, k0, kend);
       }
     }
     if (b_int && kfull) {
 #pragma unroll
       for (int ps = 0; ps < BPASS; ++ps) {
         const int f = tid + ps * 256;
-        if (BPIECES % 256 == 0 || f < BPIECES) rb[ps] = load_piece_fast<0, BMODE, BN>(p.B, p.cv, Bbase, f, n0, k0);
+        if (BPIECES % 256 == 0 || f < BPIECES) rb[ps] = load_piece_fast<0, BMODE, BN, BK>(p.B, p.cv, Bbase, f, n0, k0);
       }
     } else {
 #pragma unroll
       for (int ps = 0; ps < BPASS; ++ps) {
         const int f = tid + ps * 256;
         if (BPIECES % 256 == 0 || f < BPIECES)
-          rb[ps] = load_piece<0, BMODE, BN>(p.B, p.cv, Bbase, f, n0, p.N, k0, kend);
+          rb[ps] = load_piece<0, BMODE, BN, BK>(p.B, p.cv, Bbase, f, n0, p.N, k0, kend);
       }
     }
   };
@@ -354,12 +354,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
       const int f = tid + ps * 256;
-      if (APIECES % 256 == 0 || f < APIECES) store_piece<ASHAPE, BM, LDA>(Ad, f, ra[ps]);
+      if (APIECES % 256 == 0 || f < APIECES) store_piece<ASHAPE, BM, LDA, BK>(Ad, f, ra[ps]);
     }
 #pragma unroll
     for (int ps = 0; ps < BPASS; ++ps) {
       const int f = tid + ps * 256;
-      if (BPIECES % 256 == 0 || f < BPIECES) store_piece<BSHAPE, BN, LDB>(Bd, f, rb[ps]);
+      if (BPIECES % 256 == 0 || f < BPIECES) store_piece<BSHAPE, BN, LDB, BK>(Bd, f, rb[ps]);
     }
   };
 
@@ -460,7 +460,7 @@ __global__ void reduce_slabs_kernel(float* out, const float* slabs, int nslab, l
   }
 }
 
-template <int BM, int BN, int WR, int WC, int AMODE, int BMODE>
+template <int BM, int BN, int WR, int WC, int AMODE, int BMODE, int BK = 16>
 int launch_cfg(const GemmP& p, int batch, hipStream_t st) {
   GemmP q = p;
   q.tiles_n = (p.N + BN - 1) / BN;
@@ -471,7 +471,7 @@ int launch_cfg(const GemmP& p, int batch, hipStream_t st) {
     return SVL_ERR_INVALID_ARG;
   }
   dim3 grid((unsigned)tiles, 1, (unsigned)batch);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WR, WC, AMODE, BMODE>), grid, dim3(256), 0, st, q);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WR, WC, AMODE, BMODE, BK>), grid, dim3(256), 0, st, q);
   SVL_LAUNCH_CHECK("svl_gemm_f32");
   return SVL_OK;
 }
@@ -483,6 +483,8 @@ int launch_mode(const GemmP& p, int batch, hipStream_t st) {
   if (p.M <= 64 && p.N > 64) return launch_cfg<64, 128, 2, 2, AMODE, BMODE>(p, batch, st);
   if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, BMODE>(p, batch, st);
   if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, BMODE>(p, batch, st);
+  static const bool bk32 = getenv("SVL_GEMM_BK32") != nullptr;
+  if (bk32 && p.K >= 64) return launch_cfg<128, 128, 2, 2, AMODE, BMODE, 32>(p, batch, st);
   return launch_cfg<128, 128, 2, 2, AMODE, BMODE>(p, batch, st);
 }
 
