@@ -156,6 +156,11 @@ def main():
         top = sorted(by.items(), key=lambda kv: -kv[1][0])[:6]
         out["roofline"]["top_shapes"] = [dict(mode_MNKb=list(k), ms=round(v[0] * 1e3, 2), n=v[2],
                                               tflops=round(v[1] / v[0] / 1e12, 1)) for k, v in top]
+        if os.environ.get("SVL_BENCH_DUMP_SHAPES"):
+            allsh = sorted(by.items(), key=lambda kv: -kv[1][0])
+            with open(os.environ["SVL_BENCH_DUMP_SHAPES"], "w") as f:
+                for k, v in allsh:
+                    f.write(f"{v[0] * 1e3:9.3f} ms  n={v[2]:3d}  {v[1] / v[0] / 1e12:7.1f} TF  {k}\n")
         c = prof.get("ce_fused", [])
         if c:
             t_ce = sum(e0.elapsed_time(e1) for e0, e1, _, _ in c) * 1e-3
