@@ -270,6 +270,23 @@ int svl_seqattn_fwd(const svl_seqattn_desc* d, svl_stream_t stream);
 int svl_seqattn_bwd(const svl_seqattn_desc* d, svl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Thin (HBM-bound) convolutions of the VLG head, NHWC, stride 1, same size.
+ * ---------------------------------------------------------------------------------------------- */
+/* Conv2d(C -> 1): y[pix] = bias[0] + sum_{tap,ci} x[pix + off(tap)][ci] * w[tap*C + ci]  (vlg_head.py:190,239; w is the
+ * forward pack [1, KH*KW*C]). */
+int svl_conv_cout1_fwd(const float* x, int64_t ldx, int imgs, int H, int W, int C, int KH, int KW, int dil, int pad,
+                       const float* w, const float* bias, float* y, svl_stream_t stream);
+/* Weight gradient of Conv2d(C -> 1, 3x3): per-block partial sums slabs[nblocks][9*C] (nblocks =
+ * svl_conv_cout1_wgrad_blocks); combine with svl_reduce_slabs_f32. */
+int svl_conv_cout1_wgrad_blocks(int imgs, int H, int W);
+int svl_conv_cout1_wgrad(const float* dy, const float* x, int64_t ldx, int imgs, int H, int W, int C, int dil, int pad,
+                         float* slabs, svl_stream_t stream);
+/* out[p] = sum_tap T[p - sign*off(tap)][tap] with T [pix, KH*KW]: the shifted-tap sum that completes a Cin=1 input
+ * gradient (conv1 7x7, vlg_head.py:169,221) after the GEMM T = dY . W. */
+int svl_tap_gather(const float* T, int imgs, int H, int W, int KH, int KW, int dil, int pad, int sign, float* out,
+                   svl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Resampling on NHWC / NCHW maps.
  * ---------------------------------------------------------------------------------------------- */
 /* Bilinear resize, channels-last: x [imgs, h, w, C] (pixel stride ldx) -> y [imgs*rep, H, W, :] written at channel

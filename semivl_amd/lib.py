@@ -90,6 +90,10 @@ SIGNATURES = {
     "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_attention_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "svl_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "svl_conv_cout1_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "svl_conv_cout1_wgrad_blocks": (_I, [_I, _I, _I]),
+    "svl_conv_cout1_wgrad": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "svl_tap_gather": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "svl_seqattn_fwd": (_I, [C.POINTER(SeqAttnDesc), _P]),
     "svl_seqattn_bwd": (_I, [C.POINTER(SeqAttnDesc), _P]),
     "svl_bilinear_nhwc_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P]),

@@ -243,7 +243,7 @@ def _head_forward(m, hw, fp_masks, fp_rate, out_size, text, feats, sv):
     g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], h, w, b, N, s_up2)
     C4 = g4.shape[1]
     whf, whd = ops.pack_conv_w(m.head.weight)
-    lg = ops.conv_fwd(g4, C4, imgs, 4 * h, 4 * w, C4, whf, 1, 3, 3, 1, 1, bias=m.head.bias)  # [(b n), 4h, 4w, 1]
+    lg = ops.conv_cout1_fwd(g4, C4, imgs, 4 * h, 4 * w, C4, whf, 3, 3, 1, 1, bias=m.head.bias)  # [(b n), 4h, 4w, 1]
     lg = lg.view(b, N, 4 * h, 4 * w)
     if out_size != (4 * h, 4 * w):
         logits = ops.bilinear_planes_fwd(lg, 4 * h, 4 * w, m.align_corners, out_size[0], out_size[1])
@@ -447,7 +447,7 @@ def _head_backward_core(m, sv, dlogits, gc):
         g4 = sv["g4"]
         C4 = g4.shape[1]
         gc.put(m.head.bias, lambda d, acc: ops.colsum(dlg, out=d, accumulate=acc))
-        dwh = ops.conv_wgrad(dlg, 1, g4, C4, imgs, 4 * h, 4 * w, C4, 1, 3, 3, 1, 1)
+        dwh = ops.conv_cout1_wgrad(dlg, g4, C4, imgs, 4 * h, 4 * w, C4, 1, 1)
         gc.put_tensor(m.head.weight, ops.unpack_conv_wgrad(dwh, 1, C4, 3, 3))
         dg4 = ops.conv_dgrad(dlg, 1, imgs, 4 * h, 4 * w, 1, sv["whd"], C4, 3, 3, 1, 1)
         # ---- up2, up1
@@ -493,7 +493,8 @@ def _head_backward_core(m, sv, dlogits, gc):
         gc.put(m.conv1.bias, lambda d, acc: ops.colsum(dx1, out=d, accumulate=acc))
         dw1 = ops.conv_wgrad(dx1, Ch, sv["sim"], 1, imgs, h, w, 1, Ch, k1, k1, 1, (k1 - 1) // 2)
         gc.put_tensor(m.conv1.weight, ops.unpack_conv_wgrad(dw1, Ch, 1, k1, k1))
-        dsim = ops.conv_dgrad(dx1, Ch, imgs, h, w, Ch, sv["w1d"], 1, k1, k1, 1, (k1 - 1) // 2)  # [(b n) hw, 1]
+        wtap = m.conv1.weight.view(Ch, k1 * k1).t().contiguous()  # [tap, co]
+        dsim = ops.conv_cin1_dgrad(dx1, Ch, imgs, h, w, Ch, wtap, k1, k1, 1, (k1 - 1) // 2)  # [(b n) hw, 1]
         # ---- cosine sim: demb_n[b,p,c] = sum_n dsim[b,n,p] textn[n,c]
         dembn = ops.empty(b * HW, Ce, device=dev)
         ops.gemm(ops.A_MC, ops.B_NC, HW, Ce, N, ops.Op(dsim, HW, 0, N * HW, 0), ops.Op(sv["textn"], Ce), dembn,

@@ -142,7 +142,7 @@ def matmul_nn(a, b, out=None, accumulate=False):
 
 def _ksplit_plan(M, N, K):
     bm = 32 if M <= 32 else (64 if M <= 64 else 128)
-    bn = 128 if (M <= 64 and N > 64) else (32 if N <= 32 else (64 if N <= 64 else 128))
+    bn = (256 if N >= 256 else 128) if (M <= 64 and N > 64) else (32 if N <= 32 else (64 if N <= 64 else 128))
     tiles = math.ceil(M / bm) * math.ceil(N / bn)
     s = max(1, min(math.ceil(1024 / tiles), K // 512 if K >= 1024 else 1, 512))
     ks = math.ceil(math.ceil(K / s) / 16) * 16
@@ -421,6 +421,37 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
     slabs = empty(s, Co, N, device=dy.device)
     gemm(A_MC, B_CONVW, Co, N, Kpix, Op(dy, lddy), Op(x, ldx), slabs, batch=s, ksplit=ks, c_bso=Co * N, conv=g)
     reduce_slabs(out, slabs)
+    return out
+
+
+def conv_cout1_fwd(x, ldx, imgs, H, W, Cc, wf, KH, KW, dil, pad, bias=None):
+    """Conv2d(C -> 1) forward, HBM-bound direct kernel; wf = forward pack [1, KH*KW*C]; returns [imgs*H*W, 1]."""
+    y = empty(imgs * H * W, 1, device=x.device)
+    L.check(L.load().svl_conv_cout1_fwd(_p(x), ldx, imgs, H, W, Cc, KH, KW, dil, pad, _p(wf), _p(bias), _p(y), _st()),
+            "svl_conv_cout1_fwd")
+    return y
+
+
+def conv_cout1_wgrad(dy, x, ldx, imgs, H, W, Cc, dil, pad):
+    """Weight gradient of Conv2d(C -> 1, 3x3): returns the forward-pack layout [1, 9*C]."""
+    lib = L.load()
+    nb = lib.svl_conv_cout1_wgrad_blocks(imgs, H, W)
+    slabs = empty(nb, 9 * Cc, device=x.device)
+    L.check(lib.svl_conv_cout1_wgrad(_p(dy), _p(x), ldx, imgs, H, W, Cc, dil, pad, _p(slabs), _st()),
+            "svl_conv_cout1_wgrad")
+    out = empty(1, 9 * Cc, device=x.device)
+    reduce_slabs(out, slabs)
+    return out
+
+
+def conv_cin1_dgrad(dy, lddy, imgs, H, W, Co, wtap, KH, KW, dil, pad):
+    """Input gradient of Conv2d(1 -> Co): T = dY @ Wtap^T (GEMM, N = KH*KW taps) then the shifted-tap gather.
+    wtap [KH*KW, Co]."""
+    M = imgs * H * W
+    T = empty(M, KH * KW, device=dy.device)
+    gemm(A_KC, B_KC, M, KH * KW, Co, Op(dy, lddy), Op(wtap, Co), T)
+    out = empty(M, 1, device=dy.device)
+    L.check(L.load().svl_tap_gather(_p(T), imgs, H, W, KH, KW, dil, pad, 1, _p(out), _st()), "svl_tap_gather")
     return out
 
 

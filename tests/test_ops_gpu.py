@@ -148,6 +148,36 @@ def test_conv_fwd_dgrad_wgrad(dev, Ci, Co, k, dil, H):
     close(ops.unpack_conv_wgrad(dwf, Co, Ci, k, k), gw, atol=3e-5 * math.sqrt(n * H * W), what="conv wgrad")
 
 
+@pytest.mark.parametrize("C,H", [(32, 40), (16, 24)])
+def test_conv_cout1_thin_kernels(dev, C, H):
+    from semivl_amd import ops
+    n = 3
+    x = rnd(n, C, H, H, dev=dev, seed=60).requires_grad_(True)
+    w = rnd(1, C, 3, 3, dev=dev, scale=0.2).requires_grad_(True)
+    b = rnd(1, dev=dev)
+    ref = F.conv2d(x, w, b, padding=1)
+    wf, _ = ops.pack_conv_w(w.detach())
+    y = ops.conv_cout1_fwd(nhwc(x.detach()), C, n, H, H, C, wf, 3, 3, 1, 1, bias=b)
+    close(nchw(y, n, H, H), ref, atol=1e-4, what="cout1 fwd")
+    dy = rnd(n, 1, H, H, dev=dev)
+    (gw,) = torch.autograd.grad(ref, w, dy)
+    dwf = ops.conv_cout1_wgrad(nhwc(dy), nhwc(x.detach()), C, n, H, H, C, 1, 1)
+    close(ops.unpack_conv_wgrad(dwf, 1, C, 3, 3), gw, atol=1e-3, what="cout1 wgrad")
+
+
+def test_conv_cin1_dgrad(dev):
+    from semivl_amd import ops
+    n, Co, H, k = 4, 128, 32, 7
+    x = rnd(n, 1, H, H, dev=dev, seed=61).requires_grad_(True)
+    w = rnd(Co, 1, k, k, dev=dev, scale=0.1)
+    ref = F.conv2d(x, w, padding=3)
+    dy = rnd(n, Co, H, H, dev=dev)
+    (gx,) = torch.autograd.grad(ref, x, dy)
+    wtap = w.view(Co, k * k).t().contiguous()
+    dx = ops.conv_cin1_dgrad(nhwc(dy), Co, n, H, H, Co, wtap, k, k, 1, 3)
+    close(nchw(dx, n, H, H), gx, atol=5e-4, what="cin1 dgrad")
+
+
 def test_conv_two_source_concat(dev):
     """cat([x, repeat(skip)]) -> conv3x3 without materialising the concat (vlg_head.py:131-135)."""
     from semivl_amd import ops
