@@ -142,7 +142,7 @@ def matmul_nn(a, b, out=None, accumulate=False):
 
 def _ksplit_plan(M, N, K):
     bm = 32 if M <= 32 else (64 if M <= 64 else 128)
-    bn = (256 if N >= 256 else 128) if (M <= 64 and N > 64) else (32 if N <= 32 else (64 if N <= 64 else 128))
+    bn = 128 if (M <= 64 and N > 64) else (32 if N <= 32 else (64 if N <= 64 else 128))
     tiles = math.ceil(M / bm) * math.ceil(N / bn)
     s = max(1, min(math.ceil(1024 / tiles), K // 512 if K >= 1024 else 1, 512))
     ks = math.ceil(math.ceil(K / s) / 16) * 16

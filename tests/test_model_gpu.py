@@ -87,7 +87,7 @@ def test_train_step_matches_reference_fixture(dev, name):
         assert abs(g.norm().item() - ref[0]) < 2e-3 * ref[0] + 1e-7, f"grad norm of {k}: {g.norm().item()} vs {ref[0]}"
         if ("grad/" + k) in z.files:
             full = z["grad/" + k]
-            e = np.abs(g.cpu().numpy() - full).max() / max(np.abs(full).max(), 1e-6)
+            e = np.abs(g.cpu().numpy() - full).max() / max(np.abs(full).max(), 1e-5)
             assert e < 5e-3, f"grad of {k}: rel max err {e}"
     print(f"[{name}] worst grad-norm rel err {worst:.2e}")
 
