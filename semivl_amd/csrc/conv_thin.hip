@@ -8,6 +8,8 @@
 namespace {
 
 // y[pix] = bias + sum_{tap, ci} x[pix + off(tap)][ci] * w[tap * C + ci]
+// CQ = C/4 adjacent lanes share one pixel (one float4 of channels each) so that a wave's load instruction covers
+// 64/CQ whole pixel rows = 1 KiB of contiguous NHWC memory; the channel sum is a CQ-lane shuffle reduction.
 __global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const float* __restrict__ x, long ldx, int H, int W, int C,
                                                              int KH, int KW, int dil, int pad,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
@@ -17,27 +19,29 @@ __global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const float* __rest
   for (int i = threadIdx.x; i < nw; i += 256) ws[i] = w[i];
   __syncthreads();
   const float b0 = bias ? bias[0] : 0.f;
-  const int C4 = C >> 2;
-  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
-    const int ow = (int)(p % W);
-    const long t = p / W;
-    const int oh = (int)(t % H);
-    float acc = b0;
-    for (int ti = 0; ti < KH; ++ti) {
-      const int ih = oh + ti * dil - pad;
-      if (ih < 0 || ih >= H) continue;
-      for (int tj = 0; tj < KW; ++tj) {
-        const int iw = ow + tj * dil - pad;
-        if (iw < 0 || iw >= W) continue;
-        const float4* xr = reinterpret_cast<const float4*>(x + (p + (long)(ti * dil - pad) * W + (tj * dil - pad)) * ldx);
-        const float4* wr = reinterpret_cast<const float4*>(ws + (ti * KW + tj) * C);
-        for (int c = 0; c < C4; ++c) {
-          const float4 a = xr[c], b = wr[c];
+  const int CQ = C >> 2;             // power of two <= 64
+  const int cq = threadIdx.x % CQ;
+  const int ppb = 256 / CQ;          // pixels per block iteration
+  for (long p0 = (long)blockIdx.x * ppb; p0 < npix; p0 += (long)gridDim.x * ppb) {
+    const long p = p0 + threadIdx.x / CQ;
+    float acc = 0.f;
+    if (p < npix) {
+      const int ow = (int)(p % W);
+      const int oh = (int)((p / W) % H);
+      for (int ti = 0; ti < KH; ++ti) {
+        const int ih = oh + ti * dil - pad;
+        if (ih < 0 || ih >= H) continue;
+        for (int tj = 0; tj < KW; ++tj) {
+          const int iw = ow + tj * dil - pad;
+          if (iw < 0 || iw >= W) continue;
+          const float4 a = *reinterpret_cast<const float4*>(x + (p + (long)(ti * dil - pad) * W + (tj * dil - pad)) * ldx + 4 * cq);
+          const float4 b = *reinterpret_cast<const float4*>(ws + (ti * KW + tj) * C + 4 * cq);
           acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
         }
       }
     }
-    y[p] = acc;
+    for (int o = CQ >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (cq == 0 && p < npix) y[p] = acc + b0;
   }
 }
 
@@ -103,11 +107,11 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict
 
 extern "C" int svl_conv_cout1_fwd(const float* x, int64_t ldx, int imgs, int H, int W, int C, int KH, int KW, int dil,
                                   int pad, const float* w, const float* bias, float* y, svl_stream_t stream) {
-  SVL_CHECK_ARG(x && w && y && imgs > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && KH > 0 && KW > 0 &&
-                    (long)KH * KW * C * 4 <= 64 * 1024,
-                "svl_conv_cout1_fwd: bad args");
+  SVL_CHECK_ARG(x && w && y && imgs > 0 && H > 0 && W > 0 && C >= 4 && C <= 256 && (C & (C - 1)) == 0 && ldx % 4 == 0 &&
+                    KH > 0 && KW > 0 && (long)KH * KW * C * 4 <= 64 * 1024,
+                "svl_conv_cout1_fwd: bad args (C must be a power of two in [4, 256])");
   const long npix = (long)imgs * H * W;
-  long grid = (npix + 255) / 256;
+  long grid = (npix * (C / 4) + 255) / 256;
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(conv_cout1_fwd_kernel, dim3((unsigned)grid), dim3(256), (size_t)KH * KW * C * 4, (hipStream_t)stream,
                      x, (long)ldx, H, W, C, KH, KW, dil, pad, w, bias, npix, y);
