@@ -395,6 +395,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+      // Pin the issue order: first MFMA of this k-pair, then the LDS reads of the NEXT k-pair, then the remaining
+      // MFMAs, so the ~100-cycle ds_read latency hides under 64-cycle MFMAs instead of in front of them.
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 1, 0);
     }
     if (kt + 1 < nk) s_store(buf ^ 1);
     __syncthreads();
