@@ -188,6 +188,12 @@ int svl_maskclip_labels(const float* dense, int B, int N, int h, int w, int H, i
 int svl_concept_max_f32(const float* pred, int B, int NC, int64_t HW, const int* concept_offsets, int N,
                         float* out, svl_stream_t stream);
 
+/* Evaluation: intersectionAndUnion of third_party/unimatch/util/utils.py:91-103 as integer histograms.
+ * hist int64 [3K] (caller zeroes; accumulated): [0,K) intersection, [K,2K) prediction area, [2K,3K) target area;
+ * pixels with target == ignore_index are dropped from all three. */
+int svl_iou_hist_i64(const int64_t* pred, const int64_t* target, int64_t n, int K, int ignore_index, int64_t* hist,
+                     svl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Normalisation / elementwise / attention helpers (maskclip_vit.py:120-144, vlg_head.py:39-137).
  * ---------------------------------------------------------------------------------------------- */
@@ -221,7 +227,7 @@ int svl_colsum_f32(const float* x, int64_t rows, int C, int64_t ld, float* out, 
                    svl_stream_t stream);
 
 /* Elementwise: mode 0: out = a + b; 1: out = a * gelu'(b) (a = dY, b = pre-activation); 2: out = a * (b > 0) (relu bwd,
- * b = post-activation); 3: out = a * b; 4: out = a (copy); 5: out = gelu(a); 6: out = relu(a). n elements. */
+ * b = post-activation); 3: out = a * b; 4: out = a (copy); 5: out = gelu(a); 6: out = relu(a); 7: out = a / b. n elements. */
 int svl_eltwise_f32(int mode, const float* a, const float* b, float* out, int64_t n, svl_stream_t stream);
 /* out[r, c] = x[r, c] * mask[(r / rows_per_img) * C + c] * scale  — F.dropout2d on token layout (builder.py:79-85). */
 int svl_chanmask_f32(const float* x, const float* mask, float scale, int64_t rows, int rows_per_img, int C,

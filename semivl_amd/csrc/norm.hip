@@ -234,6 +234,7 @@ __global__ void eltwise_kernel(int mode, const float* __restrict__ a, const floa
       case 3: v = a[i] * b[i]; break;
       case 5: v = gelu_erf(a[i]); break;
       case 6: v = fmaxf(a[i], 0.f); break;
+      case 7: v = a[i] / b[i]; break;
       default: v = a[i]; break;
     }
     out[i] = v;
@@ -524,7 +525,7 @@ extern "C" int svl_colsum_f32(const float* x, int64_t rows, int C, int64_t ld, f
 }
 
 extern "C" int svl_eltwise_f32(int mode, const float* a, const float* b, float* out, int64_t n, svl_stream_t stream) {
-  SVL_CHECK_ARG(a && out && n > 0 && mode >= 0 && mode <= 6 && (mode >= 4 || b), "svl_eltwise_f32: bad args");
+  SVL_CHECK_ARG(a && out && n > 0 && mode >= 0 && mode <= 7 && ((mode >= 4 && mode <= 6) || b), "svl_eltwise_f32: bad args");
   hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, mode, a, b, out, (long)n);
   SVL_LAUNCH_CHECK("svl_eltwise_f32");
   return SVL_OK;

@@ -317,6 +317,27 @@ __global__ void concept_max_kernel(const float* pred, int B, int NC, long HW, co
   }
 }
 
+// intersectionAndUnion (third_party/unimatch/util/utils.py:91-103): integer histograms of prediction, target and
+// their agreement, ignoring target == ignore.  hist[0..K) = intersection, [K..2K) = output area, [2K..3K) = target area.
+__global__ __launch_bounds__(256) void iou_hist_kernel(const int64_t* __restrict__ pred, const int64_t* __restrict__ tgt,
+                                                       long n, int K, int ignore, unsigned long long* __restrict__ hist) {
+  extern __shared__ unsigned int sh[];  // [3K]
+  for (int i = threadIdx.x; i < 3 * K; i += 256) sh[i] = 0;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long t = tgt[i];
+    const long o = (t == ignore) ? ignore : pred[i];
+    if (o >= 0 && o < K) {
+      atomicAdd(&sh[K + (int)o], 1u);
+      if (o == t) atomicAdd(&sh[(int)o], 1u);
+    }
+    if (t >= 0 && t < K) atomicAdd(&sh[2 * K + (int)t], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * K; i += 256)
+    if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
+}
+
 inline int grid_for(long n, int per_thread = 1) {
   long g = (n + 256L * per_thread - 1) / (256L * per_thread);
   if (g < 1) g = 1;
@@ -438,5 +459,14 @@ extern "C" int svl_concept_max_f32(const float* pred, int B, int NC, int64_t HW,
   hipLaunchKernelGGL(concept_max_kernel, dim3(grid_for((long)B * N * HW)), dim3(256), 0, (hipStream_t)stream, pred, B,
                      NC, (long)HW, concept_offsets, N, out);
   SVL_LAUNCH_CHECK("svl_concept_max_f32");
+  return SVL_OK;
+}
+
+extern "C" int svl_iou_hist_i64(const int64_t* pred, const int64_t* target, int64_t n, int K, int ignore_index,
+                                int64_t* hist, svl_stream_t stream) {
+  SVL_CHECK_ARG(pred && target && hist && n > 0 && K > 0 && K <= 4096, "svl_iou_hist_i64: bad args");
+  hipLaunchKernelGGL(iou_hist_kernel, dim3(grid_for(n, 16)), dim3(256), (size_t)3 * K * sizeof(unsigned int),
+                     (hipStream_t)stream, pred, target, (long)n, K, ignore_index, (unsigned long long*)hist);
+  SVL_LAUNCH_CHECK("svl_iou_hist_i64");
   return SVL_OK;
 }

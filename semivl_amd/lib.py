@@ -73,6 +73,7 @@ SIGNATURES = {
     "svl_count_valid_i64": (_I, [_P, _L, _P, _P]),
     "svl_maskclip_labels": (_I, [_P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "svl_concept_max_f32": (_I, [_P, _I, _I, _L, _P, _I, _P, _P]),
+    "svl_iou_hist_i64": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "svl_layernorm_fwd": (_I, [_P, _P, _P, _F, _L, _I, _P, _P, _P]),
     "svl_layernorm_bwd_parts": (_I, [_L]),
     "svl_layernorm_bwd": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P]),

@@ -622,3 +622,9 @@ def semivl_gscale(counts_i64, numel_u, lam, gscale_out):
 
 def semivl_loss(sums_f64, numel_u, lam, out8):
     L.check(L.load().svl_semivl_loss(_p(sums_f64), float(numel_u), float(lam), _p(out8), _st()), "svl_semivl_loss")
+
+
+def iou_hist(pred, target, K, ignore_index, hist):
+    """hist (int64 [3K], accumulated) += intersection / prediction-area / target-area counts."""
+    L.check(L.load().svl_iou_hist_i64(_p(pred), _p(target), pred.numel(), K, ignore_index, _p(hist), _st()),
+            "svl_iou_hist_i64")

@@ -223,6 +223,18 @@ def install():
         for k, v in real.get(n, {}).items():
             setattr(m, k, v)
         sys.modules[n] = m
+    for n in names:  # make `import mmseg; mmseg.ops.resize(...)` style attribute access resolve to the sub-modules
+        if "." in n:
+            parent, child = n.rsplit(".", 1)
+            if parent in sys.modules:
+                setattr(sys.modules[parent], child, sys.modules[n])
+    # the reference's top-level `datasets/` directory is shadowed by the HuggingFace `datasets` wheel of this image
+    dc = types.ModuleType("datasets.classes")
+    dc.CLASSES = {}
+    sys.modules["datasets.classes"] = dc
+    dp = types.ModuleType("datasets.palettes")
+    dp.get_palette = lambda *a, **k: None
+    sys.modules["datasets.palettes"] = dp
     # mmseg.models re-exports the builder module and registries
     sys.modules["mmseg.models"].builder = sys.modules["mmseg.models.builder"]
     wi = sys.modules["mmcv.cnn.utils.weight_init"]

@@ -1,0 +1,72 @@
+"""Evaluation path: oracle vs the reference-captured fixture on CPU; product (HIP) vs the fixture on GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def fixture():
+    z = np.load(os.path.join(HERE, "golden", "eval_zegclip.npz"))
+    g = torch.Generator().manual_seed(77)
+    img = torch.randn(2, 3, 600, 700, generator=g)
+    img = torch.nn.functional.avg_pool2d(img, 9, stride=1, padding=4)
+    chk = np.array([img.double().sum().item(), img.double().abs().sum().item()])
+    assert np.allclose(chk, z["img_checksum"], rtol=0, atol=1e-6), "seeded image stream differs from the fixture's"
+    return z, img
+
+
+def test_oracle_eval_matches_reference_fixture():
+    from oracle import eval_oracle as E
+    z, img = fixture()
+    K, crop, stride = [int(v) for v in z["cfg"]]
+    mask = torch.from_numpy(z["mask"]).long()
+    with torch.no_grad():
+        pred, final = E.predict_zegclip_sliding_window(E.ToyModel(K), img, mask.shape[-2:], crop, stride, K)
+    assert np.array_equal(pred.numpy().astype(np.uint8), z["pred"])
+    assert np.abs(final[:, :, ::8, ::8].numpy() - z["final_s8"]).max() < 1e-6
+    i, u, t = E.intersection_and_union(pred.numpy(), mask.numpy(), K, 255)
+    assert np.array_equal(i, z["inter"]) and np.array_equal(u, z["union"]) and np.array_equal(t, z["target"])
+
+
+@pytest.mark.gpu
+def test_hip_eval_matches_reference_fixture(dev):
+    from oracle import eval_oracle as E
+    from semivl_amd import ops
+    from semivl_amd.evaluate import evaluate, intersection_and_union, predict
+    z, img = fixture()
+    K, crop, stride = [int(v) for v in z["cfg"]]
+    cfg = dict(crop_size=crop, stride=stride, nclass=K)
+    mask = torch.from_numpy(z["mask"]).long()
+    w = E.ToyModel(K).w.data.to(dev).contiguous()
+
+    class HipToy:  # same toy segmentor through the HIP GEMM: logits[b, n, p] = sum_k w[n, k] img[b, k, p]
+        def eval(self):
+            return self
+
+        def __call__(self, x):
+            b, c, h, ww = x.shape
+            out = ops.empty(b, K, h, ww, device=x.device)
+            ops.gemm(ops.A_MC, ops.B_KC, h * ww, K, c, ops.Op(x.contiguous(), h * ww, 0, c * h * ww, 0), ops.Op(w, c), out,
+                     ldc_m=1, ldc_n=h * ww, batch=b, c_bso=K * h * ww)
+            return out
+
+    model = HipToy()
+    with torch.no_grad():
+        pred, final = predict(model, img.to(dev), mask.to(dev), "zegclip_sliding_window", cfg, return_logits=True)
+    assert np.abs(final[:, :, ::8, ::8].cpu().numpy() - z["final_s8"]).max() < 1e-4
+    mism = (pred.cpu().numpy().astype(np.uint8) != z["pred"]).mean()
+    assert mism < 1e-4, f"prediction mismatch rate {mism}"
+    # integer confusion counts: bit-exact given the same prediction map
+    i, u, t = intersection_and_union(torch.from_numpy(z["pred"]).long().to(dev), mask.to(dev), K, 255)
+    assert np.array_equal(i.cpu().numpy(), z["inter"]) and np.array_equal(u.cpu().numpy(), z["union"])
+    assert np.array_equal(t.cpu().numpy(), z["target"])
+    # evaluate(): deferred single reduction == reference formula
+    miou, iou = evaluate(model, [(img[:1], mask[:1], None), (img[1:], mask[1:], None)], "zegclip_sliding_window", cfg)
+    ref_miou, _ = E.miou(z["inter"].astype(float), z["union"].astype(float))
+    assert abs(miou - ref_miou) < 0.05
+    for mode in ("sliding_window", "padded_sliding_window"):
+        with pytest.raises(NotImplementedError):
+            predict(model, img.to(dev), mask.to(dev), mode, cfg)
