@@ -1,0 +1,90 @@
+"""Full-size parity (BASELINE config dims: CLIP ViT-B/16 + VLG head, N=21, 512x512) at batch 1: the product on MI355X
+against the oracle restatement on the host CPU, same seeded weights and inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CK = dict(backbone=dict(lr_mult=0.01), text_encoder=dict(lr_mult=0.0), conv_encoder=dict(lr_mult=1.0),
+          norm=dict(decay_mult=0.0), ln=dict(decay_mult=0.0), head=dict(lr_mult=10.0))
+
+
+def build_pair(dev, nclass=21, dataset="pascal"):
+    from golden_util import seeded_state, text_feats
+    from oracle import semivl_oracle as O
+    from semivl_amd.model.builder import build_model
+    from semivl_amd.model.text_embeddings import get_class_to_concept_idxs
+    from semivl_amd.synthetic import exp40_cfg
+    cfg = exp40_cfg(1, 512, nclass, dataset)
+    hip = build_model(cfg)
+    sd = seeded_state([(k, tuple(v.shape)) for k, v in hip.state_dict().items()], 4242)
+    hip.load_state_dict(sd, strict=True)
+    t, m = text_feats()
+    orc = O.build_vlm(dict(nclass=nclass, crop=512), t, m,
+                      get_class_to_concept_idxs("configs/_base_/datasets/text_embedding/voc12_wbg_concept4_single.npy"))
+    orc.load_state_dict(sd, strict=True)
+    return cfg, hip.to(dev), orc
+
+
+def test_fullsize_step_matches_oracle(dev):
+    from oracle import semivl_oracle as O
+    from semivl_amd.train import LOSS_NAMES, semivl_train_step
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    cfg, hip, orc = build_pair(dev)
+    batch = O.synthetic_batch(1, 512, 21, seed=99)
+    g = torch.Generator().manual_seed(5)
+    masks = [(torch.rand(2, c, generator=g) > 0.5).float() for c in (768, 768, 512)]
+    cfg = dict(cfg, conf_thresh=0.06)  # random-init confidences are ~1/21: keep the unsupervised CE term alive
+    loss, aux = O.semivl_step(orc, batch, 100, 1000, conf_thresh=0.06, fp_masks=masks)
+    loss.backward()
+    losses, haux = semivl_train_step(hip, {k: v.to(dev) for k, v in batch.items()}, 100, 1000, cfg,
+                                     fp_masks=[m.to(dev) for m in masks], return_aux=True)
+    got = dict(zip(LOSS_NAMES, losses.cpu().tolist()))
+    assert abs(got["loss"] - loss.item()) < 1e-3, (got["loss"], loss.item())
+    for k in LOSS_NAMES[1:]:
+        assert abs(got[k] - aux[k].item()) < 1e-3, (k, got[k], aux[k].item())
+    assert (haux["pred_x"].cpu() - aux["pred_x"].detach()).abs().max().item() < 1e-3   # logits tolerance of north_star
+    for k in ("mask_w", "mask_w_other", "mclip", "mclip_other"):
+        mism = (haux[k].cpu() != aux[k]).float().mean().item()
+        assert mism < 5e-4, f"{k}: label mismatch rate {mism}"
+    assert (haux["conf_w"].cpu() - aux["conf_w"]).abs().max().item() < 1e-4
+    og = {n: p.grad for n, p in orc.named_parameters() if p.grad is not None}
+    hg = {n: p.grad for n, p in hip.named_parameters() if p.grad is not None}
+    assert sorted(og) == sorted(hg) and len(og) == 49 + 70
+    worst = 0.0
+    for n in og:
+        ref = og[n]
+        err = (hg[n].cpu() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        if scale > 1e-7:
+            worst = max(worst, err / scale)
+        assert err < 1e-2 * scale + 1e-8, f"{n}: grad max err {err} vs scale {scale}"
+    print(f"full-size step: worst grad rel max-err {worst:.2e}")
+
+
+def test_fullsize_ade150_head_forward(dev):
+    """N = 150 classes (ADE config): eval forward of the full model vs the oracle (exercises the seq=150 attention,
+    N=150 similarity GEMM and class-batched decoder at 150 class-images per image)."""
+    from golden_util import PKG, seeded_state
+    from oracle import semivl_oracle as O
+    from semivl_amd.model.builder import build_model
+    from semivl_amd.synthetic import exp40_cfg
+    import os
+    cfg = exp40_cfg(1, 512, 150, "ade")
+    hip = build_model(cfg)
+    sd = seeded_state([(k, tuple(v.shape)) for k, v in hip.state_dict().items()], 777)
+    hip.load_state_dict(sd, strict=True)
+    t = torch.from_numpy(np.load(os.path.join(PKG, "configs/_base_/datasets/text_embedding/ade_single.npy")))
+    orc = O.build_vlm(dict(nclass=150, crop=512), t, t)
+    orc.load_state_dict(sd, strict=True)
+    img = O.synthetic_batch(1, 512, 150, seed=3)["img_x"]
+    hip.to(dev).eval()
+    orc.eval()
+    with torch.no_grad():
+        ref = orc(img)
+        out = hip(img.to(dev))
+        rm = orc.forward_maskclip(img, 0.9)
+        hm = hip.forward_maskclip(img.to(dev), 0.9)
+    assert (out.cpu() - ref).abs().max().item() < 1e-3
+    assert (hm.cpu() != rm).float().mean().item() < 5e-4
