@@ -186,6 +186,51 @@ __device__ __forceinline__ float4 load_piece(const OperandP& op, const svl_conv_
   }
 }
 
+// Incremental im2col addressing for the interior fast path.  Decomposing a pixel index into (img, oh, ow) and a k index
+// into (tap, ci) costs integer divisions by run-time values (~40 VALU ops each); on the narrow decoder convs that address
+// arithmetic, not the MFMAs, set the pace.  The decomposition is therefore done ONCE per thread and advanced by
+// add-and-carry as the K loop walks (k += BK).
+struct ConvSt {
+  int oh, ow, img;  // output-pixel coordinates (fixed for A_CONV rows, advancing for B_CONVW k)
+  int ti, tj, ci;   // tap / channel (advancing for A_CONV k, fixed for B_CONVW rows)
+};
+__device__ __forceinline__ void conv_split_pixel(const svl_conv_geom& cv, int pix, ConvSt& s) {
+  s.ow = pix % cv.Wo;
+  const int t = pix / cv.Wo;
+  s.oh = t % cv.Ho;
+  s.img = t / cv.Ho;
+}
+__device__ __forceinline__ void conv_split_k(const svl_conv_geom& cv, int k, ConvSt& s) {
+  const int Ct = cv.C1 + cv.C2;
+  const int tap = k / Ct;
+  s.ci = k - tap * Ct;
+  s.ti = tap / cv.KW;
+  s.tj = tap - s.ti * cv.KW;
+}
+__device__ __forceinline__ float4 conv_load_st(const OperandP& op, const svl_conv_geom& cv, const ConvSt& s) {
+  const int ih = s.oh * cv.stride + cv.sign * (s.ti * cv.dil - cv.pad);
+  const int iw = s.ow * cv.stride + cv.sign * (s.tj * cv.dil - cv.pad);
+  if (ih < 0 || ih >= cv.H || iw < 0 || iw >= cv.W) return zero4();
+  return *reinterpret_cast<const float4*>(conv_src(op, cv, s.img, ih, iw, s.ci));
+}
+template <int BK>
+__device__ __forceinline__ void conv_advance_k(const svl_conv_geom& cv, ConvSt& s) {
+  const int Ct = cv.C1 + cv.C2;
+  s.ci += BK;
+  while (s.ci >= Ct) {
+    s.ci -= Ct;
+    if (++s.tj == cv.KW) { s.tj = 0; ++s.ti; }
+  }
+}
+template <int BK>
+__device__ __forceinline__ void conv_advance_pixel(const svl_conv_geom& cv, ConvSt& s) {
+  s.ow += BK;
+  while (s.ow >= cv.Wo) {
+    s.ow -= cv.Wo;
+    if (++s.oh == cv.Ho) { s.oh = 0; ++s.img; }
+  }
+}
+
 // Interior-tile fast path: every row of the panel is in range, the K panel is a full BK, and 16-byte vector loads
 // are legal -> no per-element guards (conv taps still mask their halo with ONE predicated float4 load).
 template <int IS_A, int MODE, int ROWS, int BK>
@@ -317,13 +362,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   // A's "rows" are m (or, for the RMAJOR shapes, the contiguous direction); interior tiles take the unguarded path.
   const bool a_int = p.A.vec && (m0 + BM <= p.M);
   const bool b_int = p.B.vec && (n0 + BN <= p.N);
+  constexpr bool A_IS_CONV = (AMODE == SVL_A_CONV), B_IS_CONV = (BMODE == SVL_B_CONVW);
+  ConvSt sta[APASS], stb[BPASS];
+  if constexpr (A_IS_CONV) {
+    if (a_int) {
+#pragma unroll
+      for (int ps = 0; ps < APASS; ++ps) {
+        const int f = tid + ps * 256;
+        conv_split_pixel(p.cv, m0 + f / (BK / 4), sta[ps]);
+        conv_split_k(p.cv, kbeg + ((f % (BK / 4)) << 2), sta[ps]);
+      }
+    }
+  }
+  if constexpr (B_IS_CONV) {
+    if (b_int) {
+#pragma unroll
+      for (int ps = 0; ps < BPASS; ++ps) {
+        const int f = tid + ps * 256;
+        conv_split_k(p.cv, n0 + ((f % (BN / 4)) << 2), stb[ps]);
+        conv_split_pixel(p.cv, kbeg + f / (BN / 4), stb[ps]);
+      }
+    }
+  }
   auto g_load = [&](int k0) {
     const bool kfull = (k0 + BK <= kend);
     if (a_int && kfull) {
 #pragma unroll
       for (int ps = 0; ps < APASS; ++ps) {
         const int f = tid + ps * 256;
-        if (APIECES % 256 == 0 || f < APIECES) ra[ps] = load_piece_fast<1, AMODE, BM, BK>(p.A, p.cv, Abase, f, m0, k0);
+        if (APIECES % 256 == 0 || f < APIECES) {
+          if constexpr (A_IS_CONV) {
+            ra[ps] = conv_load_st(p.A, p.cv, sta[ps]);
+            conv_advance_k<BK>(p.cv, sta[ps]);
+          } else {
+            ra[ps] = load_piece_fast<1, AMODE, BM, BK>(p.A, p.cv, Abase, f, m0, k0);
+          }
+        }
       }
     } else {
 #pragma unroll
@@ -337,7 +411,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int ps = 0; ps < BPASS; ++ps) {
         const int f = tid + ps * 256;
-        if (BPIECES % 256 == 0 || f < BPIECES) rb[ps] = load_piece_fast<0, BMODE, BN, BK>(p.B, p.cv, Bbase, f, n0, k0);
+        if (BPIECES % 256 == 0 || f < BPIECES) {
+          if constexpr (B_IS_CONV) {
+            rb[ps] = conv_load_st(p.B, p.cv, stb[ps]);
+            conv_advance_pixel<BK>(p.cv, stb[ps]);
+          } else {
+            rb[ps] = load_piece_fast<0, BMODE, BN, BK>(p.B, p.cv, Bbase, f, n0, k0);
+          }
+        }
       }
     } else {
 #pragma unroll
