@@ -170,10 +170,11 @@ class VLM(nn.Module):
 
     # -- forward_wrapper (builder.py:56-102) ---------------------------------------------------------------------
     def forward(self, img, gt=None, need_fp=False, only_fp=False, forward_mode="default", fp_masks=None,
-                split_fp=True):
+                split_fp=True, fp_range=None):
         """Logits [b, N, H, W] at input resolution; with need_fp a 2-tuple (plain, feature-perturbed) halves.
         `fp_masks` (list of three {0,1} tensors [b, C_i]) injects the F.dropout2d channel masks for parity tests;
-        `split_fp=False` returns the un-chunked [2b, ...] tensor."""
+        `split_fp=False` returns the un-chunked [2b, ...] tensor; `fp_range=(s0, s1)` (with split_fp=False) perturbs
+        and decodes only samples [s0, s1): output [b + s1 - s0, ...]."""
         if forward_mode != "default":
             raise ValueError(forward_mode)
         if only_fp:
@@ -188,8 +189,11 @@ class VLM(nn.Module):
             if masks is None:  # F.dropout2d: one Bernoulli(1-p) draw per (sample, channel); always stochastic (App. E.7)
                 masks = [torch.bernoulli(torch.full((f.shape[0], f.shape[2]), 1.0 - self.fp_rate, device=img.device))
                          for f in feats]
+            if fp_range is not None:
+                assert not split_fp, "fp_range returns the un-chunked tensor"
+                masks = [mk[fp_range[0]:fp_range[1]] for mk in masks]
         out = self.decode_head.forward_tokens(feats, self.text_feat(img.device), (hp, wp), masks, self.fp_rate,
-                                              out_size=tuple(img.shape[2:]))
+                                              out_size=tuple(img.shape[2:]), fp_range=fp_range if need_fp else None)
         if need_fp and split_fp:
             return out.chunk(2)
         return out

@@ -141,16 +141,19 @@ class VLGHead(nn.Module):
             raise NotImplementedError("SemanticTransformer head dim must be 64")
 
     # ---------------------------------------------------------------------------------------------------
-    def forward_tokens(self, feats, text, hw, fp_masks=None, fp_rate=0.5, out_size=None):
+    def forward_tokens(self, feats, text, hw, fp_masks=None, fp_rate=0.5, out_size=None, fp_range=None):
         """feats: [v0, v4, emb] token tensors [b, hw, C]; text [N, 512] (any float dtype).
         fp_masks: None, or list of three {0,1} masks [b, C_i]: the batch is doubled with the channel-dropped copy
-        (builder.py:78-89).  Returns logits [b', N, S, S]."""
+        (builder.py:78-89).  `fp_range=(s0, s1)` perturbs only samples [s0, s1) (masks [s1-s0, C_i]): the step never
+        reads the perturbed copy of the labeled half (semivl.py:247), so it need not be decoded.
+        Returns logits [b', N, S, S]."""
         params = [p for p in self.parameters() if p.requires_grad]
         need_grad = torch.is_grad_enabled() and (bool(params) or any(f.requires_grad for f in feats))
         out_size = out_size or (self.image_size, self.image_size)
         if need_grad:
-            return _HeadFn.apply(self, hw, fp_masks, fp_rate, out_size, text, feats[0], feats[1], feats[2], *params)
-        return _head_forward(self, hw, fp_masks, fp_rate, out_size, text, feats, None)
+            return _HeadFn.apply(self, hw, fp_masks, (fp_rate, fp_range), out_size, text, feats[0], feats[1], feats[2],
+                                 *params)
+        return _head_forward(self, hw, fp_masks, (fp_rate, fp_range), out_size, text, feats, None)
 
     def forward(self, inputs, force_output_pred_masks=False):
         """Reference signature (vlg_head.py:192-251): inputs = [[feature_pyramid, global], text_feats, conv_feats]."""
@@ -165,7 +168,8 @@ class VLGHead(nn.Module):
         return {"pred_masks": x} if force_output_pred_masks else x
 
 
-def _head_forward(m, hw, fp_masks, fp_rate, out_size, text, feats, sv):
+def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
+    fp_rate, fp_range = fp_cfg
     h, w = hw
     HW = h * w
     v0, v4, emb = [f.contiguous() for f in feats]
@@ -178,13 +182,14 @@ def _head_forward(m, hw, fp_masks, fp_rate, out_size, text, feats, sv):
     Ce, Cv = emb.shape[2], v0.shape[2]
     # ---- feature perturbation: cat(f, dropout2d(f)) ------------------------------------------------------
     if fp_masks is not None:
-        b = 2 * b0
+        r0, r1 = fp_range if fp_range is not None else (0, b0)
+        b = b0 + (r1 - r0)
         sc = 1.0 / (1.0 - fp_rate)
 
         def dbl(f, mk, Cc):
             out = ops.empty(b * HW, Cc, device=dev)
             ops.eltwise(4, f.view(-1), None, out=out.view(-1)[:b0 * HW * Cc])
-            ops.chanmask(f.view(b0 * HW, Cc), mk.contiguous(), sc, HW, out=out[b0 * HW:])
+            ops.chanmask(f.view(b0 * HW, Cc)[r0 * HW:r1 * HW], mk.contiguous(), sc, HW, out=out[b0 * HW:])
             return out
         v0, v4, emb = dbl(v0, fp_masks[0], Cv), dbl(v4, fp_masks[1], Cv), dbl(emb, fp_masks[2], Ce)
     else:
@@ -250,7 +255,7 @@ def _head_forward(m, hw, fp_masks, fp_rate, out_size, text, feats, sv):
     else:
         logits = lg
     if sv is not None:
-        sv.update(dims=(b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv), fp=(fp_masks, fp_rate), emb=emb, embn=embn,
+        sv.update(dims=(b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv), fp=(fp_masks, fp_rate, fp_range), emb=emb, embn=embn,
                   inv_e=inv_e, textn=textn, sim=sim, w1d=w1d, x1=x1, aspp=aspp_sv, gap=s_gap, pooled=pooled, proj=s_proj,
                   cat=cat, tp=tp, tr=tr_sv, skip=skip_sv, up1=s_up1, up2=s_up2, g4=g4, whd=whd,
                   out_size=out_size, v0=v0, v4=v4)
@@ -360,9 +365,9 @@ def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
 
 class _HeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, m, hw, fp_masks, fp_rate, out_size, text, v0, v4, emb, *params):
+    def forward(ctx, m, hw, fp_masks, fp_cfg, out_size, text, v0, v4, emb, *params):
         sv = {}
-        out = _head_forward(m, hw, fp_masks, fp_rate, out_size, text, [v0, v4, emb], sv)
+        out = _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, [v0, v4, emb], sv)
         ctx.m, ctx.sv, ctx.params, ctx.hw = m, sv, params, hw
         ctx.feat_req = (v0.requires_grad, v4.requires_grad, emb.requires_grad)
         return out
@@ -388,7 +393,8 @@ class _HeadFn(torch.autograd.Function):
                 for full, part in ((dv0, a0), (dv4, a4), (demb, ae)):
                     ops.eltwise(4, part.view(-1), None, out=full[s0 * HW:s1 * HW].view(-1))
         # ---- undo the feature-perturbation doubling
-        fp_masks, fp_rate = sv["fp"]
+        fp_masks, fp_rate, fp_range = sv["fp"]
+        r0, r1 = fp_range if fp_range is not None else (0, b0)
 
         def undbl(dfull, mk, Cc):
             if fp_masks is None:
@@ -396,7 +402,9 @@ class _HeadFn(torch.autograd.Function):
             sc = 1.0 / (1.0 - fp_rate)
             second = ops.chanmask(dfull[b0 * HW:], mk.contiguous(), sc, HW)
             first = dfull[:b0 * HW]
-            return ops.add(first, second, out=second).view(b0, HW, Cc)
+            tgt = first[r0 * HW:r1 * HW]
+            ops.add(tgt, second, out=tgt)
+            return first.view(b0, HW, Cc)
         mk = fp_masks if fp_masks is not None else (None, None, None)
         dv0 = undbl(dv0, mk[0], Cv)
         dv4 = undbl(dv4, mk[1], Cv)

@@ -92,9 +92,11 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
                                            ignore_mask=_cat2i(ign, ign_o))
         mclip, mclip_other = mclip_all[:B], mclip_all[B:]
     # predictions
-    preds4 = model(_cat2(img_x, img_w), need_fp=True, fp_masks=fp_masks, split_fp=False)  # [x, w, x_fp, w_fp]
+    # the feature-perturbed copy of the labeled half (pred_x_fp) is never read by the step (semivl.py:247): only the
+    # unlabeled half is perturbed and decoded -> [x, w, w_fp]
+    preds4 = model(_cat2(img_x, img_w), need_fp=True, fp_masks=fp_masks, split_fp=False, fp_range=(B, 2 * B))
     preds_s = model(_cat2(img_s1, img_s2))                                                 # [s1, s2]
-    pred_x, pred_w, pred_w_fp = preds4[:B], preds4[B:2 * B], preds4[3 * B:]
+    pred_x, pred_w, pred_w_fp = preds4[:B], preds4[B:2 * B], preds4[2 * B:]
     pred_s1, pred_s2 = preds_s[:B], preds_s[B:]
     conf_w, mask_w = ops.softmax_max(pred_w.detach())
     # CutMix labels
@@ -113,7 +115,7 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     thr = cfg["conf_thresh"]
     dl4 = torch.empty_like(preds4)
     dls = torch.empty_like(preds_s)
-    ops.fill(dl4[B:3 * B], 0.0)  # pred_w is detached, pred_x_fp is unused (semivl.py:247,251)
+    ops.fill(dl4[B:2 * B], 0.0)  # pred_w is detached (semivl.py:251)
     sums = ops.empty(4, 4, dtype=torch.float64, device=dev)
     ops.ce_fused(pred_x.detach(), mask_x, True, dlogits=dl4[:B], gscale=gscale[0], sums_out=sums[0])
     ops.ce_fused(pred_s1.detach(), mw1, False, conf=cw1, ign=ig1, conf_thresh=thr, mc=mc1, dlogits=dls[:B],
@@ -121,16 +123,16 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     ops.ce_fused(pred_s2.detach(), mw2, False, conf=cw2, ign=ig2, conf_thresh=thr, mc=mc2, dlogits=dls[B:],
                  gscale=gscale[2], sums_out=sums[2])
     ops.ce_fused(pred_w_fp.detach(), mask_w, False, conf=conf_w, ign=ign, conf_thresh=thr, mc=mclip,
-                 dlogits=dl4[3 * B:], gscale=gscale[3], sums_out=sums[3])
+                 dlogits=dl4[2 * B:], gscale=gscale[3], sums_out=sums[3])
     losses = ops.empty(8, device=dev)
     ops.semivl_loss(sums, numel_u, lam, losses)
     # backward (+ all-reduce) + optimizer
     if optimizer is not None:
         optimizer.zero_grad()
-    # pred_w / pred_x_fp carry exactly-zero dlogits: let the head's backward skip those samples (results identical)
+    # pred_w carries exactly-zero dlogits: let the head's backward skip those samples (results identical)
     head = getattr(model, "decode_head", None)
     if head is not None:
-        head._bwd_ranges = {4 * B: [(0, B), (3 * B, 4 * B)]}
+        head._bwd_ranges = {3 * B: [(0, B), (2 * B, 3 * B)]}
     try:
         torch.autograd.backward([preds4, preds_s], [dl4, dls])
     finally:
