@@ -576,6 +576,8 @@ int launch_mode(const GemmP& p, int batch, hipStream_t st) {
   if (p.M <= 64 && p.N > 64) return launch_cfg<64, 128, 2, 2, AMODE, BMODE>(p, batch, st);
   if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, BMODE>(p, batch, st);
   if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, BMODE>(p, batch, st);
+  static const bool wide = getenv("SVL_GEMM_WIDE") != nullptr;
+  if (wide && p.N >= 256 && p.M >= 256) return launch_cfg<128, 256, 2, 2, AMODE, BMODE>(p, batch, st);
   static const bool bk32 = getenv("SVL_GEMM_BK32") != nullptr;
   if (bk32 && p.K >= 64) return launch_cfg<128, 128, 2, 2, AMODE, BMODE, 32>(p, batch, st);
   return launch_cfg<128, 128, 2, 2, AMODE, BMODE>(p, batch, st);
