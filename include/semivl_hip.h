@@ -155,6 +155,7 @@ typedef struct svl_ce_desc {
   const float* conf;     /* [B, HW] or NULL */
   const int64_t* ign;    /* [B, HW] or NULL */
   float conf_thresh;
+  int all_pixels;        /* 1: conf_mode 'pixelavg' — w_t = 1 on every pixel (train_utils.py:43-46 sums the whole CE map) */
   const int64_t* mc_target; /* [B, HW] or NULL */
   float* partials;       /* workspace [svl_ce_num_blocks(B,N,HW)][4]: per-block {sum w*ce_t, sum ce_m, sum conf*valid, #valid} */
   float* dlogits;        /* [B, N, HW] or NULL */
@@ -168,10 +169,19 @@ int svl_ce_finalize(const float* partials, int64_t nblocks, double* sums /* [4] 
  * counts: int64[4] device = #valid of {mask_x != 255, ignore_mask_mixed1, ignore_mask_mixed2, ignore_mask} != 255.
  * gscale out: float[4][2] device = {g_t, g_m} for the branches {x, s1, s2, fp}: the factor each per-pixel CE term
  * carries in d(loss)/d(logits).  numel_u = B*H*W of one unlabeled branch; lam = current mcc lambda. */
-int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, float* gscale, svl_stream_t stream);
+int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, const double* factors, float* gscale,
+                      svl_stream_t stream);
+/* conf_mode 'pixelavg' (train_utils.py:43-46): factor[0] = sum over images b of mean_{valid pixels}(conf_b).  The
+ * unsupervised branch loss is (sum over ALL pixels of CE) * factor / #valid.  `factors` above/below: double[3] device
+ * for the branches {s1, s2, fp}, or NULL for 'pixelwise'. */
+int svl_conf_avg_factor(const float* conf, const int64_t* ign, int B, int64_t HW, double* factor, svl_stream_t stream);
 /* sums: double[4 branches][4] device (from svl_ce_finalize); out float[8] device =
  * {loss, loss_x, loss_s1, loss_s2, loss_fp, loss_mc_s1, loss_mc_s2, loss_mc_fp}. */
-int svl_semivl_loss(const double* sums, double numel_u, float lam, float* out, svl_stream_t stream);
+int svl_semivl_loss(const double* sums, double numel_u, float lam, const double* factors, float* out,
+                    svl_stream_t stream);
+/* out[b, c, p] = softmax over classes c of NCHW logits (probability accumulation of the sliding-window eval modes,
+ * supervised.py:61,113). */
+int svl_softmax_planes_f32(const float* logits, int B, int N, int64_t HW, float* out, svl_stream_t stream);
 
 /* counts-only pre-pass so the normalisers of semivl.py:38/57 exist before the fused pass:
  * counts[0] += #(map != 255) over [n] */

@@ -27,6 +27,43 @@ def predict_zegclip_sliding_window(model, img, mask_hw, crop, stride, nclass):
     return final.argmax(dim=1), final
 
 
+def predict_sliding_window(model, img, crop, nclass):
+    """supervised.py:104-117: probability accumulation over windows with stride int(2/3 crop)."""
+    b, _, h, w = img.shape
+    final = torch.zeros(b, nclass, h, w)
+    step = int(crop * 2 / 3)
+    row = 0
+    while row < h:
+        col = 0
+        while col < w:
+            pred = model(img[:, :, row:min(h, row + crop), col:min(w, col + crop)])
+            final[:, :, row:min(h, row + crop), col:min(w, col + crop)] += pred.softmax(dim=1)
+            col += step
+        row += step
+    return final.argmax(dim=1), final
+
+
+def predict_padded_sliding_window(model, img, crop, stride, nclass):
+    """supervised.py:41-68: zero-padded crops."""
+    if stride < 1:
+        stride = int(crop * stride)
+    b, _, h, w = img.shape
+    final = torch.zeros(b, nclass, h, w)
+    row = 0
+    while row < h:
+        col = 0
+        while col < w:
+            y2, x2 = min(h, row + crop), min(w, col + crop)
+            ch, cw = y2 - row, x2 - col
+            cropped = torch.zeros((b, 3, crop, crop))
+            cropped[:, :, :ch, :cw] = img[:, :, row:y2, col:x2]
+            pred = model(cropped)
+            final[:, :, row:y2, col:x2] += pred.softmax(dim=1)[:, :, :ch, :cw]
+            col += stride
+        row += stride
+    return final.argmax(dim=1), final
+
+
 def intersection_and_union(output, target, K, ignore_index=255):
     output = np.asarray(output).reshape(-1).copy()
     target = np.asarray(target).reshape(-1)

@@ -133,8 +133,9 @@ __device__ __forceinline__ float4 load_piece(const OperandP& op, const svl_conv_
         return make_float4(r[0], r[1], r[2], r[3]);
       }
     } else {  // SVL_A_PATCH: row = (img, py, px); k = (c, i, j), P = cv.patch, image NCHW [img, C1, H, W]
+      // The patch grid is ceil(H/P) x ceil(W/P): pixels beyond the image read 0 (mmseg PatchEmbed padding='corner').
       const int P = cv.patch;
-      const int npx = cv.W / P, npy = cv.H / P;
+      const int npx = (cv.W + P - 1) / P, npy = (cv.H + P - 1) / P;
       const int px = row % npx;
       const int t = row / npx;
       const int py = t % npy;
@@ -142,8 +143,10 @@ __device__ __forceinline__ float4 load_piece(const OperandP& op, const svl_conv_
       const int c = k / (P * P);
       const int r2 = k - c * P * P;
       const int i = r2 / P, j = r2 - i * P;
-      const float* ptr = base + (((long)img * cv.C1 + c) * cv.H + (py * P + i)) * cv.W + px * P + j;
-      return load4(ptr, nv, op.vec);
+      const int y = py * P + i, x = px * P + j;
+      if (y >= cv.H) return zero4();
+      const float* ptr = base + (((long)img * cv.C1 + c) * cv.H + y) * cv.W + x;
+      return load4(ptr, min(nv, cv.W - x), op.vec);
     }
   } else {  // LS_RMAJOR
     constexpr int RP = ROWS / 4;
@@ -638,10 +641,11 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     SVL_CHECK_ARG(d->batch == 1 || d->ksplit > 0, "svl_gemm_f32: conv modes are unbatched");
   }
   if (d->a_mode == SVL_A_PATCH) {
-    SVL_CHECK_ARG(cv.patch > 0 && cv.H % cv.patch == 0 && cv.W % cv.patch == 0 && cv.C1 > 0,
-                  "svl_gemm_f32: bad patch geometry");
+    SVL_CHECK_ARG(cv.patch > 0 && cv.H > 0 && cv.W > 0 && cv.C1 > 0, "svl_gemm_f32: bad patch geometry");
     SVL_CHECK_ARG(d->K == cv.C1 * cv.patch * cv.patch, "svl_gemm_f32: patch K mismatch");
-    p.A.vec = aligned16(d->A.ptr) && (cv.W % 4 == 0) && (cv.patch % 4 == 0);
+    // vector / unguarded loads only when every patch lies inside the image
+    p.A.vec = aligned16(d->A.ptr) && (cv.W % 4 == 0) && (cv.patch % 4 == 0) && (cv.H % cv.patch == 0) &&
+              (cv.W % cv.patch == 0);
   } else if (a_conv) {
     p.A.vec = conv_vec(d->A);
   } else {

@@ -97,6 +97,7 @@ struct CeP {
   const float* conf;
   const int64_t* ign;
   float conf_thresh;
+  int all_pixels;
   const int64_t* mc;
   float* partials;
   float* dlogits;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
     if (p.conf) {
       const bool v = p.ign[o] != 255;
       const float cf = p.conf[o];
-      w = (cf >= p.conf_thresh && v) ? 1.f : 0.f;
+      w = p.all_pixels ? 1.f : ((cf >= p.conf_thresh && v) ? 1.f : 0.f);
       valid = v;
       s_c = v ? cf : 0.f;
     }
@@ -228,21 +229,48 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* partials,
 // counts: int64 [4] = #valid for {x (mask_x != 255), s1, s2, fp (ignore maps != 255)}.
 // gscale out: float [4][2] = {g_t, g_m} per branch {x, s1, s2, fp}.
 // ------------------------------------------------------------------------------------------------
-__global__ void semivl_gscale_kernel(const unsigned long long* counts, double numel_u, float lam, float* gscale) {
+// factors (optional, double[3]): conf_mode 'pixelavg' multiplies the unsupervised branches {s1, s2, fp} by
+// sum_b avgconf_b (train_utils.py:43-46); NULL = 'pixelwise'.
+__global__ void semivl_gscale_kernel(const unsigned long long* counts, double numel_u, float lam, const double* factors,
+                                     float* gscale) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double c0 = (double)counts[0], c1 = (double)counts[1], c2 = (double)counts[2], c3 = (double)counts[3];
+  const double f1 = factors ? factors[0] : 1.0, f2 = factors ? factors[1] : 1.0, f3 = factors ? factors[2] : 1.0;
   gscale[0] = (float)(0.5 / c0);          gscale[1] = 0.f;
-  gscale[2] = (float)(0.125 / c1);        gscale[3] = (float)(0.25 * lam / numel_u);
-  gscale[4] = (float)(0.125 / c2);        gscale[5] = (float)(0.25 * lam / numel_u);
-  gscale[6] = (float)(0.25 / c3);         gscale[7] = (float)(0.5 * lam / numel_u);
+  gscale[2] = (float)(0.125 * f1 / c1);   gscale[3] = (float)(0.25 * lam / numel_u);
+  gscale[4] = (float)(0.125 * f2 / c2);   gscale[5] = (float)(0.25 * lam / numel_u);
+  gscale[6] = (float)(0.25 * f3 / c3);    gscale[7] = (float)(0.5 * lam / numel_u);
+}
+// factor = sum over images of (sum_p conf*valid) / (sum_p valid), one block
+__global__ __launch_bounds__(256) void conf_avg_factor_kernel(const float* __restrict__ conf, const int64_t* __restrict__ ign,
+                                                              int B, long HW, double* __restrict__ factor) {
+  __shared__ double sh[2][256];
+  double tot = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s = 0.0, c = 0.0;
+    for (long i = threadIdx.x; i < HW; i += 256) {
+      const bool v = ign[b * HW + i] != 255;
+      if (v) { s += (double)conf[b * HW + i]; c += 1.0; }
+    }
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+      __syncthreads();
+    }
+    tot += sh[0][0] / sh[1][0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) factor[0] = tot;
 }
 // sums: double [4 branches][4]; out: float[8] = {loss, loss_x, loss_s1, loss_s2, loss_fp, mc_s1, mc_s2, mc_fp}
-__global__ void semivl_loss_kernel(const double* sums, double numel_u, float lam, float* out) {
+__global__ void semivl_loss_kernel(const double* sums, double numel_u, float lam, const double* factors, float* out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double f1 = factors ? factors[0] : 1.0, f2 = factors ? factors[1] : 1.0, f3 = factors ? factors[2] : 1.0;
   const float lx = (float)(sums[0] / sums[3]);
-  const float l1 = (float)(sums[4] / sums[7]);
-  const float l2 = (float)(sums[8] / sums[11]);
-  const float lf = (float)(sums[12] / sums[15]);
+  const float l1 = (float)(sums[4] * f1 / sums[7]);
+  const float l2 = (float)(sums[8] * f2 / sums[11]);
+  const float lf = (float)(sums[12] * f3 / sums[15]);
   const float m1 = (float)(sums[5] / numel_u);
   const float m2 = (float)(sums[9] / numel_u);
   const float mf = (float)(sums[13] / numel_u);
@@ -314,6 +342,23 @@ __global__ void concept_max_kernel(const float* pred, int B, int NC, long HW, co
     float m = -INFINITY;
     for (int k = off[c]; k < off[c + 1]; ++k) m = fmaxf(m, pred[(b * NC + k) * HW + p]);
     out[i] = m;
+  }
+}
+
+// out[b, c, p] = softmax over c of logits[b, c, p]  (probability accumulation of the 'sliding_window' eval modes)
+__global__ __launch_bounds__(256) void softmax_planes_kernel(const float* __restrict__ x, int B, int N, long HW,
+                                                             float* __restrict__ y) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW, p = i - b * HW;
+    const float* xb = x + b * N * HW + p;
+    float m = -INFINITY;
+    for (int c = 0; c < N; ++c) m = fmaxf(m, xb[(long)c * HW]);
+    float s = 0.f;
+    for (int c = 0; c < N; ++c) s += expf(xb[(long)c * HW] - m);
+    const float inv = 1.f / s;
+    float* yb = y + b * N * HW + p;
+    for (int c = 0; c < N; ++c) yb[(long)c * HW] = expf(xb[(long)c * HW] - m) * inv;
   }
 }
 
@@ -410,7 +455,7 @@ extern "C" int svl_ce_fused_f32(const svl_ce_desc* d, svl_stream_t stream) {
   CeP p;
   p.logits = d->logits; p.B = d->B; p.N = d->N; p.HW = d->HW;
   p.target = d->target; p.use_ignore_t = d->use_ignore_t;
-  p.conf = d->conf; p.ign = d->ign; p.conf_thresh = d->conf_thresh;
+  p.conf = d->conf; p.ign = d->ign; p.conf_thresh = d->conf_thresh; p.all_pixels = d->all_pixels;
   p.mc = d->mc_target; p.partials = d->partials; p.dlogits = d->dlogits; p.gscale = d->gscale;
   p.P = P;
   p.blocks_per_img = (d->HW + P - 1) / P;
@@ -428,18 +473,27 @@ extern "C" int svl_ce_finalize(const float* partials, int64_t nblocks, double* s
   return SVL_OK;
 }
 
-extern "C" int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, float* gscale,
+extern "C" int svl_conf_avg_factor(const float* conf, const int64_t* ign, int B, int64_t HW, double* factor,
+                                   svl_stream_t stream) {
+  SVL_CHECK_ARG(conf && ign && factor && B > 0 && HW > 0, "svl_conf_avg_factor: bad args");
+  hipLaunchKernelGGL(conf_avg_factor_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, conf, ign, B, (long)HW, factor);
+  SVL_LAUNCH_CHECK("svl_conf_avg_factor");
+  return SVL_OK;
+}
+
+extern "C" int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, const double* factors, float* gscale,
                                  svl_stream_t stream) {
   SVL_CHECK_ARG(counts && gscale && numel_u > 0, "svl_semivl_gscale: bad args");
   hipLaunchKernelGGL(semivl_gscale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
-                     (const unsigned long long*)counts, numel_u, lam, gscale);
+                     (const unsigned long long*)counts, numel_u, lam, factors, gscale);
   SVL_LAUNCH_CHECK("svl_semivl_gscale");
   return SVL_OK;
 }
 
-extern "C" int svl_semivl_loss(const double* sums, double numel_u, float lam, float* out, svl_stream_t stream) {
+extern "C" int svl_semivl_loss(const double* sums, double numel_u, float lam, const double* factors, float* out,
+                               svl_stream_t stream) {
   SVL_CHECK_ARG(sums && out && numel_u > 0, "svl_semivl_loss: bad args");
-  hipLaunchKernelGGL(semivl_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, numel_u, lam, out);
+  hipLaunchKernelGGL(semivl_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, numel_u, lam, factors, out);
   SVL_LAUNCH_CHECK("svl_semivl_loss");
   return SVL_OK;
 }
@@ -468,5 +522,13 @@ extern "C" int svl_iou_hist_i64(const int64_t* pred, const int64_t* target, int6
   hipLaunchKernelGGL(iou_hist_kernel, dim3(grid_for(n, 16)), dim3(256), (size_t)3 * K * sizeof(unsigned int),
                      (hipStream_t)stream, pred, target, (long)n, K, ignore_index, (unsigned long long*)hist);
   SVL_LAUNCH_CHECK("svl_iou_hist_i64");
+  return SVL_OK;
+}
+
+extern "C" int svl_softmax_planes_f32(const float* logits, int B, int N, int64_t HW, float* out, svl_stream_t stream) {
+  SVL_CHECK_ARG(logits && out && B > 0 && N > 0 && HW > 0, "svl_softmax_planes_f32: bad args");
+  hipLaunchKernelGGL(softmax_planes_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, (hipStream_t)stream, logits, B, N,
+                     (long)HW, out);
+  SVL_LAUNCH_CHECK("svl_softmax_planes_f32");
   return SVL_OK;
 }

@@ -53,9 +53,38 @@ def predict(model, img, mask, mode, cfg, return_logits=False):
         preds = ops.eltwise(7, preds.view(-1), cnt.view(-1)).view(b, K, h, w)
         H, W = mask.shape[-2:]
         final = ops.bilinear_planes_fwd(preds, h, w, True, H, W) if (H, W) != (h, w) else preds
-    elif mode in ("sliding_window", "padded_sliding_window"):
-        # probability-averaging variants (Cityscapes eval, supervised.py:41-68,104-117): part of the N2 row
-        raise NotImplementedError(f"eval mode '{mode}' belongs to the Cityscapes (N2) row")
+    elif mode == "sliding_window":  # supervised.py:104-117: softmax-probability accumulation, stride int(2/3 crop)
+        grid = cfg["crop_size"]
+        b, _, h, w = img.shape
+        final = ops.zeros(b, cfg["nclass"], h, w, device=img.device)
+        step = int(grid * 2 / 3)
+        row = 0
+        while row < h:
+            col = 0
+            while col < w:
+                y2, x2 = min(h, row + grid), min(w, col + grid)
+                logit = model(_crop(img, row, y2, col, x2))
+                _window_add(final, ops.softmax_planes(logit.contiguous()), row, col)
+                col += step
+            row += step
+    elif mode == "padded_sliding_window":  # supervised.py:41-68: zero-padded crops, configurable stride
+        grid, stride = cfg["crop_size"], cfg["stride"]
+        if stride < 1:
+            stride = int(grid * stride)
+        b, c, h, w = img.shape
+        final = ops.zeros(b, cfg["nclass"], h, w, device=img.device)
+        row = 0
+        while row < h:
+            col = 0
+            while col < w:
+                y2, x2 = min(h, row + grid), min(w, col + grid)
+                ch, cw = y2 - row, x2 - col
+                padded = ops.zeros(b, c, grid, grid, device=img.device)
+                ops.copy2d(img, row * w + col, ch, h * w, w, padded, 0, ch, grid * grid, grid, b * c * ch, cw)
+                prob = ops.softmax_planes(model(padded).contiguous())
+                _window_add(final, _crop(prob, 0, ch, 0, cw), row, col)
+                col += stride
+            row += stride
     elif mode in ("original", "center_crop"):
         if mode == "center_crop":
             h, w = img.shape[-2:]

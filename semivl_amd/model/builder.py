@@ -147,8 +147,8 @@ class VLM(nn.Module):
             feats, _ = self.clip_encoder.forward_tokens(img, need_global=False)
             emb = feats[-1]  # [b, hw, 512]
             b, HW, Ce = emb.shape
-            hp = img.shape[2] // self.clip_encoder.patch_size
-            wp = img.shape[3] // self.clip_encoder.patch_size
+            ps = self.clip_encoder.patch_size
+            hp, wp = (img.shape[2] + ps - 1) // ps, (img.shape[3] + ps - 1) // ps
             text = self._on("mcc", self.loaded_mcc_text_feat, img.device)
             NC = text.shape[0]
             dense = ops.empty(b, NC, hp, wp, device=img.device)  # F.conv2d(visual_feat, text[:, :, None, None])
@@ -182,7 +182,8 @@ class VLM(nn.Module):
         if tuple(img.shape[2:]) != (self.decode_head.image_size, self.decode_head.image_size):
             raise NotImplementedError("input size != decode_head.img_size (second resize, builder.py:93-97)")
         feats, _ = self.backbone.forward_tokens(img, need_global=False)
-        hp, wp = img.shape[2] // self.backbone.patch_size, img.shape[3] // self.backbone.patch_size
+        ps = self.backbone.patch_size
+        hp, wp = (img.shape[2] + ps - 1) // ps, (img.shape[3] + ps - 1) // ps
         masks = None
         if need_fp:
             masks = fp_masks

@@ -337,10 +337,19 @@ class MaskClipVisionTransformer(nn.Module):
     def forward_tokens(self, img, need_global=False):
         """Returns (feat_tokens list of [B, P, C] tensors, global or None) on the autograd graph."""
         tr = self._trainable()
-        if torch.is_grad_enabled() and tr:
-            outs = _EncoderFn.apply(self, img, need_global, *tr)
+        Pz = self.patch_size
+        hp, wp = (img.shape[2] + Pz - 1) // Pz, (img.shape[3] + Pz - 1) // Pz
+        pos_in = None
+        if hp * wp + 1 != self.pos_embed.shape[1]:
+            # token count differs from the trained grid (e.g. 801 -> 816 -> 51x51 vs 50x50): per-forward bicubic resize
+            # (maskclip_vit.py:447-459).  The 7.7 MB resample stays on torch autograd so pos_embed keeps its gradient.
+            pos_in = self.resize_pos_embed(self.pos_embed, (hp, wp),
+                                           (self.img_size[0] // Pz, self.img_size[1] // Pz))[0].contiguous()
+            tr = [p for p in tr if p is not self.pos_embed]
+        if torch.is_grad_enabled() and (tr or (pos_in is not None and pos_in.requires_grad)):
+            outs = _EncoderFn.apply(self, img, need_global, pos_in, *tr)
         else:
-            outs = _encoder_forward(self, img, need_global, None)
+            outs = _encoder_forward(self, img, need_global, None, pos_in)
         n = len(outs) - 1
         return list(outs[:n]), outs[n]
 
@@ -354,22 +363,17 @@ class MaskClipVisionTransformer(nn.Module):
         return [tuple(f.view(B, hp, wp, f.shape[-1]).permute(0, 3, 1, 2) for f in feats), g]
 
 
-def _encoder_forward(m, img, need_global, saved):
-    if img.shape[2] % m.patch_size or img.shape[3] % m.patch_size:
-        raise NotImplementedError("corner padding of off-size inputs (Cityscapes 801) is not on the round-1 path")
+def _encoder_forward(m, img, need_global, saved, pos_in=None):
     assert img.is_cuda and img.dtype == torch.float32
     img = img.contiguous()
     B, Cin, H, W = img.shape
     Pz, E, L = m.patch_size, m.embed_dims, m.num_layers
-    hp, wp = H // Pz, W // Pz
+    hp, wp = (H + Pz - 1) // Pz, (W + Pz - 1) // Pz  # 'corner' padding: bottom/right zero-fill up to a patch multiple
     NP = hp * wp
     T = NP + 1
     dev = img.device
-    pos = m.pos_embed[0]
-    if pos.shape[0] != T:  # token count differs from the trained grid: per-forward bicubic resize (maskclip_vit.py:447-459)
-        pos = m.resize_pos_embed(m.pos_embed, (hp, wp), (m.img_size[0] // Pz, m.img_size[1] // Pz))[0].contiguous()
-        if saved is not None:
-            raise NotImplementedError("training with a resized pos_embed is not on the round-1 path")
+    pos = m.pos_embed[0] if pos_in is None else pos_in.detach()
+    assert pos.shape[0] == T, (pos.shape, T)
     x = ops.empty(B * T, E, device=dev)
     wpe = m.patch_embed.projection.weight.view(E, Cin * Pz * Pz)
     g = ops.conv_geom(H, W, Cin, Pz, Pz, patch=Pz)
@@ -423,10 +427,11 @@ def _encoder_forward(m, img, need_global, saved):
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, m, img, need_global, *params):
+    def forward(ctx, m, img, need_global, pos_in, *params):
         saved = {}
-        outs = _encoder_forward(m, img, need_global, saved)
+        outs = _encoder_forward(m, img, need_global, saved, pos_in)
         ctx.m, ctx.saved, ctx.need_global = m, saved, need_global
+        ctx.pos_is_input = pos_in is not None
         ctx.n_feats = len(outs) - 1
         ctx.params = params
         if outs[-1] is not None:
@@ -477,15 +482,20 @@ class _EncoderFn(torch.autograd.Function):
             s["layers"][i] = None  # free this block's activations
         if dx is None:
             ctx.saved = None
-            return (None, None, None) + tuple(None for _ in ctx.params)
+            return (None, None, None, None) + tuple(None for _ in ctx.params)
         # ---- ln0 + pos_embed
         dxpre = ops.layernorm_bwd(dx, s["x_pre"], s["st0"], m.ln0.weight)
-        if m.pos_embed.requires_grad:
-            def pos_fn(dst, acc):
-                # sum over the batch: rows b*T + t -> t
-                ops.copy2d(dxpre, 0, B * T, 0, E, dst.view(-1), 0, T, 0, E, T, E, accumulate=acc)
-                for b in range(1, B):
-                    ops.copy2d(dxpre, b * T * E, T, 0, E, dst.view(-1), 0, T, 0, E, T, E, accumulate=True)
+        def pos_fn(dst, acc):
+            # sum over the batch: rows b*T + t -> t
+            ops.copy2d(dxpre, 0, B * T, 0, E, dst.view(-1), 0, T, 0, E, T, E, accumulate=acc)
+            for b in range(1, B):
+                ops.copy2d(dxpre, b * T * E, T, 0, E, dst.view(-1), 0, T, 0, E, T, E, accumulate=True)
+        dpos_in = None
+        if ctx.pos_is_input:  # resized pos_embed: hand the gradient back to torch autograd (bicubic backward)
+            if m.pos_embed.requires_grad:
+                dpos_in = ops.empty(T, E, device=dev)
+                pos_fn(dpos_in, False)
+        elif m.pos_embed.requires_grad:
             grads[id(m.pos_embed)] = sink_grad(m.pos_embed, pos_fn)
         ctx.saved = None
-        return (None, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
+        return (None, None, None, dpos_in) + tuple(grads.get(id(p)) for p in ctx.params)

@@ -571,7 +571,7 @@ def count_valid(map_i64, out_count):
 
 
 def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0, mc=None, dlogits=None, gscale=None,
-             sums_out=None):
+             sums_out=None, all_pixels=False):
     """Returns sums (double[4] device): {sum w*ce_t, sum ce_m, sum conf*valid, #valid}."""
     Bn, N = logits.shape[:2]
     HW = logits[0, 0].numel()
@@ -581,7 +581,7 @@ def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0,
         raise RuntimeError(f"svl_ce_fused: unsupported N={N}")
     partials = empty(nblk, 4, device=logits.device)
     d = L.CeDesc(_p(logits), Bn, N, HW, _p(target), 1 if use_ignore_t else 0, _p(conf), _p(ign), float(conf_thresh),
-                 _p(mc), _p(partials), _p(dlogits), _p(gscale))
+                 1 if all_pixels else 0, _p(mc), _p(partials), _p(dlogits), _p(gscale))
     e0 = _prof_begin()
     L.check(lib.svl_ce_fused_f32(C.byref(d), _st()), "svl_ce_fused_f32")
     # algorithmic bytes: fwd (4N+20) + bwd (8N+20) B/px when dlogits is produced, else fwd only
@@ -615,13 +615,28 @@ def adamw_step(p, g, m, v, seg_off, seg_lr, seg_wd, nseg, beta1, beta2, eps, ste
                                     float(ema_decay), _st()), "svl_adamw_step")
 
 
-def semivl_gscale(counts_i64, numel_u, lam, gscale_out):
-    L.check(L.load().svl_semivl_gscale(_p(counts_i64), float(numel_u), float(lam), _p(gscale_out), _st()),
+def semivl_gscale(counts_i64, numel_u, lam, gscale_out, factors=None):
+    L.check(L.load().svl_semivl_gscale(_p(counts_i64), float(numel_u), float(lam), _p(factors), _p(gscale_out), _st()),
             "svl_semivl_gscale")
 
 
-def semivl_loss(sums_f64, numel_u, lam, out8):
-    L.check(L.load().svl_semivl_loss(_p(sums_f64), float(numel_u), float(lam), _p(out8), _st()), "svl_semivl_loss")
+def semivl_loss(sums_f64, numel_u, lam, out8, factors=None):
+    L.check(L.load().svl_semivl_loss(_p(sums_f64), float(numel_u), float(lam), _p(factors), _p(out8), _st()),
+            "svl_semivl_loss")
+
+
+def conf_avg_factor(conf, ign, out_f64):
+    """out_f64[0] = sum_b mean_{valid}(conf_b)  ('pixelavg' confidence weighting)."""
+    L.check(L.load().svl_conf_avg_factor(_p(conf), _p(ign), conf.shape[0], conf[0].numel(), _p(out_f64), _st()),
+            "svl_conf_avg_factor")
+
+
+def softmax_planes(logits):
+    Bn, N = logits.shape[:2]
+    out = torch.empty_like(logits)
+    L.check(L.load().svl_softmax_planes_f32(_p(logits), Bn, N, logits[0, 0].numel(), _p(out), _st()),
+            "svl_softmax_planes_f32")
+    return out
 
 
 def iou_hist(pred, target, K, ignore_index, hist):

@@ -64,9 +64,11 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     mcc_loss_reduce 'mean_all').  `batch`: the 12 step tensors on the GPU.  No host syncs: the
     returned `losses` is a device float[8] (LOSS_NAMES order).
     """
-    if cfg.get("conf_mode", "pixelwise") != "pixelwise" or cfg.get("mcc_loss_reduce", "mean_all") != "mean_all":
-        raise NotImplementedError("only conf_mode='pixelwise' / mcc_loss_reduce='mean_all' (VOC/COCO/ADE recipes); "
-                                  "'pixelavg' is the Cityscapes next-row item (SURVEY N2)")
+    conf_mode = cfg.get("conf_mode", "pixelwise")
+    if conf_mode not in ("pixelwise", "pixelavg") or cfg.get("mcc_loss_reduce", "mean_all") != "mean_all":
+        raise NotImplementedError("conf_mode in {'pixelwise','pixelavg'} and mcc_loss_reduce='mean_all' only "
+                                  "(every shipped SemiVL recipe, experiments.py:60-102,428-456)")
+    pixelavg = conf_mode == "pixelavg"
     lam_cfg = cfg.get("maskclip_consistency_lambda", [0.1, 0])
     if isinstance(lam_cfg, (list, tuple)):
         prog = iters / total_iters
@@ -110,7 +112,12 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         ops.count_valid(m_, counts[i:i + 1])
     numel_u = float(ign.numel())
     gscale = ops.empty(4, 2, device=dev)
-    ops.semivl_gscale(counts, numel_u, lam, gscale)
+    factors = None
+    if pixelavg:  # train_utils.py:43-46: (sum of the WHOLE CE map) * sum_b mean_valid(conf_b) / #valid
+        factors = ops.empty(3, dtype=torch.float64, device=dev)
+        for i, (c_, g_) in enumerate(((cw1, ig1), (cw2, ig2), (conf_w, ign))):
+            ops.conf_avg_factor(c_, g_, factors[i:i + 1])
+    ops.semivl_gscale(counts, numel_u, lam, gscale, factors)
     # fused CE forward + backward per branch
     thr = cfg["conf_thresh"]
     dl4 = torch.empty_like(preds4)
@@ -119,13 +126,13 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     sums = ops.empty(4, 4, dtype=torch.float64, device=dev)
     ops.ce_fused(pred_x.detach(), mask_x, True, dlogits=dl4[:B], gscale=gscale[0], sums_out=sums[0])
     ops.ce_fused(pred_s1.detach(), mw1, False, conf=cw1, ign=ig1, conf_thresh=thr, mc=mc1, dlogits=dls[:B],
-                 gscale=gscale[1], sums_out=sums[1])
+                 gscale=gscale[1], sums_out=sums[1], all_pixels=pixelavg)
     ops.ce_fused(pred_s2.detach(), mw2, False, conf=cw2, ign=ig2, conf_thresh=thr, mc=mc2, dlogits=dls[B:],
-                 gscale=gscale[2], sums_out=sums[2])
+                 gscale=gscale[2], sums_out=sums[2], all_pixels=pixelavg)
     ops.ce_fused(pred_w_fp.detach(), mask_w, False, conf=conf_w, ign=ign, conf_thresh=thr, mc=mclip,
-                 dlogits=dl4[2 * B:], gscale=gscale[3], sums_out=sums[3])
+                 dlogits=dl4[2 * B:], gscale=gscale[3], sums_out=sums[3], all_pixels=pixelavg)
     losses = ops.empty(8, device=dev)
-    ops.semivl_loss(sums, numel_u, lam, losses)
+    ops.semivl_loss(sums, numel_u, lam, losses, factors)
     # backward (+ all-reduce) + optimizer
     if optimizer is not None:
         optimizer.zero_grad()
@@ -231,7 +238,17 @@ class FusedAdamW:
     def zero_grad(self):
         ops.fill(self.g, 0.0)
 
+    def _fold_autograd_grads(self):
+        """Gradients that reached a parameter through torch autograd instead of the main_grad sink (e.g. pos_embed
+        behind its bicubic resize at 801x801) are added to the arena."""
+        for g_ in self.groups:
+            prm = g_["param"]
+            if prm.grad is not None:
+                ops.add(prm.main_grad.view(-1), prm.grad.contiguous().view(-1), out=prm.main_grad.view(-1))
+                prm.grad = None
+
     def step(self):
+        self._fold_autograd_grads()
         self.step_count += 1
         ops.adamw_step(self.p, self.g, self.m, self.v, self.seg_off, self.seg_lr, self.seg_wd, len(self.groups),
                        self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale, self.ema,

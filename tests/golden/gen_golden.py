@@ -31,6 +31,10 @@ CONFIGS = {
                  dec_heads=1, up=(32, 16), skip=(16, 16), seed=11, conf_thresh=0.95),
     "vlgdim": dict(S=128, B=1, embed=64, layers=3, heads=1, out_indices=[0, 1, 3], channels=128, text_channels=128,
                    dec_heads=4, up=(64, 32), skip=(32, 16), seed=12, conf_thresh=0.058),
+    # off-size crop (72 -> corner-padded to 80 -> 5x5 patches vs a 4x4 trained pos grid: per-forward bicubic pos resize,
+    # AvgPool floor 5 -> 1) with the Cityscapes recipe's conf_mode 'pixelavg' and batch 2
+    "offsize": dict(S=72, B=2, embed=64, layers=3, heads=1, out_indices=[0, 1, 3], channels=32, text_channels=32,
+                    dec_heads=1, up=(32, 16), skip=(16, 16), seed=13, conf_thresh=0.95, conf_mode="pixelavg"),
 }
 
 
@@ -153,11 +157,12 @@ def main():
                         def forward_maskclip(s, img, t):
                             return s.m.forward_maskclip(img, t)
                     loss, aux = O.semivl_step(Adapter(model), batch, iters, total_iters, conf_thresh=c["conf_thresh"],
-                                              fp_masks=fp_masks)
+                                              conf_mode=c.get("conf_mode", "pixelwise"), fp_masks=fp_masks)
                 finally:
                     F.dropout2d = orig
             else:
-                loss, aux = O.semivl_step(model, batch, iters, total_iters, conf_thresh=c["conf_thresh"], fp_masks=fp_masks)
+                loss, aux = O.semivl_step(model, batch, iters, total_iters, conf_thresh=c["conf_thresh"],
+                                          conf_mode=c.get("conf_mode", "pixelwise"), fp_masks=fp_masks)
             loss.backward()
             grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
             return loss.detach(), aux, grads

@@ -29,6 +29,12 @@ def test_oracle_eval_matches_reference_fixture():
     assert np.abs(final[:, :, ::8, ::8].numpy() - z["final_s8"]).max() < 1e-6
     i, u, t = E.intersection_and_union(pred.numpy(), mask.numpy(), K, 255)
     assert np.array_equal(i, z["inter"]) and np.array_equal(u, z["union"]) and np.array_equal(t, z["target"])
+    with torch.no_grad():
+        p_sw, f_sw = E.predict_sliding_window(E.ToyModel(K), img, crop, K)
+        p_pd, f_pd = E.predict_padded_sliding_window(E.ToyModel(K), img, crop, stride, K)
+    assert np.array_equal(p_sw.numpy().astype(np.uint8), z["pred_sw"])
+    assert np.array_equal(p_pd.numpy().astype(np.uint8), z["pred_pd"])
+    assert np.abs(f_sw[:, :, ::8, ::8].numpy() - z["final_sw_s8"]).max() < 1e-6
 
 
 @pytest.mark.gpu
@@ -67,6 +73,8 @@ def test_hip_eval_matches_reference_fixture(dev):
     miou, iou = evaluate(model, [(img[:1], mask[:1], None), (img[1:], mask[1:], None)], "zegclip_sliding_window", cfg)
     ref_miou, _ = E.miou(z["inter"].astype(float), z["union"].astype(float))
     assert abs(miou - ref_miou) < 0.05
-    for mode in ("sliding_window", "padded_sliding_window"):
-        with pytest.raises(NotImplementedError):
-            predict(model, img.to(dev), mask.to(dev), mode, cfg)
+    for mode, pk, fk in (("sliding_window", "pred_sw", "final_sw_s8"), ("padded_sliding_window", "pred_pd", "final_pd_s8")):
+        with torch.no_grad():
+            p_, f_ = predict(model, img.to(dev), mask.to(dev), mode, cfg, return_logits=True)
+        assert np.abs(f_[:, :, ::8, ::8].cpu().numpy() - z[fk]).max() < 1e-5, mode
+        assert (p_.cpu().numpy().astype(np.uint8) != z[pk]).mean() < 1e-4, mode

@@ -25,7 +25,7 @@ def test_native_library_is_loaded():
     assert "libsemivl_hip.so" in maps
 
 
-@pytest.mark.parametrize("name", ["tiny", "vlgdim"])
+@pytest.mark.parametrize("name", ["tiny", "vlgdim", "offsize"])
 def test_eval_forward_and_maskclip(dev, name):
     z, c = load_fixture(name)
     hip = build_hip(c)
@@ -54,7 +54,7 @@ def test_eval_forward_and_maskclip(dev, name):
     assert (g.detach().cpu() - rg).abs().max() < 1e-4
 
 
-@pytest.mark.parametrize("name", ["tiny", "vlgdim"])
+@pytest.mark.parametrize("name", ["tiny", "vlgdim", "offsize"])
 def test_train_step_matches_reference_fixture(dev, name):
     from semivl_amd.train import LOSS_NAMES, semivl_train_step
     z, c = load_fixture(name)
@@ -64,7 +64,7 @@ def test_train_step_matches_reference_fixture(dev, name):
     batch = to_dev(fixture_batch(z, c), dev)
     masks = [m.to(dev) for m in fixture_fp_masks(z, c)]
     iters, total = [int(v) for v in z["iters"]]
-    cfg = dict(CFG, conf_thresh=c["conf_thresh"])
+    cfg = dict(CFG, conf_thresh=c["conf_thresh"], conf_mode=c.get("conf_mode", "pixelwise"))
     hip.train()
     losses, aux = semivl_train_step(hip, batch, iters, total, cfg, fp_masks=masks, return_aux=True)
     losses = losses.cpu().numpy()

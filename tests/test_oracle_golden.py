@@ -7,7 +7,7 @@ import torch
 from golden_util import build_oracle, fixture_batch, fixture_fp_masks, fixture_state, load_fixture
 
 
-@pytest.mark.parametrize("name", ["tiny", "vlgdim"])
+@pytest.mark.parametrize("name", ["tiny", "vlgdim", "offsize"])
 def test_oracle_reproduces_reference_step(name):
     from oracle import semivl_oracle as O
     z, c = load_fixture(name)
@@ -17,7 +17,8 @@ def test_oracle_reproduces_reference_step(name):
     batch = fixture_batch(z, c)
     masks = fixture_fp_masks(z, c)
     iters, total = [int(v) for v in z["iters"]]
-    loss, aux = O.semivl_step(orc, batch, iters, total, conf_thresh=c["conf_thresh"], fp_masks=masks)
+    loss, aux = O.semivl_step(orc, batch, iters, total, conf_thresh=c["conf_thresh"],
+                              conf_mode=c.get("conf_mode", "pixelwise"), fp_masks=masks)
     loss.backward()
     assert abs(loss.item() - float(z["loss"])) < 1e-6
     for k in ("loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "loss_mc_s2", "loss_mc_fp"):
