@@ -42,11 +42,13 @@ def synthetic_batch(B, S, nclass, seed=1234, device="cpu"):
 
 def exp40_cfg(batch_size=16, crop=512, nclass=21, dataset="pascal"):
     """The flat experiment dict of experiments.py exp 40 restricted to the keys the hot path reads."""
+    cs = dataset == "cityscapes"  # exp 44 text variants / conf mode (experiments.py:428-456); the skr04 conv_encoder is N2
+    tv = "conceptavg3_single" if cs else "single"
     return dict(
         dataset=dataset, nclass=nclass, crop_size=crop, model="mmseg.vlm-vlg-aspp-s2p4-sk04-ftap-mcvitb",
-        model_args=dict(maskclip_class_filter=None), text_embedding_variant="single",
-        mcc_text="concept4_single" if dataset == "pascal" else "single", pl_text="single", method="semivl",
-        use_fp=True, conf_mode="pixelwise", conf_thresh=0.95, disable_dropout=True, pleval=True, fp_rate=0.5,
+        model_args=dict(maskclip_class_filter=None), text_embedding_variant=tv,
+        mcc_text="concept4_single" if dataset == "pascal" else ("concept3_single" if cs else "single"), pl_text=tv,
+        method="semivl", use_fp=True, conf_mode="pixelavg" if cs else "pixelwise", conf_thresh=0.95, disable_dropout=True, pleval=True, fp_rate=0.5,
         maskclip_consistency_lambda=[0.1, 0], clip_encoder="mcvit16", mcc_conf_thresh=0.9, mcc_loss_reduce="mean_all",
         criterion=dict(name="CELoss", kwargs=dict(ignore_index=255)), criterion_u="CELoss",
         optimizer=dict(type="AdamW", lr=1e-4, weight_decay=0.01, paramwise_cfg=dict(custom_keys=dict(
