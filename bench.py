@@ -70,14 +70,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X; the product path has no CPU fallback")
+    local = local % torch.cuda.device_count()  # (lets a 1-GPU box exercise the N>1 code path with SVL_DIST_BACKEND=gloo)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs an MI355X; the product path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        backend = os.environ.get("SVL_DIST_BACKEND", "nccl")  # 'nccl' == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from semivl_amd import ops
     from semivl_amd.model.builder import build_model
