@@ -331,14 +331,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 
   // XCD-aware tile map (bijective): workgroup b runs on XCD b % 8; give every XCD a CONTIGUOUS range of tiles so the
   // tiles that share an A row-panel (n-fastest order) hit the same 4 MiB L2 (cdna_hip_programming.md T1).
+  // With split-K the map runs over the combined (tile, K-slice) index, tile fastest, so the few tiles that walk the
+  // SAME K-slice (conv wgrad: the same pixels, different taps) share an XCD instead of being dealt round-robin.
   int tile = blockIdx.x;
+  int z = blockIdx.z;
   {
-    const int nt = gridDim.x, xcd = tile & 7, q = nt >> 3, r = nt & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
+    const bool comb = p.ksplit > 0;
+    const int lin = comb ? (int)(blockIdx.z * gridDim.x + blockIdx.x) : (int)blockIdx.x;
+    const int nt = comb ? (int)(gridDim.x * gridDim.z) : (int)gridDim.x;
+    const int xcd = lin & 7, q = nt >> 3, r = nt & 7;
+    const int sw = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    if (comb) {
+      tile = sw % (int)gridDim.x;
+      z = sw / (int)gridDim.x;
+    } else {
+      tile = sw;
+    }
   }
   const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
   const int m0 = tm_i * BM, n0 = tn_i * BN;
-  const int z = blockIdx.z;
   const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
 
   int kbeg = 0, kend = p.K;
