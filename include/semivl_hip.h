@@ -113,6 +113,15 @@ typedef struct svl_gemm_desc {
 
 int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream);
 
+/* Process-wide arithmetic mode of the LARGE dense GEMMs (M >= 256, N >= 96, K >= 64, dense operand modes):
+ *   0  v_mfma_f32_32x32x2_f32, exact fp32 fma chain (default);
+ *   6  fp32-accurate emulation on the bf16 matrix pipe: every operand element is split into 3 bf16 terms and the 6
+ *      leading cross products are accumulated in fp32 (error <= the fp32 path's, 2.7x the MFMA rate);
+ *   3  2-term split, 3 products (~16 mantissa bits, 5.3x the MFMA rate).
+ * Initial value: environment variable SVL_GEMM_EMU (0 if unset).  Inputs, outputs and accumulation stay fp32. */
+int svl_set_gemm_emulation(int mode);
+int svl_get_gemm_emulation(void);
+
 /* out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s*count + i]  — deterministic split-K combine. */
 int svl_reduce_slabs_f32(float* out, const float* slabs, int nslab, int64_t count, int accumulate,
                          svl_stream_t stream);

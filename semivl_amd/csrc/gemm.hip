@@ -309,6 +309,59 @@ __device__ __forceinline__ void store_piece(float* S, int f, float4 v) {
   }
 }
 
+// Shared epilogue of the MFMA GEMM kernels.  C/D layout of the 32x32 MFMAs (dtype independent on gfx950):
+// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int l31,
+                                              int hi, int zo, int zi) {
+  float* Cz = p.C;
+  const float* Rz = p.resid;
+  if (p.out_mode == SVL_OUT_STRIDED) {
+    Cz += zo * p.c_bso + zi * p.c_bsi;
+    if (Rz) Rz += zo * p.r_bso + zi * p.r_bsi;
+  }
+  // Compile-time indices only: a runtime index into acc[][] would demote the accumulators to scratch memory.
+  static_for<0, TM>([&](auto I) {
+    static_for<0, TN>([&](auto J) {
+      constexpr int i = decltype(I)::value, j = decltype(J)::value;
+      const int n = n0 + wc * WTN + j * 32 + l31;
+      const bool n_ok = n < p.N;
+      float bv = 0.f;
+      if (p.bias && n_ok) bv = p.bias[p.bias_mod > 0 ? (n % p.bias_mod) : n];
+      static_for<0, 16>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const int m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (n_ok && m < p.M) {
+          float v = acc[i][j][r] * p.alpha + bv;
+          if (p.preact) p.preact[(zo * p.c_bso + zi * p.c_bsi) + (long)m * p.ldc_m + (long)n * p.ldc_n] = v;
+          if (p.act == SVL_ACT_GELU) v = gelu_erf(v);
+          else if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
+          long off;
+          if (p.out_mode == SVL_OUT_STRIDED) {
+            off = (long)m * p.ldc_m + (long)n * p.ldc_n;
+            if (Rz) v += Rz[(long)m * p.ldr_m + (long)n * p.ldr_n];
+          } else if (p.out_mode == SVL_OUT_CONVT2X) {
+            const int w = m % p.ct_W;
+            const int t = m / p.ct_W;
+            const int h = t % p.ct_H;
+            const int img = t / p.ct_H;
+            const int ab = n / p.ct_Cout, co = n - ab * p.ct_Cout;
+            const int a_ = ab >> 1, b_ = ab & 1;
+            off = ((((long)img * (2 * p.ct_H) + (2 * h + a_)) * (2 * p.ct_W)) + (2 * w + b_)) * p.ldc_m + co;
+          } else {  // SVL_OUT_PATCH
+            const int P = p.ct_H;
+            const int img = m / P, pp = m - img * P;
+            off = ((long)img * (P + 1) + 1 + pp) * p.ldc_m + n;
+            if (Rz) v += Rz[(long)(1 + pp) * p.ldr_m + n];
+          }
+          if (p.accumulate) v += Cz[off];
+          Cz[off] = v;
+        }
+      });
+    });
+  });
+}
+
 template <int BM, int BN, int WR, int WC, int AMODE, int BMODE, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   static_assert(WR * WC == 4, "4 waves per block");
@@ -500,54 +553,304 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     __syncthreads();
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------
-  // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-  float* Cz = p.C;
-  const float* Rz = p.resid;
-  if (p.out_mode == SVL_OUT_STRIDED) {
-    Cz += zo * p.c_bso + zi * p.c_bsi;
-    if (Rz) Rz += zo * p.r_bso + zi * p.r_bsi;
+  gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wr, wc, l31, hi, zo, zi);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fp32-accurate GEMM on the bf16 matrix pipe (split emulation).  Each fp32 operand element x is written as a sum of
+// NS bf16 terms (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)); products of bf16 terms are exact in the fp32
+// accumulator, so keeping the NS(NS+1)/2 leading cross terms gives 16 (NS=2: 3 MFMAs) or 24 (NS=3: 6 MFMAs) mantissa
+// bits of the a*b products -- NS=3 is at least as accurate as the fp32 MFMA path (measured, tests/test_ops_gpu.py) while
+// v_mfma_f32_32x32x16_bf16 retires 16x the MACs per cycle of v_mfma_f32_32x32x2_f32.  Dense operands only.
+//
+// 128x128 block tile, 4 waves of 64x64, K step 16 (= one MFMA k-group).  Every thread stages 8 consecutive-k fp32
+// values of one A row and one B row per K step (k-contiguous operand: two 16 B loads, lane pairs cover a row's 64 B;
+// row-contiguous operand: eight 4 B loads, lanes along the rows), splits them in registers and stores one 16 B group per
+// plane, which is exactly the bf16 MFMA fragment of lane (row, k/8).  LDS rows are 48 B apart (conflict-free
+// ds_read_b128 / ds_write_b128), two buffers of NS planes per operand, one barrier per K step; global loads run two K
+// steps ahead of the MFMAs (two register sets), the split of step t+1 is interleaved with the MFMAs of step t.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct EmuRaw {
+  float v[8];
+};
+
+// k-contiguous operand (RM = 0): v[0..3] = 4 k of row r, v[4..7] = the same 4 k of row r + 64 (ptr2); four lanes cover
+// 64 contiguous bytes of a row.  Row-contiguous operand (RM = 1): v[0..7] = 8 consecutive k of one row, lanes along rows.
+template <int RM>
+__device__ __forceinline__ void emu_gload(EmuRaw& r, const float* ptr, const float* ptr2, long kstride, bool vec) {
+  if (RM == 0) {
+    if (vec) {
+      const float4 lo = *reinterpret_cast<const float4*>(ptr);
+      const float4 hi = *reinterpret_cast<const float4*>(ptr2);
+      r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+      r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { r.v[j] = ptr[j]; r.v[4 + j] = ptr2[j]; }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = ptr[j * kstride];
   }
-  // Compile-time indices only: a runtime index into acc[][] would demote the accumulators to scratch memory.
-  static_for<0, TM>([&](auto I) {
-    static_for<0, TN>([&](auto J) {
-      constexpr int i = decltype(I)::value, j = decltype(J)::value;
-      const int n = n0 + wc * WTN + j * 32 + l31;
-      const bool n_ok = n < p.N;
-      float bv = 0.f;
-      if (p.bias && n_ok) bv = p.bias[p.bias_mod > 0 ? (n % p.bias_mod) : n];
-      static_for<0, 16>([&](auto R) {
-        constexpr int r = decltype(R)::value;
-        const int m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (n_ok && m < p.M) {
-          float v = acc[i][j][r] * p.alpha + bv;
-          if (p.preact) p.preact[(zo * p.c_bso + zi * p.c_bsi) + (long)m * p.ldc_m + (long)n * p.ldc_n] = v;
-          if (p.act == SVL_ACT_GELU) v = gelu_erf(v);
-          else if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
-          long off;
-          if (p.out_mode == SVL_OUT_STRIDED) {
-            off = (long)m * p.ldc_m + (long)n * p.ldc_n;
-            if (Rz) v += Rz[(long)m * p.ldr_m + (long)n * p.ldr_n];
-          } else if (p.out_mode == SVL_OUT_CONVT2X) {
-            const int w = m % p.ct_W;
-            const int t = m / p.ct_W;
-            const int h = t % p.ct_H;
-            const int img = t / p.ct_H;
-            const int ab = n / p.ct_Cout, co = n - ab * p.ct_Cout;
-            const int a_ = ab >> 1, b_ = ab & 1;
-            off = ((((long)img * (2 * p.ct_H) + (2 * h + a_)) * (2 * p.ct_W)) + (2 * w + b_)) * p.ldc_m + co;
-          } else {  // SVL_OUT_PATCH
-            const int P = p.ct_H;
-            const int img = m / P, pp = m - img * P;
-            off = ((long)img * (P + 1) + 1 + pp) * p.ldc_m + n;
-            if (Rz) v += Rz[(long)(1 + pp) * p.ldr_m + n];
+}
+
+template <int RM>
+__device__ __forceinline__ void emu_gload_tail(EmuRaw& r, const float* ptr, const float* ptr2, long kstride, int nvalid) {
+  if (RM == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r.v[j] = j < nvalid ? ptr[j] : 0.f; r.v[4 + j] = j < nvalid ? ptr2[j] : 0.f; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = j < nvalid ? ptr[j * kstride] : 0.f;
+  }
+}
+
+template <int NS, int RM>
+__device__ __forceinline__ void emu_split_store(__bf16* dst, int plane_stride, int row2_off, const EmuRaw& r) {
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = r.v[j];
+#pragma unroll
+  for (int pl = 0; pl < NS; ++pl) {
+    bf16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      h[j] = (__bf16)x[j];
+      if (pl + 1 < NS) x[j] -= (float)h[j];
+    }
+    if (RM == 0) {
+      *reinterpret_cast<bf16x4*>(dst + pl * plane_stride) = __builtin_shufflevector(h, h, 0, 1, 2, 3);
+      *reinterpret_cast<bf16x4*>(dst + pl * plane_stride + row2_off) = __builtin_shufflevector(h, h, 4, 5, 6, 7);
+    } else {
+      *reinterpret_cast<bf16x8*>(dst + pl * plane_stride) = h;
+    }
+  }
+}
+
+template <int NS, int A_RM, int B_RM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x_kernel(const GemmP p) {
+  constexpr int BM = 128, BN = 128, BKE = 16, LDR = 24;  // LDR: bf16 elements per LDS row (48 B)
+  constexpr int TM = 2, TN = 2, WTM = 64, WTN = 64;
+  constexpr int APL = BM * LDR, BPL = BN * LDR;            // plane strides (elements)
+  constexpr int BUF = NS * (APL + BPL);                     // one buffer (elements)
+  __shared__ __attribute__((aligned(16))) __bf16 sm[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  int tile = blockIdx.x, z = blockIdx.z;
+  {
+    const bool comb = p.ksplit > 0;
+    const int lin = comb ? (int)(blockIdx.z * gridDim.x + blockIdx.x) : (int)blockIdx.x;
+    const int nt = comb ? (int)(gridDim.x * gridDim.z) : (int)gridDim.x;
+    const int xcd = lin & 7, q = nt >> 3, r = nt & 7;
+    const int sw = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    if (comb) { tile = sw % (int)gridDim.x; z = sw / (int)gridDim.x; } else { tile = sw; }
+  }
+  const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
+  const int m0 = tm_i * BM, n0 = tn_i * BN;
+  const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
+  int kbeg = 0, kend = p.K;
+  const float* A = p.A.p;
+  const float* B = p.B.p;
+  if (p.ksplit > 0) {
+    kbeg = z * p.ksplit;
+    kend = min(p.K, kbeg + p.ksplit);
+  } else {
+    A += zo * p.a_bso + zi * p.a_bsi;
+    B += zo * p.b_bso + zi * p.b_bsi;
+  }
+  // staging coordinates: (row, k half) of the 8-float group this thread owns in the A tile and in the B tile
+  // (k-contiguous: rows a_row and a_row + 64, k offset a_ko..+3; row-contiguous: row a_row, k offset a_ko..+7)
+  // (the k-contiguous row order 0,2,4,6,1,3,5,7 per 8 rows keeps the 8 B LDS stores of 16 consecutive lanes on
+  //  disjoint banks with the 48 B row stride)
+  const int kc_row = ((tid >> 2) & ~7) | (((tid >> 2) & 3) << 1) | ((tid >> 4) & 1);
+  const int a_row = A_RM ? (tid & 127) : kc_row, a_ko = A_RM ? 8 * (tid >> 7) : 4 * (tid & 3);
+  const int b_row = B_RM ? (tid & 127) : kc_row, b_ko = B_RM ? 8 * (tid >> 7) : 4 * (tid & 3);
+  // rows past the edge are clamped: they only feed accumulators whose outputs are never stored
+  const long a_r = min(m0 + a_row, p.M - 1), b_r = min(n0 + b_row, p.N - 1);
+  const long a_r2 = min(m0 + a_row + 64, p.M - 1), b_r2 = min(n0 + b_row + 64, p.N - 1);
+  const long a_ks = A_RM ? (long)p.A.ld : 1, b_ks = B_RM ? (long)p.B.ld : 1;
+  const float* pa = A + (A_RM ? a_r : a_r * p.A.ld) + (long)(kbeg + a_ko) * a_ks;
+  const float* pb = B + (B_RM ? b_r : b_r * p.B.ld) + (long)(kbeg + b_ko) * b_ks;
+  const long a_d2 = A_RM ? 0 : (a_r2 - a_r) * p.A.ld, b_d2 = B_RM ? 0 : (b_r2 - b_r) * p.B.ld;  // second-row offsets
+  const bool a_vec = p.A.vec, b_vec = p.B.vec;
+  const int klen = kend - kbeg;
+  const int nfull = klen > 0 ? klen / BKE : 0, nk = klen > 0 ? (klen + BKE - 1) / BKE : 0;
+  const int a_st = a_row * LDR + a_ko, b_st = NS * APL + b_row * LDR + b_ko;  // LDS store offsets
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  EmuRaw ra0, rb0, ra1, rb1, ra2, rb2;  // three raw sets: the loads run two K steps ahead of the split
+  auto gload = [&](EmuRaw& xa, EmuRaw& xb, int t) {
+    if (t < nfull) {
+      const float* qa = pa + (long)t * BKE * a_ks;
+      const float* qb = pb + (long)t * BKE * b_ks;
+      emu_gload<A_RM>(xa, qa, qa + a_d2, a_ks, a_vec);
+      emu_gload<B_RM>(xb, qb, qb + b_d2, b_ks, b_vec);
+    } else if (t < nk) {
+      const int rem = klen - t * BKE;
+      const float* qa = pa + (long)t * BKE * a_ks;
+      const float* qb = pb + (long)t * BKE * b_ks;
+      emu_gload_tail<A_RM>(xa, qa, qa + a_d2, a_ks, rem - a_ko);
+      emu_gload_tail<B_RM>(xb, qb, qb + b_d2, b_ks, rem - b_ko);
+    }
+  };
+  auto sstore = [&](const EmuRaw& xa, const EmuRaw& xb, int buf) {
+    emu_split_store<NS, A_RM>(sm + buf * BUF + a_st, APL, 64 * LDR, xa);
+    emu_split_store<NS, B_RM>(sm + buf * BUF + b_st, BPL, 64 * LDR, xb);
+  };
+  const int fa = (wr * WTM + l31) * LDR + 8 * hi, fb = NS * APL + (wc * WTN + l31) * LDR + 8 * hi;
+  auto compute = [&](int buf) {
+    const __bf16* S = sm + buf * BUF;
+    bf16x8 a[NS][TM], b[NS][TN];
+#pragma unroll
+    for (int pl = 0; pl < NS; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(S + fa + pl * APL + i * 32 * LDR);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[pl][j] = *reinterpret_cast<const bf16x8*>(S + fb + pl * BPL + j * 32 * LDR);
+    }
+    // smallest-magnitude cross terms first; the four accumulators alternate so that dependent MFMAs are 4 apart
+#define SVL_EMU_TERM(PA, PB)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =    \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][i], b[PB][j], acc[i][j], 0, 0, 0);
+    if constexpr (NS == 3) {
+      SVL_EMU_TERM(2, 0)
+      SVL_EMU_TERM(0, 2)
+      SVL_EMU_TERM(1, 1)
+    }
+    SVL_EMU_TERM(1, 0)
+    SVL_EMU_TERM(0, 1)
+    SVL_EMU_TERM(0, 0)
+#undef SVL_EMU_TERM
+  };
+
+  // invariant at step t (t % 3 == 0 at loop heads): LDS buffer t&1 holds step t, set (t+1)%3 the raw step t+1, set
+  // (t+2)%3 the raw step t+2 (in flight), set t%3 is free and receives step t+3
+  gload(ra0, rb0, 0);
+  gload(ra1, rb1, 1);
+  gload(ra2, rb2, 2);
+  if (nk > 0) sstore(ra0, rb0, 0);
+  __syncthreads();
+  int t = 0;
+  // steady state: straight-line steps (all loads full-width and in range), MFMAs interleaved with the next step's split
+  {
+    const long a_step = (long)BKE * a_ks, b_step = (long)BKE * b_ks;
+    const float* qa = pa + 3 * a_step;
+    const float* qb = pb + 3 * b_step;
+    // One K step with an explicit schedule: MFMA m of the step is followed by its share of the next step's split
+    // (one cvt_pk + residual update per pair of values and plane), fenced so that the matrix pipe and the VALU overlap
+    // inside the wave; the LDS stores of an operand follow the slice that completes it.
+    constexpr int NT = NS * (NS + 1) / 2, NMF = 4 * NT, NSL = 16 * NS / 2;  // products, MFMAs, (pair, plane) slices
+    auto fast_step = [&](EmuRaw& la, EmuRaw& lb, EmuRaw& ca, EmuRaw& cb, int buf) {
+      emu_gload<A_RM>(la, qa, qa + a_d2, a_ks, true);
+      emu_gload<B_RM>(lb, qb, qb + b_d2, b_ks, true);
+      qa += a_step;
+      qb += b_step;
+      // opaque re-definition: keeps this step's split after the previous barrier (it is pure register arithmetic on
+      // values loaded a step ago, and would otherwise be hoisted into the previous step, onto the load's latency)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        asm volatile("" : "+v"(ca.v[j]));
+        asm volatile("" : "+v"(cb.v[j]));
+      }
+      const __bf16* S = sm + buf * BUF;
+      __bf16* D = sm + (buf ^ 1) * BUF;
+      bf16x8 a[NS][TM], b[NS][TN];
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(S + fa + pl * APL + i * 32 * LDR);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[pl][j] = *reinterpret_cast<const bf16x8*>(S + fb + pl * BPL + j * 32 * LDR);
+      }
+      bf16x8 ha[NS], hb[NS];
+      static_for<0, NMF>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int term = m / 4, i = (m % 4) / 2, j = m % 2;
+        // products, smallest magnitude first: NS=3: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0); NS=2: (1,0) (0,1) (0,0)
+        constexpr int tt = term + (NS == 3 ? 0 : 3);
+        constexpr int PA = tt == 0 ? 2 : (tt == 2 || tt == 3) ? 1 : 0;
+        constexpr int PB = tt == 1 ? 2 : (tt == 2 || tt == 4) ? 1 : 0;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][i], b[PB][j], acc[i][j], 0, 0, 0);
+        static_for<m * NSL / NMF, (m + 1) * NSL / NMF>([&](auto sc) {
+          constexpr int sl = decltype(sc)::value;          // slice: operand (A: first half), pair q, plane pl
+          constexpr int isb = sl / (4 * NS), q = (sl % (4 * NS)) / NS, pl = sl % NS;
+          EmuRaw& c = isb ? cb : ca;
+          bf16x8& h = isb ? hb[pl] : ha[pl];
+          h[2 * q] = (__bf16)c.v[2 * q];
+          h[2 * q + 1] = (__bf16)c.v[2 * q + 1];
+          if constexpr (pl + 1 < NS) {
+            c.v[2 * q] -= (float)h[2 * q];
+            c.v[2 * q + 1] -= (float)h[2 * q + 1];
           }
-          if (p.accumulate) v += Cz[off];
-          Cz[off] = v;
-        }
+          if constexpr (q == 3 && pl == NS - 1) {          // operand complete: store its planes
+            __bf16* dst = D + (isb ? b_st : a_st);
+            constexpr int rm = isb ? B_RM : A_RM;
+            constexpr int pstride = isb ? BPL : APL;
+#pragma unroll
+            for (int p2 = 0; p2 < NS; ++p2) {
+              const bf16x8 hv = isb ? hb[p2] : ha[p2];
+              if constexpr (rm == 0) {
+                *reinterpret_cast<bf16x4*>(dst + p2 * pstride) = __builtin_shufflevector(hv, hv, 0, 1, 2, 3);
+                *reinterpret_cast<bf16x4*>(dst + p2 * pstride + 64 * LDR) = __builtin_shufflevector(hv, hv, 4, 5, 6, 7);
+              } else {
+                *reinterpret_cast<bf16x8*>(dst + p2 * pstride) = hv;
+              }
+            }
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
       });
-    });
-  });
+      __syncthreads();
+    };
+    if (a_vec && b_vec) {
+      for (; t + 5 < nfull; t += 3) {
+        fast_step(ra0, rb0, ra1, rb1, t & 1);
+        fast_step(ra1, rb1, ra2, rb2, (t + 1) & 1);
+        fast_step(ra2, rb2, ra0, rb0, t & 1);
+      }
+    }
+  }
+  // remaining steps (and every step of an operand that cannot use 16 B loads): range-checked loads, no explicit schedule
+  auto tail_step = [&](EmuRaw& la, EmuRaw& lb, const EmuRaw& ca, const EmuRaw& cb, int tt) {
+    gload(la, lb, tt + 3);
+    compute(tt & 1);
+    if (tt + 1 < nk) sstore(ca, cb, (tt + 1) & 1);
+    __syncthreads();
+  };
+  for (; t < nk; t += 3) {
+    tail_step(ra0, rb0, ra1, rb1, t);
+    if (t + 1 >= nk) break;
+    tail_step(ra1, rb1, ra2, rb2, t + 1);
+    if (t + 2 >= nk) break;
+    tail_step(ra2, rb2, ra0, rb0, t + 2);
+  }
+  gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wr, wc, l31, hi, zo, zi);
+}
+
+static int g_emu_mode = -1;  // -1: read SVL_GEMM_EMU once; 0 exact fp32 MFMA; 3 / 6: bf16 split emulation
+
+template <int NS>
+int launch_emu(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
+  GemmP q = p;
+  q.tiles_n = (p.N + 127) / 128;
+  const long tiles = (long)((p.M + 127) / 128) * q.tiles_n;
+  dim3 grid((unsigned)tiles, 1, (unsigned)batch);
+  if (a_rm == 0 && b_rm == 0) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 0>), grid, dim3(256), 0, st, q);
+  else if (a_rm == 0 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 1>), grid, dim3(256), 0, st, q);
+  else if (a_rm == 1 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 1>), grid, dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 0>), grid, dim3(256), 0, st, q);
+  SVL_LAUNCH_CHECK("svl_gemm_f32 (bf16 split emulation)");
+  return SVL_OK;
 }
 
 __global__ void reduce_slabs_kernel(float* out, const float* slabs, int nslab, long count, int accumulate) {
@@ -669,6 +972,16 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   if (d->out_mode == SVL_OUT_PATCH) SVL_CHECK_ARG(d->ct_H > 0, "svl_gemm_f32: bad patch-token geometry");
 
   const int am = d->a_mode, bm = d->b_mode;
+  if (g_emu_mode < 0) {
+    const char* e = getenv("SVL_GEMM_EMU");
+    g_emu_mode = e ? atoi(e) : 0;
+  }
+  if ((g_emu_mode == 3 || g_emu_mode == 6) && (am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) &&
+      (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && d->M >= 256 && d->N >= 96 &&
+      d->K >= 64) {
+    return g_emu_mode == 6 ? launch_emu<3>(p, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
+                           : launch_emu<2>(p, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
+  }
 #define SVL_MODE(AM, BM_) \
   if (am == AM && bm == BM_) return launch_mode<AM, BM_>(p, d->batch, st);
   SVL_MODE(SVL_A_KCONTIG, SVL_B_KCONTIG)
@@ -682,6 +995,13 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   svl_set_error("svl_gemm_f32: unsupported mode combination a=%d b=%d", am, bm);
   return SVL_ERR_UNSUPPORTED;
 }
+
+extern "C" int svl_set_gemm_emulation(int mode) {
+  SVL_CHECK_ARG(mode == 0 || mode == 3 || mode == 6, "svl_set_gemm_emulation: mode must be 0, 3 or 6");
+  g_emu_mode = mode;
+  return SVL_OK;
+}
+extern "C" int svl_get_gemm_emulation(void) { return g_emu_mode < 0 ? 0 : g_emu_mode; }
 
 extern "C" int svl_reduce_slabs_f32(float* out, const float* slabs, int nslab, int64_t count, int accumulate,
                                     svl_stream_t stream) {

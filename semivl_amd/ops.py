@@ -643,3 +643,12 @@ def iou_hist(pred, target, K, ignore_index, hist):
     """hist (int64 [3K], accumulated) += intersection / prediction-area / target-area counts."""
     L.check(L.load().svl_iou_hist_i64(_p(pred), _p(target), pred.numel(), K, ignore_index, _p(hist), _st()),
             "svl_iou_hist_i64")
+
+
+def set_gemm_emulation(mode):
+    """0: exact fp32 MFMA (default); 6 / 3: bf16 split emulation for the large dense GEMMs (include/semivl_hip.h)."""
+    L.check(L.load().svl_set_gemm_emulation(int(mode)), "svl_set_gemm_emulation")
+
+
+def get_gemm_emulation():
+    return L.load().svl_get_gemm_emulation()

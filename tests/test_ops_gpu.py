@@ -72,6 +72,67 @@ def test_matmul_tn_splitk(dev, M, N, K):
     assert torch.equal(o1, o2), "split-K must be deterministic"
 
 
+@pytest.fixture
+def emu_mode():
+    """Switch the large dense GEMMs to a bf16 split-emulation mode for one test, restore the exact fp32 MFMA after."""
+    from semivl_amd import ops
+
+    def use(mode):
+        ops.set_gemm_emulation(mode)
+
+    yield use
+    ops.set_gemm_emulation(0)
+
+
+def _relerr(y, ref):
+    return float((y.double() - ref).norm() / ref.norm())
+
+
+@pytest.mark.parametrize("M,N,K", [(1025, 768, 768), (2050, 768, 3072), (333, 200, 97), (4100, 2304, 768),
+                                   (257, 130, 70), (300, 96, 64), (515, 129, 1027)])
+def test_gemm_bf16_split_emulation(dev, emu_mode, M, N, K):
+    """bf16x6 must be at least as accurate as the fp32 MFMA chain (vs fp64), bf16x3 within 2^-16-ish; every dense
+    operand layout, ragged edges, K tails, unaligned leading dimensions (K = 97 / 1027 -> 4 B loads)."""
+    from semivl_amd import ops
+    x, w, b, r = rnd(M, K, dev=dev, seed=11), rnd(N, K, dev=dev), rnd(N, dev=dev), rnd(M, N, dev=dev)
+    wt, dy = w.t().contiguous(), rnd(M, N, dev=dev)
+    refs = {"nt": x.double() @ w.double().t(), "nn": x.double() @ wt.double(), "tn": dy.double().t() @ x.double()}
+    fns = {"nt": lambda: ops.linear(x, w), "nn": lambda: ops.matmul_nn(x, wt), "tn": lambda: ops.matmul_tn(dy, x)}
+    err = {}
+    for mode in (0, 6, 3):
+        emu_mode(mode)
+        assert ops.get_gemm_emulation() == mode
+        for k, fn in fns.items():
+            err[(mode, k)] = _relerr(fn(), refs[k])
+    for k in fns:
+        assert err[(6, k)] <= 1.5 * err[(0, k)] + 1e-8, (k, err)
+        assert err[(3, k)] <= 2e-5, (k, err)
+    # epilogue options go through the same code as the fp32 path
+    emu_mode(6)
+    close(ops.linear(x, w, b, act=ops.ACT_GELU, resid=r), F.gelu(x @ w.t() + b) + r, what="gelu+res",
+          atol=1e-4 * math.sqrt(K))
+    acc = r.clone()
+    ops.linear(x, w, out=acc, accumulate=True)
+    close(acc, r + x @ w.t(), what="accumulate", atol=1e-4 * math.sqrt(K))
+    assert torch.equal(ops.linear(x, w), ops.linear(x, w)), "emulated GEMM must be deterministic"
+
+
+def test_gemm_bf16_split_emulation_special_values(dev, emu_mode):
+    """Exactly representable inputs give exact results; zeros, tiny and huge magnitudes survive the split."""
+    from semivl_amd import ops
+    M, N, K = 384, 256, 128
+    x = torch.randint(-64, 64, (M, K), device=dev).float()
+    w = torch.randint(-64, 64, (N, K), device=dev).float()
+    emu_mode(6)
+    assert torch.equal(ops.linear(x, w), (x.double() @ w.double().t()).float())
+    xs = rnd(M, K, dev=dev, seed=5) * 1e-30
+    ws = rnd(N, K, dev=dev, seed=6) * 1e25
+    ref = xs.double() @ ws.double().t()
+    assert _relerr(ops.linear(xs, ws), ref) < 2e-6
+    x[::2] = 0
+    assert torch.equal(ops.linear(x, w), (x.double() @ w.double().t()).float())
+
+
 @pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (3, 17, 4), (1, 64, 2)])
 def test_vit_attention(dev, Bn, T, H):
     from semivl_amd import ops
