@@ -38,6 +38,11 @@ def parse():
     ap.add_argument("--nclass", type=int, default=21)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--gemm-arith", choices=["f32", "bf16x6", "bf16x3"], default="f32",
+                    help="arithmetic of the large dense GEMMs in the timed region (include/semivl_hip.h, "
+                         "svl_set_gemm_emulation); 'value' is always measured in this mode")
+    ap.add_argument("--no-throughput-mode", action="store_true",
+                    help="skip the extra bf16x6 measurement that is reported next to the f32 value")
     return ap.parse_args()
 
 
@@ -107,27 +112,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        losses = step(a.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    def timed(nwarm, nsteps, first):
+        for i in range(nwarm):
+            step(first + i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            losses = step(first + nwarm + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, losses
+
+    EMU = {"f32": 0, "bf16x6": 6, "bf16x3": 3}
+    ops.set_gemm_emulation(EMU[a.gemm_arith])
+    dt, losses = timed(a.warmup, a.steps, 0)
     loss_val = float(losses[0].item())
     ms = dt / a.steps * 1e3
     ips = 2.0 * a.batch * world / (dt / a.steps)
 
     out = dict(metric="train images/sec (512^2, ViT-B/16)", value=round(ips, 3), unit="images/s", n_gpus=world,
                steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 2), higher_is_better=True, scaling="weak",
-               vs_baseline=None, dtype="f32", data="synthetic",
+               vs_baseline=None, dtype="f32" if a.gemm_arith == "f32" else f"f32 ({a.gemm_arith} split-product MFMA, f32 accumulate)",
+               data="synthetic",
                config=dict(workload=f"SemiVL step, VOC12-style N={a.nclass}, ViT-B/16 + VLG head, {a.crop}x{a.crop}, "
                                     f"bs={a.batch}/GPU labeled + {a.batch}/GPU unlabeled" + (" (BASELINE configs[1])" if (a.nclass, a.crop, a.batch) == (21, 512, 16) else ""),
                            global_batch=2 * a.batch * world, parallelism=f"dp{world}", loss=round(loss_val, 5),
@@ -174,6 +186,18 @@ def main():
                                        achieved=round(by_ce / t_ce / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=round(by_ce / t_ce / 1e9 / PEAK_HBM_GBS, 4), traffic=None, launches=len(c),
                                        note="algorithmic bytes (12N+40) B/px per fwd+bwd branch (SURVEY §8(d))")
+    # ---- the same step with the ViT linears on the bf16 matrix pipe (fp32-accurate 3-way split, 6 products) ----
+    if a.gemm_arith == "f32" and not a.no_throughput_mode:
+        ops.set_gemm_emulation(6)
+        dt6, losses6 = timed(1, min(a.steps, 5), a.warmup + a.steps + 1)
+        ops.set_gemm_emulation(0)
+        n6 = min(a.steps, 5)
+        out["throughput_mode"] = dict(
+            gemm_arith="bf16x6", value=round(2.0 * a.batch * world / (dt6 / n6), 3), unit="images/s", steps=n6,
+            ms_per_step=round(dt6 / n6 * 1e3, 2), loss=round(float(losses6[0].item()), 5),
+            note="opt-in svl_set_gemm_emulation(6): dense GEMMs with M>=256 split every fp32 operand element into 3 "
+                 "bf16 terms and accumulate the 6 leading cross products in fp32 (v_mfma_f32_32x32x16_bf16); error vs "
+                 "fp64 <= the f32 MFMA chain's (tests/test_ops_gpu.py::test_gemm_bf16_split_emulation). Not used for 'value'.")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(a.crop, a.nclass)

@@ -27,9 +27,11 @@ def build_pair(dev, nclass=21, dataset="pascal"):
     return cfg, hip.to(dev), orc
 
 
-def test_fullsize_step_matches_oracle(dev):
+@pytest.fixture(scope="module")
+def fullsize_case():
+    """Oracle side of the full-size step, computed once for both GEMM arithmetic modes."""
     from oracle import semivl_oracle as O
-    from semivl_amd.train import LOSS_NAMES, semivl_train_step
+    dev = torch.device("cuda:0")
     torch.set_num_threads(min(32, torch.get_num_threads()))
     cfg, hip, orc = build_pair(dev)
     batch = O.synthetic_batch(1, 512, 21, seed=99)
@@ -38,8 +40,25 @@ def test_fullsize_step_matches_oracle(dev):
     cfg = dict(cfg, conf_thresh=0.06)  # random-init confidences are ~1/21: keep the unsupervised CE term alive
     loss, aux = O.semivl_step(orc, batch, 100, 1000, conf_thresh=0.06, fp_masks=masks)
     loss.backward()
-    losses, haux = semivl_train_step(hip, {k: v.to(dev) for k, v in batch.items()}, 100, 1000, cfg,
-                                     fp_masks=[m.to(dev) for m in masks], return_aux=True)
+    return cfg, hip, orc, batch, masks, loss, aux
+
+
+@pytest.mark.parametrize("gemm_mode", [0, 6])
+def test_fullsize_step_matches_oracle(dev, fullsize_case, gemm_mode):
+    """gemm_mode 0: exact fp32 MFMA; 6: the ViT linears on the bf16 pipe (3-way split, 6 products) -- same tolerances."""
+    from semivl_amd import ops
+    from semivl_amd.train import LOSS_NAMES, semivl_train_step
+    cfg, hip, orc, batch, masks, loss, aux = fullsize_case
+    for p_ in hip.parameters():
+        p_.grad = None
+        if hasattr(p_, "main_grad"):
+            p_.main_grad = None
+    ops.set_gemm_emulation(gemm_mode)
+    try:
+        losses, haux = semivl_train_step(hip, {k: v.to(dev) for k, v in batch.items()}, 100, 1000, cfg,
+                                         fp_masks=[m.to(dev) for m in masks], return_aux=True)
+    finally:
+        ops.set_gemm_emulation(0)
     got = dict(zip(LOSS_NAMES, losses.cpu().tolist()))
     assert abs(got["loss"] - loss.item()) < 1e-3, (got["loss"], loss.item())
     for k in LOSS_NAMES[1:]:
