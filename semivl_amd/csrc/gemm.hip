@@ -976,24 +976,66 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     const char* e = getenv("SVL_GEMM_EMU");
     g_emu_mode = e ? atoi(e) : 0;
   }
-  if ((g_emu_mode == 3 || g_emu_mode == 6) && (am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) &&
-      (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && d->M >= 256 && d->N >= 96 &&
-      d->K >= 64) {
-    return g_emu_mode == 6 ? launch_emu<3>(p, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
-                           : launch_emu<2>(p, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
-  }
+  auto launch = [&](const GemmP& q) -> int {
+    if ((g_emu_mode == 3 || g_emu_mode == 6) && (am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) &&
+        (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && q.M >= 256 && q.N >= 96 &&
+        q.K >= 64) {
+      return g_emu_mode == 6 ? launch_emu<3>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
+                             : launch_emu<2>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
+    }
 #define SVL_MODE(AM, BM_) \
-  if (am == AM && bm == BM_) return launch_mode<AM, BM_>(p, d->batch, st);
-  SVL_MODE(SVL_A_KCONTIG, SVL_B_KCONTIG)
-  SVL_MODE(SVL_A_KCONTIG, SVL_B_NCONTIG)
-  SVL_MODE(SVL_A_MCONTIG, SVL_B_NCONTIG)
-  SVL_MODE(SVL_A_MCONTIG, SVL_B_KCONTIG)
-  SVL_MODE(SVL_A_CONV, SVL_B_KCONTIG)
-  SVL_MODE(SVL_A_MCONTIG, SVL_B_CONVW)
-  SVL_MODE(SVL_A_PATCH, SVL_B_KCONTIG)
+  if (am == AM && bm == BM_) return launch_mode<AM, BM_>(q, d->batch, st);
+    SVL_MODE(SVL_A_KCONTIG, SVL_B_KCONTIG)
+    SVL_MODE(SVL_A_KCONTIG, SVL_B_NCONTIG)
+    SVL_MODE(SVL_A_MCONTIG, SVL_B_NCONTIG)
+    SVL_MODE(SVL_A_MCONTIG, SVL_B_KCONTIG)
+    SVL_MODE(SVL_A_CONV, SVL_B_KCONTIG)
+    SVL_MODE(SVL_A_MCONTIG, SVL_B_CONVW)
+    SVL_MODE(SVL_A_PATCH, SVL_B_KCONTIG)
 #undef SVL_MODE
-  svl_set_error("svl_gemm_f32: unsupported mode combination a=%d b=%d", am, bm);
-  return SVL_ERR_UNSUPPORTED;
+    svl_set_error("svl_gemm_f32: unsupported mode combination a=%d b=%d", am, bm);
+    return SVL_ERR_UNSUPPORTED;
+  };
+
+  // Ragged token count (M = images x 1025 tokens = 128 k + r): the r leftover rows would cost one more full-length
+  // block per column tile, i.e. a whole extra round of the grid on a launch whose tile count is otherwise an exact
+  // multiple of the resident-block count (measured -14 % on the N = 768 GEMMs).  Their rows are independent, so they
+  // run as a second, thin-tile launch on a helper stream, concurrent with the 128-row-aligned part.
+  static int ragged_fork = -1;
+  if (ragged_fork < 0) ragged_fork = getenv("SVL_GEMM_NO_FORK") ? 0 : 1;
+  if (ragged_fork && am == SVL_A_KCONTIG && (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) &&
+      d->out_mode == SVL_OUT_STRIDED && d->batch == 1 && d->ksplit == 0 && d->M >= 8192 && (d->M % 128) != 0 &&
+      (long)d->N * d->K >= 768 * 768) {
+    static hipStream_t aux = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (!aux) {
+      SVL_HIP_CHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+      SVL_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      SVL_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    const int m_main = (d->M / 128) * 128;
+    GemmP rem = p, mainp = p;
+    mainp.M = m_main;
+    rem.M = d->M - m_main;
+    rem.A.p = p.A.p + (long)m_main * p.A.ld;
+    rem.C = p.C + (long)m_main * p.ldc_m;
+    if (p.preact) rem.preact = p.preact + (long)m_main * p.ldc_m;
+    if (p.resid) rem.resid = p.resid + (long)m_main * p.ldr_m;
+    rem.A.vec = p.A.vec && aligned16(rem.A.p);
+    SVL_HIP_CHECK(hipEventRecord(ev_fork, st));
+    SVL_HIP_CHECK(hipStreamWaitEvent(aux, ev_fork, 0));
+    hipStream_t keep = st;
+    st = aux;
+    int rc = launch(rem);
+    st = keep;
+    if (rc != SVL_OK) return rc;
+    SVL_HIP_CHECK(hipEventRecord(ev_join, aux));
+    rc = launch(mainp);
+    if (rc != SVL_OK) return rc;
+    SVL_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+    return SVL_OK;
+  }
+  return launch(p);
 }
 
 extern "C" int svl_set_gemm_emulation(int mode) {

@@ -31,6 +31,15 @@ void svl_set_error(const char* fmt, ...);
     }                                                                 \
   } while (0)
 
+#define SVL_HIP_CHECK(call)                                           \
+  do {                                                                \
+    hipError_t e__ = (call);                                          \
+    if (e__ != hipSuccess) {                                          \
+      svl_set_error("%s failed: %s", #call, hipGetErrorString(e__));  \
+      return SVL_ERR_LAUNCH;                                          \
+    }                                                                 \
+  } while (0)
+
 // ---- device helpers --------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
