@@ -228,6 +228,7 @@ class FusedAdamW:
         self._lr_host = torch.tensor([g_["lr"] for g_ in self.groups], dtype=torch.float32).pin_memory() \
             if torch.cuda.is_available() else torch.tensor([g_["lr"] for g_ in self.groups], dtype=torch.float32)
         self.seg_lr = self._lr_host.to(dev)
+        self.seg_lr0 = self.seg_lr.clone()          # initial_lr per segment
         self.step_count = 0
         self.grad_scale = 1.0
 
@@ -254,13 +255,49 @@ class FusedAdamW:
                        self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale, self.ema,
                        self.ema_decay)
 
+    def state_dict(self):
+        """torch.optim.AdamW layout (`semivl.py:428` stores `optimizer.state_dict()`): one param group per tensor, in
+        arena order; state = step / exp_avg / exp_avg_sq per tensor.  `names` is an extra key for humans."""
+        state, groups = {}, []
+        off = self.seg_off.tolist()
+        for i, g_ in enumerate(self.groups):
+            shp = g_["param"].shape
+            n = g_["param"].numel()
+            if self.step_count > 0:
+                state[i] = dict(step=torch.tensor(float(self.step_count)),
+                                exp_avg=self.m[off[i]:off[i] + n].view(shp).detach().cpu().clone(),
+                                exp_avg_sq=self.v[off[i]:off[i] + n].view(shp).detach().cpu().clone())
+            groups.append(dict(lr=g_["lr"], initial_lr=g_["initial_lr"], weight_decay=g_["weight_decay"],
+                               betas=tuple(self.betas), eps=self.eps, amsgrad=False, params=[i]))
+        return dict(state=state, param_groups=groups, names=[g_.get("name", "") for g_ in self.groups])
+
+    def load_state_dict(self, sd):
+        assert len(sd["param_groups"]) == len(self.groups), "optimizer state does not match this model"
+        off = self.seg_off.tolist()
+        steps = set()
+        for i, (g_, sg) in enumerate(zip(self.groups, sd["param_groups"])):
+            g_["lr"], g_["initial_lr"] = sg["lr"], sg.get("initial_lr", sg["lr"])
+            self._lr_host[i] = g_["lr"]
+            st = sd["state"].get(i)
+            if st is not None:
+                n = g_["param"].numel()
+                self.m[off[i]:off[i] + n].copy_(st["exp_avg"].reshape(-1))
+                self.v[off[i]:off[i] + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+        assert len(steps) <= 1, "per-tensor step counts differ"
+        self.step_count = steps.pop() if steps else 0
+        self.seg_lr.copy_(self._lr_host)
+        self.seg_lr0.copy_(torch.tensor([g_["initial_lr"] for g_ in self.groups], dtype=torch.float32))
+
     def poly_lr(self, iters, max_iters, power=0.9):
         """semivl.py:343-345: applied after the step, for the next one."""
         f = (1 - iters / max_iters) ** power
         for i, g_ in enumerate(self.groups):
             g_["lr"] = g_["initial_lr"] * f
             self._lr_host[i] = g_["lr"]
-        self.seg_lr.copy_(self._lr_host, non_blocking=True)
+        # the factor travels as a kernel argument: no host buffer that a later call could overwrite while a copy is
+        # still queued, and no synchronisation
+        torch.mul(self.seg_lr0, f, out=self.seg_lr)
 
 
 def build_optimizer(model, optimizer_cfg):
