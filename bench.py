@@ -152,8 +152,8 @@ def main():
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         g = prof.get("gemm", []) + prof.get("attention", [])   # the two fp32-MFMA kernel families
-        t_gemm = sum(e0.elapsed_time(e1) for e0, e1, _, _ in g) * 1e-3
-        executed = sum(w for _, _, w, _ in g)
+        t_gemm = sum(e0.elapsed_time(e1) for e0, e1, *_ in g) * 1e-3
+        executed = sum(w for _, _, w, *_ in g)
         algo = (VIT_GF_PER_UNIT_B + DEC_GF_PER_UNIT_B) * 1e9 * a.batch if (a.nclass == 21 and a.crop == 512) else executed
         ach = algo / t_gemm / 1e12
         out["roofline"] = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
@@ -163,9 +163,20 @@ def main():
                                executed_tflops=round(executed / t_gemm / 1e12, 2),
                                note="achieved = algorithmic FLOPs of one step (SURVEY §8(d): (2866.6+1322.0) GF x B) / "
                                     "summed duration of all svl_gemm_f32 + svl_attention_* launches of one step (HIP events on the launch stream)")
+        # the ViT encoder alone (north_star: ">= 60 % MFMA peak on the ViT encoder"): launches issued inside the encoder's
+        # forward / backward regions (5 trainable + 2 frozen forwards, 4 backwards per step)
+        gv = [e for e in g if e[4] == "vit"]
+        if gv and (a.nclass, a.crop) == (21, 512):
+            t_v = sum(e0.elapsed_time(e1) for e0, e1, *_ in gv) * 1e-3
+            ach_v = VIT_GF_PER_UNIT_B * 1e9 * a.batch / t_v / 1e12
+            out["roofline_vit_encoder"] = dict(bound="mfma", achieved=round(ach_v, 2), peak=PEAK_F32_MFMA_TF,
+                                               unit="TFLOP/s", frac=round(ach_v / PEAK_F32_MFMA_TF, 4), launches=len(gv),
+                                               kernel_time_ms=round(t_v * 1e3, 2),
+                                               note="algorithmic ViT FLOPs (2866.6 GF x B) / summed duration of the "
+                                                    "svl_gemm_f32 + svl_attention_* launches of the encoder regions")
         # largest single launch shapes
         by = {}
-        for e0, e1, w, tag in g:
+        for e0, e1, w, tag, _scope in g:
             r = by.setdefault(tag, [0.0, 0.0, 0])
             r[0] += e0.elapsed_time(e1) * 1e-3
             r[1] += w
@@ -180,8 +191,8 @@ def main():
                     f.write(f"{v[0] * 1e3:9.3f} ms  n={v[2]:3d}  {v[1] / v[0] / 1e12:7.1f} TF  {k}\n")
         c = prof.get("ce_fused", [])
         if c:
-            t_ce = sum(e0.elapsed_time(e1) for e0, e1, _, _ in c) * 1e-3
-            by_ce = sum(w for _, _, w, _ in c)
+            t_ce = sum(e0.elapsed_time(e1) for e0, e1, *_ in c) * 1e-3
+            by_ce = sum(w for _, _, w, *_ in c)
             out["roofline_hbm"] = dict(bound="hbm", kernel="ce_fused_kernel (svl_ce_fused_f32)",
                                        achieved=round(by_ce / t_ce / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=round(by_ce / t_ce / 1e9 / PEAK_HBM_GBS, 4), traffic=None, launches=len(c),

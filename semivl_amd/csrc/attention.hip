@@ -11,6 +11,9 @@
 //             saves LSE = m + log(l) per (b, head, query).
 //   backward: D = rowsum(dO * O);   dK,dV kernel (block = 128 keys, loops query tiles);
 //             dQ kernel (block = 128 queries, loops key tiles).  Deterministic (no atomics).
+// Ragged token counts (T = 1025 = 8 x 128 + 1): a ninth block per head would cost a full block's time for the single
+// cls-token row, so up to 4 leftover rows are computed by the `*_rows_kernel`s (VALU, one block per row, helper
+// stream, concurrent with the MFMA grids), and an inner tile whose valid rows fit in 32 runs one 32-row half only.
 // qkv is the in-proj output [B*T, 3E] (q | k | v, heads contiguous 64-wide), out / dout are [B*T, E].
 #include "svl_common.h"
 
@@ -95,13 +98,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
       const float* ka = Ks + l31 * LDP + hi;
-#pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        const float a0 = ka[2 * s], a1 = ka[32 * LDP + 2 * s];
-        s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q[s], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q[s], s1, 0, 0, 0);
-      }
       const int j0 = kt * 64;
+      const bool two = p.T - j0 > 32;  // keys 32..63 of this tile exist
+      if (two) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          const float a0 = ka[2 * s], a1 = ka[32 * LDP + 2 * s];
+          s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q[s], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q[s], s1, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], q[s], s0, 0, 0, 0);
+      }
       float mloc = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -124,13 +133,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
       m = mnew;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      if (two) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float* va = Vs + crow(r, hi) * D + l31;
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s0[r], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s0[r], o1, 0, 0, 0);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32 * D], s1[r], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32 * D + 32], s1[r], o1, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          const float* va = Vs + crow(r, hi) * D + l31;
+          o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s0[r], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s0[r], o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32 * D], s1[r], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32 * D + 32], s1[r], o1, 0, 0, 0);
+        }
+      } else {  // s1 is exp(-inf) = 0 everywhere: its products are skipped
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* va = Vs + crow(r, hi) * D + l31;
+          o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s0[r], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s0[r], o1, 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -228,8 +246,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
   for (int qt = 0; qt < nqt; ++qt) {
     if (qt + 1 < nqt) gload(qt + 1);
     if (wave_active) {
+      const int nit = (p.T - qt * 64 > 32) ? 2 : 1;  // queries 32..63 of this tile exist
 #pragma unroll 1
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < nit; ++it) {
         f32x16 sa, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
@@ -318,8 +337,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
       tile_gload(rv, head + 2 * p.E, p.ld, (kt + 1) * 64, p.T, tid);
     }
     if (wave_active) {
+      const int njt = (p.T - kt * 64 > 32) ? 2 : 1;  // keys 32..63 of this tile exist
 #pragma unroll 1
-      for (int jt = 0; jt < 2; ++jt) {
+      for (int jt = 0; jt < njt; ++jt) {
         f32x16 sa, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
@@ -364,6 +384,131 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ leftover rows (VALU)
+// One block (256 threads) per (leftover row, b, head).  Phase 1: one 16-lane group per partner row computes the 64-wide
+// dot product(s) and leaves a weight in LDS; phase 2: lane d of wave g sums weight x partner-row[d] over partner rows
+// g, g+4, ..., the 4 waves are combined through LDS in fixed order (deterministic).
+constexpr int ROWS_MAX_T = 4096;
+
+__device__ __forceinline__ float dot16(const float* a_lds, const float* row, int sub) {
+  const float4 x = *reinterpret_cast<const float4*>(a_lds + 4 * sub), y = *reinterpret_cast<const float4*>(row + 4 * sub);
+  float s = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
+// out[d] = mul * sum_j w[j] * M[j][d]   (M rows `ld` apart), all 256 threads participate; result valid for tid < 64
+__device__ __forceinline__ float weighted_rowsum(const float* w, const float* M, long ld, int T, float* red, int tid) {
+  const int d = tid & 63, g = tid >> 6;
+  float acc = 0.f;
+  for (int j = g; j < T; j += 4) acc += w[j] * M[(long)j * ld + d];
+  __syncthreads();
+  red[tid] = acc;
+  __syncthreads();
+  return red[d] + red[64 + d] + red[128 + d] + red[192 + d];
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_rows_kernel(const AttnP p, int row0) {
+  __shared__ __attribute__((aligned(16))) float qv[D];
+  __shared__ float w[ROWS_MAX_T];
+  __shared__ float red[256];
+  const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+  const int z = blockIdx.y, b = z / p.H, h = z - b * p.H, qi = row0 + blockIdx.x;
+  const float* head = p.qkv + (long)b * p.T * p.ld + h * D;
+  if (tid < D) qv[tid] = head[(long)qi * p.ld + tid] * p.scale;
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j0 = 0; j0 < p.T; j0 += 16) {
+    const int j = j0 + grp;
+    const float sc = dot16(qv, head + p.E + (long)min(j, p.T - 1) * p.ld, sub);
+    if (j < p.T) {
+      if (sub == 0) w[j] = sc;
+      mx = fmaxf(mx, sc);
+    }
+  }
+  mx = block_max_256(mx, red);
+  float sum = 0.f;
+  for (int j = tid; j < p.T; j += 256) {
+    const float e = expf(w[j] - mx);
+    w[j] = e;
+    sum += e;
+  }
+  sum = block_sum_256(sum, red);
+  const float o = weighted_rowsum(w, head + 2 * p.E, p.ld, p.T, red, tid);
+  if (tid < D) p.out[((long)b * p.T + qi) * p.E + h * D + tid] = o / sum;
+  if (tid == 0 && p.lse) p.lse[(long)z * p.T + qi] = mx + logf(sum);
+}
+
+// dQ of a leftover query row
+__global__ __launch_bounds__(256) void attn_bwd_dq_rows_kernel(const AttnP p, int row0) {
+  __shared__ __attribute__((aligned(16))) float qv[D];
+  __shared__ __attribute__((aligned(16))) float ov[D];
+  __shared__ float w[ROWS_MAX_T];
+  __shared__ float red[256];
+  const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+  const int z = blockIdx.y, b = z / p.H, h = z - b * p.H, qi = row0 + blockIdx.x;
+  const float* head = p.qkv + (long)b * p.T * p.ld + h * D;
+  if (tid < D) {
+    qv[tid] = head[(long)qi * p.ld + tid] * p.scale;
+    ov[tid] = p.dout[((long)b * p.T + qi) * p.E + h * D + tid];
+  }
+  __syncthreads();
+  const float lse_i = p.lse[(long)z * p.T + qi], d_i = p.dsum[(long)z * p.T + qi];
+  for (int j0 = 0; j0 < p.T; j0 += 16) {
+    const int j = j0 + grp;
+    const float* kr = head + p.E + (long)min(j, p.T - 1) * p.ld;
+    const float sc = dot16(qv, kr, sub), dp = dot16(ov, kr + p.E, sub);
+    if (j < p.T && sub == 0) w[j] = expf(sc - lse_i) * (dp - d_i);
+  }
+  __syncthreads();
+  const float dq = weighted_rowsum(w, head + p.E, p.ld, p.T, red, tid);
+  if (tid < D) p.dqkv[((long)b * p.T + qi) * p.ld + h * D + tid] = dq * p.scale;
+}
+
+// dK, dV of a leftover key row
+__global__ __launch_bounds__(256) void attn_bwd_dkv_rows_kernel(const AttnP p, int row0) {
+  __shared__ __attribute__((aligned(16))) float kv[D];
+  __shared__ __attribute__((aligned(16))) float vv[D];
+  __shared__ float wp[ROWS_MAX_T];
+  __shared__ float wd[ROWS_MAX_T];
+  __shared__ float red[256];
+  const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+  const int z = blockIdx.y, b = z / p.H, h = z - b * p.H, kj = row0 + blockIdx.x;
+  const float* head = p.qkv + (long)b * p.T * p.ld + h * D;
+  const float* dhead = p.dout + (long)b * p.T * p.E + h * D;
+  if (tid < D) {
+    kv[tid] = head[p.E + (long)kj * p.ld + tid] * p.scale;
+    vv[tid] = head[2 * p.E + (long)kj * p.ld + tid];
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < p.T; i0 += 16) {
+    const int i = i0 + grp, ic = min(i, p.T - 1);
+    const float sc = dot16(kv, head + (long)ic * p.ld, sub), dp = dot16(vv, dhead + (long)ic * p.E, sub);
+    if (i < p.T && sub == 0) {
+      const float pv = expf(sc - p.lse[(long)z * p.T + i]);
+      wp[i] = pv;
+      wd[i] = pv * (dp - p.dsum[(long)z * p.T + i]);
+    }
+  }
+  __syncthreads();
+  const float dv = weighted_rowsum(wp, dhead, p.E, p.T, red, tid);
+  const float dk = weighted_rowsum(wd, head, p.ld, p.T, red, tid);
+  if (tid < D) {
+    float* row = p.dqkv + ((long)b * p.T + kj) * p.ld + h * D;
+    row[p.E + tid] = dk * p.scale;
+    row[2 * p.E + tid] = dv;
+  }
+}
+
+// Rows [128 * nb, T) go to the row kernels when there are at most 4 of them.
+__host__ inline int rows_split(int T, int* nb) {
+  const int full = T / 128, r = T - full * 128;
+  const bool use = r > 0 && r <= 4 && full > 0 && T <= ROWS_MAX_T;
+  *nb = use ? full : (T + 127) / 128;
+  return use ? r : 0;
+}
+
 int check(const float* qkv, int B, int T, int H, const char* who) {
   SVL_CHECK_ARG(qkv && B > 0 && T > 0 && H > 0 && (long)B * H <= 65535, "%s: bad args", who);
   SVL_CHECK_ARG(((uintptr_t)qkv & 15) == 0, "%s: qkv must be 16-byte aligned", who);
@@ -379,9 +524,19 @@ extern "C" int svl_attention_fwd(const float* qkv, int B, int T, int H, float* o
   AttnP p;
   memset(&p, 0, sizeof(p));
   p.qkv = qkv; p.out = out; p.lse = lse; p.B = B; p.T = T; p.H = H; p.E = (long)H * D; p.ld = 3 * p.E; p.scale = 0.125f;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + 127) / 128, B * H), dim3(256), 0, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  int nb = 0;
+  const int r = rows_split(T, &nb);
+  if (r > 0) {
+    hipStream_t aux = nullptr;
+    rc = svl_fork(st, &aux);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_fwd_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * 128);
+    SVL_LAUNCH_CHECK("svl_attention_fwd/rows");
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(nb, B * H), dim3(256), 0, st, p);
   SVL_LAUNCH_CHECK("svl_attention_fwd");
-  return SVL_OK;
+  return r > 0 ? svl_join(st) : SVL_OK;
 }
 
 extern "C" int svl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T,
@@ -398,9 +553,20 @@ extern "C" int svl_attention_bwd(const float* qkv, const float* out, const float
   hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, st, dout, out, dsum_ws,
                      B, T, H, p.E);
   SVL_LAUNCH_CHECK("svl_attention_bwd/dsum");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((T + 127) / 128, B * H), dim3(256), 0, st, p);
+  int nb = 0;
+  const int r = rows_split(T, &nb);
+  if (r > 0) {  // after dsum (both need it), concurrent with the MFMA grids
+    hipStream_t aux = nullptr;
+    rc = svl_fork(st, &aux);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * 128);
+    SVL_LAUNCH_CHECK("svl_attention_bwd/dkv_rows");
+    hipLaunchKernelGGL(attn_bwd_dq_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * 128);
+    SVL_LAUNCH_CHECK("svl_attention_bwd/dq_rows");
+  }
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nb, B * H), dim3(256), 0, st, p);
   SVL_LAUNCH_CHECK("svl_attention_bwd/dkv");
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, B * H), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nb, B * H), dim3(256), 0, st, p);
   SVL_LAUNCH_CHECK("svl_attention_bwd/dq");
-  return SVL_OK;
+  return r > 0 ? svl_join(st) : SVL_OK;
 }

@@ -1006,13 +1006,6 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   if (ragged_fork && am == SVL_A_KCONTIG && (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) &&
       d->out_mode == SVL_OUT_STRIDED && d->batch == 1 && d->ksplit == 0 && d->M >= 8192 && (d->M % 128) != 0 &&
       (long)d->N * d->K >= 768 * 768) {
-    static hipStream_t aux = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (!aux) {
-      SVL_HIP_CHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-      SVL_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-      SVL_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    }
     const int m_main = (d->M / 128) * 128;
     GemmP rem = p, mainp = p;
     mainp.M = m_main;
@@ -1022,18 +1015,16 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     if (p.preact) rem.preact = p.preact + (long)m_main * p.ldc_m;
     if (p.resid) rem.resid = p.resid + (long)m_main * p.ldr_m;
     rem.A.vec = p.A.vec && aligned16(rem.A.p);
-    SVL_HIP_CHECK(hipEventRecord(ev_fork, st));
-    SVL_HIP_CHECK(hipStreamWaitEvent(aux, ev_fork, 0));
-    hipStream_t keep = st;
+    hipStream_t aux = nullptr, keep = st;
+    int rc = svl_fork(st, &aux);
+    if (rc != SVL_OK) return rc;
     st = aux;
-    int rc = launch(rem);
+    rc = launch(rem);
     st = keep;
     if (rc != SVL_OK) return rc;
-    SVL_HIP_CHECK(hipEventRecord(ev_join, aux));
     rc = launch(mainp);
     if (rc != SVL_OK) return rc;
-    SVL_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
-    return SVL_OK;
+    return svl_join(st);
   }
   return launch(p);
 }

@@ -40,6 +40,12 @@ void svl_set_error(const char* fmt, ...);
     }                                                                 \
   } while (0)
 
+// Fork/join onto the library's helper stream (api.hip): independent, disjoint-output launches of one entry point run
+// concurrently with the caller's stream.  svl_fork orders the helper stream after everything queued on `st`; svl_join
+// makes `st` wait for everything queued on the helper stream.  Capture-legal (events only).
+int svl_fork(hipStream_t st, hipStream_t* aux);
+int svl_join(hipStream_t st);
+
 // ---- device helpers --------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

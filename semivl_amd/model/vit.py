@@ -349,7 +349,8 @@ class MaskClipVisionTransformer(nn.Module):
         if torch.is_grad_enabled() and (tr or (pos_in is not None and pos_in.requires_grad)):
             outs = _EncoderFn.apply(self, img, need_global, pos_in, *tr)
         else:
-            outs = _encoder_forward(self, img, need_global, None, pos_in)
+            with ops.prof_scope("vit"):
+                outs = _encoder_forward(self, img, need_global, None, pos_in)
         n = len(outs) - 1
         return list(outs[:n]), outs[n]
 
@@ -429,7 +430,8 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, img, need_global, pos_in, *params):
         saved = {}
-        outs = _encoder_forward(m, img, need_global, saved, pos_in)
+        with ops.prof_scope("vit"):
+            outs = _encoder_forward(m, img, need_global, saved, pos_in)
         ctx.m, ctx.saved, ctx.need_global = m, saved, need_global
         ctx.pos_is_input = pos_in is not None
         ctx.n_feats = len(outs) - 1
@@ -440,6 +442,11 @@ class _EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
+        with ops.prof_scope("vit"):
+            return _EncoderFn._backward(ctx, *douts)
+
+    @staticmethod
+    def _backward(ctx, *douts):
         m, s = ctx.m, ctx.saved
         B, T, NP, hp, wp = s["dims"]
         E, L = m.embed_dims, m.num_layers

@@ -23,6 +23,20 @@ def _st():
 # Optional live kernel timing (bench.py): PROFILE = {} enables HIP-event brackets around the launches of the kernel
 # families we report rooflines for.  Events are recorded on the launch stream (torch's current stream).
 PROFILE = None
+PROFILE_SCOPE = None  # name of the sub-path whose launches are being recorded ("vit" inside the encoder regions)
+
+
+class prof_scope:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global PROFILE_SCOPE
+        self.prev, PROFILE_SCOPE = PROFILE_SCOPE, self.name
+
+    def __exit__(self, *exc):
+        global PROFILE_SCOPE
+        PROFILE_SCOPE = self.prev
 
 
 def _prof_begin():
@@ -38,7 +52,7 @@ def _prof_end(name, e0, work, tag=None):
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.setdefault(name, []).append((e0, e1, work, tag))
+    PROFILE.setdefault(name, []).append((e0, e1, work, tag, PROFILE_SCOPE))
 
 
 def _p(t):

@@ -149,7 +149,8 @@ def test_vit_attention(dev, Bn, T, H):
     close(dqkv, gref, atol=5e-5, what="attn bwd")
 
 
-@pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 17, 4), (1, 64, 1), (2, 129, 3), (1, 128, 2)])
+@pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 17, 4), (1, 64, 1), (2, 129, 3), (1, 128, 2),
+                                    (2, 130, 2), (1, 260, 3), (1, 133, 2), (1, 161, 1), (1, 97, 2)])
 def test_fused_attention(dev, Bn, T, H):
     """Flash-style kernel vs explicit softmax(q k^T / 8) v and its autograd; ragged T, spiky logits (forces rescales)."""
     from semivl_amd import ops
