@@ -211,33 +211,99 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x
   __syncthreads();
   if (ry == 0 && c < C) part[(long)blockIdx.y * C + c] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
 }
-__global__ void colsum_stage2(const float* __restrict__ part, int nchunk, int C, float* __restrict__ out,
-                              int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = accumulate ? out[c] : 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[(long)k * C + c];
-  out[c] = s;
+// 16-byte variant (C % 4 == 0, 16 B aligned rows): lane = (row sub-index, group of 4 columns); `cgp` (a power of two
+// <= 64) column groups per block, 256 / cgp rows per iteration, 4 independent loads in flight per thread.
+__global__ __launch_bounds__(256) void colsum_stage1_v4(const float* __restrict__ x, long rows, int C, long ld,
+                                                        float* __restrict__ part, long rows_per_chunk, int cgp) {
+  __shared__ float4 sh[256];
+  const int tid = threadIdx.x, cgi = tid & (cgp - 1), rsub = tid / cgp, RS = 256 / cgp;
+  const int cg = blockIdx.x * cgp + cgi;
+  const bool ok = cg * 4 < C;
+  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  if (ok) {
+    const float* px = x + 4 * cg;
+    long r = r0 + rsub;
+    for (; r + 3 * RS < r1; r += 4 * RS) {
+      const float4 v0 = *reinterpret_cast<const float4*>(px + r * ld);
+      const float4 v1 = *reinterpret_cast<const float4*>(px + (r + RS) * ld);
+      const float4 v2 = *reinterpret_cast<const float4*>(px + (r + 2 * RS) * ld);
+      const float4 v3 = *reinterpret_cast<const float4*>(px + (r + 3 * RS) * ld);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; r < r1; r += RS) {
+      const float4 v0 = *reinterpret_cast<const float4*>(px + r * ld);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+  }
+  sh[tid] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                        (a0.w + a1.w) + (a2.w + a3.w));
+  __syncthreads();
+  if (rsub == 0 && ok) {
+    float4 t = sh[cgi];
+    for (int k = 1; k < RS; ++k) {
+      const float4 u = sh[k * cgp + cgi];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(part + (long)blockIdx.y * C + 4 * cg) = t;
+  }
+}
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int nchunk, int C,
+                                                     float* __restrict__ out, int accumulate) {
+  // 64 columns x 4 chunk lanes per block, four loads in flight per thread, fixed-order combine
+  __shared__ float sh[4][64];
+  const int cx = threadIdx.x & 63, ky = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int k = ky;
+    for (; k + 12 < nchunk; k += 16) {
+      s0 += part[(long)k * C + c];
+      s1 += part[(long)(k + 4) * C + c];
+      s2 += part[(long)(k + 8) * C + c];
+      s3 += part[(long)(k + 12) * C + c];
+    }
+    for (; k < nchunk; k += 4) s0 += part[(long)k * C + c];
+  }
+  sh[ky][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ky == 0 && c < C) {
+    const float t = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Elementwise
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float eltwise_op(int mode, float a, float b) {
+  switch (mode) {
+    case 0: return a + b;
+    case 1: return a * gelu_erf_grad(b);
+    case 2: return (b > 0.f) ? a : 0.f;
+    case 3: return a * b;
+    case 5: return gelu_erf(a);
+    case 6: return fmaxf(a, 0.f);
+    case 7: return a / b;
+    default: return a;
+  }
+}
 __global__ void eltwise_kernel(int mode, const float* __restrict__ a, const float* __restrict__ b,
                                float* __restrict__ out, long n) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float v;
-    switch (mode) {
-      case 0: v = a[i] + b[i]; break;
-      case 1: v = a[i] * gelu_erf_grad(b[i]); break;
-      case 2: v = (b[i] > 0.f) ? a[i] : 0.f; break;
-      case 3: v = a[i] * b[i]; break;
-      case 5: v = gelu_erf(a[i]); break;
-      case 6: v = fmaxf(a[i], 0.f); break;
-      case 7: v = a[i] / b[i]; break;
-      default: v = a[i]; break;
-    }
-    out[i] = v;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = eltwise_op(mode, a[i], b ? b[i] : 0.f);
+}
+// 16 B per lane (n % 4 == 0, 16 B aligned pointers)
+__global__ void eltwise_kernel_v4(int mode, const float4* __restrict__ a, const float4* __restrict__ b,
+                                  float4* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 x = a[i];
+    const float4 y = b ? b[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    out[i] = make_float4(eltwise_op(mode, x.x, y.x), eltwise_op(mode, x.y, y.y), eltwise_op(mode, x.z, y.z),
+                         eltwise_op(mode, x.w, y.w));
   }
 }
 __global__ void chanmask_kernel(const float* __restrict__ x, const float* __restrict__ mask, float scale, long rows,
@@ -306,32 +372,31 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __res
     stats[(img * G + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
+// Apply passes: grid = (pixel slabs, images); a thread keeps ONE channel quad (256 % CQ == 0), so the group statistics,
+// gamma/beta (and in backward the two group sums) are loop-invariant registers and the loop body is load/fma/store.
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, long ldx,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, long npix, long HW, int C,
                                                               int G, int relu, const float* __restrict__ stats,
                                                               float* __restrict__ y, long ldy) {
-  const int CQ = C >> 2;
-  const int cg = C / G;
-  const long total = npix * CQ;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long p = i / CQ;
-    const int c = (int)(i - p * CQ) * 4;
-    const long img = p / HW;
-    const int g = c / cg;
-    const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
-    const float4 v = *reinterpret_cast<const float4*>(x + p * ldx + c);
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 be = *reinterpret_cast<const float4*>(beta + c);
-    float4 o;
-    o.x = (v.x - mean) * rstd * ga.x + be.x;
-    o.y = (v.y - mean) * rstd * ga.y + be.y;
-    o.z = (v.z - mean) * rstd * ga.z + be.z;
-    o.w = (v.w - mean) * rstd * ga.w + be.w;
+  const int CQ = C >> 2, PR = 256 / CQ;
+  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ, c = 4 * cq;
+  const long img = blockIdx.y;
+  const int g = c / (C / G);
+  const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+  const float4 be = *reinterpret_cast<const float4*>(beta + c);
+  const float4 sc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
+  const float4 sh = make_float4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+  const float* xi = x + img * HW * ldx + c;
+  float* yi = y + img * HW * ldy + c;
+  for (long p = (long)blockIdx.x * PR + pr; p < HW; p += (long)gridDim.x * PR) {
+    const float4 v = *reinterpret_cast<const float4*>(xi + p * ldx);
+    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
     if (relu) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
-    *reinterpret_cast<float4*>(y + p * ldy + c) = o;
+    *reinterpret_cast<float4*>(yi + p * ldy) = o;
   }
 }
 // chan_sums[img][0][c] = sum_p dy', chan_sums[img][1][c] = sum_p dy' * xhat   (dy' = dy masked by relu)
@@ -390,18 +455,15 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_apply_kernel(const float* _
                                                                   const float* __restrict__ chan_sums, long npix,
                                                                   long HW, int C, int G, int relu,
                                                                   float* __restrict__ dx, long lddx) {
-  const int CQ = C >> 2;
+  const int CQ = C >> 2, PR = 256 / CQ;
   const int cg = C / G;
-  const long total = npix * CQ;
-  const float inv_n = 1.f / ((float)HW * cg);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long p = i / CQ;
-    const int c = (int)(i - p * CQ) * 4;
-    const long img = p / HW;
-    const int g = c / cg;
-    const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
-    // group sums S1 = sum_c gamma_c A_c, S2 = sum_c gamma_c B_c  (cg <= 64 values, L1-resident)
-    float S1 = 0.f, S2 = 0.f;
+  const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ, c = 4 * cq;
+  const long img = blockIdx.y;
+  const int g = c / cg;
+  const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
+  // group sums S1 = sum_c gamma_c A_c, S2 = sum_c gamma_c B_c  (cg <= 64 values), once per thread
+  float S1 = 0.f, S2 = 0.f;
+  {
     const float* A = chan_sums + (img * 2 + 0) * C + g * cg;
     const float* Bc = chan_sums + (img * 2 + 1) * C + g * cg;
     for (int k = 0; k < cg; ++k) {
@@ -409,23 +471,38 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_apply_kernel(const float* _
       S1 += gm * A[k];
       S2 += gm * Bc[k];
     }
-    float4 d = *reinterpret_cast<const float4*>(dy + p * lddy + c);
-    const float4 v = *reinterpret_cast<const float4*>(x + p * ldx + c);
+  }
+  const float inv_n = 1.f / ((float)HW * cg);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+  const float* di = dy + img * HW * lddy + c;
+  const float* xi = x + img * HW * ldx + c;
+  const float* yi = relu ? y + img * HW * ldy + c : nullptr;
+  float* oi = dx + img * HW * lddx + c;
+  for (long p = (long)blockIdx.x * PR + pr; p < HW; p += (long)gridDim.x * PR) {
+    float4 d = *reinterpret_cast<const float4*>(di + p * lddy);
+    const float4 v = *reinterpret_cast<const float4*>(xi + p * ldx);
     if (relu) {
-      const float4 o = *reinterpret_cast<const float4*>(y + p * ldy + c);
+      const float4 o = *reinterpret_cast<const float4*>(yi + p * ldy);
       if (!(o.x > 0.f)) d.x = 0.f;
       if (!(o.y > 0.f)) d.y = 0.f;
       if (!(o.z > 0.f)) d.z = 0.f;
       if (!(o.w > 0.f)) d.w = 0.f;
     }
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
     float4 o;
     o.x = rstd * (d.x * ga.x - inv_n * (S1 + (v.x - mean) * rstd * S2));
     o.y = rstd * (d.y * ga.y - inv_n * (S1 + (v.y - mean) * rstd * S2));
     o.z = rstd * (d.z * ga.z - inv_n * (S1 + (v.z - mean) * rstd * S2));
     o.w = rstd * (d.w * ga.w - inv_n * (S1 + (v.w - mean) * rstd * S2));
-    *reinterpret_cast<float4*>(dx + p * lddx + c) = o;
+    *reinterpret_cast<float4*>(oi + p * lddx) = o;
   }
+}
+
+inline dim3 gn_apply_grid(int imgs, long HW, int C) {
+  const long PR = 256 / (C / 4);
+  long gx = (HW + PR * 8 - 1) / (PR * 8);  // ~8 pixels per thread
+  if (gx < 1) gx = 1;
+  if (gx > 1024) gx = 1024;
+  return dim3((unsigned)gx, (unsigned)imgs);
 }
 
 inline bool gn_shape_ok(int C, int G) {
@@ -506,7 +583,7 @@ extern "C" int svl_l2norm_bwd(const float* dy, const float* y, const float* inv_
 
 extern "C" int64_t svl_colsum_ws_floats(int64_t rows, int C) {
   long nchunk = (rows + 255) / 256;
-  if (nchunk > 512) nchunk = 512;
+  if (nchunk > 1024) nchunk = 1024;
   if (nchunk < 1) nchunk = 1;
   return nchunk * C;
 }
@@ -515,10 +592,17 @@ extern "C" int svl_colsum_f32(const float* x, int64_t rows, int C, int64_t ld, f
   SVL_CHECK_ARG(x && out && ws && rows > 0 && C > 0 && ld >= C, "svl_colsum_f32: bad args");
   const int nchunk = (int)(svl_colsum_ws_floats(rows, C) / C);
   const long rpc = (rows + nchunk - 1) / nchunk;
-  hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, (hipStream_t)stream, x, (long)rows, C,
-                     (long)ld, ws, rpc);
+  if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 15) == 0) {
+    int cgp = 1;
+    while (cgp < 64 && cgp < C / 4) cgp <<= 1;
+    hipLaunchKernelGGL(colsum_stage1_v4, dim3((C / 4 + cgp - 1) / cgp, nchunk), dim3(256), 0, (hipStream_t)stream, x,
+                       (long)rows, C, (long)ld, ws, rpc, cgp);
+  } else {
+    hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, (hipStream_t)stream, x, (long)rows, C,
+                       (long)ld, ws, rpc);
+  }
   SVL_LAUNCH_CHECK("svl_colsum_f32/1");
-  hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nchunk, C, out,
+  hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, ws, nchunk, C, out,
                      accumulate);
   SVL_LAUNCH_CHECK("svl_colsum_f32/2");
   return SVL_OK;
@@ -526,7 +610,13 @@ extern "C" int svl_colsum_f32(const float* x, int64_t rows, int C, int64_t ld, f
 
 extern "C" int svl_eltwise_f32(int mode, const float* a, const float* b, float* out, int64_t n, svl_stream_t stream) {
   SVL_CHECK_ARG(a && out && n > 0 && mode >= 0 && mode <= 7 && ((mode >= 4 && mode <= 6) || b), "svl_eltwise_f32: bad args");
-  hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, mode, a, b, out, (long)n);
+  const bool v4 = (n % 4 == 0) && (((uintptr_t)a | (uintptr_t)out | (uintptr_t)b) & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL(eltwise_kernel_v4, dim3(grid_for(n / 4, 4)), dim3(256), 0, (hipStream_t)stream, mode,
+                       reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
+                       reinterpret_cast<float4*>(out), (long)(n / 4));
+  else
+    hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, mode, a, b, out, (long)n);
   SVL_LAUNCH_CHECK("svl_eltwise_f32");
   return SVL_OK;
 }
@@ -555,7 +645,7 @@ extern "C" int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma
   hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(imgs), dim3(256), 0, st, x, (long)ldx, eps, (long)HW, C, G, stats);
   SVL_LAUNCH_CHECK("svl_groupnorm_fwd/stats");
   const long npix = (long)imgs * HW;
-  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, st, x, (long)ldx, gamma, beta,
+  hipLaunchKernelGGL(groupnorm_apply_kernel, gn_apply_grid(imgs, HW, C), dim3(256), 0, st, x, (long)ldx, gamma, beta,
                      npix, (long)HW, C, G, relu, stats, y, (long)ldy);
   SVL_LAUNCH_CHECK("svl_groupnorm_fwd/apply");
   return SVL_OK;
@@ -573,7 +663,7 @@ extern "C" int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, 
                      stats, (long)HW, C, G, relu, chan_sums);
   SVL_LAUNCH_CHECK("svl_groupnorm_bwd/sums");
   const long npix = (long)imgs * HW;
-  hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, st, dy, (long)lddy, x,
+  hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, gn_apply_grid(imgs, HW, C), dim3(256), 0, st, dy, (long)lddy, x,
                      (long)ldx, y, (long)ldy, stats, gamma, chan_sums, npix, (long)HW, C, G, relu, dx, (long)lddx);
   SVL_LAUNCH_CHECK("svl_groupnorm_bwd/apply");
   return SVL_OK;

@@ -28,6 +28,10 @@ class _MHAParams(nn.Module):
         self.in_proj_weight = nn.Parameter(torch.empty(3 * dims, dims))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * dims))
         self.out_proj = nn.Linear(dims, dims)
+        # nn.MultiheadAttention._reset_parameters (the decoder's transformer layers keep this init; the ViT's
+        # init_weights overrides it)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.)
 
 
 class _AttnParams(nn.Module):

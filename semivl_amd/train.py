@@ -228,7 +228,7 @@ class FusedAdamW:
         self._lr_host = torch.tensor([g_["lr"] for g_ in self.groups], dtype=torch.float32).pin_memory() \
             if torch.cuda.is_available() else torch.tensor([g_["lr"] for g_ in self.groups], dtype=torch.float32)
         self.seg_lr = self._lr_host.to(dev)
-        self.seg_lr0 = self.seg_lr.clone()          # initial_lr per segment
+        self._lr_evt = None
         self.step_count = 0
         self.grad_scale = 1.0
 
@@ -287,17 +287,21 @@ class FusedAdamW:
         assert len(steps) <= 1, "per-tensor step counts differ"
         self.step_count = steps.pop() if steps else 0
         self.seg_lr.copy_(self._lr_host)
-        self.seg_lr0.copy_(torch.tensor([g_["initial_lr"] for g_ in self.groups], dtype=torch.float32))
 
     def poly_lr(self, iters, max_iters, power=0.9):
         """semivl.py:343-345: applied after the step, for the next one."""
         f = (1 - iters / max_iters) ** power
+        # the pinned staging buffer may still be the source of the previous call's queued copy: wait for THAT copy
+        # (issued a whole step ago, so this never stalls in the training loop) before overwriting it
+        if self._lr_evt is not None:
+            self._lr_evt.synchronize()
         for i, g_ in enumerate(self.groups):
             g_["lr"] = g_["initial_lr"] * f
             self._lr_host[i] = g_["lr"]
-        # the factor travels as a kernel argument: no host buffer that a later call could overwrite while a copy is
-        # still queued, and no synchronisation
-        torch.mul(self.seg_lr0, f, out=self.seg_lr)
+        self.seg_lr.copy_(self._lr_host, non_blocking=True)
+        if self.seg_lr.is_cuda:
+            self._lr_evt = torch.cuda.Event()
+            self._lr_evt.record()
 
 
 def build_optimizer(model, optimizer_cfg):

@@ -94,3 +94,17 @@ def test_synthetic_batch_spec():
     from oracle import semivl_oracle as O
     o = O.synthetic_batch(4, 64, 21, seed=1)
     assert all(torch.equal(b[k], o[k]) for k in b)   # product and oracle feed the same synthetic stream
+
+
+def test_fresh_model_has_no_uninitialised_parameters():
+    """Every parameter of a freshly built model (no pretrained file, no fixture state) must come from an initialiser:
+    finite and O(1) (the decoder's attention in-projection once was torch.empty)."""
+    import torch
+    from golden_util import build_hip, load_fixture
+    _, c = load_fixture("tiny")
+    for _ in range(3):   # allocator reuse makes garbage show up on later builds
+        m = build_hip(c)
+        junk = torch.empty(1 << 20).fill_(float("nan"))
+        del junk
+        for n, p in m.named_parameters():
+            assert torch.isfinite(p).all() and p.abs().max() < 50, n

@@ -335,6 +335,12 @@ def test_l2norm_colsum_eltwise(dev):
     close(ops.l2norm_bwd(dy, y, inv), g, atol=1e-5)
     big = rnd(70001, 96, dev=dev)
     close(ops.colsum(big), big.double().sum(0).float(), atol=2e-2, rtol=1e-4)
+    for rows, C in [(300001, 32), (5000, 768), (777, 4), (1025, 2304), (999, 30), (3, 64), (100000, 1)]:
+        m = rnd(rows, C, dev=dev, seed=rows % 97)
+        close(ops.colsum(m), m.double().sum(0).float(), atol=2e-5 * rows ** 0.5 + 1e-5, what=f"colsum {rows}x{C}")
+    wide = rnd(4000, 96, dev=dev)                      # strided view: 32 of 96 columns, row stride 96
+    close(ops.colsum(wide[:, 32:64], C_=32, ld=96), wide[:, 32:64].double().sum(0).float(), atol=2e-3)
+    assert torch.equal(ops.colsum(big), ops.colsum(big))
     a, b = rnd(5000, dev=dev), rnd(5000, dev=dev)
     close(ops.add(a, b), a + b, atol=0)
     bb = b.clone().requires_grad_(True)
