@@ -56,7 +56,14 @@ enum {
   SVL_B_NCONTIG = 1, /* B(n,k) = B[k*ldb + n]   (dgrad: W as [K=out][N=in]; V in P·V; X in wgrad)     */
   SVL_B_CONVW = 2    /* B(n,k): n = (tap, ci), k = NHWC pixel: im2col^T for conv wgrad                */
 };
-enum { SVL_ACT_NONE = 0, SVL_ACT_GELU = 1, SVL_ACT_RELU = 2 };
+enum {
+  SVL_ACT_NONE = 0,
+  SVL_ACT_GELU = 1,      /* erf GELU */
+  SVL_ACT_RELU = 2,
+  /* backward forms (SVL_OUT_STRIDED): `resid` is NOT added but read as the saved pre-activation z[m][n] */
+  SVL_ACT_MUL_DGELU = 3, /* v *= GELU'(z)      -- dgrad of Linear -> GELU fused with the activation's derivative */
+  SVL_ACT_MUL_DRELU = 4  /* v  = z > 0 ? v : 0 */
+};
 enum {
   SVL_OUT_STRIDED = 0, /* C + zo*bs_outer + zi*bs_inner + m*ld_m + n*ld_n                              */
   SVL_OUT_CONVT2X = 1, /* ConvTranspose2d k2 s2: m=(img,h,w), n=(a,b,co) -> pixel (img,2h+a,2w+b), co  */

@@ -339,7 +339,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
           long off;
           if (p.out_mode == SVL_OUT_STRIDED) {
             off = (long)m * p.ldc_m + (long)n * p.ldc_n;
-            if (Rz) v += Rz[(long)m * p.ldr_m + (long)n * p.ldr_n];
+            if (Rz) {
+              const float rv = Rz[(long)m * p.ldr_m + (long)n * p.ldr_n];
+              if (p.act == SVL_ACT_MUL_DGELU) v *= gelu_erf_grad(rv);
+              else if (p.act == SVL_ACT_MUL_DRELU) v = rv > 0.f ? v : 0.f;
+              else v += rv;
+            }
           } else if (p.out_mode == SVL_OUT_CONVT2X) {
             const int w = m % p.ct_W;
             const int t = m / p.ct_W;

@@ -135,8 +135,7 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False):
     wout_parts = []  # (dy, input) pairs contributing to out_proj wgrad
 
     def ffn_ln_bwd(dout, pre_ln_in, st2, h_pre, tag):
-        dh = ops.matmul_nn(dout, p["w2"])
-        dhp = ops.eltwise(1, dh, h_pre, out=dh)
+        dhp = ops.matmul_nn(dout, p["w2"], dact=ops.ACT_MUL_DGELU, z=h_pre)  # (dout W2) * GELU'(h_pre), one pass
         dy2 = ops.matmul_nn(dhp, p["w1"])
         if train_ffn_ln:
             # recompute h = gelu(h_pre) and y2 = LN(pre_ln_in) for the weight grads (cheap vs. saving them)

@@ -12,7 +12,7 @@ from . import lib as L
 
 A_KC, A_MC, A_CONV, A_PATCH = 0, 1, 2, 3
 B_KC, B_NC, B_CONVW = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL_DGELU, ACT_MUL_DRELU = 0, 1, 2, 3, 4
 OUT_STRIDED, OUT_CONVT2X, OUT_PATCH = 0, 1, 2
 
 
@@ -143,13 +143,19 @@ def copy2d(src, s_off, sgrp, src_go, src_ld, dst, d_off, dgrp, dst_go, dst_ld, r
                                     1 if accumulate else 0, _st()), "svl_copy2d_f32")
 
 
-def matmul_nn(a, b, out=None, accumulate=False):
-    """out[M,N] = a[M,K] @ b[K,N]  (dgrad: dY @ W with W [out,in])."""
+def matmul_nn(a, b, out=None, accumulate=False, dact=ACT_NONE, z=None):
+    """out[M,N] = a[M,K] @ b[K,N]  (dgrad: dY @ W with W [out,in]).  `dact` = ACT_MUL_DGELU / ACT_MUL_DRELU multiplies
+    the result by the activation derivative at the saved pre-activation `z` [M,N] in the epilogue."""
     M, K = a.shape
     N = b.shape[1]
     assert b.shape[0] == K and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
         out = empty(M, N, device=a.device)
+    if dact != ACT_NONE:
+        assert z is not None and z.shape == (M, N) and z.stride(1) == 1 and not accumulate
+        gemm(A_KC, B_NC, M, N, K, Op(a, a.stride(0)), Op(b, b.stride(0)), out, ldc_m=out.stride(0), act=dact, resid=z,
+             ldr_m=z.stride(0))
+        return out
     gemm(A_KC, B_NC, M, N, K, Op(a, a.stride(0)), Op(b, b.stride(0)), out, ldc_m=out.stride(0), accumulate=accumulate)
     return out
 

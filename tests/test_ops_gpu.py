@@ -59,6 +59,24 @@ def test_matmul_nn(dev, M, N, K):
     from semivl_amd import ops
     a, b = rnd(M, K, dev=dev, seed=2), rnd(K, N, dev=dev)
     close(ops.matmul_nn(a, b), a @ b, atol=1e-4 * math.sqrt(K))
+    # dgrad fused with the activation derivative at the saved pre-activation
+    z = rnd(M, N, dev=dev, seed=9).requires_grad_(True)
+    (gg,) = torch.autograd.grad(F.gelu(z), z, a @ b)
+    close(ops.matmul_nn(a, b, dact=ops.ACT_MUL_DGELU, z=z.detach()), gg, atol=1e-4 * math.sqrt(K), what="dgelu")
+    close(ops.matmul_nn(a, b, dact=ops.ACT_MUL_DRELU, z=z.detach()), (a @ b) * (z.detach() > 0),
+          atol=1e-4 * math.sqrt(K), what="drelu")
+
+
+def test_matmul_nn_dgelu_ragged_tokens(dev, emu_mode):
+    """M = 8 x 1025: the fused derivative must follow the leftover rows onto the helper-stream launch, both GEMM modes."""
+    from semivl_amd import ops
+    M, N, K = 8200, 3072, 768
+    a, b, z = rnd(M, K, dev=dev, seed=21), rnd(K, N, dev=dev, seed=22) * 0.05, rnd(M, N, dev=dev, seed=23)
+    zz = z.clone().requires_grad_(True)
+    (ref,) = torch.autograd.grad(F.gelu(zz), zz, a @ b)
+    for mode in (0, 6):
+        emu_mode(mode)
+        close(ops.matmul_nn(a, b, dact=ops.ACT_MUL_DGELU, z=z), ref, atol=2e-3, what=f"mode {mode}")
 
 
 @pytest.mark.parametrize("M,N,K", [(130, 70, 257), (768, 768, 4100), (2304, 768, 1025), (32, 576, 40000),
