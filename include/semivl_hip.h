@@ -356,6 +356,39 @@ int svl_adamw_step(float* p, const float* g, float* m, float* v, const int64_t* 
                    const float* seg_wd, int nseg, int64_t total, float beta1, float beta2, float eps, int step,
                    float gscale, float* ema, float ema_decay, svl_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * BatchNorm2d (batch statistics, SyncBN-ready) and MaxPool2d(3, 2, 1) on channels-last [rows, C] activations: the ops of
+ * the Cityscapes recipe's convolutional side encoder (`conv_encoder` = mmseg ResNetV1c deep stem + layer1 with
+ * norm_cfg SyncBN; reference model/vlm.py:50-53,120-121, configs/_base_/models/vlm-vlg-aspp-s2p4-skr04-ftap-mcvitb.py:50-60).
+ * Replaces torch.nn.SyncBatchNorm forward/backward (sum / sum-of-squares and sum dy / sum dy*xhat are produced as ONE
+ * [2][C] double vector each, which is what the data-parallel ranks all-reduce) and F.max_pool2d + its backward.
+ * C % 4 == 0, 16-byte aligned rows. */
+int64_t svl_bn_ws_doubles(int64_t rows, int C);
+/* sums[0][c] = sum_r x, sums[1][c] = sum_r x^2 */
+int svl_bn_stats(const float* x, int64_t ldx, int64_t rows, int C, double* sums, double* ws, svl_stream_t stream);
+/* mean, invstd from (all-reduced) sums over `count` rows; running stats updated like torch (unbiased variance) if given */
+int svl_bn_finalize(const double* sums, double count, float eps, float momentum, float* running_mean, float* running_var,
+                    int C, float* mean, float* invstd, svl_stream_t stream);
+int svl_bn_eval_invstd(const float* running_var, float eps, int C, float* invstd, svl_stream_t stream);
+/* y = [relu]((x - mean) * invstd * gamma + beta [+ resid]) */
+int svl_bn_apply(const float* x, int64_t ldx, int64_t rows, int C, const float* mean, const float* invstd,
+                 const float* gamma, const float* beta, const float* resid, int64_t ldr, int relu, float* y, int64_t ldy,
+                 svl_stream_t stream);
+/* sums[0][c] = sum dy', sums[1][c] = sum dy' * xhat, dy' = dy masked by the fused ReLU (y > 0; y may be NULL) */
+int svl_bn_bwd_reduce(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
+                      const float* mean, const float* invstd, int64_t rows, int C, double* sums, double* ws,
+                      svl_stream_t stream);
+/* dx = gamma * invstd * (dy' - sums0/count - xhat * sums1/count); dres (optional) = dy' for the residual branch;
+ * dgamma = sums1, dbeta = sums0 (of this rank's rows, i.e. BEFORE the all-reduce) */
+int svl_bn_bwd_apply(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
+                     const float* mean, const float* invstd, const float* gamma, const double* sums, double count,
+                     int64_t rows, int C, float* dx, int64_t lddx, float* dres, int64_t lddr, svl_stream_t stream);
+/* NHWC max pooling, kernel 3, stride 2, padding 1 (Ho = (H-1)/2+1); idx = winning tap 0..8 per output element */
+int svl_maxpool3x3s2_fwd(const float* x, int imgs, int H, int W, int C, float* y, unsigned char* idx,
+                         svl_stream_t stream);
+int svl_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, int imgs, int H, int W, int C, float* dx,
+                         svl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -672,3 +672,75 @@ def set_gemm_emulation(mode):
 
 def get_gemm_emulation():
     return L.load().svl_get_gemm_emulation()
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm / MaxPool
+def bn_stats(x, C, rows=None, ld=None):
+    """[2, C] float64: per-channel (sum, sum of squares) of a channels-last [rows, C] activation."""
+    rows = rows if rows is not None else x.shape[0]
+    ld = ld if ld is not None else x.stride(0)
+    lib = L.load()
+    sums = torch.empty(2, C, dtype=torch.float64, device=x.device)
+    ws = torch.empty(int(lib.svl_bn_ws_doubles(rows, C)), dtype=torch.float64, device=x.device)
+    L.check(lib.svl_bn_stats(_p(x), ld, rows, C, _p(sums), _p(ws), _st()), "svl_bn_stats")
+    return sums
+
+
+def bn_finalize(sums, count, eps, momentum, running_mean, running_var):
+    C_ = sums.shape[1]
+    mean, invstd = empty(C_, device=sums.device), empty(C_, device=sums.device)
+    L.check(L.load().svl_bn_finalize(_p(sums), float(count), eps, momentum, _p(running_mean), _p(running_var), C_,
+                                     _p(mean), _p(invstd), _st()), "svl_bn_finalize")
+    return mean, invstd
+
+
+def bn_eval_invstd(running_var, eps):
+    out = empty(running_var.numel(), device=running_var.device)
+    L.check(L.load().svl_bn_eval_invstd(_p(running_var), eps, running_var.numel(), _p(out), _st()), "svl_bn_eval_invstd")
+    return out
+
+
+def bn_apply(x, C, mean, invstd, gamma, beta, relu=False, resid=None, out=None):
+    rows = x.shape[0]
+    if out is None:
+        out = empty(rows, C, device=x.device)
+    L.check(L.load().svl_bn_apply(_p(x), x.stride(0), rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(resid),
+                                  resid.stride(0) if resid is not None else 0, 1 if relu else 0, _p(out), out.stride(0),
+                                  _st()), "svl_bn_apply")
+    return out
+
+
+def bn_bwd_reduce(dy, x, y, C, mean, invstd):
+    """[2, C] float64: (sum dy', sum dy' * xhat); y (the ReLU output) masks dy when given."""
+    rows = x.shape[0]
+    lib = L.load()
+    sums = torch.empty(2, C, dtype=torch.float64, device=x.device)
+    ws = torch.empty(int(lib.svl_bn_ws_doubles(rows, C)), dtype=torch.float64, device=x.device)
+    L.check(lib.svl_bn_bwd_reduce(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(y), y.stride(0) if y is not None else 0,
+                                  _p(mean), _p(invstd), rows, C, _p(sums), _p(ws), _st()), "svl_bn_bwd_reduce")
+    return sums
+
+
+def bn_bwd_apply(dy, x, y, C, mean, invstd, gamma, sums, count, want_dres=False):
+    rows = x.shape[0]
+    dx = empty(rows, C, device=x.device)
+    dres = empty(rows, C, device=x.device) if want_dres else None
+    L.check(L.load().svl_bn_bwd_apply(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(y), y.stride(0) if y is not None else 0,
+                                      _p(mean), _p(invstd), _p(gamma), _p(sums), float(count), rows, C, _p(dx),
+                                      dx.stride(0), _p(dres), dres.stride(0) if dres is not None else 0, _st()),
+            "svl_bn_bwd_apply")
+    return (dx, dres) if want_dres else dx
+
+
+def maxpool3x3s2_fwd(x, imgs, H, W, C):
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = empty(imgs * Ho * Wo, C, device=x.device)
+    idx = torch.empty(imgs * Ho * Wo, C, dtype=torch.uint8, device=x.device)
+    L.check(L.load().svl_maxpool3x3s2_fwd(_p(x), imgs, H, W, C, _p(y), _p(idx), _st()), "svl_maxpool3x3s2_fwd")
+    return y, idx, Ho, Wo
+
+
+def maxpool3x3s2_bwd(dy, idx, imgs, H, W, C):
+    dx = empty(imgs * H * W, C, device=dy.device)
+    L.check(L.load().svl_maxpool3x3s2_bwd(_p(dy), _p(idx), imgs, H, W, C, _p(dx), _st()), "svl_maxpool3x3s2_bwd")
+    return dx

@@ -580,3 +580,56 @@ def test_adamw(dev):
         ops.adamw_step(flat, torch.cat(grads), m, v, off, torch.tensor(lrs, device=dev), torch.tensor(wds, device=dev),
                        len(sizes), 0.9, 0.999, 1e-8, step)
         close(flat, torch.cat([p.detach() for p in params]), atol=1e-6, rtol=1e-5, what=f"adamw step {step}")
+
+
+@pytest.mark.parametrize("rows,C,relu,res", [(4 * 33 * 33, 64, True, False), (2 * 17 * 19, 256, True, True),
+                                             (3 * 50 * 50, 32, False, False), (5, 64, True, True)])
+def test_batchnorm_train_fwd_bwd(dev, rows, C, relu, res):
+    """svl_bn_* against torch.nn.functional.batch_norm (training) + residual + ReLU, incl. running statistics."""
+    from semivl_amd import ops
+    x = (rnd(rows, C, dev=dev, seed=31) * 2 + 0.5).requires_grad_(True)
+    gamma, beta = (1 + 0.1 * rnd(C, dev=dev)).requires_grad_(True), (0.1 * rnd(C, dev=dev)).requires_grad_(True)
+    r = rnd(rows, C, dev=dev, seed=32).requires_grad_(True) if res else None
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    rm_t, rv_t = rm.clone(), rv.clone()
+    ref = F.batch_norm(x, rm_t, rv_t, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    sums = ops.bn_stats(x.detach(), C)
+    mean, invstd = ops.bn_finalize(sums, rows, 1e-5, 0.1, rm, rv)
+    y = ops.bn_apply(x.detach(), C, mean, invstd, gamma.detach(), beta.detach(), relu=relu, resid=r.detach() if res else None)
+    close(y, ref, atol=2e-5, what="y")
+    close(rm, rm_t, atol=1e-6, what="running_mean")
+    close(rv, rv_t, atol=1e-5, what="running_var")
+    dy = rnd(rows, C, dev=dev, seed=33)
+    grads = torch.autograd.grad(ref, [x, gamma, beta] + ([r] if res else []), dy)
+    bs = ops.bn_bwd_reduce(dy, x.detach(), y if relu else None, C, mean, invstd)
+    out = ops.bn_bwd_apply(dy, x.detach(), y if relu else None, C, mean, invstd, gamma.detach(), bs, rows, want_dres=res)
+    dx = out[0] if res else out
+    tol = 2e-4 * max(1.0, float(grads[0].abs().max()))
+    close(dx, grads[0], atol=tol, what="dx")
+    close(bs[1].float(), grads[1], atol=1e-3 * max(1.0, float(grads[1].abs().max())), what="dgamma")
+    close(bs[0].float(), grads[2], atol=1e-3 * max(1.0, float(grads[2].abs().max())), what="dbeta")
+    if res:
+        close(out[1], grads[3], atol=1e-6, what="dres")
+    # eval mode: running statistics
+    ye = ops.bn_apply(x.detach(), C, rm, ops.bn_eval_invstd(rv, 1e-5), gamma.detach(), beta.detach())
+    close(ye, F.batch_norm(x.detach(), rm_t, rv_t, gamma.detach(), beta.detach(), training=False, eps=1e-5), atol=2e-5)
+
+
+@pytest.mark.parametrize("imgs,H,W,C", [(2, 33, 33, 64), (1, 10, 7, 32), (3, 1, 1, 4), (1, 401, 401, 64)])
+def test_maxpool3x3s2(dev, imgs, H, W, C):
+    from semivl_amd import ops
+    x = rnd(imgs, H, W, C, dev=dev, seed=41)
+    x[0, : min(H, 4), : min(W, 4)] = 1.5                      # ties: the first maximum in scan order must win
+    xt = x.permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.max_pool2d(xt, 3, 2, 1)
+    y, idx, Ho, Wo = ops.maxpool3x3s2_fwd(x.view(-1, C), imgs, H, W, C)
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    assert torch.equal(y.view(imgs, Ho, Wo, C), ref.permute(0, 2, 3, 1))
+    dy = rnd(imgs, Ho, Wo, C, dev=dev, seed=42)
+    (g,) = torch.autograd.grad(ref, xt, dy.permute(0, 3, 1, 2))
+    dx = ops.maxpool3x3s2_bwd(dy.view(-1, C), idx, imgs, H, W, C)
+    close(dx.view(imgs, H, W, C), g.permute(0, 2, 3, 1), atol=1e-6)
