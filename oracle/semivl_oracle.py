@@ -309,6 +309,49 @@ def aggregate_concept_predictions(pred, class_to_concept_idxs):  # text_embeddin
     return agg
 
 
+# ------------------------------------------------------------------------------------------------ conv_encoder
+class _Bottleneck(nn.Module):  # mmseg 0.24 resnet.Bottleneck, style 'pytorch', stride 1, dilation 1
+    def __init__(self, inplanes, planes, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idn = x if self.downsample is None else self.downsample(x)
+        o = self.relu(self.bn1(self.conv1(x)))
+        o = self.relu(self.bn2(self.conv2(o)))
+        o = self.bn3(self.conv3(o))
+        return self.relu(o + idn)
+
+
+class ResNetV1cStage1(nn.Module):
+    """mmseg `ResNetV1c(depth=101, num_stages=1, strides=[1], dilations=[1], out_indices=[0])` as the skr04 config builds it
+    (configs/_base_/models/vlm-vlg-aspp-s2p4-skr04-ftap-mcvitb.py:50-60): deep stem, MaxPool(3, 2, 1), layer1 (3
+    Bottlenecks, the first with a conv1x1+BN downsample).  mmseg is un-vendored: PARITY UNPINNED for this module itself
+    (no reference code to run); BatchNorm2d on one process == SyncBN.  Returns a tuple with the stride-4 feature map."""
+
+    def __init__(self, stem_channels=64, base_channels=64):
+        super().__init__()
+        sc = stem_channels
+        self.stem = nn.Sequential(
+            nn.Conv2d(3, sc // 2, 3, stride=2, padding=1, bias=False), nn.BatchNorm2d(sc // 2), nn.ReLU(True),
+            nn.Conv2d(sc // 2, sc // 2, 3, padding=1, bias=False), nn.BatchNorm2d(sc // 2), nn.ReLU(True),
+            nn.Conv2d(sc // 2, sc, 3, padding=1, bias=False), nn.BatchNorm2d(sc), nn.ReLU(True))
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        p = base_channels
+        down = nn.Sequential(nn.Conv2d(sc, p * 4, 1, bias=False), nn.BatchNorm2d(p * 4))
+        self.layer1 = nn.Sequential(_Bottleneck(sc, p, down), _Bottleneck(p * 4, p, None), _Bottleneck(p * 4, p, None))
+
+    def forward(self, x):
+        return (self.layer1(self.maxpool(self.stem(x))),)
+
+
 # ------------------------------------------------------------------------------------------------ VLM
 class VLM(nn.Module):
     """model/vlm.py + model/builder.py:56-102 (forward_wrapper) for the VLG configs (no conv_encoder, no renorm)."""

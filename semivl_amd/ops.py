@@ -402,15 +402,20 @@ def unpack_conv_wgrad(dwf, Co, Ci, kh, kw):
     return dwf.view(Co, kh, kw, Ci).permute(0, 3, 1, 2).contiguous()
 
 
+def conv_out_size(H, W, KH, KW, dil, pad, stride):
+    return (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1, (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+
+
 def conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, KH, KW, dil, pad, bias=None, act=ACT_NONE, out=None, ldo=None, src2=None,
-             ld2=0, C2=0, rep=1, resid=None, ldr=None):
-    """y[pix, Co] = conv(x) with packed weight wf [Co, KH*KW*(C1+C2)]."""
-    M = imgs * H * W
+             ld2=0, C2=0, rep=1, resid=None, ldr=None, stride=1):
+    """y[pix, Co] = conv(x) with packed weight wf [Co, KH*KW*(C1+C2)]; stride > 1: pix runs over the output grid."""
+    Ho, Wo = conv_out_size(H, W, KH, KW, dil, pad, stride) if stride != 1 else (H, W)
+    M = imgs * Ho * Wo
     K = KH * KW * (C1 + C2)
     if out is None:
         out = empty(M, Co, device=x.device)
         ldo = Co
-    g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2)
+    g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
     gemm(A_CONV, B_KC, M, Co, K, Op(x, ldx), Op(wf, K), out, ldc_m=ldo, bias=bias, act=act, conv=g, resid=resid,
          ldr_m=ldr)
     return out
@@ -428,11 +433,12 @@ def conv_dgrad(dy, lddy, imgs, H, W, Co, wd, Ci, KH, KW, dil, pad, out=None, ldo
     return out
 
 
-def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None, ld2=0, C2=0, rep=1):
-    """dWf[Co, KH*KW*(C1+C2)] = dy^T im2col(x), deterministic split-K over pixels."""
-    Kpix = imgs * H * W
+def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None, ld2=0, C2=0, rep=1, stride=1):
+    """dWf[Co, KH*KW*(C1+C2)] = dy^T im2col(x), deterministic split-K over (output) pixels."""
+    Ho, Wo = conv_out_size(H, W, KH, KW, dil, pad, stride) if stride != 1 else (H, W)
+    Kpix = imgs * Ho * Wo
     N = KH * KW * (C1 + C2)
-    g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2)
+    g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
     s, ks = _ksplit_plan(Co, N, Kpix)
     out = empty(Co, N, device=dy.device)
     if s == 1:
