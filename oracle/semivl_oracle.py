@@ -259,9 +259,10 @@ class Up(nn.Module):  # vlg_head.py:116-137
 class VLGHead(nn.Module):  # vlg_head.py:140-251
     def __init__(self, img_size=512, num_classes=21, text_in_channels=512, text_channels=128, up_channels=(64, 32),
                  skip_in_channels=(768, 768), skip_channels=(32, 16), num_layers=2, num_heads=4, channels=128,
-                 pool_size=(4, 4), conv1_ksize=7, align_corners=False):
+                 pool_size=(4, 4), conv1_ksize=7, align_corners=False, skip_from_conv_feat=False):
         super().__init__()
         self.image_size, self.num_classes, self.align_corners = img_size, num_classes, align_corners
+        self.skip_from_conv_feat = skip_from_conv_feat
         self.conv1 = nn.Conv2d(1, channels, conv1_ksize, padding=(conv1_ksize - 1) // 2)
         self.aspp = ASPPModule(channels)
         self.layers = nn.ModuleList([SemanticTransformer(channels, text_channels, num_heads, pool_size)
@@ -278,6 +279,9 @@ class VLGHead(nn.Module):  # vlg_head.py:140-251
         pyramid = inputs[0][0]
         img_feats = pyramid[-1]
         skip_feats = list(pyramid[:-1][::-1])
+        if self.skip_from_conv_feat:  # vlg_head.py:196-205
+            skip_feats = skip_feats + list(inputs[2][::-1])
+            assert len(skip_feats) == len(self.skip_proj)
         text = inputs[1]
         B, Cc, H, W = img_feats.shape
         text = text.repeat(B, 1, 1).float()
@@ -357,9 +361,10 @@ class VLM(nn.Module):
     """model/vlm.py + model/builder.py:56-102 (forward_wrapper) for the VLG configs (no conv_encoder, no renorm)."""
 
     def __init__(self, backbone, decode_head, clip_encoder, text_feat, mcc_text_feat, mcc_cls2con=None, fp_rate=0.5,
-                 exclude_keys=("attn", "pos_embed")):
+                 exclude_keys=("attn", "pos_embed"), conv_encoder=None, renorm_clip_img=False):
         super().__init__()
         self.backbone, self.decode_head, self.clip_encoder = backbone, decode_head, clip_encoder
+        self.conv_encoder, self.renorm_clip_img = conv_encoder, renorm_clip_img  # vlm.py:50-58
         self.register_buffer("text_feat", text_feat.clone(), persistent=False)  # fp16 on disk (vlm.py:116-117)
         self.register_buffer("mcc_text_feat", mcc_text_feat.float().clone(), persistent=False)  # vlm.py:61-62
         self.mcc_cls2con = mcc_cls2con
@@ -367,9 +372,17 @@ class VLM(nn.Module):
         for n, p in self.backbone.named_parameters():  # vlm.py:80-88
             p.requires_grad = any(k in n for k in exclude_keys)
 
+    def renormalize_img_for_clip(self, img):  # vlm.py:69-78
+        if not self.renorm_clip_img:
+            return img
+        t = lambda v: torch.tensor(v, device=img.device).view(1, -1, 1, 1)
+        lm, ls = t([0.485, 0.456, 0.406]), t([0.229, 0.224, 0.225])
+        cm, cs = t([0.48145466, 0.4578275, 0.40821073]), t([0.26862954, 0.26130258, 0.27577711])
+        return (img * ls + lm - cm) / cs
+
     def forward_maskclip(self, img, conf_tresh):  # vlm.py:90-110
         with torch.no_grad():
-            feats, _ = self.clip_encoder(img)
+            feats, _ = self.clip_encoder(self.renormalize_img_for_clip(img))
             dense = F.conv2d(feats[-1], self.mcc_text_feat[:, :, None, None])
             if dense.shape[1] != self.num_classes:
                 dense = aggregate_concept_predictions(dense, self.mcc_cls2con)
@@ -382,18 +395,24 @@ class VLM(nn.Module):
 
     def forward(self, img, need_fp=False, fp_masks=None):
         """fp_masks: optional list of 3 {0,1} masks [b, C_i] replacing F.dropout2d's RNG (builder.py:79-85)."""
-        feats, g = self.backbone(img)
+        feats, g = self.backbone(self.renormalize_img_for_clip(img))
         feats = list(feats)
+        conv_feats = list(self.conv_encoder(img)) if self.conv_encoder is not None else None  # vlm.py:119-121
         if need_fp:
-            out = []
-            for i, f in enumerate(feats):
-                if fp_masks is None:
-                    d = F.dropout2d(f, self.fp_rate)
-                else:
-                    d = f * fp_masks[i][:, :, None, None] / (1.0 - self.fp_rate)
-                out.append(torch.cat((f, d)))
-            feats = out
-        logits = self.decode_head([[feats, g], self.text_feat])
+            def both(lst, first):
+                out = []
+                for i, f in enumerate(lst):
+                    if fp_masks is None:
+                        d = F.dropout2d(f, self.fp_rate)
+                    else:
+                        d = f * fp_masks[first + i][:, :, None, None] / (1.0 - self.fp_rate)
+                    out.append(torch.cat((f, d)))
+                return out
+            nf = len(feats)
+            feats = both(feats, 0)
+            if conv_feats is not None:  # builder.py:83-85: the conv features are perturbed after the ViT ones
+                conv_feats = both(conv_feats, nf)
+        logits = self.decode_head([[feats, g], self.text_feat, conv_feats])
         logits = F.interpolate(logits, size=img.shape[2:], mode="bilinear", align_corners=self.align_corners)
         return logits.chunk(2) if need_fp else logits
 
@@ -515,8 +534,10 @@ def build_vlm(cfg, text_feat, mcc_text_feat, mcc_cls2con=None, clip_img_size=Non
     ce = MaskClipVisionTransformer((cs, cs), 16, False, 3, c["embed"], c["layers"], c["heads"], 4, None, 1e-6,
                                    c["proj"])
     head = VLGHead(S, c["nclass"], c["text_in"], c["text_channels"], c["up"], c["skip_in"], c["skip"], 2, 4,
-                   c["channels"], (4, 4), 7, False)
-    return VLM(bb, head, ce, text_feat, mcc_text_feat, mcc_cls2con)
+                   c["channels"], (4, 4), 7, False, skip_from_conv_feat=bool(c.get("conv_encoder")))
+    conv = ResNetV1cStage1() if c.get("conv_encoder") else None
+    return VLM(bb, head, ce, text_feat, mcc_text_feat, mcc_cls2con, conv_encoder=conv,
+               renorm_clip_img=bool(c.get("renorm_clip_img")))
 
 
 def synthetic_batch(B, S, nclass, seed=1234, device="cpu"):

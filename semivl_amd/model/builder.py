@@ -17,12 +17,13 @@ import torch.nn as nn
 
 from .. import ops
 from .text_embeddings import aggregate_concept_predictions, get_class_to_concept_idxs
+from .resnet import ResNetV1c
 from .vit import MaskClipVisionTransformer
 from .vlg_head import VLGHead
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-BACKBONES = {"MaskClipVisionTransformer": MaskClipVisionTransformer}
+BACKBONES = {"MaskClipVisionTransformer": MaskClipVisionTransformer, "ResNetV1c": ResNetV1c}
 HEADS = {"VLGHead": VLGHead}
 SEGMENTORS = {}
 
@@ -57,6 +58,15 @@ def builtin_model_cfg(name):
                              skip_from_conv_feat=False, num_layers=2, num_heads=4, channels=128, pool_size=(4, 4),
                              conv1_ksize=7, align_corners=False, loss_decode=None),
             freeze_backbone=True, exclude_keys=["attn", "pos_embed"]))
+    if name == "vlm-vlg-aspp-s2p4-skr04-ftap-mcvitb":   # Cityscapes recipe: side conv encoder as the second skip source
+        c = builtin_model_cfg("vlm-vlg-aspp-s2p4-sk04-ftap-mcvitb")
+        c["model"]["backbone"] = _vit_cfg(512, [4, 12])
+        c["model"]["conv_encoder"] = dict(type="ResNetV1c", pretrained="pretrained/resnet101_v1c-e67eebb6.pth",
+                                          depth=101, num_stages=1, out_indices=[0], dilations=[1], strides=[1],
+                                          norm_cfg=dict(type="SyncBN", requires_grad=True), style="pytorch",
+                                          contract_dilation=True)
+        c["model"]["decode_head"].update(skip_in_channels=(768, 256), skip_channels=(32, 32), skip_from_conv_feat=True)
+        return c
     if name == "mcvit16":
         bb = _vit_cfg(512, None)
         bb["pretrained"] = "pretrained/clip2mmseg_ViT16_clip_backbone.pth"
@@ -92,8 +102,6 @@ class VLM(nn.Module):
         super().__init__()
         assert load_text_embedding == load_pl_text_embedding
         assert maskclip_class_filter is None and maskclip_trust_head is None
-        if conv_encoder is not None or renorm_clip_img:
-            raise NotImplementedError("conv_encoder / renorm_clip_img (Cityscapes cfg, SURVEY N2) are next-row items")
         backbone = dict(backbone)
         if pretrained is not None and backbone.get("pretrained") is None:
             backbone["pretrained"] = pretrained  # EncoderDecoder forwards `pretrained` to the backbone cfg
@@ -103,7 +111,7 @@ class VLM(nn.Module):
         self.num_classes = self.decode_head.num_classes
         self.local_iter = 0
         self.clip_encoder = build_backbone(clip_encoder) if clip_encoder is not None else None
-        self.conv_encoder = None
+        self.conv_encoder = build_backbone(conv_encoder) if conv_encoder is not None else None  # vlm.py:50-53
         self.load_text_embedding = load_text_embedding
         self.decode_head.load_text_embedding = load_text_embedding
         self.load_mcc_text_embedding = load_mcc_text_embedding
@@ -117,6 +125,18 @@ class VLM(nn.Module):
         self.disable_dropout, self.fp_rate = True, 0.5
         if freeze_backbone:
             self.freeze(self.backbone, exclude_keys=exclude_keys)
+
+    def renormalize_img_for_clip(self, img):  # vlm.py:69-78: loader (ImageNet) statistics -> CLIP statistics
+        if not self.renorm_clip_img:
+            return img
+        k = ("renorm", str(img.device))
+        if k not in self._dev_cache:
+            lm, ls = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+            cm, cs = (torch.tensor([0.48145466, 0.4578275, 0.40821073]),
+                      torch.tensor([0.26862954, 0.26130258, 0.27577711]))
+            self._dev_cache[k] = tuple(t.view(1, -1, 1, 1).to(img.device) for t in (ls, lm, cm, cs))
+        ls, lm, cm, cs = self._dev_cache[k]
+        return (img * ls + lm - cm) / cs
 
     def freeze(self, model, exclude_keys=None):  # vlm.py:80-88
         for n, m in model.named_parameters():
@@ -144,6 +164,7 @@ class VLM(nn.Module):
         """int64 [b, H, W] in {0..N-1, 255}.  `ignore_mask` (optional, fused form of semivl.py:239-240): pixels where
         it equals 255 are set to 255."""
         with torch.no_grad():
+            img = self.renormalize_img_for_clip(img)
             feats, _ = self.clip_encoder.forward_tokens(img, need_global=False)
             emb = feats[-1]  # [b, hw, 512]
             b, HW, Ce = emb.shape
@@ -161,9 +182,10 @@ class VLM(nn.Module):
 
     # -- features ------------------------------------------------------------------------------------------------
     def extract_feat(self, img):  # vlm.py:112-123 (reference return format)
-        visual_feat = self.backbone(img)
+        visual_feat = self.backbone(self.renormalize_img_for_clip(img))
         self.decode_head.load_text_embedding = self.load_text_embedding
-        return [visual_feat, self.text_feat(img.device), None]
+        conv_feat = self.conv_encoder(img) if self.conv_encoder is not None else None
+        return [visual_feat, self.text_feat(img.device), conv_feat]
 
     def _decode_head_forward_test(self, x, img_metas=None):  # vlm.py:125-127
         return self.decode_head.forward(x, force_output_pred_masks=True)["pred_masks"]
@@ -181,20 +203,32 @@ class VLM(nn.Module):
             raise NotImplementedError("only_fp is not used by semivl.py (SURVEY §8(a) V4)")
         if tuple(img.shape[2:]) != (self.decode_head.image_size, self.decode_head.image_size):
             raise NotImplementedError("input size != decode_head.img_size (second resize, builder.py:93-97)")
-        feats, _ = self.backbone.forward_tokens(img, need_global=False)
+        feats, _ = self.backbone.forward_tokens(self.renormalize_img_for_clip(img), need_global=False)
+        skip0_hw = None
+        if self.conv_encoder is not None:   # vlm.py:119-121: the side encoder sees the loader-normalised image
+            if len(feats) != 2:
+                raise NotImplementedError("conv_encoder expects backbone.out_indices = [k, num_layers] (skr04)")
+            ctok, skip0_hw = self.conv_encoder.forward_tokens(img)
         ps = self.backbone.patch_size
         hp, wp = (img.shape[2] + ps - 1) // ps, (img.shape[3] + ps - 1) // ps
         masks = None
         if need_fp:
             masks = fp_masks
+            drop_order = list(feats) + ([ctok] if self.conv_encoder is not None else [])  # builder.py:80-85
             if masks is None:  # F.dropout2d: one Bernoulli(1-p) draw per (sample, channel); always stochastic (App. E.7)
                 masks = [torch.bernoulli(torch.full((f.shape[0], f.shape[2]), 1.0 - self.fp_rate, device=img.device))
-                         for f in feats]
+                         for f in drop_order]
+            assert len(masks) == len(drop_order)
             if fp_range is not None:
                 assert not split_fp, "fp_range returns the un-chunked tensor"
                 masks = [mk[fp_range[0]:fp_range[1]] for mk in masks]
+        if self.conv_encoder is not None:   # head slots [second-Up skip, first-Up skip, embedding]
+            feats = [ctok, feats[0], feats[1]]
+            if masks is not None:
+                masks = [masks[2], masks[0], masks[1]]
         out = self.decode_head.forward_tokens(feats, self.text_feat(img.device), (hp, wp), masks, self.fp_rate,
-                                              out_size=tuple(img.shape[2:]), fp_range=fp_range if need_fp else None)
+                                              out_size=tuple(img.shape[2:]), fp_range=fp_range if need_fp else None,
+                                              skip0_hw=skip0_hw)
         if need_fp and split_fp:
             return out.chunk(2)
         return out

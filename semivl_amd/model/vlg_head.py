@@ -119,8 +119,6 @@ class VLGHead(nn.Module):
                  loss_decode, align_corners, type=None):
         super().__init__()
         assert loss_decode is None
-        if skip_from_conv_feat:
-            raise NotImplementedError("skip_from_conv_feat (Cityscapes conv_encoder, SURVEY N2) is a next-row item")
         self.image_size, self.num_classes, self.align_corners = img_size, num_classes, align_corners
         self.text_in_channels, self.num_layers, self.channels = text_in_channels, num_layers, channels
         self.skip_from_conv_feat = skip_from_conv_feat
@@ -141,8 +139,10 @@ class VLGHead(nn.Module):
             raise NotImplementedError("SemanticTransformer head dim must be 64")
 
     # ---------------------------------------------------------------------------------------------------
-    def forward_tokens(self, feats, text, hw, fp_masks=None, fp_rate=0.5, out_size=None, fp_range=None):
-        """feats: [v0, v4, emb] token tensors [b, hw, C]; text [N, 512] (any float dtype).
+    def forward_tokens(self, feats, text, hw, fp_masks=None, fp_rate=0.5, out_size=None, fp_range=None, skip0_hw=None):
+        """feats: [v0, v4, emb] token tensors [b, hw, C]; text [N, 512] (any float dtype).  With
+        `skip_from_conv_feat` (vlg_head.py:196-205) slot v0 -- the skip of the second Up block -- is the conv_encoder's
+        feature [b, h0*w0, C0] on its own grid `skip0_hw` = (h0, w0).
         fp_masks: None, or list of three {0,1} masks [b, C_i]: the batch is doubled with the channel-dropped copy
         (builder.py:78-89).  `fp_range=(s0, s1)` perturbs only samples [s0, s1) (masks [s1-s0, C_i]): the step never
         reads the perturbed copy of the labeled half (semivl.py:247), so it need not be decoded.
@@ -151,9 +151,9 @@ class VLGHead(nn.Module):
         need_grad = torch.is_grad_enabled() and (bool(params) or any(f.requires_grad for f in feats))
         out_size = out_size or (self.image_size, self.image_size)
         if need_grad:
-            return _HeadFn.apply(self, hw, fp_masks, (fp_rate, fp_range), out_size, text, feats[0], feats[1], feats[2],
-                                 *params)
-        return _head_forward(self, hw, fp_masks, (fp_rate, fp_range), out_size, text, feats, None)
+            return _HeadFn.apply(self, (hw, skip0_hw or hw), fp_masks, (fp_rate, fp_range), out_size, text, feats[0],
+                                 feats[1], feats[2], *params)
+        return _head_forward(self, (hw, skip0_hw or hw), fp_masks, (fp_rate, fp_range), out_size, text, feats, None)
 
     def forward(self, inputs, force_output_pred_masks=False):
         """Reference signature (vlg_head.py:192-251): inputs = [[feature_pyramid, global], text_feats, conv_feats]."""
@@ -163,15 +163,20 @@ class VLGHead(nn.Module):
             b, c, h, w = f.shape
             hw = (h, w)
             toks.append(f.permute(0, 2, 3, 1).contiguous().view(b, h * w, c))
+        skip0_hw = None
+        if self.skip_from_conv_feat:  # skip_feats = [*pyramid[:-1][::-1], *conv_feats[::-1]] (vlg_head.py:196-205)
+            cf = inputs[2][0]
+            skip0_hw = tuple(cf.shape[2:])
+            toks = [cf.permute(0, 2, 3, 1).contiguous().view(cf.shape[0], -1, cf.shape[1])] + toks
         size = (self.image_size, self.image_size) if force_output_pred_masks else (4 * hw[0], 4 * hw[1])
-        x = self.forward_tokens(toks, inputs[1], hw, out_size=size)
+        x = self.forward_tokens(toks, inputs[1], hw, out_size=size, skip0_hw=skip0_hw)
         return {"pred_masks": x} if force_output_pred_masks else x
 
 
 def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
     fp_rate, fp_range = fp_cfg
-    h, w = hw
-    HW = h * w
+    (h, w), (h0, w0) = hw
+    HW, HW0 = h * w, h0 * w0
     v0, v4, emb = [f.contiguous() for f in feats]
     b0 = emb.shape[0]
     dev = emb.device
@@ -179,22 +184,22 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
     if N != m.num_classes:
         raise NotImplementedError("concept-level text embeddings inside VLGHead are off the BASELINE configs")
     Ch, Ct = m.channels, m.text_channels
-    Ce, Cv = emb.shape[2], v0.shape[2]
+    Ce, Cv, C0 = emb.shape[2], v4.shape[2], v0.shape[2]
     # ---- feature perturbation: cat(f, dropout2d(f)) ------------------------------------------------------
     if fp_masks is not None:
         r0, r1 = fp_range if fp_range is not None else (0, b0)
         b = b0 + (r1 - r0)
         sc = 1.0 / (1.0 - fp_rate)
 
-        def dbl(f, mk, Cc):
-            out = ops.empty(b * HW, Cc, device=dev)
-            ops.eltwise(4, f.view(-1), None, out=out.view(-1)[:b0 * HW * Cc])
-            ops.chanmask(f.view(b0 * HW, Cc)[r0 * HW:r1 * HW], mk.contiguous(), sc, HW, out=out[b0 * HW:])
+        def dbl(f, mk, Cc, hw_):
+            out = ops.empty(b * hw_, Cc, device=dev)
+            ops.eltwise(4, f.view(-1), None, out=out.view(-1)[:b0 * hw_ * Cc])
+            ops.chanmask(f.view(b0 * hw_, Cc)[r0 * hw_:r1 * hw_], mk.contiguous(), sc, hw_, out=out[b0 * hw_:])
             return out
-        v0, v4, emb = dbl(v0, fp_masks[0], Cv), dbl(v4, fp_masks[1], Cv), dbl(emb, fp_masks[2], Ce)
+        v0, v4, emb = dbl(v0, fp_masks[0], C0, HW0), dbl(v4, fp_masks[1], Cv, HW), dbl(emb, fp_masks[2], Ce, HW)
     else:
         b = b0
-        v0, v4, emb = v0.view(b * HW, Cv), v4.view(b * HW, Cv), emb.view(b * HW, Ce)
+        v0, v4, emb = v0.view(b * HW0, C0), v4.view(b * HW, Cv), emb.view(b * HW, Ce)
     imgs = b * N
     # ---- cosine similarity map (vlg_head.py:214-217) ------------------------------------------------------
     embn, inv_e = ops.l2norm_fwd(emb, 1e-12)
@@ -235,17 +240,17 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
         tr_sv.append(s_)
     # ---- skip projections (order [v4, v0], vlg_head.py:207) ----------------------------------------------------
     skips, skip_sv = [], []
-    for proj, f in zip(m.skip_proj, (v4, v0)):
+    for proj, f, (Cf, fh, fw) in zip(m.skip_proj, (v4, v0), ((Cv, h, w), (C0, h0, w0))):
         wf, wd = ops.pack_conv_w(proj[0].weight)
         Cs = proj[0].weight.shape[0]
-        sk = ops.conv_fwd(f, Cv, b, h, w, Cv, wf, Cs, 3, 3, 1, 1, bias=proj[0].bias, act=ops.ACT_RELU)
+        sk = ops.conv_fwd(f, Cf, b, fh, fw, Cf, wf, Cs, 3, 3, 1, 1, bias=proj[0].bias, act=ops.ACT_RELU)
         skips.append(sk)
-        skip_sv.append(dict(x=f, wd=wd, y=sk, Cs=Cs))
+        skip_sv.append(dict(x=f, wd=wd, y=sk, Cs=Cs, geo=(Cf, fh, fw)))
     # ---- upsampling ------------------------------------------------------------------------------------------
     s_up1 = {} if sv is not None else None
     g2 = _up_forward(m.up1, x, imgs, h, w, skips[0], h, w, b, N, s_up1)
     s_up2 = {} if sv is not None else None
-    g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], h, w, b, N, s_up2)
+    g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], h0, w0, b, N, s_up2)
     C4 = g4.shape[1]
     whf, whd = ops.pack_conv_w(m.head.weight)
     lg = ops.conv_cout1_fwd(g4, C4, imgs, 4 * h, 4 * w, C4, whf, 3, 3, 1, 1, bias=m.head.bias)  # [(b n), 4h, 4w, 1]
@@ -255,7 +260,7 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
     else:
         logits = lg
     if sv is not None:
-        sv.update(dims=(b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv), fp=(fp_masks, fp_rate, fp_range), emb=emb, embn=embn,
+        sv.update(dims=(b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0), fp=(fp_masks, fp_rate, fp_range), emb=emb, embn=embn,
                   inv_e=inv_e, textn=textn, sim=sim, w1d=w1d, x1=x1, aspp=aspp_sv, gap=s_gap, pooled=pooled, proj=s_proj,
                   cat=cat, tp=tp, tr=tr_sv, skip=skip_sv, up1=s_up1, up2=s_up2, g4=g4, whd=whd,
                   out_size=out_size, v0=v0, v4=v4)
@@ -375,7 +380,7 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         m, sv = ctx.m, ctx.sv
-        b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv = sv["dims"]
+        b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0 = sv["dims"]
         dev = dlogits.device
         gc = _GradCollector()
         dlogits = dlogits.contiguous()
@@ -386,29 +391,29 @@ class _HeadFn(torch.autograd.Function):
         if ranges is None:
             dv0, dv4, demb = _head_backward_core(m, sv, dlogits, gc)
         else:
-            dv0, dv4, demb = (ops.zeros(b * HW, Cv, device=dev), ops.zeros(b * HW, Cv, device=dev),
+            dv0, dv4, demb = (ops.zeros(b * HW0, C0, device=dev), ops.zeros(b * HW, Cv, device=dev),
                               ops.zeros(b * HW, Ce, device=dev))
             for s0, s1 in ranges:
                 a0, a4, ae = _head_backward_core(m, _slice_saved(sv, b, s0, s1), dlogits[s0:s1], gc)
-                for full, part in ((dv0, a0), (dv4, a4), (demb, ae)):
-                    ops.eltwise(4, part.view(-1), None, out=full[s0 * HW:s1 * HW].view(-1))
+                for full, part, hw_ in ((dv0, a0, HW0), (dv4, a4, HW), (demb, ae, HW)):
+                    ops.eltwise(4, part.view(-1), None, out=full[s0 * hw_:s1 * hw_].view(-1))
         # ---- undo the feature-perturbation doubling
         fp_masks, fp_rate, fp_range = sv["fp"]
         r0, r1 = fp_range if fp_range is not None else (0, b0)
 
-        def undbl(dfull, mk, Cc):
+        def undbl(dfull, mk, Cc, hw_):
             if fp_masks is None:
-                return dfull.view(b0, HW, Cc)
+                return dfull.view(b0, hw_, Cc)
             sc = 1.0 / (1.0 - fp_rate)
-            second = ops.chanmask(dfull[b0 * HW:], mk.contiguous(), sc, HW)
-            first = dfull[:b0 * HW]
-            tgt = first[r0 * HW:r1 * HW]
+            second = ops.chanmask(dfull[b0 * hw_:], mk.contiguous(), sc, hw_)
+            first = dfull[:b0 * hw_]
+            tgt = first[r0 * hw_:r1 * hw_]
             ops.add(tgt, second, out=tgt)
-            return first.view(b0, HW, Cc)
+            return first.view(b0, hw_, Cc)
         mk = fp_masks if fp_masks is not None else (None, None, None)
-        dv0 = undbl(dv0, mk[0], Cv)
-        dv4 = undbl(dv4, mk[1], Cv)
-        demb = undbl(demb, mk[2], Ce)
+        dv0 = undbl(dv0, mk[0], C0, HW0)
+        dv4 = undbl(dv4, mk[1], Cv, HW)
+        demb = undbl(demb, mk[2], Ce, HW)
         ctx.sv = None
         req = ctx.feat_req
         return (None, None, None, None, None, None, dv0 if req[0] else None, dv4 if req[1] else None,
@@ -444,7 +449,7 @@ def _slice_saved(sv, b, s0, s1):
 def _head_backward_core(m, sv, dlogits, gc):
     """Backward of the head for the (sub-)batch described by `sv`; returns grads wrt the (doubled) v0, v4, emb tokens."""
     if True:
-        b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv = sv["dims"]
+        b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0 = sv["dims"]
         dev = dlogits.device
         if sv["out_size"] != (4 * h, 4 * w):
             dlg = ops.bilinear_planes_bwd(dlogits, 4 * h, 4 * w, m.align_corners, sv["out_size"][0], sv["out_size"][1])
@@ -467,11 +472,12 @@ def _head_backward_core(m, sv, dlogits, gc):
         dfe = []
         for proj, ss, dsk in zip(m.skip_proj, sv["skip"], (dskip4, dskip0)):
             Cs = ss["Cs"]
+            Cf, fh, fw = ss["geo"]
             dpre = ops.eltwise(2, dsk, ss["y"], out=dsk)  # relu backward (post-activation mask)
             gc.put(proj[0].bias, lambda d, acc, dpre=dpre: ops.colsum(dpre, out=d, accumulate=acc))
-            dwf = ops.conv_wgrad(dpre, Cs, ss["x"], Cv, b, h, w, Cv, Cs, 3, 3, 1, 1)
-            gc.put_tensor(proj[0].weight, ops.unpack_conv_wgrad(dwf, Cs, Cv, 3, 3))
-            dfe.append(ops.conv_dgrad(dpre, Cs, b, h, w, Cs, ss["wd"], Cv, 3, 3, 1, 1))
+            dwf = ops.conv_wgrad(dpre, Cs, ss["x"], Cf, b, fh, fw, Cf, Cs, 3, 3, 1, 1)
+            gc.put_tensor(proj[0].weight, ops.unpack_conv_wgrad(dwf, Cs, Cf, 3, 3))
+            dfe.append(ops.conv_dgrad(dpre, Cs, b, fh, fw, Cs, ss["wd"], Cf, 3, 3, 1, 1))
         dv4, dv0 = dfe
         # ---- semantic transformers (reverse)
         dtp = ops.zeros(N, Ct, device=dev)

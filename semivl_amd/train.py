@@ -85,7 +85,10 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     # CutMix images (in place, like the reference)
     cutmix_img_(img_s1, b["img_s1_other"], mix1)
     cutmix_img_(img_s2, b["img_s2_other"], mix2)
-    # pseudo labels + MaskCLIP guidance
+    # pseudo labels + MaskCLIP guidance (model.eval(): the side encoder's BatchNorm uses its running statistics here,
+    # semivl.py:228-244; nothing else on the path depends on the mode)
+    was_training = model.training
+    model.eval()
     with torch.no_grad():
         pred_w_other = model(b["img_w_other"])
         conf_w_other, mask_w_other = ops.softmax_max(pred_w_other)
@@ -93,6 +96,7 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         mclip_all = model.forward_maskclip(_cat2(img_w, b["img_w_other"]), cfg.get("mcc_conf_thresh", 0.9),
                                            ignore_mask=_cat2i(ign, ign_o))
         mclip, mclip_other = mclip_all[:B], mclip_all[B:]
+    model.train(was_training or True)
     # predictions
     # the feature-perturbed copy of the labeled half (pred_x_fp) is never read by the step (semivl.py:247): only the
     # unlabeled half is perturbed and decoded -> [x, w, w_fp]

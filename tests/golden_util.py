@@ -50,10 +50,12 @@ def build_oracle(c):
     from oracle import semivl_oracle as O
     from semivl_amd.model.text_embeddings import get_class_to_concept_idxs
     t, m = text_feats()
+    skr = bool(c.get("conv_encoder"))   # Cityscapes-recipe wiring: side conv encoder as the second skip, CLIP renorm
     orc = O.build_vlm(dict(nclass=21, crop=c["S"], embed=c["embed"], layers=c["layers"], heads=c["heads"],
                            out_indices=tuple(c["out_indices"]), channels=c["channels"],
-                           text_channels=c["text_channels"], up=c["up"], skip_in=(c["embed"], c["embed"]),
-                           skip=c["skip"]), t, m, get_class_to_concept_idxs(MCC_TEXT))
+                           text_channels=c["text_channels"], up=c["up"],
+                           skip_in=(c["embed"], 256 if skr else c["embed"]), skip=c["skip"], conv_encoder=skr,
+                           renorm_clip_img=skr), t, m, get_class_to_concept_idxs(MCC_TEXT))
     for lyr in orc.decode_head.layers:
         lyr.transformer.attn.attn.num_heads = c["dec_heads"]
     return orc
@@ -73,6 +75,11 @@ def build_hip(c):
     mcfg["decode_head"].update(img_size=S, num_classes=21, text_channels=c["text_channels"], up_channels=c["up"],
                                skip_in_channels=(c["embed"], c["embed"]), skip_channels=c["skip"],
                                num_heads=c["dec_heads"], channels=c["channels"])
+    if c.get("conv_encoder"):
+        skr = copy.deepcopy(builtin_model_cfg("vlm-vlg-aspp-s2p4-skr04-ftap-mcvitb"))["model"]
+        skr["conv_encoder"].pop("pretrained", None)
+        mcfg.update(conv_encoder=skr["conv_encoder"], renorm_clip_img=True)
+        mcfg["decode_head"].update(skip_in_channels=(c["embed"], 256), skip_from_conv_feat=True)
     mcfg.pop("type")
     mcfg.pop("pretrained", None)
     return VLM(load_text_embedding=TEXT, load_mcc_text_embedding=MCC_TEXT, load_pl_text_embedding=TEXT,

@@ -37,12 +37,27 @@ def test_build_model_schema_and_freeze_policy():
 def test_unsupported_configs_fail_loudly():
     from semivl_amd.model.builder import build_model
     cfg = exp40_cfg()
-    cfg["model"] = "mmseg.vlm-vlg-aspp-s2p4-skr04-ftap-mcvitb"
+    cfg["model"] = "mmseg.vlm-dlv3p-bn11-sk4-ft-tvit-in1k"      # UniMatch-with-ViT ablation (experiments.py:433)
     with pytest.raises((ValueError, NotImplementedError)):
         build_model(cfg)
     cfg["model"] = "deeplabv3plus"
     with pytest.raises(ValueError):
         build_model(cfg)
+
+
+def test_skr04_config_builds_with_reference_key_schema():
+    """Cityscapes recipe (experiments.py:428-456): ViT out_indices [4, 12], ResNetV1c side encoder, (768, 256) skips."""
+    from semivl_amd.model.builder import build_model
+    cfg = exp40_cfg(batch_size=1, crop=64, nclass=19, dataset="cityscapes")
+    cfg["model"] = "mmseg.vlm-vlg-aspp-s2p4-skr04-ftap-mcvitb"
+    cfg["model_args"] = dict(maskclip_class_filter=None, renorm_clip_img=True)
+    m = build_model(cfg)
+    keys = list(m.state_dict())
+    assert "conv_encoder.stem.0.weight" in keys and "conv_encoder.layer1.0.downsample.1.running_var" in keys
+    assert "conv_encoder.layer1.2.bn3.num_batches_tracked" in keys
+    assert tuple(m.decode_head.skip_proj[1][0].weight.shape) == (32, 256, 3, 3)
+    assert m.renorm_clip_img and m.backbone.out_indices == [4, 12]
+    assert all(p.requires_grad for p in m.conv_encoder.parameters())
 
 
 def test_no_cpu_fallback():

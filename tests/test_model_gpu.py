@@ -197,3 +197,53 @@ def test_conv_encoder_matches_oracle(dev, B, S):
         (re,) = orc(img)
         (ge,) = hip(img.to(dev))
     assert (ge.cpu() - re).abs().max().item() < 2e-4 * max(1.0, re.abs().max().item())
+
+
+SKR = dict(S=96, B=2, embed=64, layers=3, heads=1, out_indices=[1, 3], channels=32, text_channels=32, dec_heads=1,
+           up=(32, 16), skip=(16, 16), seed=17, conv_encoder=True)
+
+
+def test_skr04_wiring_step_matches_oracle(dev):
+    """Cityscapes-recipe model (vlm-vlg-aspp-s2p4-skr04: ViT out_indices [k, L], ResNetV1c side encoder with batch-stat
+    BatchNorm as the second skip source, CLIP re-normalisation, perturbation of the conv features, eval-mode pseudo-label
+    pass) through one full SemiVL step: losses, label maps, running statistics and all gradients against the oracle."""
+    from oracle import semivl_oracle as O
+    from semivl_amd.train import LOSS_NAMES, semivl_train_step
+    c = SKR
+    torch.manual_seed(c["seed"])
+    orc = build_oracle(c)
+    hip = build_hip(c)
+    assert sorted(orc.state_dict()) == sorted(hip.state_dict())
+    with torch.no_grad():
+        for n, p in orc.named_parameters():
+            if "conv_encoder" in n and p.dim() == 1:   # zero-init bn3 would silence the residual branches
+                p.copy_(1.0 + 0.2 * torch.randn_like(p) if n.endswith("weight") else 0.1 * torch.randn_like(p))
+            elif "conv_encoder" not in n:
+                p.copy_(torch.randn_like(p) * (0.05 if p.dim() < 2 else 1.0 / np.sqrt(np.prod(p.shape[1:]))) +
+                        (1.0 if (p.dim() == 1 and n.endswith("weight")) else 0.0))
+    hip.load_state_dict(orc.state_dict(), strict=True)
+    hip.to(dev)
+    B, S = c["B"], c["S"]
+    batch = O.synthetic_batch(B, S, 21, seed=77)
+    g = torch.Generator().manual_seed(3)
+    masks = [(torch.rand(2 * B, ch, generator=g) > 0.5).float() for ch in (c["embed"], 512, 256)]   # [f_k, emb, conv]
+    cfg = dict(CFG, conf_thresh=0.05, conf_mode="pixelavg")
+    loss, aux = O.semivl_step(orc, batch, 10, 100, conf_thresh=0.05, conf_mode="pixelavg", fp_masks=masks)
+    loss.backward()
+    losses, haux = semivl_train_step(hip, to_dev(batch, dev), 10, 100, cfg, fp_masks=[m.to(dev) for m in masks],
+                                     return_aux=True)
+    got = dict(zip(LOSS_NAMES, losses.cpu().tolist()))
+    assert abs(got["loss"] - loss.item()) < 1e-3, (got["loss"], loss.item())
+    assert (haux["pred_x"].cpu() - aux["pred_x"].detach()).abs().max().item() < 1e-3
+    for k in ("mask_w", "mask_w_other", "mclip", "mclip_other"):
+        assert (haux[k].cpu() != aux[k]).float().mean().item() < 2e-3, k
+    for (n, bo), (_, bh) in zip(sorted(orc.named_buffers()), sorted(hip.named_buffers())):
+        if "conv_encoder" in n:
+            assert (bh.cpu().float() - bo.float()).abs().max().item() < 1e-4 * max(1.0, bo.float().abs().max().item()), n
+    og = {n: p.grad for n, p in orc.named_parameters() if p.grad is not None}
+    hg = {n: p.grad for n, p in hip.named_parameters() if p.grad is not None}
+    assert sorted(og) == sorted(hg), sorted(set(og) ^ set(hg))
+    assert any("conv_encoder.stem.0" in n for n in og)
+    for n in og:
+        rel = ((hg[n].cpu() - og[n]).norm() / (og[n].norm() + 1e-12)).item()
+        assert rel < 3e-2 or og[n].norm().item() < 1e-7, (n, rel, og[n].norm().item())
