@@ -194,6 +194,20 @@ class _Finder:
         pass
 
 
+class ResNetV1c(nn.Module):
+    """Stand-in for mmseg's un-vendored ResNetV1c: the oracle's restatement of the (depth 101, num_stages=1) instance the
+    skr04 config builds, accepting mmseg's kwargs.  Pins the reference's VLM / VLGHead WIRING around it (conv_encoder
+    call, skip_from_conv_feat, conv-feature perturbation, renorm) -- not the ResNet itself."""
+
+    def __new__(cls, depth=101, num_stages=1, **kw):
+        assert depth == 101 and num_stages == 1
+        from oracle.semivl_oracle import ResNetV1cStage1
+        return ResNetV1cStage1()
+
+
+BACKBONES.register_module("ResNetV1c")(ResNetV1c)
+
+
 def install():
     sys.meta_path.insert(0, _Finder())
     real = {

@@ -35,6 +35,11 @@ CONFIGS = {
     # AvgPool floor 5 -> 1) with the Cityscapes recipe's conf_mode 'pixelavg' and batch 2
     "offsize": dict(S=72, B=2, embed=64, layers=3, heads=1, out_indices=[0, 1, 3], channels=32, text_channels=32,
                     dec_heads=1, up=(32, 16), skip=(16, 16), seed=13, conf_thresh=0.95, conf_mode="pixelavg"),
+    # Cityscapes-recipe wiring (vlm-vlg-aspp-s2p4-skr04-ftap-mcvitb): ViT out_indices [k, L], conv_encoder (stand-in
+    # ResNetV1c, see _ref_shim.py) as the second skip source, renorm_clip_img, pixelavg
+    "skr": dict(S=96, B=2, embed=64, layers=3, heads=1, out_indices=[1, 3], channels=32, text_channels=32,
+                dec_heads=1, up=(32, 16), skip=(16, 16), seed=14, conf_thresh=0.05, conf_mode="pixelavg",
+                conv_encoder=True),
 }
 
 
@@ -44,13 +49,19 @@ def seeded_state(named_shapes, seed):
     g = torch.Generator().manual_seed(seed)
     out = {}
     for name, shape in named_shapes:
-        r = torch.randn(*shape, generator=g)
+        r = torch.randn(*shape, generator=g) if len(shape) else torch.zeros(())
         leaf = name.split(".")[-1]
         parent = name.split(".")[-2] if "." in name else ""
         is_norm = parent.startswith("ln") or (leaf in ("weight", "bias") and len(shape) == 1 and
                                               any(s in name for s in (".1.weight", ".1.bias", ".2.weight", ".2.bias",
                                                                       ".4.weight", ".4.bias")))
-        if is_norm and leaf == "weight":
+        if leaf == "num_batches_tracked":          # BatchNorm buffers of the conv_encoder fixtures
+            out[name] = torch.zeros(shape, dtype=torch.long)
+        elif leaf == "running_var":
+            out[name] = 1.0 + 0.1 * r.abs()
+        elif leaf == "running_mean":
+            out[name] = 0.05 * r
+        elif (is_norm or parent.startswith("bn")) and leaf == "weight":
             out[name] = 1.0 + 0.1 * r
         elif leaf == "bias" or name.endswith("in_proj_bias"):
             out[name] = 0.02 * r
@@ -68,7 +79,8 @@ def build_reference(c):
     import third_party.maskclip.models.backbones.maskclip_vit  # noqa: registers the ViT
     from model.builder import forward_wrapper
     import types
-    mcfg = runpy.run_path("configs/_base_/models/vlm-vlg-aspp-s2p4-sk04-ftap-mcvitb.py")["model"]
+    skr = bool(c.get("conv_encoder"))
+    mcfg = runpy.run_path("configs/_base_/models/vlm-vlg-aspp-s2p4-%s-ftap-mcvitb.py" % ("skr04" if skr else "sk04"))["model"]
     ccfg = runpy.run_path("configs/_base_/models/mcvit16.py")["backbone"]
     S = c["S"]
     for bb in (mcfg["backbone"], ccfg):
@@ -76,8 +88,11 @@ def build_reference(c):
         bb.pop("pretrained", None)
     mcfg["backbone"]["out_indices"] = c["out_indices"]
     mcfg["decode_head"].update(img_size=S, num_classes=21, text_channels=c["text_channels"], up_channels=c["up"],
-                               skip_in_channels=(c["embed"], c["embed"]), skip_channels=c["skip"],
+                               skip_in_channels=(c["embed"], 256 if skr else c["embed"]), skip_channels=c["skip"],
                                num_heads=c["dec_heads"], channels=c["channels"])
+    if skr:
+        mcfg["conv_encoder"].pop("pretrained", None)
+        mcfg["renorm_clip_img"] = True          # experiments.py:219-220 (exp 44)
     mcfg.pop("type")
     mcfg.pop("pretrained", None)
     for bb in (mcfg["backbone"], ccfg):
@@ -124,8 +139,10 @@ def main():
 
         orc = O.build_vlm(dict(nclass=21, crop=c["S"], embed=c["embed"], layers=c["layers"], heads=c["heads"],
                                out_indices=tuple(c["out_indices"]), channels=c["channels"],
-                               text_channels=c["text_channels"], up=c["up"], skip_in=(c["embed"], c["embed"]),
-                               skip=c["skip"]), text, mcc, cls2con)
+                               text_channels=c["text_channels"], up=c["up"],
+                               skip_in=(c["embed"], 256 if c.get("conv_encoder") else c["embed"]),
+                               skip=c["skip"], conv_encoder=bool(c.get("conv_encoder")),
+                               renorm_clip_img=bool(c.get("conv_encoder"))), text, mcc, cls2con)
         if c["dec_heads"] != 4:
             for lyr in orc.decode_head.layers:
                 lyr.transformer.attn.attn.num_heads = c["dec_heads"]
@@ -134,7 +151,8 @@ def main():
         B, S = c["B"], c["S"]
         batch = O.synthetic_batch(B, S, 21, seed=1234 + c["seed"])
         g = torch.Generator().manual_seed(c["seed"] + 100)
-        fp_masks = [(torch.rand(2 * B, ch, generator=g) > 0.5).float() for ch in (c["embed"], c["embed"], 512)]
+        fp_ch = (c["embed"], 512, 256) if c.get("conv_encoder") else (c["embed"], c["embed"], 512)  # dropout2d call order
+        fp_masks = [(torch.rand(2 * B, ch, generator=g) > 0.5).float() for ch in fp_ch]
         total_iters, iters = 100, 10
 
         # ---- reference run (its modules, the restated loop) ---------------------------------------------
@@ -167,6 +185,12 @@ def main():
             grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
             return loss.detach(), aux, grads
 
+        # eval forward + maskclip on img_x (before the step: a train-mode pass updates BatchNorm running statistics)
+        ref.eval()
+        with torch.no_grad():
+            logits_eval = ref(batch["img_x"])
+            mclip_x = ref.forward_maskclip(batch["img_x"], 0.9)
+
         rl, raux, rg = run(ref, True)
         ol, oaux, og = run(orc, False)
         print(f"[{name}] loss ref {rl.item():.8f} oracle {ol.item():.8f}  |d| {abs(rl.item() - ol.item()):.2e}")
@@ -181,12 +205,6 @@ def main():
         worst = max(((rg[k] - og[k]).abs().max() / (rg[k].abs().max() + 1e-12)).item() for k in rg)
         print(f"    {len(rg)} grads, worst rel max-err {worst:.2e}; trainable ref={sum(p.requires_grad for p in ref.parameters())}")
         assert worst < 1e-4
-
-        # eval forward + maskclip on img_x for completeness
-        ref.eval()
-        with torch.no_grad():
-            logits_eval = ref(batch["img_x"])
-            mclip_x = ref.forward_maskclip(batch["img_x"], 0.9)
 
         # one AdamW step with the reference hyper-parameters (exp 40): lr 1e-4, wd 0.01, backbone x0.01, head x10
         ck = dict(backbone=dict(lr_mult=0.01), text_encoder=dict(lr_mult=0.0), conv_encoder=dict(lr_mult=1.0),

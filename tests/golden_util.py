@@ -22,13 +22,19 @@ def seeded_state(named_shapes, seed):
     g = torch.Generator().manual_seed(seed)
     out = {}
     for name, shape in named_shapes:
-        r = torch.randn(*shape, generator=g)
+        r = torch.randn(*shape, generator=g) if len(shape) else torch.zeros(())
         leaf = name.split(".")[-1]
         parent = name.split(".")[-2] if "." in name else ""
         is_norm = parent.startswith("ln") or (leaf in ("weight", "bias") and len(shape) == 1 and
                                               any(s in name for s in (".1.weight", ".1.bias", ".2.weight", ".2.bias",
                                                                       ".4.weight", ".4.bias")))
-        if is_norm and leaf == "weight":
+        if leaf == "num_batches_tracked":          # BatchNorm buffers of the conv_encoder fixtures
+            out[name] = torch.zeros(shape, dtype=torch.long)
+        elif leaf == "running_var":
+            out[name] = 1.0 + 0.1 * r.abs()
+        elif leaf == "running_mean":
+            out[name] = 0.05 * r
+        elif (is_norm or parent.startswith("bn")) and leaf == "weight":
             out[name] = 1.0 + 0.1 * r
         elif leaf == "bias" or name.endswith("in_proj_bias"):
             out[name] = 0.02 * r
@@ -115,6 +121,7 @@ def fixture_batch(z, c):
 def fixture_fp_masks(z, c):
     flat = torch.from_numpy(z["fp_masks"]).float()
     B = c["B"]
-    sizes = [2 * B * c["embed"], 2 * B * c["embed"], 2 * B * 512]
+    chans = (c["embed"], 512, 256) if c.get("conv_encoder") else (c["embed"], c["embed"], 512)
+    sizes = [2 * B * ch for ch in chans]
     parts = flat.split(sizes)
     return [p.view(2 * B, -1) for p in parts]

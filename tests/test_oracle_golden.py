@@ -7,7 +7,7 @@ import torch
 from golden_util import build_oracle, fixture_batch, fixture_fp_masks, fixture_state, load_fixture
 
 
-@pytest.mark.parametrize("name", ["tiny", "vlgdim", "offsize"])
+@pytest.mark.parametrize("name", ["tiny", "vlgdim", "offsize", "skr"])
 def test_oracle_reproduces_reference_step(name):
     from oracle import semivl_oracle as O
     z, c = load_fixture(name)
