@@ -140,7 +140,7 @@ def main():
                steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 2), higher_is_better=True, scaling="weak",
                vs_baseline=None, dtype="f32" if a.gemm_arith == "f32" else f"f32 ({a.gemm_arith} split-product MFMA, f32 accumulate)",
                data="synthetic",
-               config=dict(workload=f"SemiVL step, VOC12-style N={a.nclass}, ViT-B/16 + VLG head, {a.crop}x{a.crop}, "
+               config=dict(workload=f"SemiVL step, {dataset} N={a.nclass}, {cfg['model'].replace('mmseg.', '')}, {a.crop}x{a.crop}, "
                                     f"bs={a.batch}/GPU labeled + {a.batch}/GPU unlabeled" + (" (BASELINE configs[1])" if (a.nclass, a.crop, a.batch) == (21, 512, 16) else ""),
                            global_batch=2 * a.batch * world, parallelism=f"dp{world}", loss=round(loss_val, 5),
                            peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)))

@@ -41,17 +41,24 @@ def synthetic_batch(B, S, nclass, seed=1234, device="cpu"):
 
 
 def exp40_cfg(batch_size=16, crop=512, nclass=21, dataset="pascal"):
-    """The flat experiment dict of experiments.py exp 40 restricted to the keys the hot path reads."""
-    cs = dataset == "cityscapes"  # exp 44 text variants / conf mode (experiments.py:428-456); the skr04 conv_encoder is N2
+    """The flat experiment dict of experiments.py exp 40 restricted to the keys the hot path reads; for
+    dataset='cityscapes' the exp 44 recipe (experiments.py:428-456): skr04 model (ResNetV1c conv_encoder), CLIP
+    re-normalisation, concept-averaged text, pixelavg, lr 5e-5, backbone / conv_encoder lr_mult 0.1."""
+    cs = dataset == "cityscapes"
     tv = "conceptavg3_single" if cs else "single"
+    margs = dict(maskclip_class_filter=None)
+    if cs:
+        margs["renorm_clip_img"] = True
     return dict(
-        dataset=dataset, nclass=nclass, crop_size=crop, model="mmseg.vlm-vlg-aspp-s2p4-sk04-ftap-mcvitb",
-        model_args=dict(maskclip_class_filter=None), text_embedding_variant=tv,
+        dataset=dataset, nclass=nclass, crop_size=crop,
+        model="mmseg.vlm-vlg-aspp-s2p4-%s-ftap-mcvitb" % ("skr04" if cs else "sk04"),
+        model_args=margs, text_embedding_variant=tv,
         mcc_text="concept4_single" if dataset == "pascal" else ("concept3_single" if cs else "single"), pl_text=tv,
         method="semivl", use_fp=True, conf_mode="pixelavg" if cs else "pixelwise", conf_thresh=0.95, disable_dropout=True, pleval=True, fp_rate=0.5,
         maskclip_consistency_lambda=[0.1, 0], clip_encoder="mcvit16", mcc_conf_thresh=0.9, mcc_loss_reduce="mean_all",
         criterion=dict(name="CELoss", kwargs=dict(ignore_index=255)), criterion_u="CELoss",
-        optimizer=dict(type="AdamW", lr=1e-4, weight_decay=0.01, paramwise_cfg=dict(custom_keys=dict(
-            backbone=dict(lr_mult=0.01), text_encoder=dict(lr_mult=0.0), conv_encoder=dict(lr_mult=1.0),
-            norm=dict(decay_mult=0.0), ln=dict(decay_mult=0.0), head=dict(lr_mult=10.0)))),
+        optimizer=dict(type="AdamW", lr=5e-5 if cs else 1e-4, weight_decay=0.01, paramwise_cfg=dict(custom_keys=dict(
+            backbone=dict(lr_mult=0.1 if cs else 0.01), text_encoder=dict(lr_mult=0.0),
+            conv_encoder=dict(lr_mult=0.1 if cs else 1.0), norm=dict(decay_mult=0.0), ln=dict(decay_mult=0.0),
+            head=dict(lr_mult=10.0)))),
         warmup_iters=0, batch_size=batch_size, epochs=80)
