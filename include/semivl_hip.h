@@ -389,6 +389,27 @@ int svl_maxpool3x3s2_fwd(const float* x, int imgs, int H, int W, int C, float* y
 int svl_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, int imgs, int H, int W, int C, float* dx,
                          svl_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * GPU-side input pipeline: the reference loader's per-sample PIL chain
+ * (third_party/unimatch/dataset/semi.py:61-127, transform.py:9-84) on uint8 HWC device images.  Statistical parity
+ * (the random streams differ); the deterministic arithmetic follows Pillow.
+ *   svl_aug_resample_u8   resize(transform.py:43-57: BILINEAR antialiased for images / NEAREST for masks) to rh x rw,
+ *                         pad right/bottom with `fill` (transform.py:9-14), crop S x S at (x0, y0) (:16-20), hflip (:25-29)
+ *   svl_aug_to_float      ToTensor + Normalize (transform.py:32-40) -> float CHW; mean3/std3 are HOST pointers
+ *   svl_aug_mask_i64      uint8 mask -> int64 with one value remapped (semi.py:122-123: 254 -> 255 / ignore_mask)
+ *   svl_aug_photometric_u8  in place: 0 brightness, 1 contrast, 2 saturation (ImageEnhance blends, semi.py:99-100 via
+ *                         torchvision ColorJitter), 3 hue shift, 4 grayscale (semi.py:101); scratch = 1 device uint64
+ *   svl_aug_gaussian_blur_u8  transform.py:60-64 (true separable Gaussian; Pillow approximates it with box filters) */
+int svl_aug_resample_u8(const unsigned char* src, int H, int W, int C, int rh, int rw, int x0, int y0, int S, int flip,
+                        int mode, int fill, unsigned char* dst, svl_stream_t stream);
+int svl_aug_to_float(const unsigned char* src, int npix, const float* mean3, const float* std3, float* dst,
+                     svl_stream_t stream);
+int svl_aug_mask_i64(const unsigned char* src, int npix, int from, int to, int64_t* dst, svl_stream_t stream);
+int svl_aug_photometric_u8(unsigned char* img, int npix, int op, float factor, unsigned long long* scratch,
+                           svl_stream_t stream);
+int svl_aug_gaussian_blur_u8(const unsigned char* src, int H, int W, float sigma, unsigned char* tmp, unsigned char* dst,
+                             svl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

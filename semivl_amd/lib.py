@@ -102,6 +102,11 @@ SIGNATURES = {
     "svl_bn_bwd_apply": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _D, _L, _I, _P, _L, _P, _L, _P]),
     "svl_maxpool3x3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "svl_maxpool3x3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "svl_aug_resample_u8": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "svl_aug_to_float": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
+    "svl_aug_mask_i64": (_I, [_P, _I, _I, _I, _P, _P]),
+    "svl_aug_photometric_u8": (_I, [_P, _I, _I, _F, _P, _P]),
+    "svl_aug_gaussian_blur_u8": (_I, [_P, _I, _I, _F, _P, _P, _P]),
     "svl_attention_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "svl_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "svl_conv_cout1_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
