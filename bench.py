@@ -146,10 +146,12 @@ def main():
                            peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)))
 
     # ---- roofline of the dominant kernel family (fp32-MFMA GEMM / implicit-GEMM), measured live with HIP events ----
-    if rank == 0 and not a.no_profile:
-        ops.PROFILE = {}
+    if not a.no_profile:   # every rank runs the step (it contains the gradient all-reduce); rank 0 records the events
+        if rank == 0:
+            ops.PROFILE = {}
         step(a.warmup + a.steps)
         torch.cuda.synchronize()
+    if rank == 0 and not a.no_profile:
         prof, ops.PROFILE = ops.PROFILE, None
         g = prof.get("gemm", []) + prof.get("attention", [])   # the two fp32-MFMA kernel families
         t_gemm = sum(e0.elapsed_time(e1) for e0, e1, *_ in g) * 1e-3
