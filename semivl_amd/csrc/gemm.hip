@@ -889,19 +889,12 @@ template <int AMODE, int BMODE>
 int launch_mode(const GemmP& p, int batch, hipStream_t st) {
   // short-M problems (conv / linear wgrad with few output channels): widen the wave tile along N so that each
   // A fragment read feeds 2-4 MFMAs (32x32 wave tiles spend one LDS read per MFMA operand).
-  static const bool sbk32 = getenv("SVL_GEMM_SHORTM_BK32") != nullptr;
-  if (sbk32 && p.K >= 256) {
-    if (p.M <= 32 && p.N > 32) return launch_cfg<32, 128, 1, 4, AMODE, BMODE, 32>(p, batch, st);
-    if (p.M <= 64 && p.N > 64) return launch_cfg<64, 128, 2, 2, AMODE, BMODE, 32>(p, batch, st);
-  }
   if (p.M <= 32 && p.N > 32) return launch_cfg<32, 128, 1, 4, AMODE, BMODE>(p, batch, st);
   if (p.M <= 64 && p.N > 64) return launch_cfg<64, 128, 2, 2, AMODE, BMODE>(p, batch, st);
   if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, BMODE>(p, batch, st);
   if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, BMODE>(p, batch, st);
-  static const bool wide = getenv("SVL_GEMM_WIDE") != nullptr;
-  if (wide && p.N >= 256 && p.M >= 256) return launch_cfg<128, 256, 2, 2, AMODE, BMODE>(p, batch, st);
-  static const bool bk32 = getenv("SVL_GEMM_BK32") != nullptr;
-  if (bk32 && p.K >= 64) return launch_cfg<128, 128, 2, 2, AMODE, BMODE, 32>(p, batch, st);
+  // (measured and rejected on this workload: BK = 32 variants -- occupancy 3 -> 2 blocks/CU, -10 %; 128x256 tiles;
+  //  256x32 / 256x64 tiles for the narrow convs: -8 ... -25 %)
   return launch_cfg<128, 128, 2, 2, AMODE, BMODE>(p, batch, st);
 }
 
