@@ -128,6 +128,9 @@ int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream);
  * Initial value: environment variable SVL_GEMM_EMU (0 if unset).  Inputs, outputs and accumulation stay fp32. */
 int svl_set_gemm_emulation(int mode);
 int svl_get_gemm_emulation(void);
+/* 1 (default): narrow (N = 32 / 64) 3x3 stride-1 convolutions run on the spatially tiled kernel; 0: implicit GEMM only.
+ * Initial value: 0 if the environment variable SVL_CONV_NO_TILED is set. */
+int svl_set_conv_tiled(int on);
 
 /* out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s*count + i]  — deterministic split-K combine. */
 int svl_reduce_slabs_f32(float* out, const float* slabs, int nslab, int64_t count, int accumulate,

@@ -1,0 +1,16 @@
+// Spatially tiled 3x3 convolution for narrow outputs (N = 32 / 64), see conv_tiled.hip.
+#pragma once
+#include "svl_common.h"
+
+struct ConvTiledP {
+  const float* src1; long ld1; int C1;
+  const float* src2; long ld2; int C2; int rep;   // second concat source (may be null), read at image img / rep
+  const float* w; int K;                            // w[n * K + tap * (C1 + C2) + ci]
+  float* out; long ldo;
+  const float* bias; int act; int accumulate;
+  int imgs, H, W, N;
+  int sign;                                         // +1: correlation taps, -1: mirrored taps (input-gradient form)
+};
+
+bool svl_conv3x3_tiled_eligible(const ConvTiledP& p);
+int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st);

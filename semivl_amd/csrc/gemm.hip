@@ -17,6 +17,7 @@
 // Operand addressing modes make the same kernel an implicit-GEMM convolution (NHWC, stride 1, dilation,
 // optional second concatenated source), the patch-embedding gather, conv wgrad (im2col^T) and split-K.
 #include "svl_common.h"
+#include "conv_tiled.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -842,6 +843,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wr, wc, l31, hi, zo, zi);
 }
 
+static int g_conv_tiled = -1;  // -1: read SVL_CONV_NO_TILED once
 static int g_emu_mode = -1;  // -1: read SVL_GEMM_EMU once; 0 exact fp32 MFMA; 3 / 6: bf16 split emulation
 
 template <int NS>
@@ -995,6 +997,23 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     return SVL_ERR_UNSUPPORTED;
   };
 
+  // Narrow 3x3 convolutions (N = 32 / 64): spatially tiled kernel (conv_tiled.hip) instead of the implicit GEMM
+  if (g_conv_tiled < 0) g_conv_tiled = getenv("SVL_CONV_NO_TILED") ? 0 : 1;
+  if (g_conv_tiled && am == SVL_A_CONV && bm == SVL_B_KCONTIG && d->out_mode == SVL_OUT_STRIDED && d->batch == 1 &&
+      d->ksplit == 0 && cv.KH == 3 && cv.KW == 3 && cv.dil == 1 && cv.pad == 1 && p.cv.stride == 1 &&
+      d->alpha == 1.0f && !d->preact && !d->resid && d->B.ld == d->K && d->ldc_n == 1 &&
+      (long)d->M % ((long)cv.H * cv.W) == 0) {
+    ConvTiledP t;
+    t.src1 = d->A.ptr; t.ld1 = d->A.ld; t.C1 = cv.C1;
+    t.src2 = cv.src2; t.ld2 = cv.ld2; t.C2 = cv.C2; t.rep = cv.rep;
+    t.w = d->B.ptr; t.K = d->K;
+    t.out = d->C; t.ldo = d->ldc_m;
+    t.bias = d->bias_mod > 0 ? nullptr : d->bias; t.act = d->act; t.accumulate = d->accumulate;
+    t.imgs = (int)((long)d->M / ((long)cv.H * cv.W)); t.H = cv.H; t.W = cv.W; t.N = d->N;
+    t.sign = cv.sign;
+    if ((d->bias == nullptr || d->bias_mod == 0) && svl_conv3x3_tiled_eligible(t)) return svl_conv3x3_tiled_launch(t, st);
+  }
+
   // Ragged token count (M = images x 1025 tokens = 128 k + r): the r leftover rows would cost one more full-length
   // block per column tile, i.e. a whole extra round of the grid on a launch whose tile count is otherwise an exact
   // multiple of the resident-block count (measured -14 % on the N = 768 GEMMs).  Their rows are independent, so they
@@ -1030,6 +1049,10 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
 extern "C" int svl_set_gemm_emulation(int mode) {
   SVL_CHECK_ARG(mode == 0 || mode == 3 || mode == 6, "svl_set_gemm_emulation: mode must be 0, 3 or 6");
   g_emu_mode = mode;
+  return SVL_OK;
+}
+extern "C" int svl_set_conv_tiled(int on) {
+  g_conv_tiled = on ? 1 : 0;
   return SVL_OK;
 }
 extern "C" int svl_get_gemm_emulation(void) { return g_emu_mode < 0 ? 0 : g_emu_mode; }
