@@ -145,3 +145,176 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st) {
   SVL_LAUNCH_CHECK("svl_gemm_f32 (tiled 3x3 conv)");
   return SVL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same narrow 3x3 convolutions:  dW[co][tap][ci] = sum_pixels dy[p][co] * x[p + tap][ci].
+// The implicit-GEMM form (A = dy^T, B = im2col(x), short M = Cout) spends its time on im2col addressing (31-45 TF).
+// Here a block owns one slab of SL = 32 input channels (a slab may straddle the two concat sources) and a strided subset of the 8 x 16 pixel patches: per patch the
+// dy tile [128 px][Cout] and the x tile with halo [180 px][SL] are staged once, the MFMA K dimension runs over the 128
+// pixels, the N dimension over (tap, ci) with the tap shift applied as an LDS offset per lane, and the Cout x 9 SL
+// accumulators stay in registers across all of the block's patches.  Partial sums per block group go to slabs that the
+// caller reduces in fixed order (deterministic).
+namespace {
+
+struct WgradTiledP {
+  const float* dy; long lddy; int Co;
+  const float* src1; long ld1; int C1;
+  const float* src2; long ld2; int C2; int rep;
+  float* slabs;                         // [groups][Co][9 * (C1 + C2)]
+  int imgs, H, W, groups;
+};
+
+template <int MT, int SL>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_tiled_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
+  constexpr int Co = 32 * MT;
+  constexpr int NCOL = 9 * SL, NT = (NCOL + 31) / 32, TILES = MT * NT, TPW = (TILES + 3) / 4;
+  constexpr int DP = (128 * Co / 4 + 255) / 256, XP = (NPIX * SL / 4 + 255) / 256;
+  __shared__ float ds[128 * Co];
+  __shared__ float xs[NPIX * SL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int g = blockIdx.x, slab = blockIdx.y;
+  const int c0 = slab * SL, Ct = p.C1 + p.C2;
+  const int npatch = p.imgs * tiles_x * tiles_y;
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+  // per-lane B-operand geometry of each of this wave's tiles: column -> (tap, ci), LDS offset of the tap shift
+  int boff[TPW];
+  bool bval[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int t = wave + 4 * u, nt = t / MT;
+    const int col = 32 * nt + l31;
+    bval[u] = t < TILES && col < NCOL;
+    const int tap = bval[u] ? col / SL : 0, ci = bval[u] ? col - tap * SL : 0;
+    boff[u] = ((tap / 3) * IW + (tap % 3)) * SL + ci;
+  }
+
+  float4 rd[DP], rx[XP];
+  auto gload = [&](int pi) {
+    int t = pi;
+    const int txi = t % tiles_x;
+    t /= tiles_x;
+    const int tyi = t % tiles_y, img = t / tiles_y;
+    const int y0 = tyi * PH, x0 = txi * PW;
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+      const int f = tid + 256 * i;
+      const int pix = f / (Co / 4), q = f - pix * (Co / 4);
+      const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
+      rd[i] = (pix < 128 && y < p.H && x < p.W)
+                  ? *reinterpret_cast<const float4*>(p.dy + (((long)img * p.H + y) * p.W + x) * p.lddy + 4 * q)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* b1 = p.src1 + ((long)img * p.H) * p.W * p.ld1;
+    const float* b2 = p.C2 > 0 ? p.src2 + ((long)(img / p.rep) * p.H) * p.W * p.ld2 : nullptr;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int f = tid + 256 * i;
+      const int pix = f / (SL / 4), q = f - pix * (SL / 4);
+      const int iy = pix / IW, ix = pix - iy * IW;
+      const int y = y0 - 1 + iy, x = x0 - 1 + ix;
+      const int c = c0 + 4 * q;                      // a slab may straddle the two concat sources (C1 % 4 == 0)
+      const float* src = c < p.C1 ? b1 + ((long)y * p.W + x) * p.ld1 + c : b2 + ((long)y * p.W + x) * p.ld2 + (c - p.C1);
+      rx[i] = (pix < NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W) ? *reinterpret_cast<const float4*>(src)
+                                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+      const int f = tid + 256 * i;
+      if (f < 128 * Co / 4) *reinterpret_cast<float4*>(ds + 4 * f) = rd[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int f = tid + 256 * i;
+      if (f < NPIX * SL / 4) *reinterpret_cast<float4*>(xs + 4 * f) = rx[i];
+    }
+  };
+
+  int pi = g;
+  if (pi < npatch) {
+    gload(pi);
+    sstore();
+  }
+  __syncthreads();
+  for (; pi < npatch; pi += p.groups) {
+    const bool more = pi + p.groups < npatch;
+    if (more) gload(pi + p.groups);
+#pragma unroll 4
+    for (int ks = 0; ks < 64; ++ks) {
+      const int q = 2 * ks + hi;                                  // pixel of the patch = MFMA k index
+      const float* da = ds + q * Co + l31;
+      const float* xb = xs + ((q >> 4) * IW + (q & 15)) * SL;      // tap (0, 0) position of pixel q in the halo tile
+      float a[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = da[32 * m];
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) {
+        const int t = wave + 4 * u;
+        if (t < TILES) {
+          const float b = bval[u] ? xb[boff[u]] : 0.f;
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t % MT], b, acc[u], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (more) {
+      sstore();
+      __syncthreads();
+    }
+  }
+  // C layout: row i = co (within the tile), column = lane -> (tap, ci)
+  float* out = p.slabs + (long)g * Co * 9 * Ct;
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int t = wave + 4 * u;
+    if (t < TILES && bval[u]) {
+      const int mt = t % MT, nt = t / MT;
+      const int col = 32 * nt + l31, tap = col / SL, ci = col - tap * SL;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        out[(long)co * 9 * Ct + tap * Ct + c0 + ci] = acc[u][r];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct) {
+  const long npatch = (long)imgs * ((H + PH - 1) / PH) * ((W + PW - 1) / PW);
+  const int nslab = Ct / 32;
+  long g = 768 / (nslab < 1 ? 1 : nslab);
+  if (g < 1) g = 1;
+  if (g > npatch) g = npatch;
+  return (int)g;
+}
+
+extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, const float* src1, int64_t ld1, int C1,
+                                       const float* src2, int64_t ld2, int C2, int rep, int imgs, int H, int W,
+                                       float* slabs, int groups, svl_stream_t stream) {
+  auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  SVL_CHECK_ARG(dy && src1 && slabs && (Co == 32 || Co == 64) && C1 > 0 && C1 % 4 == 0 && C2 >= 0 && C2 % 4 == 0 &&
+                    (C1 + C2) % 32 == 0 &&
+                    lddy % 4 == 0 && ld1 % 4 == 0 && a16(dy) && a16(src1) && imgs > 0 && H >= PH && W >= PW &&
+                    groups >= 1 && (C2 == 0 || (src2 && rep >= 1 && ld2 % 4 == 0 && a16(src2))),
+                "svl_conv3x3_wgrad_tiled: unsupported arguments");
+  const int Ct = C1 + C2;
+  WgradTiledP p;
+  p.dy = dy; p.lddy = lddy; p.Co = Co;
+  p.src1 = src1; p.ld1 = ld1; p.C1 = C1; p.src2 = src2; p.ld2 = ld2; p.C2 = C2; p.rep = rep < 1 ? 1 : rep;
+  p.slabs = slabs; p.imgs = imgs; p.H = H; p.W = W; p.groups = groups;
+  const int tx = (W + PW - 1) / PW, ty = (H + PH - 1) / PH;
+  dim3 grid((unsigned)groups, (unsigned)(Ct / 32));
+  hipStream_t st = (hipStream_t)stream;
+  if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<1, 32>), grid, dim3(256), 0, st, p, tx, ty);
+  else hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<2, 32>), grid, dim3(256), 0, st, p, tx, ty);
+  SVL_LAUNCH_CHECK("svl_conv3x3_wgrad_tiled");
+  return SVL_OK;
+}

@@ -4,6 +4,7 @@ torch is used here for device memory (torch.empty), views and the current HIP st
 path is issued through libsemivl_hip.so.  All tensors are fp32 CUDA(HIP) tensors unless stated.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -402,6 +403,9 @@ def unpack_conv_wgrad(dwf, Co, Ci, kh, kw):
     return dwf.view(Co, kh, kw, Ci).permute(0, 3, 1, 2).contiguous()
 
 
+CONV_TILED = not os.environ.get("SVL_CONV_NO_TILED")   # narrow 3x3 weight gradients on conv_tiled.hip
+
+
 def conv_out_size(H, W, KH, KW, dil, pad, stride):
     return (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1, (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
 
@@ -438,6 +442,20 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
     Ho, Wo = conv_out_size(H, W, KH, KW, dil, pad, stride) if stride != 1 else (H, W)
     Kpix = imgs * Ho * Wo
     N = KH * KW * (C1 + C2)
+    if (CONV_TILED and KH == 3 and KW == 3 and dil == 1 and pad == 1 and stride == 1 and Co in (32, 64) and
+            C1 % 4 == 0 and C2 % 4 == 0 and (C1 + C2) % 32 == 0 and H >= 8 and W >= 16 and Kpix >= 16384 and lddy % 4 == 0 and ldx % 4 == 0 and
+            (C2 == 0 or ld2 % 4 == 0)):
+        # narrow layers: spatially tiled weight-gradient kernel (conv_tiled.hip), slabs reduced in fixed order
+        lib = L.load()
+        groups = lib.svl_conv3x3_wgrad_tiled_groups(imgs, H, W, C1 + C2)
+        slabs = empty(groups, Co, N, device=dy.device)
+        e0 = _prof_begin()
+        L.check(lib.svl_conv3x3_wgrad_tiled(_p(dy), lddy, Co, _p(x), ldx, C1, _p(src2), ld2, C2, rep, imgs, H, W,
+                                            _p(slabs), groups, _st()), "svl_conv3x3_wgrad_tiled")
+        _prof_end("gemm", e0, 2.0 * Co * N * Kpix, ("wgrad3x3_tiled", Co, N, Kpix, 1))
+        out = empty(Co, N, device=dy.device)
+        reduce_slabs(out, slabs)
+        return out
     g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
     s, ks = _ksplit_plan(Co, N, Kpix)
     out = empty(Co, N, device=dy.device)

@@ -633,3 +633,34 @@ def test_maxpool3x3s2(dev, imgs, H, W, C):
     (g,) = torch.autograd.grad(ref, xt, dy.permute(0, 3, 1, 2))
     dx = ops.maxpool3x3s2_bwd(dy.view(-1, C), idx, imgs, H, W, C)
     close(dx.view(imgs, H, W, C), g.permute(0, 2, 3, 1), atol=1e-6)
+
+
+@pytest.mark.parametrize("b,N,H,W,C1,C2,Co", [(2, 6, 32, 48, 48, 16, 32), (1, 4, 64, 64, 32, 0, 32), (2, 4, 40, 56, 96, 32, 64),
+                                              (1, 3, 72, 80, 64, 0, 64), (3, 8, 19, 37, 16, 16, 32)])
+def test_tiled_narrow_conv3x3(dev, b, N, H, W, C1, C2, Co):
+    """conv_tiled.hip (forward, input gradient, weight gradient; two concat sources with class repetition; ragged H, W
+    against the 8 x 16 patch) vs torch.  Sizes are above the 16384-pixel switch-over so the tiled kernels are the ones
+    that run."""
+    from semivl_amd import ops
+    imgs = b * N
+    assert imgs * H * W >= 16384
+    x1 = rnd(imgs, H, W, C1, dev=dev, seed=51)
+    x2 = rnd(b, H, W, C2, dev=dev, seed=52) if C2 else None
+    w = rnd(Co, C1 + C2, 3, 3, dev=dev, seed=53) * 0.1
+    wf, wd = ops.pack_conv_w(w)
+    y = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, src2=x2.view(-1, C2) if C2 else None,
+                     ld2=C2, C2=C2, rep=N)
+    xin = (x1 if not C2 else torch.cat([x1, x2.repeat_interleave(N, 0)], -1)).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wt = w.clone().requires_grad_(True)
+    ref = F.conv2d(xin, wt, padding=1)
+    close(y.view(imgs, H, W, Co), ref.permute(0, 2, 3, 1), atol=2e-4, what="fwd")
+    dy = rnd(imgs, H, W, Co, dev=dev, seed=54)
+    gx, gw = torch.autograd.grad(ref, [xin, wt], dy.permute(0, 3, 1, 2))
+    dx = ops.conv_dgrad(dy.view(-1, Co), Co, imgs, H, W, Co, wd, C1 + C2, 3, 3, 1, 1)
+    close(dx.view(imgs, H, W, C1 + C2), gx.permute(0, 2, 3, 1), atol=2e-4, what="dgrad")
+    dwf = ops.conv_wgrad(dy.view(-1, Co), Co, x1.view(-1, C1), C1, imgs, H, W, C1, Co, 3, 3, 1, 1,
+                         src2=x2.view(-1, C2) if C2 else None, ld2=C2, C2=C2, rep=N)
+    dw = ops.unpack_conv_wgrad(dwf, Co, C1 + C2, 3, 3)
+    close(dw, gw, atol=3e-5 * math.sqrt(imgs * H * W) * 3, rtol=2e-4, what="wgrad")
+    o1, o2 = (ops.conv_wgrad(dy.view(-1, Co), Co, x1.view(-1, C1), C1, imgs, H, W, C1, Co, 3, 3, 1, 1) for _ in range(2))
+    assert torch.equal(o1, o2), "tiled wgrad must be deterministic"
