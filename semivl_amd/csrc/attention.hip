@@ -402,7 +402,8 @@ __device__ __forceinline__ float dot16(const float* a_lds, const float* row, int
 __device__ __forceinline__ float weighted_rowsum(const float* w, const float* M, long ld, int T, float* red, int tid) {
   const int d = tid & 63, g = tid >> 6;
   float acc = 0.f;
-  for (int j = g; j < T; j += 4) acc += w[j] * M[(long)j * ld + d];
+#pragma unroll 8
+  for (int j = g; j < T; j += 4) acc += w[j] * M[(long)j * ld + d];   // 8 independent row loads in flight
   __syncthreads();
   red[tid] = acc;
   __syncthreads();
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(256) void attn_fwd_rows_kernel(const AttnP p, int r
   if (tid < D) qv[tid] = head[(long)qi * p.ld + tid] * p.scale;
   __syncthreads();
   float mx = -INFINITY;
+#pragma unroll 4
   for (int j0 = 0; j0 < p.T; j0 += 16) {
     const int j = j0 + grp;
     const float sc = dot16(qv, head + p.E + (long)min(j, p.T - 1) * p.ld, sub);
