@@ -176,6 +176,16 @@ def main():
                                                kernel_time_ms=round(t_v * 1e3, 2),
                                                note="algorithmic ViT FLOPs (2866.6 GF x B) / summed duration of the "
                                                     "svl_gemm_f32 + svl_attention_* launches of the encoder regions")
+        # phase split of the MFMA time: launches inside the ViT regions / the VLG head regions / elsewhere
+        gh = [e for e in g if e[4] == "head"]
+        t_h = sum(e0.elapsed_time(e1) for e0, e1, *_ in gh)
+        t_vv = sum(e0.elapsed_time(e1) for e0, e1, *_ in gv)
+        out["phase_ms"] = dict(step=round(ms, 1), vit_encoder_mfma=round(t_vv, 1), vlg_head_mfma=round(t_h, 1),
+                               other_mfma=round(t_gemm * 1e3 - t_vv - t_h, 1),
+                               pixel_loss=round(sum(e0.elapsed_time(e1) for e0, e1, *_ in prof.get("ce_fused", []) +
+                                                    prof.get("softmax_max", [])), 2),
+                               note="HIP-event durations of the timed kernel families in one step; the rest of the step is "
+                                    "normalisation / elementwise / resampling / optimizer passes (profiles/)")
         # largest single launch shapes
         by = {}
         for e0, e1, w, tag, _scope in g:

@@ -153,7 +153,8 @@ class VLGHead(nn.Module):
         if need_grad:
             return _HeadFn.apply(self, (hw, skip0_hw or hw), fp_masks, (fp_rate, fp_range), out_size, text, feats[0],
                                  feats[1], feats[2], *params)
-        return _head_forward(self, (hw, skip0_hw or hw), fp_masks, (fp_rate, fp_range), out_size, text, feats, None)
+        with ops.prof_scope("head"):
+            return _head_forward(self, (hw, skip0_hw or hw), fp_masks, (fp_rate, fp_range), out_size, text, feats, None)
 
     def forward(self, inputs, force_output_pred_masks=False):
         """Reference signature (vlg_head.py:192-251): inputs = [[feature_pyramid, global], text_feats, conv_feats]."""
@@ -372,13 +373,19 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, hw, fp_masks, fp_cfg, out_size, text, v0, v4, emb, *params):
         sv = {}
-        out = _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, [v0, v4, emb], sv)
+        with ops.prof_scope("head"):
+            out = _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, [v0, v4, emb], sv)
         ctx.m, ctx.sv, ctx.params, ctx.hw = m, sv, params, hw
         ctx.feat_req = (v0.requires_grad, v4.requires_grad, emb.requires_grad)
         return out
 
     @staticmethod
     def backward(ctx, dlogits):
+        with ops.prof_scope("head"):
+            return _HeadFn._backward(ctx, dlogits)
+
+    @staticmethod
+    def _backward(ctx, dlogits):
         m, sv = ctx.m, ctx.sv
         b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0 = sv["dims"]
         dev = dlogits.device
