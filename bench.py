@@ -15,8 +15,11 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# the host driver only supports dmabuf IPC: must be in the environment before the HIP/HSA runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
