@@ -19,7 +19,6 @@ semantics themselves remain "parity unpinned" by reference tests
 """
 import math
 
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

@@ -10,7 +10,6 @@ reference.  Parity with the reference is statistical: its PIL chain is reproduce
 against Pillow itself), the random streams are not.
 """
 import ctypes as C
-import math
 import random
 
 import numpy as np

@@ -11,7 +11,6 @@ for the first one), 1x1 convs as plain GEMMs, BatchNorm through `svl_bn_*` (batc
 torch.distributed initialised the [2, C] sum vectors are all-reduced = SyncBN), max pooling through `svl_maxpool3x3s2_*`.
 One `autograd.Function` spans the encoder; weight gradients go to the parameters' `main_grad` sinks when present.
 """
-import math
 import os
 
 import torch

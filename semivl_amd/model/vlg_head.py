@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .vit import TransformerEncoderLayer, sink_grad
+from .vit import TransformerEncoderLayer
 
 
 # ------------------------------------------------------------------------------------------------ parameter containers

@@ -7,7 +7,6 @@ Mirrors (same names / argument meaning):
   semivl.py:123-125,339-345    mmcv param-wise AdamW + poly LR -> FusedAdamW
   semivl.py:139-140            DistributedDataParallel -> GradAllReducer (RCCL all-reduce of the flat grad arena)
 """
-import math
 
 import torch
 import torch.distributed as dist
@@ -87,7 +86,6 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     cutmix_img_(img_s2, b["img_s2_other"], mix2)
     # pseudo labels + MaskCLIP guidance (model.eval(): the side encoder's BatchNorm uses its running statistics here,
     # semivl.py:228-244; nothing else on the path depends on the mode)
-    was_training = model.training
     model.eval()
     with torch.no_grad():
         pred_w_other = model(b["img_w_other"])
@@ -96,7 +94,7 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         mclip_all = model.forward_maskclip(_cat2(img_w, b["img_w_other"]), cfg.get("mcc_conf_thresh", 0.9),
                                            ignore_mask=_cat2i(ign, ign_o))
         mclip, mclip_other = mclip_all[:B], mclip_all[B:]
-    model.train(was_training or True)
+    model.train()          # semivl.py:246: unconditionally back to train mode
     # predictions
     # the feature-perturbed copy of the labeled half (pred_x_fp) is never read by the step (semivl.py:247): only the
     # unlabeled half is perturbed and decoded -> [x, w, w_fp]
