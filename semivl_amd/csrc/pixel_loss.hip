@@ -241,27 +241,40 @@ __global__ void semivl_gscale_kernel(const unsigned long long* counts, double nu
   gscale[4] = (float)(0.125 * f2 / c2);   gscale[5] = (float)(0.25 * lam / numel_u);
   gscale[6] = (float)(0.25 * f3 / c3);    gscale[7] = (float)(0.5 * lam / numel_u);
 }
-// factor = sum over images of (sum_p conf*valid) / (sum_p valid), one block
-__global__ __launch_bounds__(256) void conf_avg_factor_kernel(const float* __restrict__ conf, const int64_t* __restrict__ ign,
-                                                              int B, long HW, double* __restrict__ factor) {
-  __shared__ double sh[2][256];
+// factor = sum over images of (sum_p conf*valid) / (sum_p valid)   (train_utils.py:43-46, conf_mode 'pixelavg')
+// stage 1: grid (CONF_CHUNKS, B), per-(image, chunk) partial sums in double; stage 2: one block, fixed order.
+constexpr int CONF_CHUNKS = 64;
+__global__ __launch_bounds__(256) void conf_avg_partial_kernel(const float* __restrict__ conf, const int64_t* __restrict__ ign,
+                                                               long HW, double* __restrict__ part) {
+  __shared__ double sh[2][4];
+  const int b = blockIdx.y;
+  const long per = (HW + CONF_CHUNKS - 1) / CONF_CHUNKS;
+  const long i0 = (long)blockIdx.x * per, i1 = min(HW, i0 + per);
+  double s = 0.0, c = 0.0;
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+    if (ign[b * HW + i] != 255) { s += (double)conf[b * HW + i]; c += 1.0; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((long)b * CONF_CHUNKS + blockIdx.x) * 2 + 0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    part[((long)b * CONF_CHUNKS + blockIdx.x) * 2 + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  }
+}
+__global__ void conf_avg_final_kernel(const double* __restrict__ part, int B, double* __restrict__ factor) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double tot = 0.0;
   for (int b = 0; b < B; ++b) {
     double s = 0.0, c = 0.0;
-    for (long i = threadIdx.x; i < HW; i += 256) {
-      const bool v = ign[b * HW + i] != 255;
-      if (v) { s += (double)conf[b * HW + i]; c += 1.0; }
+    for (int k = 0; k < CONF_CHUNKS; ++k) {
+      s += part[((long)b * CONF_CHUNKS + k) * 2];
+      c += part[((long)b * CONF_CHUNKS + k) * 2 + 1];
     }
-    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = c;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-      __syncthreads();
-    }
-    tot += sh[0][0] / sh[1][0];
-    __syncthreads();
+    tot += s / c;
   }
-  if (threadIdx.x == 0) factor[0] = tot;
+  factor[0] = tot;
 }
 // sums: double [4 branches][4]; out: float[8] = {loss, loss_x, loss_s1, loss_s2, loss_fp, mc_s1, mc_s2, mc_fp}
 __global__ void semivl_loss_kernel(const double* sums, double numel_u, float lam, const double* factors, float* out) {
@@ -475,8 +488,13 @@ extern "C" int svl_ce_finalize(const float* partials, int64_t nblocks, double* s
 
 extern "C" int svl_conf_avg_factor(const float* conf, const int64_t* ign, int B, int64_t HW, double* factor,
                                    svl_stream_t stream) {
-  SVL_CHECK_ARG(conf && ign && factor && B > 0 && HW > 0, "svl_conf_avg_factor: bad args");
-  hipLaunchKernelGGL(conf_avg_factor_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, conf, ign, B, (long)HW, factor);
+  SVL_CHECK_ARG(conf && ign && factor && B > 0 && B <= 4096 && HW > 0, "svl_conf_avg_factor: bad args");
+  static double* scratch = nullptr;   // [4096][CONF_CHUNKS][2] partial sums (stream-ordered reuse)
+  if (!scratch) SVL_HIP_CHECK(hipMalloc(&scratch, sizeof(double) * 4096 * CONF_CHUNKS * 2));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conf_avg_partial_kernel, dim3(CONF_CHUNKS, B), dim3(256), 0, st, conf, ign, (long)HW, scratch);
+  SVL_LAUNCH_CHECK("svl_conf_avg_factor/partial");
+  hipLaunchKernelGGL(conf_avg_final_kernel, dim3(1), dim3(64), 0, st, scratch, B, factor);
   SVL_LAUNCH_CHECK("svl_conf_avg_factor");
   return SVL_OK;
 }

@@ -337,6 +337,18 @@ class MaskClipVisionTransformer(nn.Module):
     def _trainable(self):
         return [p for p in self.parameters() if p.requires_grad]
 
+    def _pos_resize_matrix(self, hw):
+        """R [hw0*hw1, ph*pw] with resize_pos_embed(pos)[patches] == R @ pos[patches] (cached per target grid/device)."""
+        Pz = self.patch_size
+        ph, pw = self.img_size[0] // Pz, self.img_size[1] // Pz
+        key = (hw, (ph, pw), str(self.pos_embed.device))
+        cache = self.__dict__.setdefault("_pos_R", {})
+        if key not in cache:
+            with torch.no_grad():
+                eye = torch.eye(ph * pw, device=self.pos_embed.device).view(ph * pw, 1, ph, pw)
+                cache[key] = F.interpolate(eye, size=hw, mode="bicubic", align_corners=False).view(ph * pw, -1).t().contiguous()
+        return cache[key]
+
     def forward_tokens(self, img, need_global=False):
         """Returns (feat_tokens list of [B, P, C] tensors, global or None) on the autograd graph."""
         tr = self._trainable()
@@ -345,9 +357,11 @@ class MaskClipVisionTransformer(nn.Module):
         pos_in = None
         if hp * wp + 1 != self.pos_embed.shape[1]:
             # token count differs from the trained grid (e.g. 801 -> 816 -> 51x51 vs 50x50): per-forward bicubic resize
-            # (maskclip_vit.py:447-459).  The 7.7 MB resample stays on torch autograd so pos_embed keeps its gradient.
-            pos_in = self.resize_pos_embed(self.pos_embed, (hp, wp),
-                                           (self.img_size[0] // Pz, self.img_size[1] // Pz))[0].contiguous()
+            # (maskclip_vit.py:447-459).  Bicubic interpolation is a fixed linear map of the patch positions: it is
+            # tabulated once per (grid, grid') pair as a matrix R by pushing the identity through F.interpolate, and every
+            # forward is then one GEMM R @ pos (backward R^T @ d) on the library -- ATen's bicubic kernel takes 6 ms on
+            # this 7.7 MB tensor, 4 x per step.
+            pos_in = _PosResizeFn.apply(self.pos_embed, self._pos_resize_matrix((hp, wp)))
             tr = [p for p in tr if p is not self.pos_embed]
         if torch.is_grad_enabled() and (tr or (pos_in is not None and pos_in.requires_grad)):
             outs = _EncoderFn.apply(self, img, need_global, pos_in, *tr)
@@ -427,6 +441,29 @@ def _encoder_forward(m, img, need_global, saved, pos_in=None):
         gp = ops.linear(c, wproj)
         glob, _ = ops.l2norm_fwd(gp, 0.0)
     return tuple(feats) + (glob,)
+
+
+class _PosResizeFn(torch.autograd.Function):
+    """pos_embed [1, 1 + P, C] -> [1 + P', C] with the patch rows mapped through the tabulated bicubic matrix R [P', P]."""
+
+    @staticmethod
+    def forward(ctx, pos, R):
+        ctx.R = R
+        C = pos.shape[2]
+        out = ops.empty(R.shape[0] + 1, C, device=pos.device)
+        ops.eltwise(4, pos[0, 0].contiguous(), None, out=out[0])
+        ops.matmul_nn(R, pos[0, 1:].contiguous(), out=out[1:])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        R = ctx.R
+        dout = dout.contiguous()
+        C = dout.shape[1]
+        dpos = ops.empty(1, R.shape[1] + 1, C, device=dout.device)
+        ops.eltwise(4, dout[0].contiguous(), None, out=dpos[0, 0])
+        ops.matmul_tn(R, dout[1:], out=dpos[0, 1:])
+        return dpos, None
 
 
 class _EncoderFn(torch.autograd.Function):
