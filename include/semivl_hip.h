@@ -338,6 +338,10 @@ int svl_tap_gather(const float* T, int imgs, int H, int W, int KH, int KW, int d
 int svl_bilinear_nhwc_fwd(const float* x, int64_t ldx, int imgs, int h, int w, int C, int align_corners, int rep,
                           int H, int W, float* y, int64_t ldy, int accumulate, svl_stream_t stream);
 /* dx[imgs,h,w,C] (=|+=) sum over rep and taps of dy. Deterministic gather form. */
+/* out[g][row][c] = sum_{r < rep} src[g * rep + r][row][c]  (src rows `ld` apart, out packed [groups][rows][C]): the
+ * class-repeated skip gradient of vlg_head.py:131-135 summed over its classes before the bilinear backward. */
+int svl_sum_rep_f32(const float* src, int64_t ld, int64_t groups, int rep, int64_t rows, int C, float* out,
+                    svl_stream_t stream);
 int svl_bilinear_nhwc_bwd(const float* dy, int64_t lddy, int imgs, int h, int w, int C, int align_corners, int rep,
                           int H, int W, float* dx, int64_t lddx, int accumulate, svl_stream_t stream);
 /* Bilinear resize of planes: x [planes, h, w] -> y [planes, H, W] (NCHW logits, vlg_head.py:247, builder.py:93-97). */

@@ -77,6 +77,33 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_fwd_kernel(const float* __r
   }
 }
 
+// out[g][row][c] = sum_r src[(g * rep + r)][row][c]: the class-repeated skip gradient summed over its `rep` class-images
+// before the (then small) bilinear backward; lanes run along (row, c), every one of the rep loads is coalesced.
+__global__ __launch_bounds__(256) void sum_rep_kernel(const float* __restrict__ src, long ld, long groups, int rep, long rows,
+                                                      int C, float* __restrict__ out) {
+  const int CQ = C >> 2;
+  const long total = groups * rows * CQ;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CQ) * 4;
+    const long t = i / CQ;
+    const long row = t % rows, g = t / rows;
+    const float* p = src + ((g * rep) * rows + row) * ld + c;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int r = 0;
+    for (; r + 1 < rep; r += 2) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (long)r * rows * ld);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (long)(r + 1) * rows * ld);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    }
+    if (r < rep) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (long)r * rows * ld);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    *reinterpret_cast<float4*>(out + (g * rows + row) * C + c) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  }
+}
+
 __global__ __launch_bounds__(256) void bilinear_nhwc_bwd_kernel(const float* __restrict__ dy, long lddy, int imgs, int h,
                                                                 int w, int C, int align, int rep, int H, int W,
                                                                 float* __restrict__ dx, long lddx, int accumulate) {
@@ -257,6 +284,16 @@ extern "C" int svl_bilinear_nhwc_bwd(const float* dy, int64_t lddy, int imgs, in
   hipLaunchKernelGGL(bilinear_nhwc_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy,
                      imgs, h, w, C, align_corners, rep, H, W, dx, (long)lddx, accumulate);
   SVL_LAUNCH_CHECK("svl_bilinear_nhwc_bwd");
+  return SVL_OK;
+}
+extern "C" int svl_sum_rep_f32(const float* src, int64_t ld, int64_t groups, int rep, int64_t rows, int C, float* out,
+                               svl_stream_t stream) {
+  SVL_CHECK_ARG(src && out && groups > 0 && rep > 0 && rows > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 &&
+                    ((uintptr_t)src & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                "svl_sum_rep_f32: bad args");
+  hipLaunchKernelGGL(sum_rep_kernel, dim3(grid_for(groups * rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, src,
+                     (long)ld, (long)groups, rep, (long)rows, C, out);
+  SVL_LAUNCH_CHECK("svl_sum_rep_f32");
   return SVL_OK;
 }
 extern "C" int svl_bilinear_planes_fwd(const float* x, int64_t planes, int h, int w, int align_corners, int H, int W,

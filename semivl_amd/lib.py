@@ -119,6 +119,7 @@ SIGNATURES = {
     "svl_seqattn_fwd": (_I, [C.POINTER(SeqAttnDesc), _P]),
     "svl_seqattn_bwd": (_I, [C.POINTER(SeqAttnDesc), _P]),
     "svl_bilinear_nhwc_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P]),
+    "svl_sum_rep_f32": (_I, [_P, _L, _L, _I, _L, _I, _P, _P]),
     "svl_bilinear_nhwc_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P]),
     "svl_bilinear_planes_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _P]),
     "svl_bilinear_planes_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _P]),

@@ -539,6 +539,11 @@ def bilinear_nhwc_fwd(x, ldx, imgs, h, w, Cc, align, rep, H, W, y, ldy, accumula
 
 
 def bilinear_nhwc_bwd(dy, lddy, imgs, h, w, Cc, align, rep, H, W, dx, lddx, accumulate=False):
+    if rep > 1 and Cc % 4 == 0 and lddy % 4 == 0:
+        # sum the class repeats first (one coalesced pass), then a rep = 1 backward on the per-image map
+        summed = empty(imgs * H * W, Cc, device=dy.device)
+        L.check(L.load().svl_sum_rep_f32(_p(dy), lddy, imgs, rep, H * W, Cc, _p(summed), _st()), "svl_sum_rep_f32")
+        dy, lddy, rep = summed, Cc, 1
     L.check(L.load().svl_bilinear_nhwc_bwd(_p(dy), lddy, imgs, h, w, Cc, 1 if align else 0, rep, H, W, _p(dx), lddx,
                                            1 if accumulate else 0, _st()), "svl_bilinear_nhwc_bwd")
 
