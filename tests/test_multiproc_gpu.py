@@ -1,6 +1,7 @@
-"""SyncBN exchange of the Cityscapes side encoder across data-parallel ranks: two processes (gloo, sharing the one GPU of
-the test box) each push half of a batch through ResNetV1c; outputs, running statistics and the rank-summed parameter
-gradients must equal a single-process run on the whole batch (= what torch.nn.SyncBatchNorm guarantees)."""
+"""Multi-process checks on the GPU box (two gloo processes sharing its one GPU).  (1) SyncBN exchange of the Cityscapes
+side encoder across data-parallel ranks: the two processes each push half of a batch through ResNetV1c; outputs, running statistics and the rank-summed parameter
+gradients must equal a single-process run on the whole batch (= what torch.nn.SyncBatchNorm guarantees).  (2) One full
+training step through GradAllReducer + FusedAdamW on two ranks."""
 import os
 import sys
 
