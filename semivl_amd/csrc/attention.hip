@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) float Qs[64 * LDP];
   __shared__ __attribute__((aligned(16))) float Os[64 * LDP];
   __shared__ float Ls[64], Ds[64];
