@@ -13,7 +13,7 @@ constexpr int PH = 8, PW = 16, IH = PH + 2, IW = PW + 2, SLAB = 16, XS = SLAB + 
 constexpr int NPIX = IH * IW;  // 180
 
 template <int TN>
-__global__ __launch_bounds__(256) void conv3x3_tiled_kernel(const ConvTiledP p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv3x3_tiled_kernel(const ConvTiledP p, int tiles_x, int tiles_y) {
   constexpr int N = 32 * TN;
   constexpr int XP = (NPIX * 4 + 255) / 256;       // input float4 pieces per thread (3)
   __shared__ float xs[NPIX * XS];
