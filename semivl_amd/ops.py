@@ -165,7 +165,9 @@ def _ksplit_plan(M, N, K):
     bm = 32 if M <= 32 else (64 if M <= 64 else 128)
     bn = 128 if (M <= 64 and N > 64) else (32 if N <= 32 else (64 if N <= 64 else 128))
     tiles = math.ceil(M / bm) * math.ceil(N / bn)
-    s = max(1, min(math.ceil(1024 / tiles), K // 512 if K >= 1024 else 1, 512))
+    # slices so that tiles x slices fills, but does not exceed, ONE round of resident blocks (256 CUs x 3): 36 tiles x 29
+    # slices = 1044 blocks was 1.36 rounds, i.e. a second, mostly idle round
+    s = max(1, min(768 // tiles if tiles <= 768 else 1, K // 512 if K >= 1024 else 1, 512))
     ks = math.ceil(math.ceil(K / s) / 16) * 16
     s = math.ceil(K / ks)
     return s, ks
