@@ -135,7 +135,7 @@ int svl_set_conv_tiled(int on);
  * second concat source (read at image img / rep): slabs[g][co][tap * (C1 + C2) + ci] for g < groups (forward-pack
  * layout per slab); the caller sums the slabs (svl_reduce_slabs_f32).  Replaces the conv2d weight-gradient of
  * vlg_head.py:121-127 (Up.conv) for the layers whose implicit-GEMM form is im2col-address bound.  C1, C2 % 4 == 0, (C1 + C2) % 32 == 0. */
-int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct);
+int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, int Co);
 int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, const float* src1, int64_t ld1, int C1,
                             const float* src2, int64_t ld2, int C2, int rep, int imgs, int H, int W, float* slabs,
                             int groups, svl_stream_t stream);

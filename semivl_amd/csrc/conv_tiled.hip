@@ -165,7 +165,7 @@ struct WgradTiledP {
 };
 
 template <int MT, int SL>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_tiled_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3 : 2))) void conv3x3_wgrad_tiled_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
   constexpr int Co = 32 * MT;
   constexpr int NCOL = 9 * SL, NT = (NCOL + 31) / 32, TILES = MT * NT, TPW = (TILES + 3) / 4;
   constexpr int DP = (128 * Co / 4 + 255) / 256, XP = (NPIX * SL / 4 + 255) / 256;
@@ -287,10 +287,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tiled_kernel(const WgradTil
 
 }  // namespace
 
-extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct) {
+extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, int Co) {
   const long npatch = (long)imgs * ((H + PH - 1) / PH) * ((W + PW - 1) / PW);
   const int nslab = Ct / 32;
-  long g = 768 / (nslab < 1 ? 1 : nslab);
+  // measured: Co = 64 is best with one full round of its 2 resident blocks per CU, Co = 32 with 1.5x that
+  long g = (Co > 32 ? 512 : 768) / (nslab < 1 ? 1 : nslab);
   if (g < 1) g = 1;
   if (g > npatch) g = npatch;
   return (int)g;

@@ -64,7 +64,7 @@ SIGNATURES = {
     "svl_set_gemm_emulation": (_I, [_I]),
     "svl_get_gemm_emulation": (_I, []),
     "svl_set_conv_tiled": (_I, [_I]),
-    "svl_conv3x3_wgrad_tiled_groups": (_I, [_I, _I, _I, _I]),
+    "svl_conv3x3_wgrad_tiled_groups": (_I, [_I, _I, _I, _I, _I]),
     "svl_conv3x3_wgrad_tiled": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _P]),
     "svl_reduce_slabs_f32": (_I, [_P, _P, _I, _L, _I, _P]),
     "svl_softmax_max_f32": (_I, [_P, _I, _I, _L, _P, _P, _P]),

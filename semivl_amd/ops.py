@@ -449,7 +449,7 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
             (C2 == 0 or ld2 % 4 == 0)):
         # narrow layers: spatially tiled weight-gradient kernel (conv_tiled.hip), slabs reduced in fixed order
         lib = L.load()
-        groups = lib.svl_conv3x3_wgrad_tiled_groups(imgs, H, W, C1 + C2)
+        groups = lib.svl_conv3x3_wgrad_tiled_groups(imgs, H, W, C1 + C2, Co)
         slabs = empty(groups, Co, N, device=dy.device)
         e0 = _prof_begin()
         L.check(lib.svl_conv3x3_wgrad_tiled(_p(dy), lddy, Co, _p(x), ldx, C1, _p(src2), ld2, C2, rep, imgs, H, W,
