@@ -161,13 +161,16 @@ def matmul_nn(a, b, out=None, accumulate=False, dact=ACT_NONE, z=None):
     return out
 
 
-def _ksplit_plan(M, N, K):
+def _ksplit_plan(M, N, K, dense=False):
     bm = 32 if M <= 32 else (64 if M <= 64 else 128)
     bn = 128 if (M <= 64 and N > 64) else (32 if N <= 32 else (64 if N <= 64 else 128))
     tiles = math.ceil(M / bm) * math.ceil(N / bn)
+    slots = 768
+    if dense and M >= 256 and N >= 96 and get_gemm_emulation():
+        tiles, slots = math.ceil(M / 128) * math.ceil(N / 128), 512   # the emulated kernel keeps 2 blocks per CU
     # slices so that tiles x slices fills, but does not exceed, ONE round of resident blocks (256 CUs x 3): 36 tiles x 29
     # slices = 1044 blocks was 1.36 rounds, i.e. a second, mostly idle round
-    s = max(1, min(768 // tiles if tiles <= 768 else 1, K // 512 if K >= 1024 else 1, 512))
+    s = max(1, min(slots // tiles if tiles <= slots else 1, K // 512 if K >= 1024 else 1, 512))
     ks = math.ceil(math.ceil(K / s) / 16) * 16
     s = math.ceil(K / ks)
     return s, ks
@@ -182,7 +185,7 @@ def matmul_tn(a, b, out=None, accumulate=False):
         out = empty(M, N, device=a.device)
         accumulate = False
     assert out.is_contiguous()
-    s, ks = _ksplit_plan(M, N, K)
+    s, ks = _ksplit_plan(M, N, K, dense=True)
     if s == 1:
         gemm(A_MC, B_NC, M, N, K, Op(a, a.stride(0)), Op(b, b.stride(0)), out, accumulate=accumulate)
         return out
