@@ -97,10 +97,15 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     model.train()          # semivl.py:246: unconditionally back to train mode
     # predictions
     # the feature-perturbed copy of the labeled half (pred_x_fp) is never read by the step (semivl.py:247): only the
-    # unlabeled half is perturbed and decoded -> [x, w, w_fp]
-    preds4 = model(_cat2(img_x, img_w), need_fp=True, fp_masks=fp_masks, split_fp=False, fp_range=(B, 2 * B))
+    # unlabeled half is perturbed and decoded.  The batch is ordered [w, x] (the reference: [x, w]; every op is
+    # per-sample or a permutation-invariant batch statistic) so that the decoded batch is [w, x, w_fp]: the two
+    # gradient-carrying thirds are CONTIGUOUS and the head's backward runs once on 2B samples (full grid rounds)
+    # instead of twice on B.
+    if fp_masks is not None:   # injected masks come in the reference's [x, w] row order
+        fp_masks = [torch.cat((m_[B:2 * B], m_[:B])) for m_ in fp_masks]
+    preds4 = model(_cat2(img_w, img_x), need_fp=True, fp_masks=fp_masks, split_fp=False, fp_range=(0, B))
     preds_s = model(_cat2(img_s1, img_s2))                                                 # [s1, s2]
-    pred_x, pred_w, pred_w_fp = preds4[:B], preds4[B:2 * B], preds4[2 * B:]
+    pred_w, pred_x, pred_w_fp = preds4[:B], preds4[B:2 * B], preds4[2 * B:]
     pred_s1, pred_s2 = preds_s[:B], preds_s[B:]
     conf_w, mask_w = ops.softmax_max(pred_w.detach())
     # CutMix labels
@@ -124,9 +129,9 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     thr = cfg["conf_thresh"]
     dl4 = torch.empty_like(preds4)
     dls = torch.empty_like(preds_s)
-    ops.fill(dl4[B:2 * B], 0.0)  # pred_w is detached (semivl.py:251)
+    ops.fill(dl4[:B], 0.0)  # pred_w is detached (semivl.py:251)
     sums = ops.empty(4, 4, dtype=torch.float64, device=dev)
-    ops.ce_fused(pred_x.detach(), mask_x, True, dlogits=dl4[:B], gscale=gscale[0], sums_out=sums[0])
+    ops.ce_fused(pred_x.detach(), mask_x, True, dlogits=dl4[B:2 * B], gscale=gscale[0], sums_out=sums[0])
     ops.ce_fused(pred_s1.detach(), mw1, False, conf=cw1, ign=ig1, conf_thresh=thr, mc=mc1, dlogits=dls[:B],
                  gscale=gscale[1], sums_out=sums[1], all_pixels=pixelavg)
     ops.ce_fused(pred_s2.detach(), mw2, False, conf=cw2, ign=ig2, conf_thresh=thr, mc=mc2, dlogits=dls[B:],
@@ -141,7 +146,7 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     # pred_w carries exactly-zero dlogits: let the head's backward skip those samples (results identical)
     head = getattr(model, "decode_head", None)
     if head is not None:
-        head._bwd_ranges = {3 * B: [(0, B), (2 * B, 3 * B)]}
+        head._bwd_ranges = {3 * B: [(B, 3 * B)]}
     try:
         torch.autograd.backward([preds4, preds_s], [dl4, dls])
     finally:
