@@ -29,14 +29,22 @@ def get_class_to_concept_idxs(save_path):
     raise ValueError(save_path)
 
 
+_OFFS_CACHE = {}
+
+
 def concept_offsets(class_to_concept_idxs, device):
-    """int32 prefix offsets [N+1] for svl_concept_max_f32 (concepts of a class are contiguous channels)."""
+    """int32 prefix offsets [N+1] for svl_concept_max_f32 (concepts of a class are contiguous channels).  Cached per
+    (concept counts, device): building the tensor is a synchronous host-to-device copy, once per step otherwise."""
+    key = (tuple(len(class_to_concept_idxs[i]) for i in range(len(class_to_concept_idxs))), str(device))
+    if key in _OFFS_CACHE:
+        return _OFFS_CACHE[key]
     offs = [0]
     for i in range(len(class_to_concept_idxs)):
         idx = class_to_concept_idxs[i]
         assert idx == list(range(offs[-1], offs[-1] + len(idx))), "concept channels must be contiguous per class"
         offs.append(offs[-1] + len(idx))
-    return torch.tensor(offs, dtype=torch.int32, device=device)
+    _OFFS_CACHE[key] = torch.tensor(offs, dtype=torch.int32, device=device)
+    return _OFFS_CACHE[key]
 
 
 def aggregate_concept_predictions(pred, class_to_concept_idxs):
