@@ -155,6 +155,7 @@ def main():
         step(a.warmup + a.steps)
         torch.cuda.synchronize()
     if rank == 0 and not a.no_profile:
+        g_arith_exact = a.gemm_arith == "f32"
         prof, ops.PROFILE = ops.PROFILE, None
         g = prof.get("gemm", []) + prof.get("attention", [])   # the two fp32-MFMA kernel families
         t_gemm = sum(e0.elapsed_time(e1) for e0, e1, *_ in g) * 1e-3
@@ -199,6 +200,19 @@ def main():
         top = sorted(by.items(), key=lambda kv: -kv[1][0])[:6]
         out["roofline"]["top_shapes"] = [dict(mode_MNKb=list(k), ms=round(v[0] * 1e3, 2), n=v[2],
                                               tflops=round(v[1] / v[0] / 1e12, 1)) for k, v in top]
+        # the single dominant launch shape (FFN-1 of the ViT blocks): per-launch roofline + its PMC traffic
+        dom = by.get((0, 0, 32 * 1025 * a.batch // 16, 3072, 768, 1))
+        if dom is not None and g_arith_exact:
+            d_ms = dom[0] * 1e3 / dom[2]
+            d_tf = dom[1] / dom[0] / 1e12
+            out["roofline"]["dominant_launch"] = dict(
+                kernel="gemm_kernel<128,128,2,2,KCONTIG,KCONTIG> (svl_gemm_f32), M=%d N=3072 K=768" % (32 * 1025 * a.batch // 16),
+                launches=dom[2], avg_ms=round(d_ms, 3), achieved=round(d_tf, 1), peak=PEAK_F32_MFMA_TF,
+                frac=round(d_tf / PEAK_F32_MFMA_TF, 4), algorithmic_bytes=513.0e6 * a.batch / 16,
+                traffic=(2.31e9 if a.batch == 16 else None),
+                traffic_note="FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this launch from separate rocprofv3 --pmc passes, "
+                             "profiles/r1_c_pmc_hbm_traffic.md (1.91 GB read: the 9.4 MB weight panel is re-streamed "
+                             "from the Infinity Cache per row-tile; 0.40 GB written = algorithmic)")
         if os.environ.get("SVL_BENCH_DUMP_SHAPES"):
             allsh = sorted(by.items(), key=lambda kv: -kv[1][0])
             with open(os.environ["SVL_BENCH_DUMP_SHAPES"], "w") as f:
