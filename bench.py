@@ -209,10 +209,10 @@ def main():
                 kernel="gemm_kernel<128,128,2,2,KCONTIG,KCONTIG> (svl_gemm_f32), M=%d N=3072 K=768" % (32 * 1025 * a.batch // 16),
                 launches=dom[2], avg_ms=round(d_ms, 3), achieved=round(d_tf, 1), peak=PEAK_F32_MFMA_TF,
                 frac=round(d_tf / PEAK_F32_MFMA_TF, 4), algorithmic_bytes=513.0e6 * a.batch / 16,
-                traffic=(2.31e9 if a.batch == 16 else None),
+                traffic=(1.27e9 if a.batch == 16 else None),
                 traffic_note="FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this launch from separate rocprofv3 --pmc passes, "
-                             "profiles/r1_c_pmc_hbm_traffic.md (1.91 GB read: the 9.4 MB weight panel is re-streamed "
-                             "from the Infinity Cache per row-tile; 0.40 GB written = algorithmic)")
+                             "profiles/r1_l_pmc_gemm_traffic.md (0.87 GB read with the banded tile order, 1.89 GB before it "
+                             "-- operands 0.11 GB; 0.40 GB written = algorithmic)")
         if os.environ.get("SVL_BENCH_DUMP_SHAPES"):
             allsh = sorted(by.items(), key=lambda kv: -kv[1][0])
             with open(os.environ["SVL_BENCH_DUMP_SHAPES"], "w") as f:
