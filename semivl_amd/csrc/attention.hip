@@ -20,7 +20,13 @@
 namespace {
 
 constexpr int D = 64;
-constexpr int LDP = D + 1;  // padded LDS row for row-varying (A-operand style) reads
+constexpr int LDP = D + 4;  // padded LDS row: 16-byte aligned rows, conflict-free for b128 (A-style) and b32 (B-style) reads
+constexpr float RESCALE_LOG2 = 8.f;
+constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+
+// exp(x - m) as one fma + v_exp_f32: 2^(x * log2(e) - m2) with m2 = m * log2(e) rounded ONCE per row, so every
+// probability of a row (and the running rescale factor) refers to the same m2 and the rounding cancels in p / l.
+__device__ __forceinline__ float exp_sub2(float x, float m2) { return __builtin_amdgcn_exp2f(fmaf(x, LOG2E, -m2)); }
 
 struct AttnP {
   const float* qkv;
@@ -52,10 +58,26 @@ __device__ __forceinline__ void tile_sstore(float* S, const float4 (&rg)[4], int
   for (int p = 0; p < 4; ++p) {
     const int f = tid + 256 * p;
     const int row = f >> 4, c = (f & 15) << 2;
-    float* d = S + row * LD + c;
-    d[0] = rg[p].x * mul; d[1] = rg[p].y * mul; d[2] = rg[p].z * mul; d[3] = rg[p].w * mul;
+    *reinterpret_cast<float4*>(S + row * LD + c) = make_float4(rg[p].x * mul, rg[p].y * mul, rg[p].z * mul, rg[p].w * mul);
   }
 }
+
+// A-operand row of an LDS tile / a register-resident partner row.  The 64-long dot product is taken in the k order
+// (lane >> 5) * 32 + s  (s = MFMA step): each lane's 32 values are then CONTIGUOUS, so they move as 8 ds_read_b128
+// (or global dwordx4) instead of 32 scalar reads; both operands use the same order, which is all a dot product needs.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void row_gload32(float (&r)[32], const float* p, float mul) {
+#pragma unroll
+  for (int s4 = 0; s4 < 8; ++s4) {
+    const float4 v = ld4(p + 4 * s4);
+    r[4 * s4] = v.x * mul; r[4 * s4 + 1] = v.y * mul; r[4 * s4 + 2] = v.z * mul; r[4 * s4 + 3] = v.w * mul;
+  }
+}
+#define MFMA4(acc, a4, breg, s4)                                                   \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a4).x, breg[4 * (s4)], acc, 0, 0, 0);     \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a4).y, breg[4 * (s4) + 1], acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a4).z, breg[4 * (s4) + 2], acc, 0, 0, 0); \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a4).w, breg[4 * (s4) + 3], acc, 0, 0, 0);
 
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
@@ -68,15 +90,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
   const bool wave_active = q0 < p.T;
   const float* head = p.qkv + (long)b * p.T * p.ld + h * D;  // q slice; k at +E, v at +2E
   float q[32];
-  {
-    const float* qr = head + (long)min(qi, p.T - 1) * p.ld + hi;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) q[s] = qr[2 * s] * p.scale;
-  }
+  row_gload32(q, head + (long)min(qi, p.T - 1) * p.ld + hi * 32, p.scale);
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m = -INFINITY, l = 0.f;
+  float m2 = -INFINITY, l = 0.f;  // m2 = (reference max of the row) * log2(e)
   const int nkt = (p.T + 63) >> 6;
   float4 rk[4], rv[4];
   tile_gload(rk, head + p.E, p.ld, 0, p.T, tid);
@@ -97,42 +115,63 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-      const float* ka = Ks + l31 * LDP + hi;
+      const float* ka = Ks + l31 * LDP + hi * 32;
       const int j0 = kt * 64;
       const bool two = p.T - j0 > 32;  // keys 32..63 of this tile exist
       if (two) {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-          const float a0 = ka[2 * s], a1 = ka[32 * LDP + 2 * s];
-          s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q[s], s0, 0, 0, 0);
-          s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q[s], s1, 0, 0, 0);
+        for (int s4 = 0; s4 < 8; ++s4) {
+          const float4 a0 = ld4(ka + 4 * s4), a1 = ld4(ka + 32 * LDP + 4 * s4);
+          s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, q[4 * s4], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, q[4 * s4], s1, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, q[4 * s4 + 1], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, q[4 * s4 + 1], s1, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, q[4 * s4 + 2], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, q[4 * s4 + 2], s1, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, q[4 * s4 + 3], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, q[4 * s4 + 3], s1, 0, 0, 0);
         }
       } else {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], q[s], s0, 0, 0, 0);
+        for (int s4 = 0; s4 < 8; ++s4) {
+          const float4 a0 = ld4(ka + 4 * s4);
+          MFMA4(s0, a0, q, s4)
+        }
       }
-      float mloc = -INFINITY;
+      if (j0 + 64 > p.T) {  // only the last key tile is ragged
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = j0 + crow(r, hi);
-        if (key >= p.T) s0[r] = -INFINITY;
-        if (key + 32 >= p.T) s1[r] = -INFINITY;
-        mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
+        for (int r = 0; r < 16; ++r) {
+          const int key = j0 + crow(r, hi);
+          if (key >= p.T) s0[r] = -INFINITY;
+          if (key + 32 >= p.T) s1[r] = -INFINITY;
+        }
       }
+      float mloc = fmaxf(s0[0], s1[0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      const float mnew = fmaxf(m, mloc);
-      const float alpha = expf(m - mnew);
+      // Lazy rescale: the running max m is only raised when a row's tile max exceeds it by more than 2^RESCALE_LOG2
+      // (probabilities then stay below that bound, far inside fp32 range), so the accumulator rescale - 96 VALU
+      // instructions per tile - runs for the first tile and almost never again.  Exact: out = o / l and
+      // lse = m + log(l) hold for ANY per-row reference m.
+      const float mloc2 = mloc * LOG2E;
+      const bool raise = mloc2 > m2 + RESCALE_LOG2;
+      if (__any(raise)) {
+        const float mnew2 = raise ? mloc2 : m2;
+        const float alpha = __builtin_amdgcn_exp2f(m2 - mnew2);
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        m2 = mnew2;
+      }
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s0[r] = expf(s0[r] - mnew);
-        s1[r] = expf(s1[r] - mnew);
+        s0[r] = exp_sub2(s0[r], m2);
+        s1[r] = exp_sub2(s1[r], m2);
         sum += s0[r] + s1[r];
       }
-      l = l * alpha + sum;
-      m = mnew;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      l += sum;
       if (two) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -174,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
       *reinterpret_cast<float4*>(orow + 32 + d0) =
           make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
     }
-    if (p.lse && hi == 0) p.lse[(long)z * p.T + qi] = m + logf(lt);
+    if (p.lse && hi == 0) p.lse[(long)z * p.T + qi] = (m2 + __log2f(lt)) * LN2;
   } else if (wave_active) {
     (void)__shfl_xor(l, 32, 64);
   }
@@ -216,9 +255,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* dhead = p.dout + (long)b * p.T * p.E + h * D;
   float kreg[32], vreg[32];
   {
-    const float* kr = head + p.E + (long)min(kj, p.T - 1) * p.ld + hi;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) { kreg[s] = kr[2 * s]; vreg[s] = kr[p.E + 2 * s]; }
+    const float* kr = head + p.E + (long)min(kj, p.T - 1) * p.ld + hi * 32;
+    row_gload32(kreg, kr, 1.f);
+    row_gload32(vreg, kr + p.E, 1.f);
   }
   f32x16 dv0, dv1, dk0, dk1;
 #pragma unroll
@@ -231,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     tile_gload(ro, dhead, p.E, qt * 64, p.T, tid);
     if (tid < 64) {
       const int qi = qt * 64 + tid;
-      ln = (qi < p.T) ? p.lse[(long)z * p.T + qi] : INFINITY;  // exp(s - inf) = 0 for padded queries
+      ln = (qi < p.T) ? p.lse[(long)z * p.T + qi] * LOG2E : INFINITY;  // 2^(s - inf) = 0 for padded queries
       dn = (qi < p.T) ? p.dsum[(long)z * p.T + qi] : 0.f;
     }
   };
@@ -252,17 +291,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x16 sa, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
-        const float* qa = Qs + (it * 32 + l31) * LDP + hi;
-        const float* oa = Os + (it * 32 + l31) * LDP + hi;
+        const float* qa = Qs + (it * 32 + l31) * LDP + hi * 32;
+        const float* oa = Os + (it * 32 + l31) * LDP + hi * 32;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * s], kreg[s], sa, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[2 * s], vreg[s], dp, 0, 0, 0);
+        for (int s4 = 0; s4 < 8; ++s4) {
+          const float4 a0 = ld4(qa + 4 * s4), a1 = ld4(oa + 4 * s4);
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, kreg[4 * s4], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, vreg[4 * s4], dp, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, kreg[4 * s4 + 1], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, vreg[4 * s4 + 1], dp, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, kreg[4 * s4 + 2], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, vreg[4 * s4 + 2], dp, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, kreg[4 * s4 + 3], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, vreg[4 * s4 + 3], dp, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int qi = it * 32 + crow(r, hi);
-          const float pv = key_ok ? expf(sa[r] - Ls[qi]) : 0.f;
+          const float pv = key_ok ? exp_sub2(sa[r], Ls[qi]) : 0.f;
           sa[r] = pv;
           dp[r] = pv * (dp[r] - Ds[qi]);
         }
@@ -314,12 +360,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
   float qreg[32], oreg[32];
   {
     const int qc = min(qi, p.T - 1);
-    const float* qr = head + (long)qc * p.ld + hi;
-    const float* orr = dhead + (long)qc * p.E + hi;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) { qreg[s] = qr[2 * s] * p.scale; oreg[s] = orr[2 * s]; }
+    row_gload32(qreg, head + (long)qc * p.ld + hi * 32, p.scale);
+    row_gload32(oreg, dhead + (long)qc * p.E + hi * 32, 1.f);
   }
-  const float lse_i = p.lse[(long)z * p.T + min(qi, p.T - 1)];
+  const float lse2_i = p.lse[(long)z * p.T + min(qi, p.T - 1)] * LOG2E;
   const float d_i = p.dsum[(long)z * p.T + min(qi, p.T - 1)];
   f32x16 dq0, dq1;
 #pragma unroll
@@ -343,19 +387,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
         f32x16 sa, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
-        const float* ka = Ks + (jt * 32 + l31) * LDP + hi;
-        const float* va = Vs + (jt * 32 + l31) * LDP + hi;
+        const float* ka = Ks + (jt * 32 + l31) * LDP + hi * 32;
+        const float* va = Vs + (jt * 32 + l31) * LDP + hi * 32;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qreg[s], sa, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * s], oreg[s], dp, 0, 0, 0);
+        for (int s4 = 0; s4 < 8; ++s4) {
+          const float4 a0 = ld4(ka + 4 * s4), a1 = ld4(va + 4 * s4);
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, qreg[4 * s4], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, oreg[4 * s4], dp, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, qreg[4 * s4 + 1], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, oreg[4 * s4 + 1], dp, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, qreg[4 * s4 + 2], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, oreg[4 * s4 + 2], dp, 0, 0, 0);
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, qreg[4 * s4 + 3], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, oreg[4 * s4 + 3], dp, 0, 0, 0);
+        }
+        if (kt * 64 + jt * 32 + 32 > p.T) {  // ragged last half-tile
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * 64 + jt * 32 + crow(r, hi) >= p.T) sa[r] = -INFINITY;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * 64 + jt * 32 + crow(r, hi);
-          const float pv = (key < p.T) ? expf(sa[r] - lse_i) : 0.f;
-          dp[r] = pv * (dp[r] - d_i);
-        }
+        for (int r = 0; r < 16; ++r) dp[r] = exp_sub2(sa[r], lse2_i) * (dp[r] - d_i);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float* kb = Ks + (jt * 32 + crow(r, hi)) * LDP + l31;
