@@ -197,6 +197,10 @@ def main():
             r[0] += e0.elapsed_time(e1) * 1e-3
             r[1] += w
             r[2] += 1
+        if os.environ.get("SVL_BENCH_SHAPES"):  # every launch shape of the step, for tuning (tools/README.md)
+            with open(os.environ["SVL_BENCH_SHAPES"], "w") as f:
+                for k, v in sorted(by.items(), key=lambda kv: -kv[1][0]):
+                    f.write("%-44s n=%3d  %8.2f ms  %6.1f TF\n" % (k, v[2], v[0] * 1e3, v[1] / v[0] / 1e12))
         top = sorted(by.items(), key=lambda kv: -kv[1][0])[:6]
         out["roofline"]["top_shapes"] = [dict(mode_MNKb=list(k), ms=round(v[0] * 1e3, 2), n=v[2],
                                               tflops=round(v[1] / v[0] / 1e12, 1)) for k, v in top]

@@ -584,6 +584,140 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Short-K dense GEMM (K = 64 / 128, millions of rows): the per-pixel linears and 1x1 convolutions of the VLG head
+// ([B*N*64*64, 64] x [192, 64]^T ...).  They are HBM-bound streams (12-50 flop/B), but a tile of the general kernel
+// lives for only K/16 = 4-8 pipeline steps, so its load -> LDS -> MFMA -> store chain never overlaps with itself and the
+// launch runs at ~1 TB/s.  Here the B panel (a <= 192-column chunk, all of K) is staged in LDS ONCE per block, every
+// WAVE then streams its own 32-row blocks of A straight from global memory into MFMA A-operand registers (k order
+// (lane >> 5) * 32 + s, see attention.hip: 8 x dwordx4 per lane, no LDS, no block barrier in the loop) with the next
+// block's loads in flight under the current block's MFMAs, and writes its 32 x chunk outputs through the shared epilogue.
+template <int TN, bool FAST_EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_shortk_kernel(const GemmP p, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float Bs[];  // [TN * 32][K + 4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int LDB = p.K + 4;
+  const int chunk = blockIdx.x % nchunk, grp = blockIdx.x / nchunk, ngrp = gridDim.x / nchunk;
+  const int n0 = chunk * TN * 32;
+  {  // stage B rows n0 .. n0 + 32 TN (rows beyond N are zero)
+    const int k4 = p.K >> 2;
+    for (int f = tid; f < TN * 32 * k4; f += 256) {
+      const int row = f / k4, c = (f - row * k4) << 2;
+      const int n = n0 + row;
+      const float4 v = n < p.N ? *reinterpret_cast<const float4*>(p.B.p + (long)n * p.B.ld + c) : zero4();
+      *reinterpret_cast<float4*>(Bs + row * LDB + c) = v;
+    }
+  }
+  __syncthreads();
+  const int nkc = p.K >> 6;                       // 64-deep K chunks
+  const long nrb = ((long)p.M + 31) >> 5;         // 32-row blocks
+  const long total = nrb * nkc;                   // work items of this wave: it = (row block, k chunk), k fastest
+  const long wstride = (long)ngrp * 4;
+  long rb = (long)grp * 4 + wave;
+  int kc = 0;
+  float a[32], an[32];
+  auto a_load = [&](float (&dst)[32], long rbi, int kci) {
+    const long row = min(rbi * 32 + l31, (long)p.M - 1);
+    const float* src = p.A.p + row * p.A.ld + kci * 64 + hi * 32;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + 4 * s4);
+      dst[4 * s4] = v.x; dst[4 * s4 + 1] = v.y; dst[4 * s4 + 2] = v.z; dst[4 * s4 + 3] = v.w;
+    }
+  };
+  (void)total;
+  if (rb < nrb) a_load(a, rb, 0);
+  f32x16 acc[1][TN];
+  while (rb < nrb) {
+    // next work item of this wave
+    long rbn = rb;
+    int kcn = kc + 1;
+    if (kcn == nkc) { kcn = 0; rbn = rb + wstride; }
+    if (rbn < nrb) a_load(an, rbn, kcn);
+    if (kc == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    }
+    const float* bp = Bs + l31 * LDB + kc * 64 + hi * 32;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+      float4 b[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(bp + j * 32 * LDB + 4 * s4);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4], b[j].x, acc[0][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 1], b[j].y, acc[0][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 2], b[j].z, acc[0][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * s4 + 3], b[j].w, acc[0][j], 0, 0, 0);
+    }
+    if (kc == nkc - 1) {
+      const int m0 = (int)(rb * 32);
+      if constexpr (FAST_EPI) {
+        // Separable output address  C + rowoff(m) + coloff(n)  (row-major, or the ConvTranspose2d k2 s2 scatter
+        // m = (img, h, w), n = (a, b, co) -> pixel (img, 2h + a, 2w + b)); optional bias / ReLU / GELU.
+        const bool ct = p.out_mode == SVL_OUT_CONVT2X;
+        int coloff[TN];
+        float bv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + j * 32 + l31;
+          const int nc = min(n, p.N - 1);
+          bv[j] = p.bias ? p.bias[p.bias_mod > 0 ? (nc % p.bias_mod) : nc] : 0.f;
+          if (ct) {
+            const int ab = nc / p.ct_Cout, co = nc - ab * p.ct_Cout;
+            coloff[j] = (int)((((ab >> 1) * 2 * p.ct_W) + (ab & 1)) * p.ldc_m) + co;
+          } else {
+            coloff[j] = n;
+          }
+        }
+        int w0 = 0, h0 = 0, i0 = 0;
+        if (ct) {
+          const int mm = m0 + 4 * hi;
+          w0 = mm % p.ct_W;
+          const int t = mm / p.ct_W;
+          h0 = t % p.ct_H;
+          i0 = t / p.ct_H;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const int m = m0 + 4 * hi + c;
+          if (m < p.M) {
+            long rowoff;
+            if (ct) {
+              int ww = w0 + c, hh = h0, ii = i0;
+              while (ww >= p.ct_W) { ww -= p.ct_W; ++hh; }
+              while (hh >= p.ct_H) { hh -= p.ct_H; ++ii; }
+              rowoff = ((((long)ii * (2 * p.ct_H) + 2 * hh) * (2 * p.ct_W)) + 2 * ww) * p.ldc_m;
+            } else {
+              rowoff = (long)m * p.ldc_m;
+            }
+            float* rowp = p.C + rowoff;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              float v = acc[0][j][r] * p.alpha + bv[j];
+              if (p.act == SVL_ACT_GELU) v = gelu_erf(v);
+              else if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
+              if (n0 + j * 32 + l31 < p.N) rowp[coloff[j]] = v;
+            }
+          }
+        }
+      } else {
+        gemm_epilogue<1, TN, 32, TN * 32>(p, acc, m0, n0, 0, 0, l31, hi, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) a[s] = an[s];
+    rb = rbn;
+    kc = kcn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // fp32-accurate GEMM on the bf16 matrix pipe (split emulation).  Each fp32 operand element x is written as a sum of
 // NS bf16 terms (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)); products of bf16 terms are exact in the fp32
 // accumulator, so keeping the NS(NS+1)/2 leading cross terms gives 16 (NS=2: 3 MFMAs) or 24 (NS=3: 6 MFMAs) mantissa
@@ -931,6 +1065,46 @@ int launch_mode(const GemmP& p, int batch, hipStream_t st) {
   return launch_cfg<128, 128, 2, 2, AMODE, BMODE>(p, batch, st);
 }
 
+// Short-K stream kernel launch: column chunk width 32 * TN chosen to waste the fewest MFMA columns with the B chunk
+// (all of K) inside 80 KB of LDS (two blocks per CU); the grid is one resident set of blocks, persistent over rows.
+template <int TN>
+int launch_shortk_tn(const GemmP& p, bool fast, hipStream_t st) {
+  const int nchunk = (p.N + 32 * TN - 1) / (32 * TN);
+  const size_t lds = (size_t)TN * 32 * (p.K + 4) * sizeof(float);
+  const long nrb4 = (((long)p.M + 31) / 32 + 3) / 4;
+  long ngrp = 512 / nchunk;
+  if (ngrp < 1) ngrp = 1;
+  if (ngrp > nrb4) ngrp = nrb4;
+  auto go = [&](auto kern) -> int {
+    static bool attr_set = false;  // one flag per instantiation (the lambda's closure type is per call site + kern type)
+    if (!attr_set) {
+      SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        96 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ngrp * nchunk)), dim3(256), lds, st, p, nchunk);
+    SVL_LAUNCH_CHECK("svl_gemm_f32/shortk");
+    return SVL_OK;
+  };
+  return fast ? go(gemm_shortk_kernel<TN, true>) : go(gemm_shortk_kernel<TN, false>);
+}
+int launch_shortk(const GemmP& p, bool fast, hipStream_t st) {
+  int best = 0, best_cost = 1 << 30;
+  for (int tn : {6, 5, 4, 2}) {
+    if ((size_t)tn * 32 * (p.K + 4) * sizeof(float) > 80 * 1024) continue;
+    const int cost = ((p.N + 32 * tn - 1) / (32 * tn)) * tn;
+    if (cost < best_cost) { best_cost = cost; best = tn; }
+  }
+  switch (best) {
+    case 6: return launch_shortk_tn<6>(p, fast, st);
+    case 5: return launch_shortk_tn<5>(p, fast, st);
+    case 4: return launch_shortk_tn<4>(p, fast, st);
+    case 2: return launch_shortk_tn<2>(p, fast, st);
+  }
+  svl_set_error("svl_gemm_f32: no short-K configuration for K=%d", p.K);
+  return SVL_ERR_UNSUPPORTED;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -1027,6 +1201,22 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     svl_set_error("svl_gemm_f32: unsupported mode combination a=%d b=%d", am, bm);
     return SVL_ERR_UNSUPPORTED;
   };
+
+  // Short-K row streams (per-pixel linears / 1x1 convolutions of the head): dedicated persistent kernel
+  static int shortk = -1;
+  if (shortk < 0) shortk = getenv("SVL_GEMM_NO_SHORTK") ? 0 : 1;
+  {
+    const bool a_dense = am == SVL_A_KCONTIG ||
+                         (a_conv && cv.KH == 1 && cv.KW == 1 && cv.pad == 0 && p.cv.stride == 1 && cv.C2 == 0 &&
+                          p.cv.Ho == cv.H && p.cv.Wo == cv.W);
+    if (shortk && a_dense && bm == SVL_B_KCONTIG && d->batch == 1 && d->ksplit == 0 && d->K % 64 == 0 && d->K >= 64 &&
+        d->K <= 128 && d->M >= 32768 && d->N >= 96 && p.A.vec && p.B.vec &&
+        (d->out_mode == SVL_OUT_STRIDED || d->out_mode == SVL_OUT_CONVT2X)) {
+      const bool fast = (d->ldc_n == 1 || d->out_mode == SVL_OUT_CONVT2X) && !d->resid && !d->preact && !d->accumulate &&
+                        (d->act == SVL_ACT_NONE || d->act == SVL_ACT_RELU || d->act == SVL_ACT_GELU);
+      return launch_shortk(p, fast, st);
+    }
+  }
 
   // Narrow 3x3 convolutions (N = 32 / 64): spatially tiled kernel (conv_tiled.hip) instead of the implicit GEMM
   if (g_conv_tiled < 0) g_conv_tiled = getenv("SVL_CONV_NO_TILED") ? 0 : 1;

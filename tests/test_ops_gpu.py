@@ -290,6 +290,42 @@ def test_convT2x(dev):
     assert (out[:, Co:] == 0).all()
 
 
+@pytest.mark.parametrize("M,N,K,act", [(40003, 192, 64, 0), (33000, 200, 128, 1), (32768, 640, 128, 2), (36000, 96, 64, 0)])
+def test_gemm_shortk_stream(dev, M, N, K, act):
+    """K = 64 / 128 row streams with >= 32768 rows take gemm_shortk_kernel (persistent, B panel in LDS)."""
+    from semivl_amd import ops
+    x, w, b = rnd(M, K, dev=dev, seed=21), rnd(N, K, dev=dev, scale=0.2), rnd(N, dev=dev)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+    out = ops.linear(x, w, b, act=act)
+    close(out, ref.float(), atol=2e-4, what="short-K linear")
+    # general epilogue (residual add + saved pre-activation) through the same kernel
+    res = rnd(M, N, dev=dev, seed=22)
+    pre = torch.empty(M, N, device=dev)
+    out2 = ops.linear(x, w, b, resid=res, preact=pre)
+    lin = (x.double() @ w.double().t() + b.double()).float()
+    close(pre, lin, atol=2e-4, what="short-K preact")
+    close(out2, lin + res, atol=2e-4, what="short-K resid")
+
+
+def test_gemm_shortk_convT_and_1x1(dev):
+    from semivl_amd import ops
+    n, Ci, Co, H = 9, 64, 48, 64  # 36864 pixels: ConvTranspose2d k2 s2 as [pix, 64] x [4*48, 64]^T with scatter epilogue
+    x = rnd(n, Ci, H, H, dev=dev, seed=23)
+    w = rnd(Ci, Co, 2, 2, dev=dev, scale=0.1)
+    b = rnd(Co, dev=dev)
+    ref = F.conv_transpose2d(x, w, b, stride=2)
+    wp = w.permute(2, 3, 1, 0).reshape(4 * Co, Ci).contiguous()
+    out = torch.zeros(n * 4 * H * H, Co + 16, device=dev)
+    ops.convT2x_fwd(nhwc(x), Ci, n, H, H, Ci, wp, Co, b, out, Co + 16)
+    close(nchw(out, n, 2 * H, 2 * H)[:, :Co], ref, atol=5e-4, what="short-K convT")
+    assert (out[:, Co:] == 0).all()
+    w1 = rnd(128, Ci, 1, 1, dev=dev, scale=0.1)
+    y = ops.conv_fwd(nhwc(x), Ci, n, H, H, Ci, w1.view(128, Ci).contiguous(), 128, 1, 1, 1, 0, bias=b.repeat(3)[:128],
+                     act=2)
+    close(nchw(y, n, H, H), F.relu(F.conv2d(x, w1, b.repeat(3)[:128])), atol=5e-4, what="short-K 1x1 conv")
+
+
 def test_patch_embed(dev):
     from semivl_amd import ops
     n, S, P, E = 2, 64, 16, 768
