@@ -341,6 +341,74 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
     Cz += zo * p.c_bso + zi * p.c_bsi;
     if (Rz) Rz += zo * p.r_bso + zi * p.r_bsi;
   }
+  // Fast path: row-major output (and residual) with unit column stride.  Every uniform decision (bias / saved
+  // pre-activation / activation / residual / accumulate) is taken ONCE per 32x32 block around a straight-line loop over
+  // its 16 registers instead of once per element, all reads of the block are issued before its first store (C, preact
+  // and resid may alias as far as the compiler knows, so a load behind a store would wait for it), and the addressing
+  // is one 64-bit row pointer plus compile-time multiples of the row pitch.
+  if (p.out_mode == SVL_OUT_STRIDED && p.ldc_n == 1 && (Rz == nullptr || p.ldr_n == 1)) {
+    float* Pz = p.preact ? p.preact + (zo * p.c_bso + zi * p.c_bsi) : nullptr;
+    static_for<0, TM>([&](auto I) {
+      static_for<0, TN>([&](auto J) {
+        constexpr int i = decltype(I)::value, j = decltype(J)::value;
+        const int n = n0 + wc * WTN + j * 32 + l31;
+        const int mb = m0 + wr * WTM + i * 32 + 4 * hi;  // row of register 0; register r is row mb + (r&3) + 8*(r>>2)
+        if (n < p.N && mb < p.M) {
+          const int mrem = p.M - mb;
+          const float bv = p.bias ? p.bias[p.bias_mod > 0 ? (n % p.bias_mod) : n] : 0.f;
+          float* cp = Cz + (long)mb * p.ldc_m + n;
+          float v[16], rv[16];
+          if (Rz) {
+            const float* rp = Rz + (long)mb * p.ldr_m + n;
+            static_for<0, 16>([&](auto R) {
+              constexpr int r = decltype(R)::value, c = (r & 3) + 8 * (r >> 2);
+              rv[r] = c < mrem ? rp[c * p.ldr_m] : 0.f;
+            });
+          }
+          if (p.accumulate) {
+            static_for<0, 16>([&](auto R) {
+              constexpr int r = decltype(R)::value, c = (r & 3) + 8 * (r >> 2);
+              v[r] = c < mrem ? cp[c * p.ldc_m] : 0.f;
+            });
+          }
+          float a[16];
+          static_for<0, 16>([&](auto R) { a[decltype(R)::value] = acc[i][j][decltype(R)::value] * p.alpha + bv; });
+          if (Pz) {
+            float* pp = Pz + (long)mb * p.ldc_m + n;
+            static_for<0, 16>([&](auto R) {
+              constexpr int r = decltype(R)::value, c = (r & 3) + 8 * (r >> 2);
+              if (c < mrem) pp[c * p.ldc_m] = a[r];
+            });
+          }
+          if (p.act == SVL_ACT_GELU) {
+            static_for<0, 16>([&](auto R) { a[decltype(R)::value] = gelu_erf(a[decltype(R)::value]); });
+          } else if (p.act == SVL_ACT_RELU) {
+            static_for<0, 16>([&](auto R) { a[decltype(R)::value] = fmaxf(a[decltype(R)::value], 0.f); });
+          }
+          if (Rz) {
+            if (p.act == SVL_ACT_MUL_DGELU) {
+              static_for<0, 16>([&](auto R) { a[decltype(R)::value] *= gelu_erf_grad(rv[decltype(R)::value]); });
+            } else if (p.act == SVL_ACT_MUL_DRELU) {
+              static_for<0, 16>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                a[r] = rv[r] > 0.f ? a[r] : 0.f;
+              });
+            } else {
+              static_for<0, 16>([&](auto R) { a[decltype(R)::value] += rv[decltype(R)::value]; });
+            }
+          }
+          if (p.accumulate) {
+            static_for<0, 16>([&](auto R) { a[decltype(R)::value] += v[decltype(R)::value]; });
+          }
+          static_for<0, 16>([&](auto R) {
+            constexpr int r = decltype(R)::value, c = (r & 3) + 8 * (r >> 2);
+            if (c < mrem) cp[c * p.ldc_m] = a[r];
+          });
+        }
+      });
+    });
+    return;
+  }
   // Compile-time indices only: a runtime index into acc[][] would demote the accumulators to scratch memory.
   static_for<0, TM>([&](auto I) {
     static_for<0, TN>([&](auto J) {
@@ -389,7 +457,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[TM][
 }
 
 template <int BM, int BN, int WR, int WC, int AMODE, int BMODE, int BK>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM >= 64 ? 3 : 2))) void gemm_kernel(const GemmP p) {
   static_assert(WR * WC == 4, "4 waves per block");
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int WTM = BM / WR, WTN = BN / WC;  // wave tile
