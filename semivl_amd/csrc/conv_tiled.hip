@@ -105,22 +105,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     }
   }
   // C layout: column = output channel (l31 + 32 j), row i = (r & 3) + 8 (r >> 2) + 4 hi = pixel (i >> 4, i & 15) of the wave
+  // Straight-line epilogue (see gemm_epilogue): uniform decisions once per 32-channel block, previous values (accumulate)
+  // read before the first store, one pointer per block plus per-register pixel offsets.
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = l31 + 32 * j;
     const float bv = p.bias ? p.bias[co] : 0.f;
+    float* ob = p.out + (long)img * p.H * p.W * p.ldo + co;
+    float v[16];
+    long off[16];
+    bool ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
       const int y = y0 + wave * 2 + (i >> 4), x = x0 + (i & 15);
-      if (y < p.H && x < p.W) {
-        float v = acc[j][r] + bv;
-        if (p.act == SVL_ACT_GELU) v = gelu_erf(v);
-        else if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
-        float* o = p.out + (((long)img * p.H + y) * p.W + x) * p.ldo + co;
-        *o = p.accumulate ? *o + v : v;
-      }
+      ok[r] = y < p.H && x < p.W;
+      off[r] = ((long)y * p.W + x) * p.ldo;
+      v[r] = acc[j][r] + bv;
     }
+    if (p.act == SVL_ACT_GELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+    } else if (p.act == SVL_ACT_RELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (p.accumulate) {
+      float prev[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[r] = ok[r] ? ob[off[r]] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += prev[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) ob[off[r]] = v[r];
   }
 }
 
