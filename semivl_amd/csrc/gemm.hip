@@ -607,15 +607,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM >= 64 ? 
   };
 
   const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk > 0) {
-    g_load(kbeg);
-    s_store(0);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) g_load(kbeg + (kt + 1) * BK);
+  // One k step on LDS buffer `buf`: fragment reads run one k-pair ahead of the MFMAs (register double buffer).
+  auto mfma_step = [&](int buf) {
     const float* Ac = As + buf * BK * LDA + wr * WTM + l31;
     const float* Bc = Bs + buf * BK * LDB + wc * WTN + l31;
     // fragment reads run one k-pair ahead of the MFMAs (register double buffer)
@@ -644,6 +637,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM >= 64 ? 
       __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 1, 0);
     }
+  };
+  if constexpr (!A_IS_CONV && !B_IS_CONV && AMODE != SVL_A_PATCH) {
+    // Dense interior tile with whole K panels only: the panel loads carry no run-time guards, so a K step is one basic
+    // block (the guarded loop below re-tests tile / panel bounds on every step: ~30 scalar branches per step that also
+    // keep the scheduler from moving loads across them).
+    if (a_int && b_int && nk > 0 && (kend - kbeg) % BK == 0) {
+      auto g_load_fast = [&](int k0) {
+#pragma unroll
+        for (int ps = 0; ps < APASS; ++ps) {
+          const int f = tid + ps * 256;
+          if (APIECES % 256 == 0 || f < APIECES) ra[ps] = load_piece_fast<1, AMODE, BM, BK>(p.A, p.cv, Abase, f, m0, k0);
+        }
+#pragma unroll
+        for (int ps = 0; ps < BPASS; ++ps) {
+          const int f = tid + ps * 256;
+          if (BPIECES % 256 == 0 || f < BPIECES) rb[ps] = load_piece_fast<0, BMODE, BN, BK>(p.B, p.cv, Bbase, f, n0, k0);
+        }
+      };
+      g_load_fast(kbeg);
+      s_store(0);
+      __syncthreads();
+      for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) g_load_fast(kbeg + (kt + 1) * BK);
+        mfma_step(buf);
+        if (kt + 1 < nk) s_store(buf ^ 1);
+        __syncthreads();
+      }
+      gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wr, wc, l31, hi, zo, zi);
+      return;
+    }
+  }
+  if (nk > 0) {
+    g_load(kbeg);
+    s_store(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) g_load(kbeg + (kt + 1) * BK);
+    mfma_step(buf);
     if (kt + 1 < nk) s_store(buf ^ 1);
     __syncthreads();
   }
