@@ -638,8 +638,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM >= 64 ? 
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 1, 0);
     }
   };
-  if constexpr (!A_IS_CONV && !B_IS_CONV && AMODE != SVL_A_PATCH) {
-    // Dense interior tile with whole K panels only: the panel loads carry no run-time guards, so a K step is one basic
+  {
+    // Interior tile with whole K panels only: the panel loads carry no run-time guards, so a K step is one basic
     // block (the guarded loop below re-tests tile / panel bounds on every step: ~30 scalar branches per step that also
     // keep the scheduler from moving loads across them).
     if (a_int && b_int && nk > 0 && (kend - kbeg) % BK == 0) {
@@ -647,12 +647,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM >= 64 ? 
 #pragma unroll
         for (int ps = 0; ps < APASS; ++ps) {
           const int f = tid + ps * 256;
-          if (APIECES % 256 == 0 || f < APIECES) ra[ps] = load_piece_fast<1, AMODE, BM, BK>(p.A, p.cv, Abase, f, m0, k0);
+          if (APIECES % 256 == 0 || f < APIECES) {
+            if constexpr (A_IS_CONV) {
+              ra[ps] = conv_load_st(p.A, p.cv, sta[ps]);
+              conv_advance_k<BK>(p.cv, sta[ps]);
+            } else {
+              ra[ps] = load_piece_fast<1, AMODE, BM, BK>(p.A, p.cv, Abase, f, m0, k0);
+            }
+          }
         }
 #pragma unroll
         for (int ps = 0; ps < BPASS; ++ps) {
           const int f = tid + ps * 256;
-          if (BPIECES % 256 == 0 || f < BPIECES) rb[ps] = load_piece_fast<0, BMODE, BN, BK>(p.B, p.cv, Bbase, f, n0, k0);
+          if (BPIECES % 256 == 0 || f < BPIECES) {
+            if constexpr (B_IS_CONV) {
+              rb[ps] = conv_load_st(p.B, p.cv, stb[ps]);
+              conv_advance_pixel<BK>(p.cv, stb[ps]);
+            } else {
+              rb[ps] = load_piece_fast<0, BMODE, BN, BK>(p.B, p.cv, Bbase, f, n0, k0);
+            }
+          }
         }
       };
       g_load_fast(kbeg);
