@@ -701,6 +701,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM >= 64 ? 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Conv2d(1 -> N) forward (the head's first 3x3 on the 1-channel correlation maps, K = KH*KW <= 49 taps): as an implicit
+// GEMM it is a K = 9 problem that fills 9/16 of one K step and runs at 8 TF while writing 1.4 GB; it is an HBM-bound
+// elementwise op.  One thread = one pixel x 4 output channels (its 4 x K weights live in registers, the <= 49 input
+// taps are L1 broadcasts across the N/4 threads of a pixel), one float4 store per thread, rows fully coalesced.
+template <int KK>
+__global__ __launch_bounds__(256) void conv_cin1_fwd_kernel(const GemmP p) {
+  const int nq = p.N >> 2;  // 256 % nq == 0 (host-checked): a thread keeps its 4 channels for all of its pixels
+  const svl_conv_geom& cv = p.cv;
+  const int q = threadIdx.x % nq;
+  const int c = q << 2;
+  float w[4][KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < KK; ++k) w[j][k] = p.B.p[(long)(c + j) * p.B.ld + k];
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[p.bias_mod > 0 ? ((c + j) % p.bias_mod) : (c + j)] : 0.f;
+  const int ppb = 256 / nq;  // pixels per block per pass
+  for (int pix = blockIdx.x * ppb + threadIdx.x / nq; pix < p.M; pix += gridDim.x * ppb) {
+    const int ow = pix % cv.Wo;
+    const int t2 = pix / cv.Wo;
+    const int oh = t2 % cv.Ho;
+    const int img = t2 / cv.Ho;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      const int ti = k / cv.KW, tj = k - ti * cv.KW;
+      const int ih = oh + cv.sign * (ti * cv.dil - cv.pad), iw = ow + cv.sign * (tj * cv.dil - cv.pad);
+      const float x = (ih >= 0 && ih < cv.H && iw >= 0 && iw < cv.W) ? p.A.p[(((long)img * cv.H + ih) * cv.W + iw) * p.A.ld] : 0.f;
+      a0 = fmaf(x, w[0][k], a0); a1 = fmaf(x, w[1][k], a1); a2 = fmaf(x, w[2][k], a2); a3 = fmaf(x, w[3][k], a3);
+    }
+    float v[4] = {a0 * p.alpha, a1 * p.alpha, a2 * p.alpha, a3 * p.alpha};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] += bv[j];
+      if (p.act == SVL_ACT_GELU) v[j] = gelu_erf(v[j]);
+      else if (p.act == SVL_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+    }
+    *reinterpret_cast<float4*>(p.C + (long)pix * p.ldc_m + c) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Short-K dense GEMM (K = 64 / 128, millions of rows): the per-pixel linears and 1x1 convolutions of the VLG head
 // ([B*N*64*64, 64] x [192, 64]^T ...).  They are HBM-bound streams (12-50 flop/B), but a tile of the general kernel
 // lives for only K/16 = 4-8 pipeline steps, so its load -> LDS -> MFMA -> store chain never overlaps with itself and the
@@ -1333,6 +1377,19 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
                         (d->act == SVL_ACT_NONE || d->act == SVL_ACT_RELU || d->act == SVL_ACT_GELU);
       return launch_shortk(p, fast, st);
     }
+  }
+
+  // Conv2d(1 -> N) forward with a 3x3 kernel: elementwise kernel instead of a K = 9 implicit GEMM
+  if (shortk && a_conv && bm == SVL_B_KCONTIG && cv.C1 == 1 && cv.C2 == 0 && d->K == 9 && cv.KH == 3 && p.cv.stride == 1 &&
+      d->batch == 1 && d->ksplit == 0 && d->out_mode == SVL_OUT_STRIDED && d->ldc_n == 1 && !d->resid && !d->preact &&
+      !d->accumulate && d->N % 4 == 0 && 256 % (d->N / 4) == 0 && d->ldc_m % 4 == 0 && aligned16(d->C) && d->M >= 32768 &&
+      (d->act == SVL_ACT_NONE || d->act == SVL_ACT_RELU || d->act == SVL_ACT_GELU)) {
+    const int ppb = 256 / (d->N / 4);
+    long blocks = ((long)d->M + ppb - 1) / ppb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(conv_cin1_fwd_kernel<9>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    SVL_LAUNCH_CHECK("svl_gemm_f32/conv_cin1");
+    return SVL_OK;
   }
 
   // Narrow 3x3 convolutions (N = 32 / 64): spatially tiled kernel (conv_tiled.hip) instead of the implicit GEMM

@@ -245,6 +245,20 @@ def test_conv_cout1_thin_kernels(dev, C, H):
     close(ops.unpack_conv_wgrad(dwf, 1, C, 3, 3), gw, atol=1e-3, what="cout1 wgrad")
 
 
+def test_conv_cin1_fwd_elementwise(dev):
+    """Conv2d(1 -> 32, 3x3) on >= 32768 pixels takes conv_cin1_fwd_kernel (elementwise) instead of the K = 9 GEMM."""
+    from semivl_amd import ops
+    n, Co, H, W = 5, 32, 96, 80
+    x = rnd(n, 1, H, W, dev=dev, seed=31)
+    w = rnd(Co, 1, 3, 3, dev=dev, scale=0.3)
+    b = rnd(Co, dev=dev)
+    wf = w.permute(0, 2, 3, 1).reshape(Co, 9).contiguous()
+    y = ops.conv_fwd(nhwc(x), 1, n, H, W, 1, wf, Co, 3, 3, 1, 1, bias=b, act=2)
+    close(nchw(y, n, H, W), F.relu(F.conv2d(x, w, b, padding=1)), atol=1e-5, what="cin1 fwd")
+    y2 = ops.conv_fwd(nhwc(x), 1, n, H, W, 1, wf, Co, 3, 3, 2, 2)
+    close(nchw(y2, n, H, W), F.conv2d(x, w, None, padding=2, dilation=2), atol=1e-5, what="cin1 fwd dilated")
+
+
 def test_conv_cin1_dgrad(dev):
     from semivl_amd import ops
     n, Co, H, k = 4, 128, 32, 7
