@@ -135,6 +135,11 @@ class VLGHead(nn.Module):
         self.up2 = Up(up_channels[0], up_channels[1], skip_channels[1])
         self.head = nn.Conv2d(up_channels[1], 1, kernel_size=3, stride=1, padding=1)
         self.load_text_embedding = None
+        # memory plan (see _chunk_plan / _head_forward): class-images per chunk, allocated-bytes ceiling above which a
+        # chunk's activations are not kept but recomputed in backward (None: keep everything), live sample ranges
+        self.chunk_class_images = 1344
+        self.act_limit_bytes = None
+        self._bwd_ranges = None
         if (channels + text_channels) % num_heads or (channels + text_channels) // num_heads != 64:
             raise NotImplementedError("SemanticTransformer head dim must be 64")
 
@@ -154,7 +159,7 @@ class VLGHead(nn.Module):
             return _HeadFn.apply(self, (hw, skip0_hw or hw), fp_masks, (fp_rate, fp_range), out_size, text, feats[0],
                                  feats[1], feats[2], *params)
         with ops.prof_scope("head"):
-            return _head_forward(self, (hw, skip0_hw or hw), fp_masks, (fp_rate, fp_range), out_size, text, feats, None)
+            return _head_forward(self, (hw, skip0_hw or hw), fp_masks, (fp_rate, fp_range), out_size, text, feats, None)[0]
 
     def forward(self, inputs, force_output_pred_masks=False):
         """Reference signature (vlg_head.py:192-251): inputs = [[feature_pyramid, global], text_feats, conv_feats]."""
@@ -174,7 +179,36 @@ class VLGHead(nn.Module):
         return {"pred_masks": x} if force_output_pred_masks else x
 
 
-def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
+def _chunk_plan(m, b, N):
+    """Sample chunks [(s0, s1, live)] of a decoded batch of b samples x N class-images.  Every op of the head is
+    per-sample (the SemanticTransformer couples the N classes of ONE sample, vlg_head.py:44-62), so the batch can be cut
+    anywhere along b.  `m._bwd_ranges = {b: [(s0, s1), ...]}` (set by the training step) names the sample ranges whose
+    dlogits are not identically zero; everything else is 'dead': decoded, never saved, never back-propagated.
+    Chunks hold at most `m.chunk_class_images` class-images (the head's transient + saved activations scale with it:
+    ~33 MB per class-image at 512^2)."""
+    ranges = (getattr(m, "_bwd_ranges", None) or {}).get(b)
+    segs, pos = [], 0
+    for s0, s1 in (ranges if ranges is not None else [(0, b)]):
+        if s0 > pos:
+            segs.append((pos, s0, False))
+        segs.append((s0, s1, True))
+        pos = s1
+    if pos < b:
+        segs.append((pos, b, False))
+    per = max(1, int(getattr(m, "chunk_class_images", 1344)) // N)
+    out = []
+    for s0, s1, live in segs:
+        n = -(-(s1 - s0) // per)
+        size = -(-(s1 - s0) // n)
+        for c0 in range(s0, s1, size):
+            out.append((c0, min(s1, c0 + size), live))
+    return out
+
+
+def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, chunks_out):
+    """Whole-batch forward, executed chunk by chunk.  chunks_out: None (inference) or a list that receives
+    (s0, s1, live, saved-or-None) per chunk; `saved` is None for dead chunks and for chunks whose activations did not
+    fit under `m.act_limit_bytes` (they are recomputed in backward).  Returns (logits [b, N, S, S], shared dict)."""
     fp_rate, fp_range = fp_cfg
     (h, w), (h0, w0) = hw
     HW, HW0 = h * w, h0 * w0
@@ -184,7 +218,6 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
     N = text.shape[0]
     if N != m.num_classes:
         raise NotImplementedError("concept-level text embeddings inside VLGHead are off the BASELINE configs")
-    Ch, Ct = m.channels, m.text_channels
     Ce, Cv, C0 = emb.shape[2], v4.shape[2], v0.shape[2]
     # ---- feature perturbation: cat(f, dropout2d(f)) ------------------------------------------------------
     if fp_masks is not None:
@@ -201,15 +234,43 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
     else:
         b = b0
         v0, v4, emb = v0.view(b * HW0, C0), v4.view(b * HW, Cv), emb.view(b * HW, Ce)
+    # ---- class-side tensors shared by every chunk ------------------------------------------------------------
+    textf = text.float().contiguous()
+    textn, _ = ops.l2norm_fwd(textf, 1e-12)
+    tp = ops.linear(textn, m.text_proj[0].weight, m.text_proj[0].bias, act=ops.ACT_RELU)
+    shared = dict(textn=textn, tp=tp, b0=b0, b=b, N=N, hw=hw, out_size=out_size, fp=(fp_masks, fp_rate, fp_range),
+                  feats=(v0, v4, emb))
+    logits = ops.empty(b, N, out_size[0], out_size[1], device=dev)
+    limit = getattr(m, "act_limit_bytes", None)
+    over = False
+    for s0, s1, live in _chunk_plan(m, b, N):
+        sv = {} if (chunks_out is not None and live and not over) else None
+        _head_core_forward(m, shared, s0, s1, sv, logits[s0:s1])
+        if sv is not None and limit is not None and torch.cuda.memory_allocated(dev) > limit:
+            sv, over = None, True    # does not fit: drop, recompute this chunk (and the following ones) in backward
+        if chunks_out is not None:
+            chunks_out.append((s0, s1, live, sv))
+    return logits, shared
+
+
+def _head_core_forward(m, shared, s0, s1, sv, logits_out):
+    """Forward of samples [s0, s1) of the (doubled) batch.  sv: dict receiving what backward needs, or None.
+    logits_out: contiguous [s1-s0, N, S, S] slice to write, or None (backward-time recompute: activations only)."""
+    (h, w), (h0, w0) = shared["hw"]
+    HW, HW0 = h * w, h0 * w0
+    N, out_size, textn, tp = shared["N"], shared["out_size"], shared["textn"], shared["tp"]
+    b = s1 - s0
+    v0, v4, emb = shared["feats"]
+    v0, v4, emb = v0[s0 * HW0:s1 * HW0], v4[s0 * HW:s1 * HW], emb[s0 * HW:s1 * HW]
+    dev = emb.device
+    Ch, Ct = m.channels, m.text_channels
+    Ce, Cv, C0 = emb.shape[1], v4.shape[1], v0.shape[1]
     imgs = b * N
     # ---- cosine similarity map (vlg_head.py:214-217) ------------------------------------------------------
     embn, inv_e = ops.l2norm_fwd(emb, 1e-12)
-    textf = text.float().contiguous()
-    textn, _ = ops.l2norm_fwd(textf, 1e-12)
     sim = ops.empty(imgs * HW, 1, device=dev)  # [(b n), h, w, 1]
     ops.gemm(ops.A_KC, ops.B_KC, HW, N, Ce, ops.Op(embn, Ce, 0, HW * Ce, 0), ops.Op(textn, Ce), sim, ldc_m=1, ldc_n=HW,
              batch=b, c_bso=N * HW)
-    S = {} if sv is not None else None
     # ---- conv1 7x7 -----------------------------------------------------------------------------------------
     k1 = m.conv1_ksize
     w1f, w1d = ops.pack_conv_w(m.conv1.weight)
@@ -233,7 +294,6 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
     x2 = _conv_gn_fwd(cat, 5 * Ch, imgs, h, w, 5 * Ch, m.aspp.project[0], m.aspp.project[1], 1, 1, s_proj)
     x = ops.add(x2, x1)  # y = x + project(cat); new buffer: x2 stays intact as the ReLU mask of the project GN
     # ---- semantic reasoning ----------------------------------------------------------------------------------
-    tp = ops.linear(textn, m.text_proj[0].weight, m.text_proj[0].bias, act=ops.ACT_RELU)
     tr_sv = []
     for lyr in m.layers:
         s_ = {} if sv is not None else None
@@ -254,18 +314,18 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, sv):
     g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], h0, w0, b, N, s_up2)
     C4 = g4.shape[1]
     whf, whd = ops.pack_conv_w(m.head.weight)
-    lg = ops.conv_cout1_fwd(g4, C4, imgs, 4 * h, 4 * w, C4, whf, 3, 3, 1, 1, bias=m.head.bias)  # [(b n), 4h, 4w, 1]
-    lg = lg.view(b, N, 4 * h, 4 * w)
-    if out_size != (4 * h, 4 * w):
-        logits = ops.bilinear_planes_fwd(lg, 4 * h, 4 * w, m.align_corners, out_size[0], out_size[1])
-    else:
-        logits = lg
+    if logits_out is not None:
+        direct = out_size == (4 * h, 4 * w)
+        lg = ops.conv_cout1_fwd(g4, C4, imgs, 4 * h, 4 * w, C4, whf, 3, 3, 1, 1, bias=m.head.bias,
+                                out=logits_out.view(-1, 1) if direct else None)  # [(b n), 4h, 4w, 1]
+        if not direct:
+            ops.bilinear_planes_fwd(lg.view(b, N, 4 * h, 4 * w), 4 * h, 4 * w, m.align_corners, out_size[0], out_size[1],
+                                    out=logits_out)
     if sv is not None:
-        sv.update(dims=(b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0), fp=(fp_masks, fp_rate, fp_range), emb=emb, embn=embn,
+        sv.update(dims=(b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0), embn=embn,
                   inv_e=inv_e, textn=textn, sim=sim, w1d=w1d, x1=x1, aspp=aspp_sv, gap=s_gap, pooled=pooled, proj=s_proj,
                   cat=cat, tp=tp, tr=tr_sv, skip=skip_sv, up1=s_up1, up2=s_up2, g4=g4, whd=whd,
-                  out_size=out_size, v0=v0, v4=v4)
-    return logits
+                  out_size=out_size)
 
 
 def _semtr_forward(lyr, x, tp, imgs, b, N, h, w, Ch, Ct, sv):
@@ -372,10 +432,10 @@ def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
 class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, hw, fp_masks, fp_cfg, out_size, text, v0, v4, emb, *params):
-        sv = {}
+        chunks = []
         with ops.prof_scope("head"):
-            out = _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, [v0, v4, emb], sv)
-        ctx.m, ctx.sv, ctx.params, ctx.hw = m, sv, params, hw
+            out, shared = _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, [v0, v4, emb], chunks)
+        ctx.m, ctx.chunks, ctx.shared, ctx.params = m, chunks, shared, params
         ctx.feat_req = (v0.requires_grad, v4.requires_grad, emb.requires_grad)
         return out
 
@@ -386,26 +446,34 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, dlogits):
-        m, sv = ctx.m, ctx.sv
-        b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0 = sv["dims"]
+        m, sh = ctx.m, ctx.shared
+        b0, b, N = sh["b0"], sh["b"], sh["N"]
+        (h, w), (h0, w0) = sh["hw"]
+        HW, HW0 = h * w, h0 * w0
+        v0f, v4f, embf = sh["feats"]
+        C0, Cv, Ce = v0f.shape[1], v4f.shape[1], embf.shape[1]
         dev = dlogits.device
         gc = _GradCollector()
         dlogits = dlogits.contiguous()
         # Samples whose dlogits are identically zero (pred_w is detached, pred_x_fp unused: semivl.py:247,251) contribute
-        # exactly nothing to any gradient: every op of the head is per-sample.  The step announces the live sample
-        # ranges and the backward runs on those contiguous sub-batches only.
-        ranges = (getattr(m, "_bwd_ranges", None) or {}).get(b)
-        if ranges is None:
-            dv0, dv4, demb = _head_backward_core(m, sv, dlogits, gc)
-        else:
-            dv0, dv4, demb = (ops.zeros(b * HW0, C0, device=dev), ops.zeros(b * HW, Cv, device=dev),
-                              ops.zeros(b * HW, Ce, device=dev))
-            for s0, s1 in ranges:
-                a0, a4, ae = _head_backward_core(m, _slice_saved(sv, b, s0, s1), dlogits[s0:s1], gc)
-                for full, part, hw_ in ((dv0, a0, HW0), (dv4, a4, HW), (demb, ae, HW)):
-                    ops.eltwise(4, part.view(-1), None, out=full[s0 * hw_:s1 * hw_].view(-1))
+        # exactly nothing to any gradient: every op of the head is per-sample.  The step announced the live sample
+        # ranges before the forward (`_bwd_ranges`); dead chunks were decoded without saving anything and are skipped here.
+        all_live = all(c[2] for c in ctx.chunks)
+        mk_ = ops.empty if (all_live and len(ctx.chunks) == 1) else ops.zeros
+        dv0, dv4, demb = mk_(b * HW0, C0, device=dev), mk_(b * HW, Cv, device=dev), mk_(b * HW, Ce, device=dev)
+        for i, (s0, s1, live, sv) in enumerate(ctx.chunks):
+            if not live:
+                continue
+            if sv is None:     # activations were not kept (memory plan): recompute this chunk's forward, no logits
+                sv = {}
+                _head_core_forward(m, sh, s0, s1, sv, None)
+            a0, a4, ae = _head_backward_core(m, sv, dlogits[s0:s1], gc)
+            ctx.chunks[i] = None
+            del sv
+            for full, part, hw_ in ((dv0, a0, HW0), (dv4, a4, HW), (demb, ae, HW)):
+                ops.eltwise(4, part.view(-1), None, out=full[s0 * hw_:s1 * hw_].view(-1))
         # ---- undo the feature-perturbation doubling
-        fp_masks, fp_rate, fp_range = sv["fp"]
+        fp_masks, fp_rate, fp_range = sh["fp"]
         r0, r1 = fp_range if fp_range is not None else (0, b0)
 
         def undbl(dfull, mk, Cc, hw_):
@@ -421,42 +489,16 @@ class _HeadFn(torch.autograd.Function):
         dv0 = undbl(dv0, mk[0], C0, HW0)
         dv4 = undbl(dv4, mk[1], Cv, HW)
         demb = undbl(demb, mk[2], Ce, HW)
-        ctx.sv = None
+        ctx.chunks = ctx.shared = None
         req = ctx.feat_req
         return (None, None, None, None, None, None, dv0 if req[0] else None, dv4 if req[1] else None,
                 demb if req[2] else None) + tuple(gc.out.get(id(p)) for p in ctx.params)
 
 
-_SHARED_KEYS = {"textn", "tp", "w1d", "whd", "wd", "wp"}  # saved tensors that are NOT per-sample
-
-
-def _slice_saved(sv, b, s0, s1):
-    """View of the saved activations restricted to samples [s0, s1) (all per-sample tensors are batch-major)."""
-    def sl(k, v):
-        if isinstance(v, torch.Tensor):
-            if k in _SHARED_KEYS or v.dim() == 0:
-                return v
-            assert v.shape[0] % b == 0, (k, tuple(v.shape), b)
-            r = v.shape[0] // b
-            return v[s0 * r:s1 * r]
-        if isinstance(v, dict):
-            return {kk: sl(kk, vv) for kk, vv in v.items()}
-        if isinstance(v, list):
-            return [sl(k, vv) for vv in v]
-        if k == "geom":
-            return (v[0] // b * (s1 - s0),) + tuple(v[1:])
-        return v
-    out = {k: sl(k, v) for k, v in sv.items() if k not in ("dims", "fp")}
-    d = sv["dims"]
-    out["dims"] = (d[0], s1 - s0, d[2], d[3], d[4], d[5], d[6] // b * (s1 - s0)) + tuple(d[7:])
-    out["fp"] = sv["fp"]
-    return out
-
-
 def _head_backward_core(m, sv, dlogits, gc):
     """Backward of the head for the (sub-)batch described by `sv`; returns grads wrt the (doubled) v0, v4, emb tokens."""
     if True:
-        b0, b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0 = sv["dims"]
+        b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0 = sv["dims"]
         dev = dlogits.device
         if sv["out_size"] != (4 * h, 4 * w):
             dlg = ops.bilinear_planes_bwd(dlogits, 4 * h, 4 * w, m.align_corners, sv["out_size"][0], sv["out_size"][1])

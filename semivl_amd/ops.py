@@ -473,9 +473,10 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
     return out
 
 
-def conv_cout1_fwd(x, ldx, imgs, H, W, Cc, wf, KH, KW, dil, pad, bias=None):
+def conv_cout1_fwd(x, ldx, imgs, H, W, Cc, wf, KH, KW, dil, pad, bias=None, out=None):
     """Conv2d(C -> 1) forward, HBM-bound direct kernel; wf = forward pack [1, KH*KW*C]; returns [imgs*H*W, 1]."""
-    y = empty(imgs * H * W, 1, device=x.device)
+    y = empty(imgs * H * W, 1, device=x.device) if out is None else out
+    assert y.is_contiguous() and y.numel() == imgs * H * W
     L.check(L.load().svl_conv_cout1_fwd(_p(x), ldx, imgs, H, W, Cc, KH, KW, dil, pad, _p(wf), _p(bias), _p(y), _st()),
             "svl_conv_cout1_fwd")
     return y
@@ -553,9 +554,10 @@ def bilinear_nhwc_bwd(dy, lddy, imgs, h, w, Cc, align, rep, H, W, dx, lddx, accu
                                            1 if accumulate else 0, _st()), "svl_bilinear_nhwc_bwd")
 
 
-def bilinear_planes_fwd(x, h, w, align, H, W):
+def bilinear_planes_fwd(x, h, w, align, H, W, out=None):
     planes = x.numel() // (h * w)
-    y = empty(*x.shape[:-2], H, W, device=x.device)
+    y = empty(*x.shape[:-2], H, W, device=x.device) if out is None else out
+    assert y.is_contiguous() and y.numel() == planes * H * W
     L.check(L.load().svl_bilinear_planes_fwd(_p(x), planes, h, w, 1 if align else 0, H, W, _p(y), _st()),
             "svl_bilinear_planes_fwd")
     return y

@@ -84,6 +84,8 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     # CutMix images (in place, like the reference)
     cutmix_img_(img_s1, b["img_s1_other"], mix1)
     cutmix_img_(img_s2, b["img_s2_other"], mix2)
+    if getattr(model, "decode_head", None) is not None:
+        model.decode_head._bwd_ranges = None
     # pseudo labels + MaskCLIP guidance (model.eval(): the side encoder's BatchNorm uses its running statistics here,
     # semivl.py:228-244; nothing else on the path depends on the mode)
     model.eval()
@@ -103,6 +105,17 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     # instead of twice on B.
     if fp_masks is not None:   # injected masks come in the reference's [x, w] row order
         fp_masks = [torch.cat((m_[B:2 * B], m_[:B])) for m_ in fp_masks]
+    # pred_w is detached (semivl.py:251) -> exactly-zero dlogits: the head decodes those samples without keeping
+    # activations and its backward skips them (results identical).  Memory plan: activations of the remaining chunks are
+    # kept while the allocation stays under `act_mem_fraction` of the device, the others are recomputed in backward.
+    head = getattr(model, "decode_head", None)
+    if head is not None:
+        head._bwd_ranges = {3 * B: [(B, 3 * B)]}
+        if cfg.get("head_chunk_class_images"):
+            head.chunk_class_images = int(cfg["head_chunk_class_images"])
+        frac = cfg.get("act_mem_fraction", 0.62)
+        head.act_limit_bytes = (None if frac is None or not img_x.is_cuda else
+                                int(frac * torch.cuda.get_device_properties(dev).total_memory))
     preds4 = model(_cat2(img_w, img_x), need_fp=True, fp_masks=fp_masks, split_fp=False, fp_range=(0, B))
     preds_s = model(_cat2(img_s1, img_s2))                                                 # [s1, s2]
     pred_w, pred_x, pred_w_fp = preds4[:B], preds4[B:2 * B], preds4[2 * B:]
@@ -143,10 +156,6 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     # backward (+ all-reduce) + optimizer
     if optimizer is not None:
         optimizer.zero_grad()
-    # pred_w carries exactly-zero dlogits: let the head's backward skip those samples (results identical)
-    head = getattr(model, "decode_head", None)
-    if head is not None:
-        head._bwd_ranges = {3 * B: [(B, 3 * B)]}
     try:
         torch.autograd.backward([preds4, preds_s], [dl4, dls])
     finally:

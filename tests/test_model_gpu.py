@@ -251,3 +251,35 @@ def test_skr04_wiring_step_matches_oracle(dev):
     for n in og:
         rel = ((hg[n].cpu() - og[n]).norm() / (og[n].norm() + 1e-12)).item()
         assert rel < 3e-2 or og[n].norm().item() < 1e-7, (n, rel, og[n].norm().item())
+
+
+def test_head_memory_plan_is_exact(dev):
+    """Memory plan of the class-batched decoder (sample chunks, budgeted save / backward-time recompute): cutting the
+    decoded batch into chunks only re-orders parameter-gradient sums; recomputing a chunk's activations in backward
+    instead of keeping them is bit-identical."""
+    from semivl_amd.train import semivl_train_step
+    z, c = load_fixture("vlgdim")
+    hip = build_hip(c)
+    hip.load_state_dict(fixture_state(z, c, hip), strict=True)
+    hip.to(dev).train()
+    masks = [m.to(dev) for m in fixture_fp_masks(z, c)]
+    iters, total = [int(v) for v in z["iters"]]
+    cfg0 = dict(CFG, conf_thresh=c["conf_thresh"], conf_mode=c.get("conf_mode", "pixelwise"))
+
+    def run(**kw):
+        for p_ in hip.parameters():
+            p_.grad = None
+        batch = to_dev(fixture_batch(z, c), dev)
+        losses = semivl_train_step(hip, batch, iters, total, dict(cfg0, **kw), fp_masks=masks)
+        return losses.cpu(), {k: p.grad.clone() for k, p in hip.named_parameters() if p.grad is not None}
+
+    l_one, g_one = run(head_chunk_class_images=1 << 20, act_mem_fraction=None)       # one chunk per live range, all kept
+    l_chk, g_chk = run(head_chunk_class_images=21, act_mem_fraction=None)            # one sample per chunk, all kept
+    l_rec, g_rec = run(head_chunk_class_images=21, act_mem_fraction=0.0)             # ... nothing kept: all recomputed
+    assert torch.equal(l_one, l_chk) and torch.equal(l_chk, l_rec)                   # forward values never change
+    assert sorted(g_one) == sorted(g_chk) == sorted(g_rec)
+    for k in g_one:
+        assert torch.equal(g_chk[k], g_rec[k]), f"{k}: recompute must be bit-identical to keeping the activations"
+        scale = g_one[k].abs().max().item()
+        assert (g_chk[k] - g_one[k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
+    hip.decode_head.chunk_class_images = 1344

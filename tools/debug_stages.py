@@ -24,9 +24,12 @@ with torch.no_grad():
     cmp('global', g, rg)
     # decoder with oracle feats (isolates the head)
     toks = [f.permute(0,2,3,1).reshape(B, hp*hp, -1).contiguous().to(dev) for f in rf]
-    sv = {}
     text = hip.text_feat(dev)
-    out = VH._head_forward(hip.decode_head, (hp,hp), None, 0.5, (c['S'],c['S']), text, toks, sv)
+    chunks = []
+    out, _ = VH._head_forward(hip.decode_head, ((hp,hp),(hp,hp)), None, (0.5, None), (c['S'],c['S']), text,
+                              [toks[0], toks[1], toks[2]], chunks)
+    assert len(chunks) == 1, 'debug_stages expects a single chunk'
+    sv = chunks[0][3]
     H = orc.decode_head
     N = 21
     imgf = F.normalize(rf[-1], dim=1); tx = F.normalize(orc.text_feat.float(), dim=-1)
