@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 # algorithmic work per step per unit batch, VOC N=21, 512^2
 VIT_GF_PER_UNIT_B = 2866.6      # 5 ViT fwd (231.0) + 2 frozen fwd (209.2) + 4 bwd (323.3) GFLOP
 DEC_GF_PER_UNIT_B = 1322.0      # 7 decoder fwd + 6 x 2 fwd-equivalents bwd, 69.6 GFLOP/img
+# (nclass, crop) -> (ViT, decoder) algorithmic GFLOP per step per unit batch
+ALGO_GF = {(21, 512): (2866.6, 1322.0), (81, 512): (2866.6, 5075.0), (150, 512): (2866.6, 9412.0),
+           (19, 801): (5 * 725.0 + 2 * 669.8 + 4 * 1098.1, 3027.0)}
 PEAK_F32_MFMA_TF = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
 
@@ -39,42 +42,111 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="labeled (= unlabeled) images per GPU per step")
     ap.add_argument("--crop", type=int, default=512)
     ap.add_argument("--nclass", type=int, default=21)
+    ap.add_argument("--config", choices=["voc", "cityscapes", "ade", "coco"], default=None,
+                    help="BASELINE.json config presets: voc = configs[1] (N=21, 512, bs 16); cityscapes = configs[2] "
+                         "(N=19, 801, bs 8, skr04); ade = configs[3] (N=150, bs 16); coco = configs[4] (N=81, bs 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, nargs=2, default=(1, 3), metavar=("WARM", "TIMED"),
+                    help="oracle steps on the host cores (SURVEY §8(d) asks for 3 5; the default 1 3 keeps the default "
+                         "run within a few minutes)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--gemm-arith", choices=["f32", "bf16x6", "bf16x3"], default="f32",
                     help="arithmetic of the large dense GEMMs in the timed region (include/semivl_hip.h, "
                          "svl_set_gemm_emulation); 'value' is always measured in this mode")
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the extra bf16x6 measurement that is reported next to the f32 value")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config is not None:
+        a.nclass, a.crop, a.batch = {"voc": (21, 512, 16), "cityscapes": (19, 801, 8), "ade": (150, 512, 16),
+                                     "coco": (81, 512, 16)}[a.config]
+    return a
 
 
-def cpu_baseline(crop, nclass):
-    """The oracle restatement (kind 'port') on the host cores, bounded sample: ONE step at bs=1 of the same workload."""
+def respawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run, the same
+    way the driver does, and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(crop, nclass, warm, timed):
+    """the oracle restatement (kind 'port': the reference's Python cannot travel to the GPU box) on BASELINE
+    configs[0] -- VOC N=21, 512^2, bs=2, world_size 1 -- with torch.set_num_threads(all physical cores); `warm` warm-up +
+    `timed` timed full steps (forward, losses, backward, AdamW), median."""
     from oracle import semivl_oracle as O
     torch.manual_seed(0)
-    cores = min(os.cpu_count() or 1, 16)  # the CPU path stops scaling (and oversubscribes) beyond ~16 threads at bs=1
+    cores = physical_cores()
     torch.set_num_threads(cores)
+    bs = 2
     text, mcc = O.synthetic_text(nclass), O.synthetic_text(nclass, seed=8)
     model = O.build_vlm(dict(nclass=nclass, crop=crop), text, mcc)
     model.backbone.init_weights_()
     model.clip_encoder.init_weights_()
-    batch = O.synthetic_batch(1, crop, nclass, seed=1234)
+    batch = O.synthetic_batch(bs, crop, nclass, seed=1234)
     params = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith("clip_encoder")]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
-    t0 = time.time()
-    loss, _ = O.semivl_step(model, batch, 0, 100)
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
-    dt = time.time() - t0
-    return dict(value=2.0 / dt, unit="images/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 full SemiVL step of oracle/semivl_oracle.py (PyTorch CPU fp32) at VOC N={nclass}, {crop}x{crop}, "
-                       f"bs=1 (2 images/step), {dt:.1f} s")
+    times = []
+    for i in range(warm + timed):
+        t0 = time.time()
+        loss, _ = O.semivl_step(model, batch, i, 100)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+    dt = sorted(times[warm:])[len(times[warm:]) // 2]
+    return dict(value=2.0 * bs / dt, unit="images/s", cores=torch.get_num_threads(), kind="port", cpu=cpu_model(),
+                s_per_step=round(dt, 2),
+                sample=f"{warm} warm-up + {timed} timed full SemiVL steps (median) of oracle/semivl_oracle.py (PyTorch CPU "
+                       f"fp32) at VOC N={nclass}, {crop}x{crop}, bs={bs} ({2 * bs} images/step, BASELINE configs[0]), "
+                       f"{cores} threads = all physical cores of {cpu_model()}; {sum(times):.0f} s of CPU work")
+
+
+def pmc_traffic_record(batch):
+    """HBM-side bytes of the dominant launch from a committed rocprofv3 --pmc record (profiles/pmc_gemm_traffic.json,
+    written by tools/pmc_traffic.sh): used only when it was measured on the SAME kernel source (sha256 of gemm.hip)."""
+    import hashlib
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_gemm_traffic.json")))
+        sha = hashlib.sha256(open(os.path.join(ROOT, "semivl_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
+        if rec.get("gemm_hip_sha16") == sha and rec.get("M") == 32 * 1025 * batch // 16:
+            return rec["traffic_bytes"], rec.get("note", "")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, "no PMC record for this kernel source (profiles/pmc_gemm_traffic.json absent or from another gemm.hip)"
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        respawn_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -144,7 +216,10 @@ def main():
                vs_baseline=None, dtype="f32" if a.gemm_arith == "f32" else f"f32 ({a.gemm_arith} split-product MFMA, f32 accumulate)",
                data="synthetic",
                config=dict(workload=f"SemiVL step, {dataset} N={a.nclass}, {cfg['model'].replace('mmseg.', '')}, {a.crop}x{a.crop}, "
-                                    f"bs={a.batch}/GPU labeled + {a.batch}/GPU unlabeled" + (" (BASELINE configs[1])" if (a.nclass, a.crop, a.batch) == (21, 512, 16) else ""),
+                                    f"bs={a.batch}/GPU labeled + {a.batch}/GPU unlabeled" +
+                                    {(21, 512, 16): " (BASELINE configs[1])", (19, 801, 8): " (BASELINE configs[2])",
+                                     (150, 512, 16): " (BASELINE configs[3])", (81, 512, 16): " (BASELINE configs[4])"}.get(
+                                        (a.nclass, a.crop, a.batch), ""),
                            global_batch=2 * a.batch * world, parallelism=f"dp{world}", loss=round(loss_val, 5),
                            peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)))
 
@@ -160,15 +235,20 @@ def main():
         g = prof.get("gemm", []) + prof.get("attention", [])   # the two fp32-MFMA kernel families
         t_gemm = sum(e0.elapsed_time(e1) for e0, e1, *_ in g) * 1e-3
         executed = sum(w for _, _, w, *_ in g)
-        algo = (VIT_GF_PER_UNIT_B + DEC_GF_PER_UNIT_B) * 1e9 * a.batch if (a.nclass == 21 and a.crop == 512) else executed
+        algo = sum(ALGO_GF[(a.nclass, a.crop)]) * 1e9 * a.batch if (a.nclass, a.crop) in ALGO_GF else executed
         ach = algo / t_gemm / 1e12
+        step_tf = algo / (ms * 1e-3) / 1e12
         out["roofline"] = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
                                frac=round(ach / PEAK_F32_MFMA_TF, 4), traffic=None,
+                               frac_executed=round(executed / t_gemm / 1e12 / PEAK_F32_MFMA_TF, 4),
+                               frac_whole_step=round(step_tf / PEAK_F32_MFMA_TF, 4), whole_step_tflops=round(step_tf, 2),
                                kernel="gemm_kernel + attn_{fwd,bwd}_kernel (svl_gemm_f32, svl_attention_*; v_mfma_f32_32x32x2_f32)", launches=len(g),
                                kernel_time_ms=round(t_gemm * 1e3, 2),
                                executed_tflops=round(executed / t_gemm / 1e12, 2),
                                note="achieved = algorithmic FLOPs of one step (SURVEY §8(d): (2866.6+1322.0) GF x B) / "
-                                    "summed duration of all svl_gemm_f32 + svl_attention_* launches of one step (HIP events on the launch stream)")
+                                    "summed duration of all svl_gemm_f32 + svl_attention_* launches of one step (HIP events on the launch stream); "
+                                    "frac_executed = FLOPs actually issued by those launches / the same time; frac_whole_step = "
+                                    "algorithmic FLOPs / the WHOLE step time (every non-MFMA pass counted against the MFMA peak)")
         # the ViT encoder alone (north_star: ">= 60 % MFMA peak on the ViT encoder"): launches issued inside the encoder's
         # forward / backward regions (5 trainable + 2 frozen forwards, 4 backwards per step)
         gv = [e for e in g if e[4] == "vit"]
@@ -209,14 +289,13 @@ def main():
         if dom is not None and g_arith_exact:
             d_ms = dom[0] * 1e3 / dom[2]
             d_tf = dom[1] / dom[0] / 1e12
+            traffic, tnote = pmc_traffic_record(a.batch)
             out["roofline"]["dominant_launch"] = dict(
                 kernel="gemm_kernel<128,128,2,2,KCONTIG,KCONTIG> (svl_gemm_f32), M=%d N=3072 K=768" % (32 * 1025 * a.batch // 16),
                 launches=dom[2], avg_ms=round(d_ms, 3), achieved=round(d_tf, 1), peak=PEAK_F32_MFMA_TF,
                 frac=round(d_tf / PEAK_F32_MFMA_TF, 4), algorithmic_bytes=513.0e6 * a.batch / 16,
-                traffic=(1.27e9 if a.batch == 16 else None),
-                traffic_note="FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this launch from separate rocprofv3 --pmc passes, "
-                             "profiles/r1_l_pmc_gemm_traffic.md (0.87 GB read with the banded tile order, 1.89 GB before it "
-                             "-- operands 0.11 GB; 0.40 GB written = algorithmic)")
+                traffic=traffic, traffic_note=tnote)
+            out["roofline"]["traffic"] = traffic
         if os.environ.get("SVL_BENCH_DUMP_SHAPES"):
             allsh = sorted(by.items(), key=lambda kv: -kv[1][0])
             with open(os.environ["SVL_BENCH_DUMP_SHAPES"], "w") as f:
@@ -244,9 +323,9 @@ def main():
                  "fp64 <= the f32 MFMA chain's (tests/test_ops_gpu.py::test_gemm_bf16_split_emulation). Not used for 'value'.")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(a.crop, a.nclass)
+            out["cpu_baseline"] = cpu_baseline(512, 21, *a.cpu_baseline_steps)
         except Exception as e:  # the baseline leg must never take the GPU number down with it
-            out["cpu_baseline"] = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port",
+            out["cpu_baseline"] = dict(value=None, unit="images/s", cores=physical_cores(), kind="port",
                                        sample=f"failed: {type(e).__name__}: {e}")
     if rank == 0:
         print(json.dumps(out), flush=True)

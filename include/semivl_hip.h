@@ -6,12 +6,22 @@
  * This header is the operator boundary a maintainer would bind from Python (ctypes stub in INTEGRATION.md);
  * `semivl_amd/` is the host-side mirror of the reference's Python surface built on top of it.
  *
- * Conventions (all entry points):
- *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller;
- *   - the library never allocates/frees device memory, never synchronises, enqueues only on `stream`;
+ * Conventions (all entry points) -- what is TRUE of the library, checked by tests/test_abi.py and
+ * tests/test_ops_gpu.py::test_two_streams_*:
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller, including every
+ *     scratch buffer (svl_*_ws_* size queries): the library never allocates or frees device memory;
+ *   - it never synchronises the device or a stream.  Work is enqueued on `stream` of the caller's CURRENT device.
+ *     Two entry-point families (svl_gemm_f32 on ragged token counts, svl_attention_{fwd,bwd}) additionally run a thin,
+ *     disjoint-output launch on a HELPER stream that is event-forked from and event-joined back into `stream` inside
+ *     the same call (capture-legal: events only), so from the caller's point of view everything is ordered on `stream`;
+ *   - host-side state: one helper stream + two events per (device, caller stream) pair, created lazily under a mutex on
+ *     first use and kept until svl_stream_release(stream) / svl_shutdown(); per-device kernel attributes set once per
+ *     device; and the process-wide configuration switches svl_set_gemm_emulation / svl_set_conv_tiled (relaxed
+ *     atomics seeded from the environment, read once per call, selecting between kernels that compute the same
+ *     function).  Nothing else is mutable: the library is re-entrant across host threads, devices and streams -- calls
+ *     that use different streams never share a helper stream, an event or a buffer;
  *   - tensors are dense fp32 unless stated; token tensors are [rows, C] row-major ("NHWC"/[B,T,C]);
- *   - returns 0 (SVL_OK) or a negative svl_status; svl_last_error() gives the message (thread-local);
- *   - re-entrant per (device, stream); no mutable globals.
+ *   - returns 0 (SVL_OK) or a negative svl_status; svl_last_error() gives the message (thread-local).
  */
 #ifndef SEMIVL_HIP_H_
 #define SEMIVL_HIP_H_
@@ -32,7 +42,12 @@ typedef enum svl_status {
   SVL_ERR_UNSUPPORTED = -3
 } svl_status;
 
-int svl_version(void);
+int svl_version(void); /* 200: round-2 ABI (helper-stream contexts, caller-owned scratch everywhere) */
+/* Destroys the helper stream/events this library created for `stream` on the current device (no-op if none), or for
+ * every stream.  Call after the stream has been synchronised; not required before process exit. */
+int svl_stream_release(svl_stream_t stream);
+int svl_shutdown(void);
+int svl_num_stream_contexts(void); /* live (device, stream) helper contexts -- introspection for tests */
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
 int svl_last_error(char* buf, size_t len);
 
@@ -120,7 +135,7 @@ typedef struct svl_gemm_desc {
 
 int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream);
 
-/* Process-wide arithmetic mode of the LARGE dense GEMMs (M >= 256, N >= 96, K >= 64, dense operand modes):
+/* Process-wide (relaxed-atomic, read once per svl_gemm_f32 call) arithmetic mode of the LARGE dense GEMMs (M >= 256, N >= 96, K >= 64, dense operand modes):
  *   0  v_mfma_f32_32x32x2_f32, exact fp32 fma chain (default);
  *   6  fp32-accurate emulation on the bf16 matrix pipe: every operand element is split into 3 bf16 terms and the 6
  *      leading cross products are accumulated in fp32 (error <= the fp32 path's, 2.7x the MFMA rate);
@@ -201,7 +216,9 @@ int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, const do
 /* conf_mode 'pixelavg' (train_utils.py:43-46): factor[0] = sum over images b of mean_{valid pixels}(conf_b).  The
  * unsupervised branch loss is (sum over ALL pixels of CE) * factor / #valid.  `factors` above/below: double[3] device
  * for the branches {s1, s2, fp}, or NULL for 'pixelwise'. */
-int svl_conf_avg_factor(const float* conf, const int64_t* ign, int B, int64_t HW, double* factor, svl_stream_t stream);
+int64_t svl_conf_avg_ws_doubles(int B); /* size of `workspace` below, in doubles */
+int svl_conf_avg_factor(const float* conf, const int64_t* ign, int B, int64_t HW, double* factor, double* workspace,
+                        svl_stream_t stream);
 /* sums: double[4 branches][4] device (from svl_ce_finalize); out float[8] device =
  * {loss, loss_x, loss_s1, loss_s2, loss_fp, loss_mc_s1, loss_mc_s2, loss_mc_fp}. */
 int svl_semivl_loss(const double* sums, double numel_u, float lam, const double* factors, float* out,

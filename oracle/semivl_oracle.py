@@ -379,7 +379,9 @@ class VLM(nn.Module):
         cm, cs = t([0.48145466, 0.4578275, 0.40821073]), t([0.26862954, 0.26130258, 0.27577711])
         return (img * ls + lm - cm) / cs
 
-    def forward_maskclip(self, img, conf_tresh):  # vlm.py:90-110
+    def forward_maskclip(self, img, conf_tresh, return_prob=False):  # vlm.py:90-110
+        """`return_prob=True` (test aid, not in the reference) also returns the top-2 class probabilities [b, 2, H, W]
+        so that tests can tell a genuine label error from a flip at a floating-point tie / at the threshold."""
         with torch.no_grad():
             feats, _ = self.clip_encoder(self.renormalize_img_for_clip(img))
             dense = F.conv2d(feats[-1], self.mcc_text_feat[:, :, None, None])
@@ -390,6 +392,8 @@ class VLM(nn.Module):
             cert, pred = dense.max(dim=1)
             out = pred.clone()
             out[cert < conf_tresh] = 255
+        if return_prob:
+            return out, dense.topk(2, dim=1).values
         return out
 
     def forward(self, img, need_fp=False, fp_masks=None):
@@ -459,6 +463,9 @@ def semivl_step(model, batch, iters, total_iters, conf_thresh=0.95, conf_mode="p
         pred_w_other = model(b["img_w_other"]).detach()
         conf_w_other, mask_w_other = pred_w_other.softmax(dim=1).max(dim=1)
         mclip = model.forward_maskclip(torch.cat((b["img_w"], b["img_w_other"])), mcc_conf_thresh)
+        mclip_top2 = None
+        if isinstance(model, VLM):   # test aid: top-2 probabilities of the guidance (tie / threshold masks)
+            _, mclip_top2 = model.forward_maskclip(torch.cat((b["img_w"], b["img_w_other"])), mcc_conf_thresh, True)
         nb = b["img_w"].shape[0]
         mclip, mclip_other = mclip.split([nb, nb])
         mclip[b["ignore_mask"] == 255] = 255
@@ -491,7 +498,8 @@ def semivl_step(model, batch, iters, total_iters, conf_thresh=0.95, conf_mode="p
     loss = loss + loss_mc_fp * 0.5 * lam
     aux = dict(loss_x=loss_x, loss_s1=loss_s1, loss_s2=loss_s2, loss_fp=loss_fp, loss_mc_s1=loss_mc_s1,
                loss_mc_s2=loss_mc_s2, loss_mc_fp=loss_mc_fp, mask_w=mask_w, mask_w_other=mask_w_other, mclip=mclip,
-               mclip_other=mclip_other, conf_w=conf_w, pred_x=pred_x, pred_s1=pred_s1)
+               mclip_other=mclip_other, conf_w=conf_w, pred_x=pred_x, pred_s1=pred_s1, pred_w=pred_w,
+               pred_w_other=pred_w_other, mclip_top2=mclip_top2)
     return loss, aux
 
 

@@ -1,6 +1,10 @@
-// Error plumbing + version for libsemivl_hip.so.
+// Error plumbing, version, and the per-(device, stream) helper-stream contexts of libsemivl_hip.so.
 #include "svl_common.h"
 #include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 
 static thread_local char g_err[512] = {0};
 
@@ -11,7 +15,7 @@ void svl_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int svl_version(void) { return 100; }
+extern "C" int svl_version(void) { return 200; }
 
 extern "C" int svl_last_error(char* buf, size_t len) {
   const size_t n = strlen(g_err);
@@ -23,24 +27,93 @@ extern "C" int svl_last_error(char* buf, size_t len) {
   return (int)n;
 }
 
-// ---- helper stream (svl_common.h) -------------------------------------------------------------------------------
-static hipStream_t g_aux = nullptr;
-static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+// ---- helper streams (svl_common.h) ------------------------------------------------------------------------------
+// A few entry points (svl_gemm_f32 on ragged token counts, svl_attention_*) run an independent, disjoint-output thin
+// launch next to their main grid.  Each (device, caller stream) pair owns its OWN helper stream and fork/join events,
+// created on first use on that stream's device and kept until svl_stream_release / svl_shutdown: calls on different
+// caller streams (or devices, or host threads) never share one.  Host-side objects only -- no device memory.
+namespace {
+struct StreamCtx {
+  hipStream_t aux = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+std::mutex g_mu;
+std::map<std::pair<int, hipStream_t>, StreamCtx> g_ctx;
+
+int stream_device(hipStream_t st, int* dev) {
+  if (hipGetDevice(dev) != hipSuccess) {   // the caller's current device is where the kernels of this call are launched
+    svl_set_error("hipGetDevice failed");
+    return SVL_ERR_LAUNCH;
+  }
+  (void)st;
+  return SVL_OK;
+}
+
+int ctx_for(hipStream_t st, StreamCtx* out) {
+  int dev = 0;
+  int rc = stream_device(st, &dev);
+  if (rc != SVL_OK) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto key = std::make_pair(dev, st);
+  auto it = g_ctx.find(key);
+  if (it == g_ctx.end()) {
+    StreamCtx c;
+    SVL_HIP_CHECK(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+    SVL_HIP_CHECK(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
+    SVL_HIP_CHECK(hipEventCreateWithFlags(&c.join, hipEventDisableTiming));
+    it = g_ctx.emplace(key, c).first;
+  }
+  *out = it->second;
+  return SVL_OK;
+}
+
+void destroy(StreamCtx& c) {
+  if (c.aux) (void)hipStreamDestroy(c.aux);
+  if (c.fork) (void)hipEventDestroy(c.fork);
+  if (c.join) (void)hipEventDestroy(c.join);
+}
+}  // namespace
 
 int svl_fork(hipStream_t st, hipStream_t* aux) {
-  if (!g_aux) {
-    SVL_HIP_CHECK(hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking));
-    SVL_HIP_CHECK(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
-    SVL_HIP_CHECK(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
-  }
-  SVL_HIP_CHECK(hipEventRecord(g_ev_fork, st));
-  SVL_HIP_CHECK(hipStreamWaitEvent(g_aux, g_ev_fork, 0));
-  *aux = g_aux;
+  StreamCtx c;
+  int rc = ctx_for(st, &c);
+  if (rc != SVL_OK) return rc;
+  SVL_HIP_CHECK(hipEventRecord(c.fork, st));
+  SVL_HIP_CHECK(hipStreamWaitEvent(c.aux, c.fork, 0));
+  *aux = c.aux;
   return SVL_OK;
 }
 
 int svl_join(hipStream_t st) {
-  SVL_HIP_CHECK(hipEventRecord(g_ev_join, g_aux));
-  SVL_HIP_CHECK(hipStreamWaitEvent(st, g_ev_join, 0));
+  StreamCtx c;
+  int rc = ctx_for(st, &c);
+  if (rc != SVL_OK) return rc;
+  SVL_HIP_CHECK(hipEventRecord(c.join, c.aux));
+  SVL_HIP_CHECK(hipStreamWaitEvent(st, c.join, 0));
   return SVL_OK;
+}
+
+extern "C" int svl_stream_release(svl_stream_t stream) {
+  int dev = 0;
+  int rc = stream_device((hipStream_t)stream, &dev);
+  if (rc != SVL_OK) return rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_ctx.find(std::make_pair(dev, (hipStream_t)stream));
+  if (it != g_ctx.end()) {
+    destroy(it->second);
+    g_ctx.erase(it);
+  }
+  return SVL_OK;
+}
+
+extern "C" int svl_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_ctx) destroy(kv.second);
+  g_ctx.clear();
+  return SVL_OK;
+}
+
+extern "C" int svl_num_stream_contexts(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return (int)g_ctx.size();
 }

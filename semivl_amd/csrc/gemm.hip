@@ -18,6 +18,7 @@
 // optional second concatenated source), the patch-embedding gather, conv wgrad (im2col^T) and split-K.
 #include "svl_common.h"
 #include "conv_tiled.h"
+#include <atomic>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -1160,13 +1161,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wr, wc, l31, hi, zo, zi);
 }
 
+// Process-wide configuration switches (include/semivl_hip.h): relaxed atomics, read once per entry-point call; the
+// environment seeds them on first use.  They select between kernels computing the same function, never touch device
+// state, and are the only mutable globals of the library besides the per-(device, stream) helper contexts (api.hip).
+static int env_int(const char* name, int dflt) { return getenv(name) ? atoi(getenv(name)) : dflt; }
+static std::atomic<int> g_band{-1};
 static int svl_band_n(int tiles_n) {
-  static int band = -1;
-  if (band < 0) band = getenv("SVL_GEMM_BAND") ? atoi(getenv("SVL_GEMM_BAND")) : 8;
+  int band = g_band.load(std::memory_order_relaxed);
+  if (band < 0) {
+    band = env_int("SVL_GEMM_BAND", 8);
+    if (band < 0) band = 0;
+    g_band.store(band, std::memory_order_relaxed);
+  }
   return (band <= 0 || tiles_n <= band) ? tiles_n : band;
 }
-static int g_conv_tiled = -1;  // -1: read SVL_CONV_NO_TILED once
-static int g_emu_mode = -1;  // -1: read SVL_GEMM_EMU once; 0 exact fp32 MFMA; 3 / 6: bf16 split emulation
+static std::atomic<int> g_conv_tiled{-1};  // -1: read SVL_CONV_NO_TILED once
+static std::atomic<int> g_emu_mode{-1};    // -1: read SVL_GEMM_EMU once; 0 exact fp32 MFMA; 3 / 6: bf16 split emulation
+static std::atomic<int> g_ragged_fork{-1};
+// hipFuncSetAttribute is per device: one bit per device ordinal and kernel instantiation
+static bool attr_needed(std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
+}
 
 template <int NS>
 int launch_emu(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
@@ -1237,12 +1255,10 @@ int launch_shortk_tn(const GemmP& p, bool fast, hipStream_t st) {
   if (ngrp < 1) ngrp = 1;
   if (ngrp > nrb4) ngrp = nrb4;
   auto go = [&](auto kern) -> int {
-    static bool attr_set = false;  // one flag per instantiation (the lambda's closure type is per call site + kern type)
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_mask{0};  // one mask per instantiation (the closure type is per call site + kern type)
+    if (attr_needed(attr_mask))
       SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         96 * 1024));
-      attr_set = true;
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)(ngrp * nchunk)), dim3(256), lds, st, p, nchunk);
     SVL_LAUNCH_CHECK("svl_gemm_f32/shortk");
     return SVL_OK;
@@ -1338,15 +1354,16 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   if (d->out_mode == SVL_OUT_PATCH) SVL_CHECK_ARG(d->ct_H > 0, "svl_gemm_f32: bad patch-token geometry");
 
   const int am = d->a_mode, bm = d->b_mode;
-  if (g_emu_mode < 0) {
-    const char* e = getenv("SVL_GEMM_EMU");
-    g_emu_mode = e ? atoi(e) : 0;
+  int emu_mode = g_emu_mode.load(std::memory_order_relaxed);
+  if (emu_mode < 0) {
+    emu_mode = env_int("SVL_GEMM_EMU", 0);
+    g_emu_mode.store(emu_mode, std::memory_order_relaxed);
   }
   auto launch = [&](const GemmP& q) -> int {
-    if ((g_emu_mode == 3 || g_emu_mode == 6) && (am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) &&
+    if ((emu_mode == 3 || emu_mode == 6) && (am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) &&
         (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && q.M >= 256 && q.N >= 96 &&
         q.K >= 64) {
-      return g_emu_mode == 6 ? launch_emu<3>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
+      return emu_mode == 6 ? launch_emu<3>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
                              : launch_emu<2>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
     }
 #define SVL_MODE(AM, BM_) \
@@ -1364,8 +1381,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   };
 
   // Short-K row streams (per-pixel linears / 1x1 convolutions of the head): dedicated persistent kernel
-  static int shortk = -1;
-  if (shortk < 0) shortk = getenv("SVL_GEMM_NO_SHORTK") ? 0 : 1;
+  static const int shortk = getenv("SVL_GEMM_NO_SHORTK") ? 0 : 1;   // thread-safe one-time init, immutable afterwards
   {
     const bool a_dense = am == SVL_A_KCONTIG ||
                          (a_conv && cv.KH == 1 && cv.KW == 1 && cv.pad == 0 && p.cv.stride == 1 && cv.C2 == 0 &&
@@ -1393,8 +1409,12 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   }
 
   // Narrow 3x3 convolutions (N = 32 / 64): spatially tiled kernel (conv_tiled.hip) instead of the implicit GEMM
-  if (g_conv_tiled < 0) g_conv_tiled = getenv("SVL_CONV_NO_TILED") ? 0 : 1;
-  if (g_conv_tiled && am == SVL_A_CONV && bm == SVL_B_KCONTIG && d->out_mode == SVL_OUT_STRIDED && d->batch == 1 &&
+  int conv_tiled = g_conv_tiled.load(std::memory_order_relaxed);
+  if (conv_tiled < 0) {
+    conv_tiled = getenv("SVL_CONV_NO_TILED") ? 0 : 1;
+    g_conv_tiled.store(conv_tiled, std::memory_order_relaxed);
+  }
+  if (conv_tiled && am == SVL_A_CONV && bm == SVL_B_KCONTIG && d->out_mode == SVL_OUT_STRIDED && d->batch == 1 &&
       d->ksplit == 0 && cv.KH == 3 && cv.KW == 3 && cv.dil == 1 && cv.pad == 1 && p.cv.stride == 1 &&
       d->alpha == 1.0f && !d->preact && !d->resid && d->B.ld == d->K && d->ldc_n == 1 &&
       (long)d->M % ((long)cv.H * cv.W) == 0) {
@@ -1413,8 +1433,11 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   // block per column tile, i.e. a whole extra round of the grid on a launch whose tile count is otherwise an exact
   // multiple of the resident-block count (measured -14 % on the N = 768 GEMMs).  Their rows are independent, so they
   // run as a second, thin-tile launch on a helper stream, concurrent with the 128-row-aligned part.
-  static int ragged_fork = -1;
-  if (ragged_fork < 0) ragged_fork = getenv("SVL_GEMM_NO_FORK") ? 0 : 1;
+  int ragged_fork = g_ragged_fork.load(std::memory_order_relaxed);
+  if (ragged_fork < 0) {
+    ragged_fork = getenv("SVL_GEMM_NO_FORK") ? 0 : 1;
+    g_ragged_fork.store(ragged_fork, std::memory_order_relaxed);
+  }
   if (ragged_fork && am == SVL_A_KCONTIG && (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) &&
       d->out_mode == SVL_OUT_STRIDED && d->batch == 1 && d->ksplit == 0 && d->M >= 8192 && (d->M % 128) != 0 &&
       (long)d->N * d->K >= 768 * 768) {
@@ -1443,14 +1466,17 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
 
 extern "C" int svl_set_gemm_emulation(int mode) {
   SVL_CHECK_ARG(mode == 0 || mode == 3 || mode == 6, "svl_set_gemm_emulation: mode must be 0, 3 or 6");
-  g_emu_mode = mode;
+  g_emu_mode.store(mode, std::memory_order_relaxed);
   return SVL_OK;
 }
 extern "C" int svl_set_conv_tiled(int on) {
-  g_conv_tiled = on ? 1 : 0;
+  g_conv_tiled.store(on ? 1 : 0, std::memory_order_relaxed);
   return SVL_OK;
 }
-extern "C" int svl_get_gemm_emulation(void) { return g_emu_mode < 0 ? 0 : g_emu_mode; }
+extern "C" int svl_get_gemm_emulation(void) {
+  const int m = g_emu_mode.load(std::memory_order_relaxed);
+  return m < 0 ? 0 : m;
+}
 
 extern "C" int svl_reduce_slabs_f32(float* out, const float* slabs, int nslab, int64_t count, int accumulate,
                                     svl_stream_t stream) {

@@ -486,11 +486,12 @@ extern "C" int svl_ce_finalize(const float* partials, int64_t nblocks, double* s
   return SVL_OK;
 }
 
+extern "C" int64_t svl_conf_avg_ws_doubles(int B) { return (int64_t)(B > 0 ? B : 0) * CONF_CHUNKS * 2; }
+
 extern "C" int svl_conf_avg_factor(const float* conf, const int64_t* ign, int B, int64_t HW, double* factor,
-                                   svl_stream_t stream) {
-  SVL_CHECK_ARG(conf && ign && factor && B > 0 && B <= 4096 && HW > 0, "svl_conf_avg_factor: bad args");
-  static double* scratch = nullptr;   // [4096][CONF_CHUNKS][2] partial sums (stream-ordered reuse)
-  if (!scratch) SVL_HIP_CHECK(hipMalloc(&scratch, sizeof(double) * 4096 * CONF_CHUNKS * 2));
+                                   double* workspace, svl_stream_t stream) {
+  SVL_CHECK_ARG(conf && ign && factor && workspace && B > 0 && HW > 0, "svl_conf_avg_factor: bad args");
+  double* scratch = workspace;   // [B][CONF_CHUNKS][2] partial sums, caller-owned (svl_conf_avg_ws_doubles)
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(conf_avg_partial_kernel, dim3(CONF_CHUNKS, B), dim3(256), 0, st, conf, ign, (long)HW, scratch);
   SVL_LAUNCH_CHECK("svl_conf_avg_factor/partial");

@@ -185,8 +185,8 @@ extern "C" int svl_seqattn_fwd(const svl_seqattn_desc* d, svl_stream_t stream) {
   if (rc) return rc;
   SVL_CHECK_ARG(d->out, "svl_seqattn_fwd: out missing");
   const size_t lds = lds_bytes(p.seq);
-  if (lds > 64 * 1024)
-    hipFuncSetAttribute((const void*)seqattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024)   // idempotent per-device attribute: set on every call that needs it (cheap host call, no global state)
+    SVL_HIP_CHECK(hipFuncSetAttribute((const void*)seqattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(seqattn_fwd_kernel, dim3(p.groups * p.heads), dim3(256), lds, (hipStream_t)stream, p);
   SVL_LAUNCH_CHECK("svl_seqattn_fwd");
   return SVL_OK;
@@ -199,7 +199,7 @@ extern "C" int svl_seqattn_bwd(const svl_seqattn_desc* d, svl_stream_t stream) {
   SVL_CHECK_ARG(d->dout && d->dqkv && d->dscores, "svl_seqattn_bwd: dout/dqkv/dscores missing");
   const size_t lds = lds_bytes(p.seq);
   if (lds > 64 * 1024)
-    hipFuncSetAttribute((const void*)seqattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SVL_HIP_CHECK(hipFuncSetAttribute((const void*)seqattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(seqattn_bwd_kernel, dim3(p.groups * p.heads), dim3(256), lds, (hipStream_t)stream, p);
   SVL_LAUNCH_CHECK("svl_seqattn_bwd");
   return SVL_OK;

@@ -75,7 +75,11 @@ SIGNATURES = {
     "svl_ce_finalize": (_I, [_P, _L, _P, _P]),
     "svl_semivl_gscale": (_I, [_P, _D, _F, _P, _P, _P]),
     "svl_semivl_loss": (_I, [_P, _D, _F, _P, _P, _P]),
-    "svl_conf_avg_factor": (_I, [_P, _P, _I, _L, _P, _P]),
+    "svl_conf_avg_ws_doubles": (_L, [_I]),
+    "svl_conf_avg_factor": (_I, [_P, _P, _I, _L, _P, _P, _P]),
+    "svl_stream_release": (_I, [_P]),
+    "svl_shutdown": (_I, []),
+    "svl_num_stream_contexts": (_I, []),
     "svl_softmax_planes_f32": (_I, [_P, _I, _I, _L, _P, _P]),
     "svl_count_valid_i64": (_I, [_P, _L, _P, _P]),
     "svl_maskclip_labels": (_I, [_P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),

@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from .. import ops
+from .. import gradsync, ops
 from .vlg_head import _GradCollector
 
 
@@ -38,7 +38,11 @@ class Bottleneck(nn.Module):
 
 
 def _sync_sums(sums):
-    """SyncBN: the ranks exchange per-channel sums; returns the number of ranks that contributed."""
+    """SyncBN: the ranks exchange per-channel sums; returns the number of ranks that contributed.
+    One small ([2, C] doubles) SUM all-reduce per BatchNorm layer per direction, stream-ordered under RCCL (no host
+    sync).  The 13 exchanges cannot be merged into one: layer k+1's input is layer k's output normalised with the GLOBAL
+    statistics, so each exchange depends on the previous one (same in backward) -- torch.nn.SyncBatchNorm has the same
+    structure."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         return dist.get_world_size()
@@ -166,6 +170,7 @@ class _ResNetFn(torch.autograd.Function):
         sv = {}
         x, H, W = _encoder_forward(m, img, sv)
         ctx.m, ctx.sv, ctx.params = m, sv, params
+        gradsync.expect(params)
         return x.view(img.shape[0], H * W, x.shape[1])
 
     @staticmethod
@@ -174,6 +179,7 @@ class _ResNetFn(torch.autograd.Function):
         gc = _GradCollector()
         _encoder_backward(m, dfeat.contiguous().view(-1, dfeat.shape[-1]), sv, gc)
         ctx.sv = None
+        gradsync.ready(ctx.params)
         return (None, None) + tuple(gc.out.get(id(p)) for p in ctx.params)
 
 

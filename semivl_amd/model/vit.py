@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import gradsync, ops
 
 
 # ------------------------------------------------------------------------------------------------ parameter holders
@@ -476,6 +476,7 @@ class _EncoderFn(torch.autograd.Function):
         ctx.pos_is_input = pos_in is not None
         ctx.n_feats = len(outs) - 1
         ctx.params = params
+        gradsync.expect(params)
         if outs[-1] is not None:
             ctx.mark_non_differentiable(outs[-1])  # the global embedding is a side output (unused by VLGHead)
         return outs
@@ -527,7 +528,12 @@ class _EncoderFn(torch.autograd.Function):
             grads[id(a.in_proj_weight)], grads[id(a.in_proj_bias)] = wg["win"], wg["bin"]
             grads[id(a.out_proj.weight)], grads[id(a.out_proj.bias)] = wg["wout"], wg["bout"]
             s["layers"][i] = None  # free this block's activations
+            # this block's attention gradients are complete for this graph: their all-reduce bucket may go (train.py)
+            gradsync.ready([q for q in (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias)
+                            if any(q is r_ for r_ in ctx.params)])
+        rest = [q for q in ctx.params if q is m.pos_embed or not any(q is r_ for l_ in m.layers for r_ in l_.parameters())]
         if dx is None:
+            gradsync.ready(rest)
             ctx.saved = None
             return (None, None, None, None) + tuple(None for _ in ctx.params)
         # ---- ln0 + pos_embed
@@ -544,5 +550,6 @@ class _EncoderFn(torch.autograd.Function):
                 pos_fn(dpos_in, False)
         elif m.pos_embed.requires_grad:
             grads[id(m.pos_embed)] = sink_grad(m.pos_embed, pos_fn)
+        gradsync.ready(rest)
         ctx.saved = None
         return (None, None, None, dpos_in) + tuple(grads.get(id(p)) for p in ctx.params)

@@ -10,7 +10,7 @@ Forward and backward of the whole head are explicit kernel sequences inside one 
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import gradsync, ops
 from .vit import TransformerEncoderLayer
 
 
@@ -436,6 +436,7 @@ class _HeadFn(torch.autograd.Function):
         with ops.prof_scope("head"):
             out, shared = _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, [v0, v4, emb], chunks)
         ctx.m, ctx.chunks, ctx.shared, ctx.params = m, chunks, shared, params
+        gradsync.expect(params)
         ctx.feat_req = (v0.requires_grad, v4.requires_grad, emb.requires_grad)
         return out
 
@@ -490,6 +491,7 @@ class _HeadFn(torch.autograd.Function):
         dv4 = undbl(dv4, mk[1], Cv, HW)
         demb = undbl(demb, mk[2], Ce, HW)
         ctx.chunks = ctx.shared = None
+        gradsync.ready(ctx.params)     # the decoder's gradients of this graph are in the arena
         req = ctx.feat_req
         return (None, None, None, None, None, None, dv0 if req[0] else None, dv4 if req[1] else None,
                 demb if req[2] else None) + tuple(gc.out.get(id(p)) for p in ctx.params)

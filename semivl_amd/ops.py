@@ -683,7 +683,9 @@ def semivl_loss(sums_f64, numel_u, lam, out8, factors=None):
 
 def conf_avg_factor(conf, ign, out_f64):
     """out_f64[0] = sum_b mean_{valid}(conf_b)  ('pixelavg' confidence weighting)."""
-    L.check(L.load().svl_conf_avg_factor(_p(conf), _p(ign), conf.shape[0], conf[0].numel(), _p(out_f64), _st()),
+    lib = L.load()
+    ws = torch.empty(int(lib.svl_conf_avg_ws_doubles(conf.shape[0])), dtype=torch.float64, device=conf.device)
+    L.check(lib.svl_conf_avg_factor(_p(conf), _p(ign), conf.shape[0], conf[0].numel(), _p(out_f64), _p(ws), _st()),
             "svl_conf_avg_factor")
 
 

@@ -92,7 +92,8 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     with torch.no_grad():
         pred_w_other = model(b["img_w_other"])
         conf_w_other, mask_w_other = ops.softmax_max(pred_w_other)
-        del pred_w_other
+        if not return_aux:
+            del pred_w_other
         mclip_all = model.forward_maskclip(_cat2(img_w, b["img_w_other"]), cfg.get("mcc_conf_thresh", 0.9),
                                            ignore_mask=_cat2i(ign, ign_o))
         mclip, mclip_other = mclip_all[:B], mclip_all[B:]
@@ -162,13 +163,14 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         if head is not None:
             head._bwd_ranges = None
     if reducer is not None:
-        reducer.reduce()
+        reducer.finish()    # folds autograd-delivered grads, flushes / waits for the overlapped all-reduce buckets
     if optimizer is not None:
         optimizer.step()
         optimizer.poly_lr(iters, cfg.get("scheduler_max_iters", total_iters))
     if return_aux:
         aux = dict(mask_w=mask_w, mask_w_other=mask_w_other, mclip=mclip, mclip_other=mclip_other, conf_w=conf_w,
-                   pred_x=pred_x.detach(), pred_s1=pred_s1.detach(), dl4=dl4, dls=dls)
+                   pred_x=pred_x.detach(), pred_s1=pred_s1.detach(), pred_w=pred_w.detach(),
+                   pred_w_other=pred_w_other, dl4=dl4, dls=dls)
         return losses, aux
     return losses
 
@@ -326,34 +328,102 @@ def build_optimizer(model, optimizer_cfg):
 
 # ------------------------------------------------------------------------------------------------ data parallel
 class GradAllReducer:
-    """Data-parallel gradient mean over the flat grad arena (replaces DDP's reducer, semivl.py:139-140).
+    """Data-parallel gradient mean over the flat grad arena, overlapped with backward (replaces DDP's reducer,
+    semivl.py:139-140: the reference's all-reduce buckets fire from autograd hooks inside `loss.backward()`, :327).
 
     One process per GPU, `torch.distributed` backend 'nccl' (= RCCL over xGMI on ROCm; 'gloo' for the CPU tests).
-    The arena holds only the 31.4 M live gradients (125 MB) — the reference's DDP also reduces the 86.8 M
-    never-updated clip_encoder gradients.  The arena is cut into buckets that are all-reduced (SUM)
-    back to back in stream order on the caller's stream -- the plain, blocking-semantics `dist.all_reduce`, which for
-    NCCL/RCCL only enqueues the collective and a stream dependency.  125 MB over xGMI is ~1 ms against a 730 ms step
-    and nothing runs after backward that it could overlap with, so no side stream / async handles: that variant was
-    measured to stall for 20 s per step under gloo on GPU tensors (2-process dry run) and buys nothing under RCCL.
-    The optimizer divides by world_size inside its kernel (grad_scale) instead of a separate pass.
-    Loss normalisers stay per-rank as in the reference.
-    """
+    The arena holds only the 31.4 M live gradients (125 MB) -- the reference's DDP also reduces the 86.8 M never-updated
+    clip_encoder gradients.  It is cut at parameter boundaries into contiguous buckets of ~`bucket_mb`.
+    The backward regions announce contributions through `gradsync.expect / ready`; a bucket whose parameters have all
+    received every expected contribution (two per step: the [w, x, w_fp] graph and the [s1, s2] graph both reach every
+    trainable tensor) is all-reduced (SUM) at once on a dedicated communication stream that is event-ordered after the
+    last gradient write, so the collective runs under the remaining backward compute: the decoder's bucket under the
+    second ViT backward, layers 11..3 under the layers below them.  `finish()` (after backward) folds gradients that
+    arrived through torch autograd (pos_embed behind its resize), flushes whatever is left in bucket order (same order on
+    every rank) and makes the compute stream wait for all collectives before AdamW.  xGMI is point-to-point (~153 GB/s per
+    link): a 25 MB bucket is ~0.3 ms on the ring, so few, large buckets; the 1/W of the mean is folded into the AdamW
+    kernel (grad_scale).  Loss normalisers stay per-rank as in the reference.
+    With `overlap=False`, or on backends that cannot run stream-ordered collectives on GPU tensors (gloo: it stages
+    through the host and stalls the launching thread), the same buckets are reduced back to back in finish()."""
 
-    def __init__(self, optimizer, bucket_mb=32, group=None):
+    def __init__(self, optimizer, bucket_mb=25, group=None, overlap=None):
         self.opt, self.group = optimizer, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         optimizer.grad_scale = 1.0 / self.world
         n = optimizer.g.numel()
         per = max(1, int(bucket_mb * 1024 * 1024 // 4))
-        self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
+        groups = getattr(optimizer, "groups", None)
+        self._slot = {}          # id(param) -> bucket index
+        self._expected, self._done = {}, {}
+        if groups:               # cut at parameter boundaries (arena order = model.named_parameters() order)
+            offs = optimizer.seg_off.tolist()
+            self.buckets, start, members = [], 0, []
+            for i, g_ in enumerate(groups):
+                members.append(g_["param"])
+                if offs[i + 1] - start >= per or i == len(groups) - 1:
+                    self.buckets.append((start, offs[i + 1]))
+                    for prm in members:
+                        self._slot[id(prm)] = len(self.buckets) - 1
+                    start, members = offs[i + 1], []
+        else:                    # bare arena (tests)
+            self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
+        self._members = [0] * len(self.buckets)
+        for b_ in self._slot.values():
+            self._members[b_] += 1
+        backend = dist.get_backend(group) if (dist.is_initialized() and self.world > 1) else None
+        self.overlap = (backend == "nccl") if overlap is None else bool(overlap)
+        self._async = backend == "nccl"
+        self._comm = torch.cuda.Stream() if (self._async and optimizer.g.is_cuda) else None
+        self._works, self._fired, self._complete = [], set(), [0] * len(self.buckets)
+        self.early_fires = 0
+        if self.world > 1 and groups:
+            for g_ in groups:
+                g_["param"]._svl_reducer = self
+
+    # ---- region hooks (gradsync.expect / gradsync.ready) ---------------------------------------------------------
+    def _expect(self, prm):
+        self._expected[id(prm)] = self._expected.get(id(prm), 0) + 1
+
+    def _ready(self, prm):
+        k = id(prm)
+        self._done[k] = self._done.get(k, 0) + 1
+        if self._done[k] == self._expected.get(k, 0):
+            b_ = self._slot[k]
+            self._complete[b_] += 1
+            if self.overlap and self._complete[b_] == self._members[b_]:
+                self.early_fires += 1           # (statistics: buckets launched from inside backward)
+                self._fire(b_)
+
+    def _fire(self, b_):
+        if b_ in self._fired:
+            return
+        self._fired.add(b_)
+        s, e = self.buckets[b_]
+        g = self.opt.g[s:e]
+        if self._comm is not None:
+            self._comm.wait_stream(torch.cuda.current_stream())     # ordered after the last gradient write
+            with torch.cuda.stream(self._comm):
+                self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_params(self, src=0):
         if self.world > 1:
             dist.broadcast(self.opt.p, src, group=self.group)
 
-    def reduce(self):
-        if self.world == 1:
-            return
-        g = self.opt.g
-        for s, e in self.buckets:
-            dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
+    def finish(self):
+        """After backward: every gradient in the arena, every bucket reduced, compute stream ordered after them."""
+        if hasattr(self.opt, "_fold_autograd_grads"):
+            self.opt._fold_autograd_grads()     # e.g. pos_embed behind its bicubic resize: BEFORE its bucket is reduced
+        if self.world > 1:
+            for b_ in range(len(self.buckets)):
+                self._fire(b_)
+            for w in self._works:
+                w.wait()                         # stream-level wait (no host sync) for NCCL/RCCL works
+            if self._comm is not None:
+                torch.cuda.current_stream().wait_stream(self._comm)
+        self._works, self._fired = [], set()
+        self._complete = [0] * len(self.buckets)
+        self._expected, self._done = {}, {}
+
+    reduce = finish

@@ -22,6 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from golden_util import seeded_state, smooth_batch, tie_masks  # noqa: E402  (shared with the tests: one weight / input stream)
 
 TEXT = "configs/_base_/datasets/text_embedding/voc12_wbg_single.npy"
 MCC_TEXT = "configs/_base_/datasets/text_embedding/voc12_wbg_concept4_single.npy"
@@ -40,37 +42,13 @@ CONFIGS = {
     "skr": dict(S=96, B=2, embed=64, layers=3, heads=1, out_indices=[1, 3], channels=32, text_channels=32,
                 dec_heads=1, up=(32, 16), skip=(16, 16), seed=14, conf_thresh=0.05, conf_mode="pixelavg",
                 conv_encoder=True),
+    # peaked predictions (decoder's last conv x150, low-passed inputs): with conf_mode 'pixelwise' at the shipped threshold
+    # 0.95 a large share of the pixels passes the confidence gate, so loss_s1 / loss_s2 / loss_fp are non-zero against
+    # the reference's own confidence_weighted_loss (train_utils.py:30-49)
+    "conf": dict(S=128, B=2, embed=64, layers=3, heads=1, out_indices=[0, 1, 3], channels=32, text_channels=32,
+                 dec_heads=1, up=(32, 16), skip=(16, 16), seed=15, conf_thresh=0.95, logit_gain=150.0,
+                 smooth_inputs=True),
 }
-
-
-def seeded_state(named_shapes, seed):
-    """Deterministic non-trivial parameters: LN/GN gains 1+0.1n, biases 0.02n, cls/pos/weights 0.05n (conv/linear
-    fan-in scaled so activations stay O(1))."""
-    g = torch.Generator().manual_seed(seed)
-    out = {}
-    for name, shape in named_shapes:
-        r = torch.randn(*shape, generator=g) if len(shape) else torch.zeros(())
-        leaf = name.split(".")[-1]
-        parent = name.split(".")[-2] if "." in name else ""
-        is_norm = parent.startswith("ln") or (leaf in ("weight", "bias") and len(shape) == 1 and
-                                              any(s in name for s in (".1.weight", ".1.bias", ".2.weight", ".2.bias",
-                                                                      ".4.weight", ".4.bias")))
-        if leaf == "num_batches_tracked":          # BatchNorm buffers of the conv_encoder fixtures
-            out[name] = torch.zeros(shape, dtype=torch.long)
-        elif leaf == "running_var":
-            out[name] = 1.0 + 0.1 * r.abs()
-        elif leaf == "running_mean":
-            out[name] = 0.05 * r
-        elif (is_norm or parent.startswith("bn")) and leaf == "weight":
-            out[name] = 1.0 + 0.1 * r
-        elif leaf == "bias" or name.endswith("in_proj_bias"):
-            out[name] = 0.02 * r
-        elif len(shape) >= 2:
-            fan_in = int(np.prod(shape[1:]))
-            out[name] = r * (1.0 / np.sqrt(fan_in))
-        else:
-            out[name] = 0.05 * r
-    return out
 
 
 def build_reference(c):
@@ -134,7 +112,7 @@ def main():
         torch.manual_seed(c["seed"])
         ref = build_reference(c)
         shapes = [(k, tuple(v.shape)) for k, v in ref.state_dict().items()]
-        sd = seeded_state(shapes, c["seed"])
+        sd = seeded_state(shapes, c["seed"], c.get("logit_gain"))
         ref.load_state_dict(sd, strict=True)
 
         orc = O.build_vlm(dict(nclass=21, crop=c["S"], embed=c["embed"], layers=c["layers"], heads=c["heads"],
@@ -150,6 +128,8 @@ def main():
 
         B, S = c["B"], c["S"]
         batch = O.synthetic_batch(B, S, 21, seed=1234 + c["seed"])
+        if c.get("smooth_inputs"):
+            batch = smooth_batch(batch)
         g = torch.Generator().manual_seed(c["seed"] + 100)
         fp_ch = (c["embed"], 512, 256) if c.get("conv_encoder") else (c["embed"], c["embed"], 512)  # dropout2d call order
         fp_masks = [(torch.rand(2 * B, ch, generator=g) > 0.5).float() for ch in fp_ch]
@@ -190,6 +170,10 @@ def main():
         with torch.no_grad():
             logits_eval = ref(batch["img_x"])
             mclip_x = ref.forward_maskclip(batch["img_x"], 0.9)
+            orc.eval()
+            o_mx, o_top2 = orc.forward_maskclip(batch["img_x"], 0.9, True)
+            assert torch.equal(o_mx, mclip_x)
+            tie_mx = ((o_top2[:, 0] - o_top2[:, 1]) < 1e-6) | ((o_top2[:, 0] - 0.9).abs() < 1e-6)
 
         rl, raux, rg = run(ref, True)
         ol, oaux, og = run(orc, False)
@@ -198,6 +182,8 @@ def main():
             print(f"    {k:11s} ref {raux[k].item():.8f}  |d| {abs(raux[k].item() - oaux[k].item()):.2e}")
         for k in ("mask_w", "mask_w_other", "mclip", "mclip_other"):
             assert torch.equal(raux[k], oaux[k]), f"{k} differs"
+        ties = tie_masks(oaux, B)
+        print("    fp-tie pixels:", {k: int(v.sum()) for k, v in ties.items()})
         print("    frac conf_w >= thr:", (raux["conf_w"] >= c["conf_thresh"]).float().mean().item())
         print("    label maps bit-exact; conf_w |d|", (raux["conf_w"] - oaux["conf_w"]).abs().max().item(),
               " pred_x |d|", (raux["pred_x"] - oaux["pred_x"]).abs().max().item())
@@ -225,6 +211,7 @@ def main():
             pred_x_s4=raux["pred_x"].detach()[:, :, ::4, ::4].numpy(), logits_eval_s4=logits_eval[:, :, ::4, ::4].numpy(),
             mclip_x=mclip_x.numpy().astype(np.uint8),
             fp_masks=np.concatenate([m.numpy().ravel() for m in fp_masks]).astype(np.uint8),
+            **{"tie/" + k: np.packbits(v.numpy()) for k, v in ties.items()}, **{"tie/mclip_x": np.packbits(tie_mx.numpy())},
             grad_names=np.array(sorted(rg)), opt_group_lr=np.array([gr["lr"] for gr in groups]),
             opt_group_wd=np.array([gr["weight_decay"] for gr in groups]), opt_group_names=np.array(names),
         )

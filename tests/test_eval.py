@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from golden_util import assert_labels
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -63,18 +65,27 @@ def test_hip_eval_matches_reference_fixture(dev):
     with torch.no_grad():
         pred, final = predict(model, img.to(dev), mask.to(dev), "zegclip_sliding_window", cfg, return_logits=True)
     assert np.abs(final[:, :, ::8, ::8].cpu().numpy() - z["final_s8"]).max() < 1e-4
-    mism = (pred.cpu().numpy().astype(np.uint8) != z["pred"]).mean()
-    assert mism < 1e-4, f"prediction mismatch rate {mism}"
+    # bit-exact prediction map; a flip is tolerated only where the reference's own top-2 logit gap is an fp tie
+    with torch.no_grad():
+        _, ofinal = E.predict_zegclip_sliding_window(E.ToyModel(K), img, mask.shape[-2:], crop, stride, K)
+    t2 = ofinal.topk(2, dim=1).values
+    tie = ((t2[:, 0] - t2[:, 1]) < 1e-6).numpy()
+    hip_pred = pred.cpu().numpy().astype(np.uint8)
+    flips = assert_labels(hip_pred, z["pred"], tie, "zegclip_sliding_window prediction")
     # integer confusion counts: bit-exact given the same prediction map
     i, u, t = intersection_and_union(torch.from_numpy(z["pred"]).long().to(dev), mask.to(dev), K, 255)
     assert np.array_equal(i.cpu().numpy(), z["inter"]) and np.array_equal(u.cpu().numpy(), z["union"])
     assert np.array_equal(t.cpu().numpy(), z["target"])
     # evaluate(): deferred single reduction == reference formula
     miou, iou = evaluate(model, [(img[:1], mask[:1], None), (img[1:], mask[1:], None)], "zegclip_sliding_window", cfg)
+    # the metric is a pure function of the integer counts: it must match the reference formula on the SAME prediction to
+    # rounding, and the fixture's mIoU itself whenever the prediction map is identical (no tie flips)
+    hi, hu, _ = E.intersection_and_union(hip_pred, mask.numpy(), K, 255)
+    assert abs(miou - E.miou(hi.astype(float), hu.astype(float))[0]) < 1e-9
     ref_miou, _ = E.miou(z["inter"].astype(float), z["union"].astype(float))
-    assert abs(miou - ref_miou) < 0.05
+    assert flips > 0 or abs(miou - ref_miou) < 1e-9
     for mode, pk, fk in (("sliding_window", "pred_sw", "final_sw_s8"), ("padded_sliding_window", "pred_pd", "final_pd_s8")):
         with torch.no_grad():
             p_, f_ = predict(model, img.to(dev), mask.to(dev), mode, cfg, return_logits=True)
         assert np.abs(f_[:, :, ::8, ::8].cpu().numpy() - z[fk]).max() < 1e-5, mode
-        assert (p_.cpu().numpy().astype(np.uint8) != z[pk]).mean() < 1e-4, mode
+        assert (p_.cpu().numpy().astype(np.uint8) != z[pk]).mean() < 1e-5, mode   # (probability-averaged windows)

@@ -1,57 +1,61 @@
-"""Full-size parity (BASELINE config dims: CLIP ViT-B/16 + VLG head, N=21, 512x512) at batch 1: the product on MI355X
-against the oracle restatement on the host CPU, same seeded weights and inputs."""
+"""Full-size parity (BASELINE config dims: CLIP ViT-B/16 + VLG head at every class count of BASELINE.json's configs --
+VOC N=21, COCO N=81, ADE N=150 at 512x512 and the Cityscapes recipe N=19 at 801x801 with the ResNetV1c side encoder) at
+batch 1: the product on MI355X against the oracle restatement on the host CPU, same seeded weights and inputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-CK = dict(backbone=dict(lr_mult=0.01), text_encoder=dict(lr_mult=0.0), conv_encoder=dict(lr_mult=1.0),
-          norm=dict(decay_mult=0.0), ln=dict(decay_mult=0.0), head=dict(lr_mult=10.0))
+TEXT_DIR = "configs/_base_/datasets/text_embedding/"
 
 
-def build_pair(dev, nclass=21, dataset="pascal"):
-    from golden_util import seeded_state, text_feats
+def build_pair(dev, nclass=21, dataset="pascal", crop=512, seed=4242):
+    from golden_util import PKG, seeded_state
     from oracle import semivl_oracle as O
     from semivl_amd.model.builder import build_model
     from semivl_amd.model.text_embeddings import get_class_to_concept_idxs
     from semivl_amd.synthetic import exp40_cfg
-    cfg = exp40_cfg(1, 512, nclass, dataset)
+    cfg = exp40_cfg(1, crop, nclass, dataset)
     hip = build_model(cfg)
-    sd = seeded_state([(k, tuple(v.shape)) for k, v in hip.state_dict().items()], 4242)
+    sd = seeded_state([(k, tuple(v.shape)) for k, v in hip.state_dict().items()], seed)
     hip.load_state_dict(sd, strict=True)
-    t, m = text_feats()
-    orc = O.build_vlm(dict(nclass=nclass, crop=512), t, m,
-                      get_class_to_concept_idxs("configs/_base_/datasets/text_embedding/voc12_wbg_concept4_single.npy"))
+    prefix = {"pascal": "voc12_wbg", "cityscapes": "cityscapes", "coco": "coco", "ade": "ade"}[dataset]
+    tpath = f"{TEXT_DIR}{prefix}_{cfg['text_embedding_variant']}.npy"
+    mpath = f"{TEXT_DIR}{prefix}_{cfg['mcc_text']}.npy"
+    t = torch.from_numpy(np.load(os.path.join(PKG, tpath)))
+    m = torch.from_numpy(np.load(os.path.join(PKG, mpath)))
+    cls2con = get_class_to_concept_idxs(mpath) if m.shape[0] != nclass else None
+    ocfg = dict(nclass=nclass, crop=crop)
+    kw = {}
+    if dataset == "cityscapes":    # exp 44: skr04 model, CLIP renorm; the frozen CLIP keeps its 512^2 position grid
+        ocfg.update(out_indices=(4, 12), skip_in=(768, 256), skip=(32, 32), conv_encoder=True, renorm_clip_img=True)
+        kw["clip_img_size"] = 512
+    orc = O.build_vlm(ocfg, t, m, cls2con, **kw)
     orc.load_state_dict(sd, strict=True)
     return cfg, hip.to(dev), orc
 
 
-@pytest.fixture(scope="module")
-def fullsize_case():
-    """Oracle side of the full-size step, computed once for both GEMM arithmetic modes."""
+def oracle_step(orc, cfg, batch, masks, conf_thresh):
     from oracle import semivl_oracle as O
-    dev = torch.device("cuda:0")
-    torch.set_num_threads(min(32, torch.get_num_threads()))
-    cfg, hip, orc = build_pair(dev)
-    batch = O.synthetic_batch(1, 512, 21, seed=99)
-    g = torch.Generator().manual_seed(5)
-    masks = [(torch.rand(2, c, generator=g) > 0.5).float() for c in (768, 768, 512)]
-    # random-init confidences are ~1/21: conf_thresh = 0 keeps the whole unsupervised CE term alive WITHOUT putting
-    # thousands of pixels within rounding distance of the threshold (at 0.06 a 2e-6 logit perturbation moved pixels in
-    # and out of the loss and the gradients by several per cent -- thresholding itself is covered by the fixtures)
-    cfg = dict(cfg, conf_thresh=0.0)
-    loss, aux = O.semivl_step(orc, batch, 100, 1000, conf_thresh=0.0, fp_masks=masks)
+    for p_ in orc.parameters():
+        p_.grad = None
+    loss, aux = O.semivl_step(orc, batch, 100, 1000, conf_thresh=conf_thresh, conf_mode=cfg["conf_mode"],
+                              fp_masks=masks)
     loss.backward()
-    return cfg, hip, orc, batch, masks, loss, aux
+    return loss, aux
 
 
-@pytest.mark.parametrize("gemm_mode", [0, 6])
-def test_fullsize_step_matches_oracle(dev, fullsize_case, gemm_mode):
-    """gemm_mode 0: exact fp32 MFMA; 6: the ViT linears on the bf16 pipe (3-way split, 6 products) -- same tolerances."""
+def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, grad_tol=1e-2, noisy=()):
+    """Losses / logits within north_star's 1e-3; label maps bit-exact except at fp ties of the oracle (a flip needs the
+    oracle's top-2 logit gap to be below twice the logit error measured in this very run; MaskCLIP labels: top-2
+    probability gap or distance to the 0.9 threshold below 1e-4 -- its softmax runs at temperature 100); every parameter
+    gradient against the oracle's."""
+    from golden_util import assert_labels
     from semivl_amd import ops
     from semivl_amd.train import LOSS_NAMES, semivl_train_step
-    cfg, hip, orc, batch, masks, loss, aux = fullsize_case
     for p_ in hip.parameters():
         p_.grad = None
         if hasattr(p_, "main_grad"):
@@ -66,41 +70,126 @@ def test_fullsize_step_matches_oracle(dev, fullsize_case, gemm_mode):
     assert abs(got["loss"] - loss.item()) < 1e-3, (got["loss"], loss.item())
     for k in LOSS_NAMES[1:]:
         assert abs(got[k] - aux[k].item()) < 1e-3, (k, got[k], aux[k].item())
-    assert (haux["pred_x"].cpu() - aux["pred_x"].detach()).abs().max().item() < 1e-3   # logits tolerance of north_star
-    for k in ("mask_w", "mask_w_other", "mclip", "mclip_other"):
-        mism = (haux[k].cpu() != aux[k]).float().mean().item()
-        assert mism < 5e-4, f"{k}: label mismatch rate {mism}"
+    errs = {}
+    for k in ("pred_x", "pred_s1", "pred_w", "pred_w_other"):
+        errs[k] = (haux[k].cpu() - aux[k].detach()).abs().max().item()
+        assert errs[k] < 1e-3, (k, errs[k])   # logits tolerance of north_star
+    B = batch["img_w"].shape[0]
+
+    def gap(logits):
+        t = logits.detach().topk(2, dim=1).values
+        return t[:, 0] - t[:, 1]
+    t2 = aux["mclip_top2"]
+    mtie = ((t2[:, 0] - t2[:, 1]) < 1e-4) | ((t2[:, 0] - cfg["mcc_conf_thresh"]).abs() < 1e-4)
+    ties = dict(mask_w=gap(aux["pred_w"]) <= 2 * errs["pred_w"], mask_w_other=gap(aux["pred_w_other"]) <= 2 * errs["pred_w_other"],
+                mclip=mtie[:B], mclip_other=mtie[B:])
+    flips = {k: assert_labels(haux[k].cpu().numpy(), aux[k].numpy(), ties[k].numpy(), k)
+             for k in ("mask_w", "mask_w_other", "mclip", "mclip_other")}
+    for k, n in flips.items():
+        assert n <= 5e-4 * aux[k].numel(), (k, n)
     assert (haux["conf_w"].cpu() - aux["conf_w"]).abs().max().item() < 1e-4
     og = {n: p.grad for n, p in orc.named_parameters() if p.grad is not None}
     hg = {n: p.grad for n, p in hip.named_parameters() if p.grad is not None}
     assert sorted(og) == sorted(hg) and len(og) > 100, sorted(set(og) ^ set(hg))
-    worst = 0.0
     table = sorted(((hg[n].cpu() - og[n]).abs().max().item() / max(og[n].abs().max().item(), 1e-12), n) for n in og)
-    print(f"[gemm_mode {gemm_mode}] largest grad max-err / scale:", [(f"{v:.1e}", n) for v, n in table[-6:]])
+    print(f"[gemm_mode {gemm_mode}] logit errs {errs}, label flips at ties {flips}; largest grad max-err / scale:",
+          [(f"{v:.1e}", n) for v, n in table[-6:]])
     for n in og:
         ref = og[n]
         err = (hg[n].cpu() - ref).abs().max().item()
         scale = ref.abs().max().item()
-        if scale > 1e-7:
-            worst = max(worst, err / scale)
         # head.bias' gradient is sum(softmax - onehot) over all pixels: exactly 0 in exact arithmetic, pure rounding noise here
-        floor = 1e-6 if n == "decode_head.head.bias" else 1e-8
+        floor = 1e-5 if n == "decode_head.head.bias" else 1e-8   # (noise grows with the number of class planes summed)
         # element-wise bound at 1 % of the tensor's largest entry, or (for tensors at the far end of the 12-layer chain
         # whose entries are ~1e-6, e.g. pos_embed: a sum of cancelling terms) 2 % in the L2 sense with a 5 % element-wise cap
         rel2 = ((hg[n].cpu() - ref).norm() / (ref.norm() + 1e-20)).item()
-        assert err < 1e-2 * scale + floor or (rel2 < 2e-2 and err < 5e-2 * scale), \
+        tol = grad_tol
+        if any(s in n for s in noisy):   # ReLU-on-BatchNorm stacks: a pre-activation within rounding of 0 flips (see
+            tol = 3e-2                   # test_model_gpu.py::test_conv_encoder_matches_oracle)
+            assert rel2 < tol or ref.norm().item() < 1e-7, f"{n}: rel L2 {rel2}"
+            continue
+        assert err < tol * scale + floor or (rel2 < 2 * tol and err < 5 * tol * scale), \
             f"{n}: grad max err {err} vs scale {scale} (rel L2 {rel2})"
-    print(f"full-size step: worst grad rel max-err {worst:.2e}")
+    return haux
+
+
+def fp_masks_for(chans, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.rand(2, c, generator=g) > 0.5).float() for c in chans]
+
+
+@pytest.fixture(scope="module")
+def fullsize_case():
+    """Oracle side of the full-size VOC step, computed once for both GEMM arithmetic modes."""
+    from oracle import semivl_oracle as O
+    dev = torch.device("cuda:0")
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    cfg, hip, orc = build_pair(dev)
+    batch = O.synthetic_batch(1, 512, 21, seed=99)
+    masks = fp_masks_for((768, 768, 512))
+    # random-init confidences are ~1/21: conf_thresh = 0 keeps the whole unsupervised CE term alive WITHOUT putting
+    # thousands of pixels within rounding distance of the threshold (at 0.06 a 2e-6 logit perturbation moved pixels in
+    # and out of the loss and the gradients by several per cent -- thresholding itself is covered by the fixtures)
+    cfg = dict(cfg, conf_thresh=0.0)
+    loss, aux = oracle_step(orc, cfg, batch, masks, 0.0)
+    return cfg, hip, orc, batch, masks, loss, aux
+
+
+@pytest.mark.parametrize("gemm_mode", [0, 6])
+def test_fullsize_step_matches_oracle(dev, fullsize_case, gemm_mode):
+    """gemm_mode 0: exact fp32 MFMA; 6: the ViT linears on the bf16 pipe (3-way split, 6 products) -- same tolerances."""
+    cfg, hip, orc, batch, masks, loss, aux = fullsize_case
+    check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode)
+
+
+@pytest.mark.parametrize("nclass,dataset", [(81, "coco"), (150, "ade")])
+def test_fullsize_step_large_class_counts(dev, nclass, dataset):
+    """BASELINE configs 4 / 5 (experiments.py:373-424): the whole training step at N = 81 / 150 class-images per image
+    (SemanticTransformer sequence length N, N-wide similarity GEMM, CE over N planes, chunked decoder) against the oracle."""
+    from oracle import semivl_oracle as O
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    cfg, hip, orc = build_pair(dev, nclass, dataset, seed=4300 + nclass)
+    cfg = dict(cfg, conf_thresh=0.0, head_chunk_class_images=2 * nclass)   # two samples per chunk: several chunks at B = 1
+    batch = O.synthetic_batch(1, 512, nclass, seed=100 + nclass)
+    masks = fp_masks_for((768, 768, 512), seed=nclass)
+    loss, aux = oracle_step(orc, cfg, batch, masks, 0.0)
+    check_step(dev, cfg, hip, orc, batch, masks, loss, aux)
+    hip.decode_head.chunk_class_images = 1344
+
+
+def test_fullsize_cityscapes_recipe(dev):
+    """BASELINE config 3 as the reference defines it (experiments.py:428-456): N=19 at 801x801 (51x51 ragged patch grid,
+    per-forward bicubic pos-embed resize, AvgPool floor 51 -> 12), skr04 model with the ResNetV1c side encoder as the
+    second skip source, CLIP re-normalisation, cityscapes_conceptavg3 text / concept3 (54 -> 19) MaskCLIP aggregation,
+    conf_mode 'pixelavg'."""
+    from oracle import semivl_oracle as O
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    cfg, hip, orc = build_pair(dev, 19, "cityscapes", crop=801, seed=4319)
+    with torch.no_grad():   # zero-init bn3 of the torchvision-style bottlenecks would silence the residual branches
+        sd = orc.state_dict()
+        g = torch.Generator().manual_seed(9)
+        for n, p in orc.named_parameters():
+            if "conv_encoder" in n and p.dim() == 1:
+                r = torch.randn(p.shape, generator=g)
+                p.copy_(1.0 + 0.2 * r if n.endswith("weight") else 0.1 * r)
+        hip.load_state_dict({k: v.clone() for k, v in orc.state_dict().items()}, strict=True)
+    assert cfg["conf_mode"] == "pixelavg" and cfg["model"].endswith("skr04-ftap-mcvitb")
+    batch = O.synthetic_batch(1, 801, 19, seed=119)
+    masks = fp_masks_for((768, 512, 256), seed=19)     # dropout2d call order: [v4, emb, conv feature]
+    loss, aux = oracle_step(orc, cfg, batch, masks, cfg["conf_thresh"])
+    check_step(dev, cfg, hip, orc, batch, masks, loss, aux, noisy=("conv_encoder", "skip_proj.1", "up2"))
+    for (n, bo), (_, bh) in zip(sorted(orc.named_buffers()), sorted(hip.named_buffers())):
+        if "conv_encoder" in n:   # SyncBN running statistics after the train-mode passes
+            assert (bh.cpu().float() - bo.float()).abs().max().item() < 1e-4 * max(1.0, bo.float().abs().max().item()), n
 
 
 def test_fullsize_ade150_head_forward(dev):
     """N = 150 classes (ADE config): eval forward of the full model vs the oracle (exercises the seq=150 attention,
     N=150 similarity GEMM and class-batched decoder at 150 class-images per image)."""
-    from golden_util import PKG, seeded_state
+    from golden_util import PKG, assert_labels, seeded_state
     from oracle import semivl_oracle as O
     from semivl_amd.model.builder import build_model
     from semivl_amd.synthetic import exp40_cfg
-    import os
     cfg = exp40_cfg(1, 512, 150, "ade")
     hip = build_model(cfg)
     sd = seeded_state([(k, tuple(v.shape)) for k, v in hip.state_dict().items()], 777)
@@ -114,7 +203,8 @@ def test_fullsize_ade150_head_forward(dev):
     with torch.no_grad():
         ref = orc(img)
         out = hip(img.to(dev))
-        rm = orc.forward_maskclip(img, 0.9)
+        rm, top2 = orc.forward_maskclip(img, 0.9, True)
         hm = hip.forward_maskclip(img.to(dev), 0.9)
     assert (out.cpu() - ref).abs().max().item() < 1e-3
-    assert (hm.cpu() != rm).float().mean().item() < 5e-4
+    tie = ((top2[:, 0] - top2[:, 1]) < 1e-4) | ((top2[:, 0] - 0.9).abs() < 1e-4)
+    assert_labels(hm.cpu().numpy(), rm.numpy(), tie.numpy(), "maskclip labels")

@@ -1,7 +1,8 @@
 """Multi-process checks on the GPU box (two gloo processes sharing its one GPU).  (1) SyncBN exchange of the Cityscapes
 side encoder across data-parallel ranks: the two processes each push half of a batch through ResNetV1c; outputs, running statistics and the rank-summed parameter
 gradients must equal a single-process run on the whole batch (= what torch.nn.SyncBatchNorm guarantees).  (2) One full
-training step through GradAllReducer + FusedAdamW on two ranks."""
+training step through GradAllReducer + FusedAdamW on two ranks with different data shards (gloo on the one GPU; RCCL
+when the box has two)."""
 import os
 import sys
 
@@ -72,51 +73,105 @@ def test_syncbn_two_ranks_equal_one_big_batch(dev):
         assert e < 3e-2, (n, e)                           # ReLU sign flips at rounding distance, see test_model_gpu
 
 
-def _step_worker(rank, world, port, q):
+STEP_CFG = dict(conf_thresh=0.05, conf_mode="pixelwise", mcc_conf_thresh=0.9, mcc_loss_reduce="mean_all",
+                maskclip_consistency_lambda=[0.1, 0])
+
+
+def _step_worker(rank, world, port, name, backend, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    q.put((rank, _one_step(torch.device("cuda:0"), distributed=True)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank,) + _one_step(dev, name, shards=[rank], world=world))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _one_step(dev, distributed):
-    from golden_util import build_hip, fixture_batch, fixture_fp_masks, fixture_state, load_fixture
+def _shard(c, rank):
+    """Rank `rank`'s slice of the step inputs: DIFFERENT data on every rank (seed 500 + rank)."""
+    from semivl_amd.synthetic import synthetic_batch
+    return synthetic_batch(c["B"], c["S"], 21, seed=500 + rank)
+
+
+def _one_step(dev, name, shards, world):
+    """world > 1: this process is ONE rank, runs shard[0] and all-reduces.  world == 1: the single-process statement of
+    what data parallelism must compute -- every shard's backward (each with its OWN loss normalisers)
+    accumulated into one gradient arena, then one AdamW step on the mean (grad_scale = 1/len(shards))."""
+    from golden_util import build_hip, fixture_fp_masks, fixture_state, load_fixture
     from semivl_amd.synthetic import exp40_cfg
     from semivl_amd.train import FusedAdamW, GradAllReducer, semivl_train_step
-    z, c = load_fixture("tiny")
+    z, c = load_fixture(name)
     hip = build_hip(c)
     hip.load_state_dict(fixture_state(z, c, hip), strict=True)
     hip.to(dev)
     opt = FusedAdamW(hip, exp40_cfg()["optimizer"])
-    red = GradAllReducer(opt, bucket_mb=0.05) if distributed else None
-    if red is not None:
+    masks = [m.to(dev) for m in fixture_fp_masks(z, c)]
+    cfg = dict(STEP_CFG, conf_mode=c.get("conf_mode", "pixelwise"))
+    early = 0
+    if world > 1:
+        red = GradAllReducer(opt, bucket_mb=0.05, overlap=True)     # several buckets even for this tiny model
         red.broadcast_params()
-    batch = {k: v.to(dev) for k, v in fixture_batch(z, c).items()}
-    cfg = dict(conf_thresh=0.05, conf_mode="pixelwise", mcc_conf_thresh=0.9, mcc_loss_reduce="mean_all",
-               maskclip_consistency_lambda=[0.1, 0])
-    semivl_train_step(hip, batch, 3, 50, cfg, optimizer=opt, reducer=red, fp_masks=[m.to(dev) for m in fixture_fp_masks(z, c)])
+        batch = {k: v.to(dev) for k, v in _shard(c, shards[0]).items()}
+        semivl_train_step(hip, batch, 3, 50, cfg, optimizer=opt, reducer=red, fp_masks=masks)
+        early = red.early_fires
+    else:
+        opt.zero_grad()
+        for r in shards:
+            batch = {k: v.to(dev) for k, v in _shard(c, r).items()}
+            semivl_train_step(hip, batch, 3, 50, cfg, fp_masks=masks)          # accumulates into the arena
+        opt.grad_scale = 1.0 / len(shards)
+        opt.step()
     torch.cuda.synchronize()
-    return opt.p.cpu().numpy()
+    return opt.g.cpu().numpy(), opt.p.cpu().numpy(), early
 
 
-def test_two_rank_step_with_identical_shards_equals_single_process(dev):
-    """GradAllReducer (bucketed SUM on the side stream) + grad_scale 1/W inside FusedAdamW on GPU tensors: with the same
-    shard on both ranks the mean gradient is the single-process gradient, so the updated arenas must match."""
-    single = _one_step(dev, distributed=False)
+def _run_two_ranks(name, backend):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + os.getpid() % 90
-    procs = [ctx.Process(target=_step_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_step_worker, args=(r, world, port, name, backend, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert np.array_equal(res[0][1], res[1][1]), "ranks diverged"
-    # (a + a) / 2 == a exactly, so only the reduction's summation order could differ: none here
-    assert np.abs(res[0][1] - single).max() < 1e-7
+    return res
+
+
+def _check_two_ranks(dev, name, backend):
+    g1, p1, _ = _one_step(dev, name, shards=[0, 1], world=1)
+    res = _run_two_ranks(name, backend)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), "ranks diverged"
+    assert res[0][3] > 0, "no bucket was launched from inside backward"
+    g2, p2 = res[0][1], res[0][2]
+    # a broken / missing reduce leaves each rank with its own shard's gradient: the shards differ by O(1) relative
+    own = _one_step(dev, name, shards=[0], world=1)[0]
+    assert np.abs(own - g1).max() > 1e-2 * np.abs(g1).max(), "shards too similar for this test to mean anything"
+    assert np.abs(g2 - g1).max() < 1e-5 * np.abs(g1).max() + 1e-9, np.abs(g2 - g1).max()
+    # parameters after AdamW on the mean gradient (first step: |update| = lr per element, sign flips where the gradient is
+    # rounding noise -> bound by 2 lr with lr <= 1e-3 for the decoder group)
+    assert np.abs(p2 - p1).max() < 2.1e-3
+    assert np.mean(np.abs(p2 - p1) > 1e-6) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["tiny", "offsize"])
+def test_two_rank_step_different_shards_equals_accumulated_single_process(dev, name):
+    """GradAllReducer (buckets launched from inside backward, SUM) + grad_scale 1/W inside FusedAdamW, two gloo ranks
+    with DIFFERENT shards == one process that accumulates both shards' gradients (per-rank loss normalisers).  'offsize'
+    runs an off-grid crop: pos_embed's gradient arrives through torch autograd (bicubic resize) and must be folded into
+    the arena BEFORE the all-reduce."""
+    _check_two_ranks(dev, name, "gloo")
+
+
+def test_two_rank_step_rccl(dev):
+    """The same check over RCCL (backend 'nccl') with the collectives on the communication stream; needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank; this box has %d" % torch.cuda.device_count())
+    _check_two_ranks(dev, "tiny", "nccl")

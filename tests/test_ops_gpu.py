@@ -714,3 +714,75 @@ def test_tiled_narrow_conv3x3(dev, b, N, H, W, C1, C2, Co):
     close(dw, gw, atol=3e-5 * math.sqrt(imgs * H * W) * 3, rtol=2e-4, what="wgrad")
     o1, o2 = (ops.conv_wgrad(dy.view(-1, Co), Co, x1.view(-1, C1), C1, imgs, H, W, C1, Co, 3, 3, 1, 1) for _ in range(2))
     assert torch.equal(o1, o2), "tiled wgrad must be deterministic"
+
+
+# ------------------------------------------------------------------------------------------------ ABI contract: re-entrancy
+def test_two_streams_own_their_helper_contexts(dev):
+    """include/semivl_hip.h: calls on different caller streams never share a helper stream or an event.  Ragged-M GEMMs
+    (M = k*1025: the leftover rows run on the helper stream) and fused attention (cls-token rows on the helper stream)
+    are issued back to back on two torch streams without any synchronisation between them; both results must be exact
+    w.r.t. the same call on a quiet device, and the library must hold one context per (device, stream)."""
+    import semivl_amd.lib as L
+    from semivl_amd import ops
+    lib = L.load()
+    torch.cuda.synchronize()
+    lib.svl_shutdown()
+    M, N, K = 8 * 1025, 768, 768
+    a1, a2 = rnd(M, K, dev=dev, seed=31), rnd(M, K, dev=dev, seed=32)
+    w1, w2 = rnd(N, K, dev=dev, seed=33, scale=0.05), rnd(N, K, dev=dev, seed=34, scale=0.05)
+    Bn, T, H = 2, 1025, 12
+    q1, q2 = rnd(Bn * T, 3 * H * 64, dev=dev, seed=35, scale=0.5), rnd(Bn * T, 3 * H * 64, dev=dev, seed=36, scale=0.5)
+    ref1, ref2 = ops.linear(a1, w1), ops.linear(a2, w2)           # quiet device, default stream
+    o1, _ = ops.attention_fwd(q1, Bn, T, H)
+    o2, _ = ops.attention_fwd(q2, Bn, T, H)
+    torch.cuda.synchronize()
+    n0 = lib.svl_num_stream_contexts()
+    assert n0 == 1, n0                                             # the default stream's context
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for it in range(6):                                            # interleaved: s1, s2, s1, s2 ... no sync in between
+        for s_, a_, w_, q_ in ((s1, a1, w1, q1), (s2, a2, w2, q2)):
+            with torch.cuda.stream(s_):
+                y = ops.linear(a_, w_)
+                o, _ = ops.attention_fwd(q_, Bn, T, H)
+                if it == 5:
+                    outs.append((y, o))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], ref1) and torch.equal(outs[1][0], ref2)
+    assert torch.equal(outs[0][1], o1) and torch.equal(outs[1][1], o2)
+    assert lib.svl_num_stream_contexts() == n0 + 2
+    assert lib.svl_stream_release(s1.cuda_stream) == 0 and lib.svl_num_stream_contexts() == n0 + 1
+    assert lib.svl_shutdown() == 0 and lib.svl_num_stream_contexts() == 0
+    y = ops.linear(a1, w1)                                         # contexts come back on demand
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref1)
+
+
+def test_two_host_threads_two_streams(dev):
+    """The same from two host threads (each with its own stream): the helper-context table is mutex-protected."""
+    import threading
+    from semivl_amd import ops
+    M, N, K = 4 * 1025, 768, 768
+    data = [(rnd(M, K, dev=dev, seed=41 + i), rnd(N, K, dev=dev, seed=51 + i, scale=0.05)) for i in range(2)]
+    refs = [ops.linear(a_, w_) for a_, w_ in data]
+    torch.cuda.synchronize()
+    res, errs = [None, None], []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(dev)
+            s_ = torch.cuda.Stream()
+            with torch.cuda.stream(s_):
+                for _ in range(8):
+                    y = ops.linear(*data[i])
+            s_.synchronize()
+            res[i] = y
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert torch.equal(res[0], refs[0]) and torch.equal(res[1], refs[1])

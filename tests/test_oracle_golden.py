@@ -7,7 +7,7 @@ import torch
 from golden_util import build_oracle, fixture_batch, fixture_fp_masks, fixture_state, load_fixture
 
 
-@pytest.mark.parametrize("name", ["tiny", "vlgdim", "offsize", "skr"])
+@pytest.mark.parametrize("name", ["tiny", "vlgdim", "offsize", "skr", "conf"])
 def test_oracle_reproduces_reference_step(name):
     from oracle import semivl_oracle as O
     z, c = load_fixture(name)
@@ -40,11 +40,15 @@ def test_oracle_reproduces_reference_step(name):
     assert np.allclose([g["lr"] for g in groups], z["opt_group_lr"]) and np.allclose(
         [g["weight_decay"] for g in groups], z["opt_group_wd"])
     names = [g.pop("name") for g in groups]
+    lrs = {k: g["lr"] for k, g in zip(names, groups)}
     torch.optim.AdamW(groups, lr=1e-4, weight_decay=0.01).step()
     sd = orc.state_dict()
     for k in names:
         ref = z["after/" + k]
-        assert abs(sd[k].double().sum().item() - ref[0]) < 1e-5 * max(1.0, abs(ref[0])), k
+        # Adam's first step moves every element by lr * sign(g): entries whose gradient is pure rounding noise (the key
+        # bias of an attention layer has an exactly-zero gradient in exact arithmetic) may go either way
+        noise = int((grads[k].abs() < 1e-6 * grads[k].abs().max()).sum())
+        assert abs(sd[k].double().sum().item() - ref[0]) < 1e-5 * max(1.0, abs(ref[0])) + 2.0 * lrs[k] * noise, k
 
 
 def test_oracle_eval_and_maskclip():

@@ -4,7 +4,7 @@ import sqlite3
 import sys
 
 db = sys.argv[1]
-top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 10 ** 9   # every kernel unless a cut is asked for
 c = sqlite3.connect(db)
 rows = c.execute("""select s.kernel_name, count(*), sum(d.end - d.start), min(d.end - d.start), max(d.end - d.start)
                     from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
