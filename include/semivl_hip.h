@@ -366,12 +366,14 @@ int svl_bilinear_planes_fwd(const float* x, int64_t planes, int h, int w, int al
                             svl_stream_t stream);
 int svl_bilinear_planes_bwd(const float* dy, int64_t planes, int h, int w, int align_corners, int H, int W,
                             float* dx, svl_stream_t stream);
-/* AvgPool PxP (floor) on NHWC + concat of a per-class text vector: x [imgs, H, W, C] ->
- * y [imgs, H/P, W/P, C + Ct], y[..., C:] = text[(img % nclass), :] (vlg_head.py:43-53). text may be NULL (Ct=0). */
-int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C, int P, const float* text, int Ct, int nclass,
-                        float* y, svl_stream_t stream);
+/* AvgPool PH x PW (floor) on NHWC + concat of a per-class text vector: x [imgs, H, W, C] ->
+ * y [imgs, H/PH, W/PW, C + Ct], y[..., C:] = text[(img % nclass), :] (vlg_head.py:43-53; PH = H, PW = W is the global
+ * average pool of ASPPPooling, vlg_head.py:70-81, on any map shape). text may be NULL (Ct=0). */
+int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C, int PH, int PW, const float* text, int Ct,
+                        int nclass, float* y, svl_stream_t stream);
 /* dx [imgs,H,W,C] = avgpool backward of dy[..., :C] (ld = C+Ct); pixels outside the floor region get 0. */
-int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int C, int P, int Ct, float* dx, svl_stream_t stream);
+int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int C, int PH, int PW, int Ct, float* dx,
+                        svl_stream_t stream);
 /* dtext [nclass, Ct] = sum over images of class n (img % nclass == n) and pooled pixels of dy[..., C + ct]. */
 int svl_avgpool_cat_bwd_text(const float* dy, int imgs, int64_t HWp, int C, int Ct, int nclass, float* dtext,
                              svl_stream_t stream);
@@ -425,15 +427,18 @@ int svl_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, int imgs, in
  * GPU-side input pipeline: the reference loader's per-sample PIL chain
  * (third_party/unimatch/dataset/semi.py:61-127, transform.py:9-84) on uint8 HWC device images.  Statistical parity
  * (the random streams differ); the deterministic arithmetic follows Pillow.
- *   svl_aug_resample_u8   resize(transform.py:43-57: BILINEAR antialiased for images / NEAREST for masks) to rh x rw,
- *                         pad right/bottom with `fill` (transform.py:9-14), crop S x S at (x0, y0) (:16-20), hflip (:25-29)
+ *   svl_aug_resample_u8   resize to rh x rw -- mode 0 / 1: Pillow BILINEAR (antialiased) / NEAREST (transform.py:43-57, the
+ *                         img_scale=None branch); mode 2 / 3: OpenCV INTER_LINEAR / INTER_NEAREST semantics (mmseg `Resize`
+ *                         = mmcv.imrescale, semi.py:53-71: the img_scale branch and the val transform; mmcv/cv2 are
+ *                         un-vendored -> parity unpinned, +-1 level vs cv2's fixed-point arithmetic) -- then pad
+ *                         right/bottom with `fill` (transform.py:9-14), crop OH x OW at (x0, y0) (:16-20), hflip (:25-29)
  *   svl_aug_to_float      ToTensor + Normalize (transform.py:32-40) -> float CHW; mean3/std3 are HOST pointers
  *   svl_aug_mask_i64      uint8 mask -> int64 with one value remapped (semi.py:122-123: 254 -> 255 / ignore_mask)
  *   svl_aug_photometric_u8  in place: 0 brightness, 1 contrast, 2 saturation (ImageEnhance blends, semi.py:99-100 via
  *                         torchvision ColorJitter), 3 hue shift, 4 grayscale (semi.py:101); scratch = 1 device uint64
  *   svl_aug_gaussian_blur_u8  transform.py:60-64 (true separable Gaussian; Pillow approximates it with box filters) */
-int svl_aug_resample_u8(const unsigned char* src, int H, int W, int C, int rh, int rw, int x0, int y0, int S, int flip,
-                        int mode, int fill, unsigned char* dst, svl_stream_t stream);
+int svl_aug_resample_u8(const unsigned char* src, int H, int W, int C, int rh, int rw, int x0, int y0, int OH, int OW,
+                        int flip, int mode, int fill, unsigned char* dst, svl_stream_t stream);
 int svl_aug_to_float(const unsigned char* src, int npix, const float* mean3, const float* std3, float* dst,
                      svl_stream_t stream);
 int svl_aug_mask_i64(const unsigned char* src, int npix, int from, int to, int64_t* dst, svl_stream_t stream);

@@ -6,7 +6,9 @@
   (`maskclip_vit.py:378-410`).
 * `save_checkpoint` / `load_checkpoint` -- the `{'model', 'optimizer', 'epoch'}` file of `semivl.py:426-433` and the
   loading rules of `third_party/unimatch/eval.py:131-139` (strip the DDP `module.` prefix, drop `clip_encoder.*`,
-  optional `ema_model`), so files written here load in the reference's eval script and vice versa.
+  optional `ema_model`), so the 'model' entry of files written here loads in the reference's eval script and vice versa
+  (the 'optimizer' entry indexes only the parameters that can receive a gradient and is NOT interchangeable with the
+  reference's per-parameter mmcv groups; `FusedAdamW.load_state_dict` verifies the stored parameter names).
 
 Host-side plumbing only: nothing here runs inside a training step.
 """

@@ -14,15 +14,19 @@ __device__ __forceinline__ unsigned char clip8_round(float v) { return (unsigned
 __device__ __forceinline__ unsigned char clip8_trunc(float v) { return v <= 0.f ? 0 : (v >= 255.f ? 255 : (unsigned char)v); }
 __device__ __forceinline__ int lum(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
 
-// resize (src HxW -> rh x rw) + pad to >= S + crop at (x0, y0) + optional flip, one thread per output pixel
+// resize (src HxW -> rh x rw) + pad to >= (OH, OW) + crop at (x0, y0) + optional flip, one thread per output pixel
 // mode 0: Pillow BILINEAR (triangle filter, support scaled when shrinking, horizontal pass rounded to 8 bit first);
-// mode 1: NEAREST.
+// mode 1: Pillow NEAREST;
+// mode 2: OpenCV INTER_LINEAR semantics (mmcv.imrescale inside mmseg `Resize`, semi.py:55,64): half-pixel centres,
+//         two taps per axis, NO antialiasing, border clamped; float arithmetic, rounded (cv2 itself uses 11-bit
+//         fixed-point coefficients: results agree to +-1 level);
+// mode 3: OpenCV INTER_NEAREST: source index = floor(dst * scale), clamped.
 __global__ void resample_kernel(const unsigned char* __restrict__ src, int H, int W, int C, int rh, int rw, int x0, int y0,
-                                int S, int flip, int mode, int fill, unsigned char* __restrict__ dst) {
+                                int OH, int OW, int flip, int mode, int fill, unsigned char* __restrict__ dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= S * S) return;
-  const int oy = i / S, ox0 = i - oy * S;
-  const int ox = flip ? S - 1 - ox0 : ox0;
+  if (i >= OH * OW) return;
+  const int oy = i / OW, ox0 = i - oy * OW;
+  const int ox = flip ? OW - 1 - ox0 : ox0;
   const int ry = y0 + oy, rx = x0 + ox;                 // coordinates in the resized (then padded) image
   unsigned char* o = dst + (long)i * C;
   if (ry >= rh || rx >= rw) {
@@ -30,6 +34,27 @@ __global__ void resample_kernel(const unsigned char* __restrict__ src, int H, in
     return;
   }
   const float sy = (float)H / rh, sx = (float)W / rw;
+  if (mode == 3) {
+    const int yy = min(H - 1, (int)floor((double)ry * ((double)H / rh))), xx = min(W - 1, (int)floor((double)rx * ((double)W / rw)));
+    for (int c = 0; c < C; ++c) o[c] = src[((long)yy * W + xx) * C + c];
+    return;
+  }
+  if (mode == 2) {
+    float fy = (ry + 0.5f) * sy - 0.5f, fx = (rx + 0.5f) * sx - 0.5f;
+    int y1 = (int)floorf(fy), x1 = (int)floorf(fx);
+    fy -= y1; fx -= x1;
+    if (y1 < 0) { y1 = 0; fy = 0.f; }
+    if (x1 < 0) { x1 = 0; fx = 0.f; }
+    if (y1 >= H - 1) { y1 = H - 1; fy = 0.f; }
+    if (x1 >= W - 1) { x1 = W - 1; fx = 0.f; }
+    const int y2 = min(H - 1, y1 + 1), x2 = min(W - 1, x1 + 1);
+    for (int c = 0; c < C; ++c) {
+      const float a = src[((long)y1 * W + x1) * C + c], b = src[((long)y1 * W + x2) * C + c];
+      const float d = src[((long)y2 * W + x1) * C + c], e = src[((long)y2 * W + x2) * C + c];
+      o[c] = clip8_round((1.f - fy) * ((1.f - fx) * a + fx * b) + fy * ((1.f - fx) * d + fx * e));
+    }
+    return;
+  }
   if (mode == 1) {  // Pillow's NEAREST resize (Geometry.c, ImagingScaleAffine): xo = a/2, then xo += a per pixel, in
                     // double -- reproduced as the same running sum so that exact-boundary pixels round identically
     const double ax = (double)W / rw, ay = (double)H / rh;
@@ -166,13 +191,13 @@ inline int g1(long n) { return (int)((n + 255) / 256); }
 
 }  // namespace
 
-extern "C" int svl_aug_resample_u8(const unsigned char* src, int H, int W, int C, int rh, int rw, int x0, int y0, int S,
-                                   int flip, int mode, int fill, unsigned char* dst, svl_stream_t stream) {
-  SVL_CHECK_ARG(src && dst && H > 0 && W > 0 && (C == 1 || C == 3) && rh > 0 && rw > 0 && S > 0 && x0 >= 0 && y0 >= 0 &&
-                    (mode == 0 || mode == 1) && fill >= 0 && fill <= 255,
+extern "C" int svl_aug_resample_u8(const unsigned char* src, int H, int W, int C, int rh, int rw, int x0, int y0, int OH,
+                                   int OW, int flip, int mode, int fill, unsigned char* dst, svl_stream_t stream) {
+  SVL_CHECK_ARG(src && dst && H > 0 && W > 0 && (C == 1 || C == 3) && rh > 0 && rw > 0 && OH > 0 && OW > 0 && x0 >= 0 &&
+                    y0 >= 0 && mode >= 0 && mode <= 3 && fill >= 0 && fill <= 255,
                 "svl_aug_resample_u8: bad args");
-  hipLaunchKernelGGL(resample_kernel, dim3(g1((long)S * S)), dim3(256), 0, (hipStream_t)stream, src, H, W, C, rh, rw, x0,
-                     y0, S, flip, mode, fill, dst);
+  hipLaunchKernelGGL(resample_kernel, dim3(g1((long)OH * OW)), dim3(256), 0, (hipStream_t)stream, src, H, W, C, rh, rw, x0,
+                     y0, OH, OW, flip, mode, fill, dst);
   SVL_LAUNCH_CHECK("svl_aug_resample_u8");
   return SVL_OK;
 }

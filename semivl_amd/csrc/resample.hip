@@ -200,11 +200,11 @@ __global__ __launch_bounds__(256) void bilinear_planes_bwd_kernel(const float* _
 }
 
 __global__ __launch_bounds__(256) void avgpool_cat_fwd_kernel(const float* __restrict__ x, int imgs, int H, int W, int C,
-                                                              int P, const float* __restrict__ text, int Ct, int nclass,
-                                                              float* __restrict__ y) {
-  const int Hp = H / P, Wp = W / P, Co = C + Ct;
+                                                              int P, int PW, const float* __restrict__ text, int Ct,
+                                                              int nclass, float* __restrict__ y) {
+  const int Hp = H / P, Wp = W / PW, Co = C + Ct;
   const long total = (long)imgs * Hp * Wp * Co;
-  const float inv = 1.f / (float)(P * P);
+  const float inv = 1.f / (float)(P * PW);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % Co);
     long t = i / Co;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void avgpool_cat_fwd_kernel(const float* __res
     if (c < C) {
       float s = 0.f;
       for (int a = 0; a < P; ++a)
-        for (int b = 0; b < P; ++b) s += x[((img * H + py * P + a) * W + px * P + b) * C + c];
+        for (int b = 0; b < PW; ++b) s += x[((img * H + py * P + a) * W + px * PW + b) * C + c];
       v = s * inv;
     } else {
       v = text[(img % nclass) * Ct + (c - C)];
@@ -225,10 +225,10 @@ __global__ __launch_bounds__(256) void avgpool_cat_fwd_kernel(const float* __res
   }
 }
 __global__ __launch_bounds__(256) void avgpool_cat_bwd_kernel(const float* __restrict__ dy, int imgs, int H, int W, int C,
-                                                              int P, int Ct, float* __restrict__ dx) {
-  const int Hp = H / P, Wp = W / P, Co = C + Ct;
+                                                              int P, int PW, int Ct, float* __restrict__ dx) {
+  const int Hp = H / P, Wp = W / PW, Co = C + Ct;
   const long total = (long)imgs * H * W * C;
-  const float inv = 1.f / (float)(P * P);
+  const float inv = 1.f / (float)(P * PW);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     long t = i / C;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void avgpool_cat_bwd_kernel(const float* __res
     t /= W;
     const int yy = (int)(t % H);
     const long img = t / H;
-    const int py = yy / P, px = xx / P;
+    const int py = yy / P, px = xx / PW;
     dx[i] = (py < Hp && px < Wp) ? dy[((img * Hp + py) * Wp + px) * Co + c] * inv : 0.f;
   }
 }
@@ -312,22 +312,23 @@ extern "C" int svl_bilinear_planes_bwd(const float* dy, int64_t planes, int h, i
   SVL_LAUNCH_CHECK("svl_bilinear_planes_bwd");
   return SVL_OK;
 }
-extern "C" int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C, int P, const float* text, int Ct,
-                                   int nclass, float* y, svl_stream_t stream) {
-  SVL_CHECK_ARG(x && y && imgs > 0 && H >= P && W >= P && C > 0 && P > 0 && (Ct == 0 || (text && nclass > 0)),
+extern "C" int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C, int PH, int PW, const float* text,
+                                   int Ct, int nclass, float* y, svl_stream_t stream) {
+  SVL_CHECK_ARG(x && y && imgs > 0 && PH > 0 && PW > 0 && H >= PH && W >= PW && C > 0 && (Ct == 0 || (text && nclass > 0)),
                 "svl_avgpool_cat_fwd: bad args");
-  const long total = (long)imgs * (H / P) * (W / P) * (C + Ct);
+  const long total = (long)imgs * (H / PH) * (W / PW) * (C + Ct);
   hipLaunchKernelGGL(avgpool_cat_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, imgs, H, W, C,
-                     P, text, Ct, nclass > 0 ? nclass : 1, y);
+                     PH, PW, text, Ct, nclass > 0 ? nclass : 1, y);
   SVL_LAUNCH_CHECK("svl_avgpool_cat_fwd");
   return SVL_OK;
 }
-extern "C" int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int C, int P, int Ct, float* dx,
+extern "C" int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int C, int PH, int PW, int Ct, float* dx,
                                    svl_stream_t stream) {
-  SVL_CHECK_ARG(dy && dx && imgs > 0 && H >= P && W >= P && C > 0 && P > 0 && Ct >= 0, "svl_avgpool_cat_bwd: bad args");
+  SVL_CHECK_ARG(dy && dx && imgs > 0 && PH > 0 && PW > 0 && H >= PH && W >= PW && C > 0 && Ct >= 0,
+                "svl_avgpool_cat_bwd: bad args");
   const long total = (long)imgs * H * W * C;
   hipLaunchKernelGGL(avgpool_cat_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, imgs, H, W,
-                     C, P, Ct, dx);
+                     C, PH, PW, Ct, dx);
   SVL_LAUNCH_CHECK("svl_avgpool_cat_bwd");
   return SVL_OK;
 }

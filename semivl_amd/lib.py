@@ -109,7 +109,7 @@ SIGNATURES = {
     "svl_bn_bwd_apply": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _D, _L, _I, _P, _L, _P, _L, _P]),
     "svl_maxpool3x3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "svl_maxpool3x3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
-    "svl_aug_resample_u8": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "svl_aug_resample_u8": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "svl_aug_to_float": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
     "svl_aug_mask_i64": (_I, [_P, _I, _I, _I, _P, _P]),
     "svl_aug_photometric_u8": (_I, [_P, _I, _I, _F, _P, _P]),
@@ -127,8 +127,8 @@ SIGNATURES = {
     "svl_bilinear_nhwc_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P]),
     "svl_bilinear_planes_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _P]),
     "svl_bilinear_planes_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _P]),
-    "svl_avgpool_cat_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
-    "svl_avgpool_cat_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "svl_avgpool_cat_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
+    "svl_avgpool_cat_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "svl_avgpool_cat_bwd_text": (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
     "svl_adamw_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _I, _F, _P, _F, _P]),
 }

@@ -201,8 +201,8 @@ class VLM(nn.Module):
             raise ValueError(forward_mode)
         if only_fp:
             raise NotImplementedError("only_fp is not used by semivl.py (SURVEY §8(a) V4)")
-        if tuple(img.shape[2:]) != (self.decode_head.image_size, self.decode_head.image_size):
-            raise NotImplementedError("input size != decode_head.img_size (second resize, builder.py:93-97)")
+        S_ = self.decode_head.image_size
+        in_size = tuple(img.shape[2:])
         feats, _ = self.backbone.forward_tokens(self.renormalize_img_for_clip(img), need_global=False)
         skip0_hw = None
         if self.conv_encoder is not None:   # vlm.py:119-121: the side encoder sees the loader-normalised image
@@ -226,12 +226,31 @@ class VLM(nn.Module):
             feats = [ctok, feats[0], feats[1]]
             if masks is not None:
                 masks = [masks[2], masks[0], masks[1]]
+        # the head resizes its 4x map to (img_size, img_size) (vlg_head.py:247), forward_wrapper then resizes to the input
+        # size (builder.py:93-97): one and the same interpolation when the input IS img_size (every training crop), two
+        # chained ones for evaluation windows of another shape (supervised.py:104-133)
         out = self.decode_head.forward_tokens(feats, self.text_feat(img.device), (hp, wp), masks, self.fp_rate,
-                                              out_size=tuple(img.shape[2:]), fp_range=fp_range if need_fp else None,
+                                              out_size=(S_, S_), fp_range=fp_range if need_fp else None,
                                               skip0_hw=skip0_hw)
+        if in_size != (S_, S_):
+            out = _PlanesResizeFn.apply(out, in_size, self.align_corners)
         if need_fp and split_fp:
             return out.chunk(2)
         return out
+
+
+class _PlanesResizeFn(torch.autograd.Function):
+    """F.interpolate(x [b, N, h, w], size, mode='bilinear', align_corners) on the library (mmseg.ops.resize, builder.py:93)."""
+
+    @staticmethod
+    def forward(ctx, x, size, align):
+        ctx.geo = (x.shape[2], x.shape[3], size, align)
+        return ops.bilinear_planes_fwd(x.contiguous(), x.shape[2], x.shape[3], align, size[0], size[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w, size, align = ctx.geo
+        return ops.bilinear_planes_bwd(dy.contiguous(), h, w, align, size[0], size[1]), None, None
 
 
 SEGMENTORS["VLM"] = VLM
@@ -270,6 +289,10 @@ def build_model(cfg):
         mcfg["model"]["clip_encoder"] = ccfg["backbone"]
     if "model_args" in cfg:
         mcfg["model"].update(cfg["model_args"])
+    if cfg.get("allow_random_init"):   # (not a reference key) synthetic-weight benchmarks / tests: no CLIP file on disk
+        for sub in ("backbone", "clip_encoder", "conv_encoder"):
+            if isinstance(mcfg["model"].get(sub), dict):
+                mcfg["model"][sub]["allow_random_init"] = True
     mdict = dict(mcfg["model"])
     model = SEGMENTORS[mdict.pop("type")](**mdict)
     model.disable_dropout = cfg["disable_dropout"]

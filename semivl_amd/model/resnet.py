@@ -187,7 +187,7 @@ class ResNetV1c(nn.Module):
     def __init__(self, depth=101, in_channels=3, stem_channels=64, base_channels=64, num_stages=1, strides=(1,),
                  dilations=(1,), out_indices=(0,), style="pytorch", deep_stem=True, avg_down=False,
                  norm_cfg=dict(type="SyncBN", requires_grad=True), norm_eval=False, contract_dilation=True,
-                 zero_init_residual=True, pretrained=None, init_cfg=None, type=None, **kw):
+                 zero_init_residual=True, pretrained=None, init_cfg=None, type=None, allow_random_init=False, **kw):
         super().__init__()
         ok = (depth == 101 and num_stages == 1 and tuple(strides) == (1,) and tuple(dilations) == (1,) and
               tuple(out_indices) == (0,) and style == "pytorch" and deep_stem and not avg_down and in_channels == 3 and
@@ -195,7 +195,7 @@ class ResNetV1c(nn.Module):
         if not ok:
             raise NotImplementedError("ResNetV1c (HIP): only the SemiVL conv_encoder configuration (depth 101, stem + "
                                       "layer1, stride 4) is implemented")
-        self.norm_eval, self.pretrained = norm_eval, pretrained
+        self.norm_eval, self.pretrained, self.allow_random_init = norm_eval, pretrained, allow_random_init
         sc = stem_channels
         self.stem = nn.Sequential(
             nn.Conv2d(in_channels, sc // 2, 3, stride=2, padding=1, bias=False), nn.BatchNorm2d(sc // 2), nn.ReLU(True),
@@ -213,10 +213,16 @@ class ResNetV1c(nn.Module):
     def init_weights(self):
         """mmseg ResNet.init_weights: pretrained file when present, else kaiming (fan_out) convs, unit norms and
         zero-initialised last norm of every residual branch."""
+        if isinstance(self.pretrained, str) and not os.path.exists(self.pretrained) and not self.allow_random_init:
+            raise FileNotFoundError(f"pretrained weights '{self.pretrained}' not found (cwd {os.getcwd()}); pass "
+                                    f"allow_random_init=True (cfg['allow_random_init']) for synthetic-weight runs")
         if isinstance(self.pretrained, str) and os.path.exists(self.pretrained):
+            import warnings
             ck = torch.load(self.pretrained, map_location="cpu")
             sd = ck.get("state_dict", ck)
-            self.load_state_dict({k.replace("backbone.", ""): v for k, v in sd.items()}, strict=False)
+            res = self.load_state_dict({k.replace("backbone.", ""): v for k, v in sd.items()}, strict=False)
+            if res.missing_keys:   # (the ImageNet file also holds layer2-4 / fc: unexpected keys are normal here)
+                warnings.warn(f"{self.pretrained}: missing keys {res.missing_keys}")
             return
         for mod in self.modules():
             if isinstance(mod, nn.Conv2d):

@@ -242,7 +242,8 @@ class MaskClipVisionTransformer(nn.Module):
                  act_cfg=dict(type='GELU'), patch_norm=False, pre_norm=False, final_norm=False, return_qkv=False,
                  return_clip_embed=False, skip_last_attn=False, interpolate_mode='bicubic', num_fcs=2,
                  norm_eval=False, with_cp=False, pretrained=None, num_prompt_tokens=None, lora_layers=[], lora_r=4,
-                 lora_scaling=1, lora_dropout=0, lora_targets='qkvo', init_cfg=None, type=None):
+                 lora_scaling=1, lora_dropout=0, lora_targets='qkvo', init_cfg=None, type=None,
+                 allow_random_init=False):
         super().__init__()
         if isinstance(img_size, int):
             img_size = (img_size, img_size)
@@ -259,6 +260,7 @@ class MaskClipVisionTransformer(nn.Module):
         self.embed_dims, self.num_layers, self.num_heads = embed_dims, num_layers, num_heads
         self.eps = norm_cfg.get("eps", 1e-5)
         self.pretrained = pretrained
+        self.allow_random_init = allow_random_init   # benchmarks / tests without the CLIP file (build_model cfg key)
         self.patch_embed = _PatchEmbedParams(in_channels, embed_dims, patch_size, False)
         npatch = (img_size[0] // patch_size) * (img_size[1] // patch_size)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dims))
@@ -289,8 +291,17 @@ class MaskClipVisionTransformer(nn.Module):
     # -- init -----------------------------------------------------------------------------------------------
     def init_weights(self):
         """maskclip_vit.py:378-429.  The pretrained CLIP file (pretrained/clip2mmseg_ViT16_clip_backbone.pth) is
-        loaded when present (bicubic pos-embed resize included); otherwise the reference's own random init."""
+        loaded (bicubic pos-embed resize included).  A configured-but-missing file raises, like mmcv's load_checkpoint:
+        a silently random backbone -- and a random frozen clip_encoder feeding garbage MaskCLIP guidance -- is never
+        what a training run wants.  `pretrained=None` (or allow_random_init=True) gives the reference's own random
+        init (maskclip_vit.py:416-429)."""
         import os
+        import warnings
+        if isinstance(self.pretrained, str) and not os.path.exists(self.pretrained) and not self.allow_random_init:
+            raise FileNotFoundError(
+                f"pretrained weights '{self.pretrained}' not found (cwd {os.getcwd()}); convert them with "
+                f"`python -m semivl_amd.tools.convert_clip_weights`, or pass allow_random_init=True "
+                f"(cfg['allow_random_init']) for synthetic-weight benchmarking")
         if isinstance(self.pretrained, str) and os.path.exists(self.pretrained):
             ck = torch.load(self.pretrained, map_location="cpu")
             sd = ck.get("state_dict", ck)
@@ -302,7 +313,9 @@ class MaskClipVisionTransformer(nn.Module):
                                                         (n, n))
             if "proj.weight" in sd and sd["proj.weight"].dim() == 2:
                 sd["proj.weight"] = sd["proj.weight"][:, :, None, None]
-            self.load_state_dict(sd, strict=False)
+            res = self.load_state_dict(sd, strict=False)
+            if res.missing_keys or res.unexpected_keys:
+                warnings.warn(f"{self.pretrained}: missing keys {res.missing_keys}, unexpected keys {res.unexpected_keys}")
             return
         with torch.no_grad():
             nn.init.trunc_normal_(self.pos_embed, std=.02)

@@ -284,9 +284,7 @@ def _head_core_forward(m, shared, s0, s1, sv, logits_out):
         _conv_gn_fwd(x1, Ch, imgs, h, w, Ch, seq[0], seq[1], 1 if d == 1 else 3, d, s_, y=cat[:, j * Ch:], ldy=5 * Ch)
         aspp_sv.append(s_)
     gap = m.aspp.aspp_convs[4].gap
-    pooled = ops.avgpool_cat_fwd(x1, imgs, h, w, Ch, h, None, 1) if h == w else None
-    if pooled is None:
-        raise NotImplementedError("non-square feature maps")
+    pooled = ops.avgpool_cat_fwd(x1, imgs, h, w, Ch, (h, w), None, 1)      # AdaptiveAvgPool2d(1) on any map shape
     s_gap = {} if sv is not None else None
     gy = _conv_gn_fwd(pooled, Ch, imgs, 1, 1, Ch, gap[1], gap[2], 1, 1, s_gap)
     ops.bilinear_nhwc_fwd(gy, Ch, imgs, 1, 1, Ch, True, 1, h, w, cat[:, 4 * Ch:], 5 * Ch)
@@ -550,7 +548,7 @@ def _head_backward_core(m, sv, dlogits, gc):
         ops.bilinear_nhwc_bwd(dcat[:, 4 * Ch:], 5 * Ch, imgs, 1, 1, Ch, True, 1, h, w, dgy, Ch)
         dpooled = _conv_gn_bwd(dgy, Ch, gap[1], gap[2], sv["gap"], gc)  # [imgs, Ch]
         # avgpool over the whole map: every pixel gets dpooled / HW
-        dgap, _ = ops.avgpool_cat_bwd(dpooled, imgs, h, w, Ch, h, 0, 1)
+        dgap, _ = ops.avgpool_cat_bwd(dpooled, imgs, h, w, Ch, (h, w), 0, 1)
         ops.add(dx1, dgap, out=dx1)
         sv["aspp"] = sv["cat"] = sv["proj"] = None
         # ---- conv1

@@ -572,21 +572,24 @@ def bilinear_planes_bwd(dy, h, w, align, H, W):
 
 
 def avgpool_cat_fwd(x, imgs, H, W, Cc, P, text, nclass):
+    """P: int (square window) or (PH, PW)."""
+    PH, PW = (P, P) if isinstance(P, int) else P
     Ct = text.shape[1] if text is not None else 0
-    y = empty(imgs * (H // P) * (W // P), Cc + Ct, device=x.device)
-    L.check(L.load().svl_avgpool_cat_fwd(_p(x), imgs, H, W, Cc, P, _p(text), Ct, nclass, _p(y), _st()),
+    y = empty(imgs * (H // PH) * (W // PW), Cc + Ct, device=x.device)
+    L.check(L.load().svl_avgpool_cat_fwd(_p(x), imgs, H, W, Cc, PH, PW, _p(text), Ct, nclass, _p(y), _st()),
             "svl_avgpool_cat_fwd")
     return y
 
 
 def avgpool_cat_bwd(dy, imgs, H, W, Cc, P, Ct, nclass):
+    PH, PW = (P, P) if isinstance(P, int) else P
     dx = empty(imgs * H * W, Cc, device=dy.device)
     lib = L.load()
-    L.check(lib.svl_avgpool_cat_bwd(_p(dy), imgs, H, W, Cc, P, Ct, _p(dx), _st()), "svl_avgpool_cat_bwd")
+    L.check(lib.svl_avgpool_cat_bwd(_p(dy), imgs, H, W, Cc, PH, PW, Ct, _p(dx), _st()), "svl_avgpool_cat_bwd")
     dtext = None
     if Ct > 0:
         dtext = empty(nclass, Ct, device=dy.device)
-        L.check(lib.svl_avgpool_cat_bwd_text(_p(dy), imgs, (H // P) * (W // P), Cc, Ct, nclass, _p(dtext), _st()),
+        L.check(lib.svl_avgpool_cat_bwd_text(_p(dy), imgs, (H // PH) * (W // PW), Cc, Ct, nclass, _p(dtext), _st()),
                 "svl_avgpool_cat_bwd_text")
     return dx, dtext
 

@@ -61,4 +61,5 @@ def exp40_cfg(batch_size=16, crop=512, nclass=21, dataset="pascal"):
             backbone=dict(lr_mult=0.1 if cs else 0.01), text_encoder=dict(lr_mult=0.0),
             conv_encoder=dict(lr_mult=0.1 if cs else 1.0), norm=dict(decay_mult=0.0), ln=dict(decay_mult=0.0),
             head=dict(lr_mult=10.0)))),
-        warmup_iters=0, batch_size=batch_size, epochs=80)
+        warmup_iters=0, warmup_ratio=1e-6, batch_size=batch_size, epochs=80,
+        allow_random_init=True)   # synthetic weights: pretrained/clip2mmseg_ViT16_clip_backbone.pth is not in the container

@@ -166,7 +166,8 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         reducer.finish()    # folds autograd-delivered grads, flushes / waits for the overlapped all-reduce buckets
     if optimizer is not None:
         optimizer.step()
-        optimizer.poly_lr(iters, cfg.get("scheduler_max_iters", total_iters))
+        optimizer.poly_lr(iters, cfg.get("scheduler_max_iters", total_iters), warmup_iters=cfg.get("warmup_iters", 0),
+                          warmup_ratio=cfg.get("warmup_ratio", 1e-6))
     if return_aux:
         aux = dict(mask_w=mask_w, mask_w_other=mask_w_other, mclip=mclip, mclip_other=mclip_other, conf_w=conf_w,
                    pred_x=pred_x.detach(), pred_s1=pred_s1.detach(), pred_w=pred_w.detach(),
@@ -275,7 +276,10 @@ class FusedAdamW:
 
     def state_dict(self):
         """torch.optim.AdamW layout (`semivl.py:428` stores `optimizer.state_dict()`): one param group per tensor, in
-        arena order; state = step / exp_avg / exp_avg_sq per tensor.  `names` is an extra key for humans."""
+        arena order; state = step / exp_avg / exp_avg_sq per tensor.  Only parameters that can receive a gradient are
+        indexed (the reference's mmcv constructor also lists the frozen backbone / clip_encoder tensors, whose state stays
+        empty): the 'optimizer' entry of a checkpoint is therefore NOT index-compatible with the reference's -- only the
+        'model' entry is.  `names` (arena order) is stored and verified on load."""
         state, groups = {}, []
         off = self.seg_off.tolist()
         for i, g_ in enumerate(self.groups):
@@ -291,6 +295,10 @@ class FusedAdamW:
 
     def load_state_dict(self, sd):
         assert len(sd["param_groups"]) == len(self.groups), "optimizer state does not match this model"
+        if "names" in sd:
+            mine = [g_.get("name", "") for g_ in self.groups]
+            assert list(sd["names"]) == mine, "optimizer state was saved for different parameters: %s" % (
+                sorted(set(sd["names"]) ^ set(mine))[:6],)
         off = self.seg_off.tolist()
         steps = set()
         for i, (g_, sg) in enumerate(zip(self.groups, sd["param_groups"])):
@@ -306,9 +314,13 @@ class FusedAdamW:
         self.step_count = steps.pop() if steps else 0
         self.seg_lr.copy_(self._lr_host)
 
-    def poly_lr(self, iters, max_iters, power=0.9):
-        """semivl.py:343-345: applied after the step, for the next one."""
-        f = (1 - iters / max_iters) ** power
+    def poly_lr(self, iters, max_iters, power=0.9, warmup_iters=0, warmup_ratio=1e-6):
+        """semivl.py:339-345: applied after the step, for the next one; linear warm-up while iters < warmup_iters
+        (semivl.py:339-342: lr = initial_lr * (1 - (1 - iters / warmup_iters) * (1 - warmup_ratio)))."""
+        if iters < warmup_iters:
+            f = 1 - (1 - iters / warmup_iters) * (1 - warmup_ratio)
+        else:
+            f = (1 - iters / max_iters) ** power
         # the pinned staging buffer may still be the source of the previous call's queued copy: wait for THAT copy
         # (issued a whole step ago, so this never stalls in the training loop) before overwriting it
         if self._lr_evt is not None:

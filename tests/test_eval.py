@@ -89,3 +89,77 @@ def test_hip_eval_matches_reference_fixture(dev):
             p_, f_ = predict(model, img.to(dev), mask.to(dev), mode, cfg, return_logits=True)
         assert np.abs(f_[:, :, ::8, ::8].cpu().numpy() - z[fk]).max() < 1e-5, mode
         assert (p_.cpu().numpy().astype(np.uint8) != z[pk]).mean() < 1e-5, mode   # (probability-averaged windows)
+
+
+# ------------------------------------------------------------------------------------------------ through the real model
+def vlm_fixture():
+    import ast
+    sys_path = os.path.join(HERE, "golden")
+    z = np.load(os.path.join(sys_path, "eval_vlm.npz"))
+    c = ast.literal_eval(str(z["cfg"]))
+    g = torch.Generator().manual_seed(c["seed"])
+    img = torch.randn(2, 3, c["H"], c["W"], generator=g)
+    img = torch.nn.functional.avg_pool2d(img, 9, stride=1, padding=4)
+    img = img / img.std()
+    chk = np.array([img.double().sum().item(), img.double().abs().sum().item()])
+    assert np.allclose(chk, z["img_checksum"], rtol=0, atol=1e-6), "seeded image stream differs from the fixture's"
+    return z, c, img, torch.from_numpy(z["mask"]).long()
+
+
+MODES = ("sliding_window", "zegclip_sliding_window", "original")
+
+
+def test_oracle_eval_through_vlm_matches_reference_fixture():
+    """The oracle VLM under the oracle `predict` restatements == the reference's VLM under the reference's `predict` on a
+    160x150 image (windows of 128x128, 128x65, 75x128, 75x65 pixels; whole-image mode)."""
+    from golden_util import build_oracle, fixture_state
+    from oracle import eval_oracle as E
+    z, c, img, mask = vlm_fixture()
+    torch.set_num_threads(8)
+    orc = build_oracle(c)
+    orc.load_state_dict(fixture_state(z, c, orc), strict=True)
+    orc.eval()
+    with torch.no_grad():
+        res = dict(sliding_window=E.predict_sliding_window(orc, img, c["S"], 21),
+                   zegclip_sliding_window=E.predict_zegclip_sliding_window(orc, img, mask.shape[-2:], c["S"], c["stride"], 21))
+        fo = orc(img)
+        res["original"] = (fo.argmax(dim=1), fo)
+    for mode in MODES:
+        pred, final = res[mode]
+        assert np.array_equal(pred.numpy().astype(np.uint8), z[f"pred/{mode}"]), mode
+        assert np.abs(final[:, :, ::4, ::4].numpy() - z[f"final_s4/{mode}"]).max() < 1e-5, mode
+        i, u, t = E.intersection_and_union(pred.numpy(), mask.numpy(), 21, 255)
+        assert np.array_equal(i, z[f"inter/{mode}"]) and np.array_equal(u, z[f"union/{mode}"]), mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_hip_evaluate_through_vlm_matches_reference_fixture(dev, mode):
+    """semivl_amd.evaluate.predict / evaluate driving the PRODUCT VLM on windows that are not img_size: off-size and
+    non-square token grids (8x5, 5x8, 5x5, 10x10 patches vs the 8x8 trained grid), per-forward pos-embed resize, the
+    two chained output resizes (vlg_head.py:247, builder.py:93-97)."""
+    from golden_util import build_hip, fixture_state
+    from oracle import eval_oracle as E
+    from semivl_amd.evaluate import evaluate, predict
+    z, c, img, mask = vlm_fixture()
+    hip = build_hip(c)
+    hip.load_state_dict(fixture_state(z, c, hip), strict=True)
+    hip.to(dev).eval()
+    cfg = dict(crop_size=c["S"], stride=c["stride"], nclass=21)
+    with torch.no_grad():
+        pred, final = predict(hip, img.to(dev), mask.to(dev), mode, cfg, return_logits=True)
+    ref = z[f"final_s4/{mode}"]
+    err = np.abs(final[:, :, ::4, ::4].cpu().numpy() - ref).max()
+    assert err < (1e-3 if mode != "sliding_window" else 1e-5), err      # logits 1e-3; probabilities (sum of <= 4 softmaxes)
+    hp = pred.cpu().numpy().astype(np.uint8)
+    # bit-exact prediction map; a flip needs the reference's own top-2 gap at that pixel to be below the error measured in
+    # this very run (x4: the error is measured on a 1/16 subsample of the map)
+    tie = z[f"gap/{mode}"] <= max(1e-6, 4.0 * err)
+    flips = assert_labels(hp, z[f"pred/{mode}"], tie, mode)
+    assert flips <= 1e-4 * hp.size, flips
+    print(f"[{mode}] max logit err {err:.2e}, label flips at ties {flips}")
+    miou, _ = evaluate(hip, [(img[:1], mask[:1], None), (img[1:], mask[1:], None)], mode, cfg)
+    hi, hu, _ = E.intersection_and_union(hp, mask.numpy(), 21, 255)
+    assert abs(miou - E.miou(hi.astype(float), hu.astype(float))[0]) < 1e-9
+    if flips == 0:
+        assert abs(miou - E.miou(z[f"inter/{mode}"].astype(float), z[f"union/{mode}"].astype(float))[0]) < 1e-9

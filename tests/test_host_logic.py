@@ -123,3 +123,54 @@ def test_fresh_model_has_no_uninitialised_parameters():
         del junk
         for n, p in m.named_parameters():
             assert torch.isfinite(p).all() and p.abs().max() < 50, n
+
+
+def test_reference_experiment_cfgs_drop_in():
+    """`build_model` accepts, unchanged, the flat dicts the reference's own experiments.generate_experiment_cfgs(40|42|43|44)
+    emits (tests/golden/experiment_cfgs.json, dumped by tests/golden/gen_golden_cfgs.py), and the package's built-in model
+    hyper-parameters equal the evaluated contents of the reference's configs/_base_/models/*.py."""
+    import json
+    import os
+    from semivl_amd.model.builder import build_model, builtin_model_cfg
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "experiment_cfgs.json")))
+
+    def norm(o):   # JSON turned tuples into lists
+        if isinstance(o, dict):
+            return {k: norm(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [norm(v) for v in o]
+        return o
+    for name, ref in d["model_cfgs"].items():
+        mine = norm(builtin_model_cfg(name))     # (the reference files may hold extra module-level helpers, e.g. norm_cfg)
+        assert mine == {k: norm(ref[k]) for k in mine}, name
+    want = {"40": (21, 512, False), "42": (81, 512, False), "43": (150, 512, False), "44": (19, 801, True)}
+    for e, cfg in d["experiments"].items():
+        nclass, crop, conv = want[e]
+        assert (cfg["nclass"], cfg["crop_size"]) == (nclass, crop)
+        # a configured-but-missing pretrained file must fail loudly (mmcv load_checkpoint behaviour) ...
+        with pytest.raises(FileNotFoundError):
+            build_model(cfg)
+        # ... and builds with the explicit synthetic-weight switch
+        with torch.device("meta"):
+            m = build_model(dict(cfg, allow_random_init=True))
+        assert m.num_classes == nclass and m.decode_head.image_size == crop and (m.conv_encoder is not None) == conv
+        assert m.backbone.pos_embed.shape[1] == (crop // 16) ** 2 + 1
+        assert m.clip_encoder.pos_embed.shape[1] == 32 * 32 + 1          # mcc_fix_resize_pos unset: frozen CLIP keeps 512^2
+        assert m._text_feat.shape[0] == nclass
+        trainable = [n for n, p in m.backbone.named_parameters() if p.requires_grad]
+        assert len(trainable) == 49 and all(("attn" in n or "pos_embed" in n) for n in trainable)
+
+
+def test_warmup_then_poly_lr():
+    from semivl_amd.train import FusedAdamW
+    class _O(FusedAdamW):
+        def __init__(self):
+            self.groups = [dict(initial_lr=1e-3, lr=1e-3), dict(initial_lr=1e-5, lr=1e-5)]
+            self._lr_host, self.seg_lr, self._lr_evt = torch.zeros(2), torch.zeros(2), None
+    o = _O()
+    o.poly_lr(5, 100, warmup_iters=10, warmup_ratio=1e-6)        # semivl.py:339-342
+    k = (1 - 5 / 10) * (1 - 1e-6)
+    assert math.isclose(o.groups[0]["lr"], 1e-3 * (1 - k)) and math.isclose(o.groups[1]["lr"], 1e-5 * (1 - k))
+    o.poly_lr(50, 100, warmup_iters=10)                          # :343-345
+    assert math.isclose(o.groups[0]["lr"], 1e-3 * 0.5 ** 0.9)
+    assert torch.allclose(o.seg_lr, torch.tensor([g["lr"] for g in o.groups]))

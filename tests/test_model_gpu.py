@@ -288,3 +288,38 @@ def test_head_memory_plan_is_exact(dev):
         scale = g_one[k].abs().max().item()
         assert (g_chk[k] - g_one[k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
     hip.decode_head.chunk_class_images = 1344
+
+
+def test_extract_feat_and_fused_optimizer_ema(dev):
+    """VLM.extract_feat in the reference's return format (vlm.py:112-123) against the oracle's backbone, and the EMA
+    teacher extension of FusedAdamW through a real step."""
+    from semivl_amd.synthetic import exp40_cfg
+    from semivl_amd.train import FusedAdamW, semivl_train_step
+    z, c = load_fixture("skr")
+    hip = build_hip(c)
+    sd = fixture_state(z, c, hip)
+    hip.load_state_dict(sd, strict=True)
+    hip.to(dev).eval()
+    orc = build_oracle(c)
+    orc.load_state_dict(sd, strict=True)
+    orc.eval()
+    batch = fixture_batch(z, c)
+    img = batch["img_x"]
+    with torch.no_grad():
+        visual, text, conv = hip.extract_feat(img.to(dev))
+        rf, rg = orc.backbone(orc.renormalize_img_for_clip(img))       # renorm_clip_img is on for the skr04 recipe
+        rc = orc.conv_encoder(img)                                     # the side encoder sees the loader-normalised image
+    feats, glob = visual
+    assert len(feats) == len(rf) == 2 and text.dtype == torch.float16 and tuple(text.shape) == (21, 512)
+    for a, b_ in zip(feats, rf):
+        assert a.shape == b_.shape and (a.cpu() - b_).abs().max() < 1e-3
+    assert (glob.cpu() - rg).abs().max() < 1e-4
+    assert isinstance(conv, (tuple, list)) and conv[0].shape == rc[0].shape and (conv[0].cpu() - rc[0]).abs().max() < 1e-3
+    # EMA through a real step: ema = d * theta_0 + (1 - d) * theta_1
+    hip.train()
+    opt = FusedAdamW(hip, exp40_cfg()["optimizer"], ema_decay=0.9)
+    p0 = opt.p.clone()
+    semivl_train_step(hip, to_dev(batch, dev), 1, 10, dict(CFG, conf_thresh=0.05, conf_mode="pixelavg"), optimizer=opt,
+                      fp_masks=[m.to(dev) for m in fixture_fp_masks(z, c)])
+    assert not torch.equal(opt.p, p0)
+    assert torch.allclose(opt.ema, 0.9 * p0 + 0.1 * opt.p, atol=1e-7, rtol=1e-6)

@@ -632,6 +632,30 @@ def test_adamw(dev):
         close(flat, torch.cat([p.detach() for p in params]), atol=1e-6, rtol=1e-5, what=f"adamw step {step}")
 
 
+def test_adamw_ema_and_grad_scale(dev):
+    """X1 (extension): theta_ema <- d theta_ema + (1 - d) theta, fused into the AdamW launch, tracking the
+    POST-update parameters; grad_scale = 1/W folds the data-parallel mean into the same launch."""
+    from semivl_amd import ops
+    torch.manual_seed(23)
+    n, d_ = 3000, 0.99
+    p0 = torch.randn(n, device=dev)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.01)
+    flat, ema = p0.clone(), p0.clone()
+    ema_ref = p0.clone()
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    off = torch.tensor([0, 1000, n], dtype=torch.int64, device=dev)
+    lr, wd = torch.full((2,), 1e-3, device=dev), torch.full((2,), 0.01, device=dev)
+    for step in range(1, 5):
+        g = torch.randn(n, device=dev)
+        ref.grad = (g * 0.25).clone()
+        opt.step()
+        ema_ref = d_ * ema_ref + (1 - d_) * ref.detach()
+        ops.adamw_step(flat, g, m, v, off, lr, wd, 2, 0.9, 0.999, 1e-8, step, 0.25, ema, d_)
+        close(flat, ref.detach(), atol=1e-6, rtol=1e-5, what=f"adamw (grad_scale) step {step}")
+        close(ema, ema_ref, atol=1e-6, rtol=1e-6, what=f"ema step {step}")
+
+
 @pytest.mark.parametrize("rows,C,relu,res", [(4 * 33 * 33, 64, True, False), (2 * 17 * 19, 256, True, True),
                                              (3 * 50 * 50, 32, False, False), (5, 64, True, True)])
 def test_batchnorm_train_fwd_bwd(dev, rows, C, relu, res):
