@@ -46,8 +46,8 @@ def parse():
                     help="BASELINE.json config presets: voc = configs[1] (N=21, 512, bs 16); cityscapes = configs[2] "
                          "(N=19, 801, bs 8, skr04); ade = configs[3] (N=150, bs 16); coco = configs[4] (N=81, bs 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-steps", type=int, nargs=2, default=(1, 3), metavar=("WARM", "TIMED"),
-                    help="oracle steps on the host cores (SURVEY §8(d) asks for 3 5; the default 1 3 keeps the default "
+    ap.add_argument("--cpu-baseline-steps", type=int, nargs=2, default=(1, 2), metavar=("WARM", "TIMED"),
+                    help="oracle steps on the host cores (SURVEY §8(d) asks for 3 5; the default 1 2 keeps the default "
                          "run within a few minutes)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--gemm-arith", choices=["f32", "bf16x6", "bf16x3"], default="f32",
@@ -99,12 +99,12 @@ def cpu_model():
 
 def cpu_baseline(crop, nclass, warm, timed):
     """the oracle restatement (kind 'port': the reference's Python cannot travel to the GPU box) on BASELINE
-    configs[0] -- VOC N=21, 512^2, bs=2, world_size 1 -- with torch.set_num_threads(all physical cores); `warm` warm-up +
-    `timed` timed full steps (forward, losses, backward, AdamW), median."""
+    configs[0] -- VOC N=21, 512^2, bs=2, world_size 1: full steps (forward, losses, backward, AdamW), `warm` warm-up +
+    `timed` timed, median.  Run with torch.set_num_threads(all physical cores) as the protocol says AND with 32 threads
+    (PyTorch's CPU kernels on this many-class-image workload scale negatively on a 2-socket 128-core host); `value` is
+    the FASTER of the two, i.e. the figure most favourable to the CPU; both are reported."""
     from oracle import semivl_oracle as O
     torch.manual_seed(0)
-    cores = physical_cores()
-    torch.set_num_threads(cores)
     bs = 2
     text, mcc = O.synthetic_text(nclass), O.synthetic_text(nclass, seed=8)
     model = O.build_vlm(dict(nclass=nclass, crop=crop), text, mcc)
@@ -113,20 +113,38 @@ def cpu_baseline(crop, nclass, warm, timed):
     batch = O.synthetic_batch(bs, crop, nclass, seed=1234)
     params = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith("clip_encoder")]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
-    times = []
-    for i in range(warm + timed):
-        t0 = time.time()
-        loss, _ = O.semivl_step(model, batch, i, 100)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        times.append(time.time() - t0)
-    dt = sorted(times[warm:])[len(times[warm:]) // 2]
-    return dict(value=2.0 * bs / dt, unit="images/s", cores=torch.get_num_threads(), kind="port", cpu=cpu_model(),
-                s_per_step=round(dt, 2),
-                sample=f"{warm} warm-up + {timed} timed full SemiVL steps (median) of oracle/semivl_oracle.py (PyTorch CPU "
-                       f"fp32) at VOC N={nclass}, {crop}x{crop}, bs={bs} ({2 * bs} images/step, BASELINE configs[0]), "
-                       f"{cores} threads = all physical cores of {cpu_model()}; {sum(times):.0f} s of CPU work")
+
+    def run(threads, nwarm, ntimed):
+        torch.set_num_threads(threads)
+        times = []
+        for i in range(nwarm + ntimed):
+            t0 = time.time()
+            loss, _ = O.semivl_step(model, batch, i, 100)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            times.append(time.time() - t0)
+        tt = sorted(times[nwarm:])
+        med = tt[len(tt) // 2] if len(tt) % 2 else 0.5 * (tt[len(tt) // 2 - 1] + tt[len(tt) // 2])
+        return med, sum(times)
+
+    cores = physical_cores()
+    runs, total = {}, 0.0
+    for threads, (w_, t_) in ((min(32, cores), (warm, timed)), (cores, (1, 1))):
+        if threads in runs:
+            continue
+        med, spent = run(threads, w_, t_)
+        runs[threads] = dict(threads=threads, s_per_step=round(med, 2), images_per_s=round(2.0 * bs / med, 4),
+                             protocol=f"{w_} warm-up + {t_} timed, median")
+        total += spent
+    best = min(runs.values(), key=lambda r: r["s_per_step"])
+    return dict(value=best["images_per_s"], unit="images/s", cores=best["threads"], kind="port", cpu=cpu_model(),
+                physical_cores=cores, s_per_step=best["s_per_step"], runs=list(runs.values()),
+                sample=f"full SemiVL steps of oracle/semivl_oracle.py (PyTorch CPU fp32) at VOC N={nclass}, {crop}x{crop}, "
+                       f"bs={bs} ({2 * bs} images/step, BASELINE configs[0]) on {cpu_model()} ({cores} physical cores): "
+                       f"{best['protocol']} at {best['threads']} threads (the faster of the thread counts tried: "
+                       f"{', '.join(str(r['threads']) + ' thr -> ' + str(r['s_per_step']) + ' s/step' for r in runs.values())}); "
+                       f"{total:.0f} s of CPU work")
 
 
 def pmc_traffic_record(batch):

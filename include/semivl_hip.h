@@ -146,6 +146,42 @@ int svl_get_gemm_emulation(void);
 /* 1 (default): narrow (N = 32 / 64) 3x3 stride-1 convolutions run on the spatially tiled kernel; 0: implicit GEMM only.
  * Initial value: 0 if the environment variable SVL_CONV_NO_TILED is set. */
 int svl_set_conv_tiled(int on);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32-accurate GEMM with PRE-SPLIT operands (the fast form of emulation mode 6; csrc/gemm_planes.hip).
+ * An fp32 matrix X [rows, K] (K % 16 == 0) is held as three bf16 "planes" x = x0 + x1 + x2 in the k-group-blocked
+ * layout planes[K/16][rows][3][16] (96-byte records; svl_planes_bytes(rows, K) bytes, 16-byte aligned).  Weights are
+ * split once, activations once by their producer; the GEMM then runs loads + v_mfma_f32_32x32x16_bf16 only (6 cross
+ * products, fp32 accumulate).  Replaces F.linear / its input gradient on the ViT linears (maskclip_vit.py:110-144 via
+ * mmcv MultiheadAttention / FFN) when svl_set_gemm_emulation(6) is active.
+ *   svl_split_planes_bf16x3   element (r, k) read at x[r * ld + k * k_stride] (k_stride 1: row-major; ld 1 + k_stride =
+ *                             leading dim: the transpose of a row-major matrix), written to rows [row_off, row_off+rows)
+ *                             of a plane buffer with planes_rows rows
+ *   svl_gemm_planes_f32       C[m, n] = epi(sum_k A[m, k] B[n, k]) for rows m in [m_off, m_off + M): bias[n], act
+ *                             (svl_act: GELU / RELU; MUL_DGELU / MUL_DRELU multiply by the activation derivative at
+ *                             resid = saved pre-activation), preact (pre-activation copy out), resid (added), accumulate
+ *                             (into C); outputs: C fp32 row-major (ldc) and / or planes_out = the result split into
+ *                             planes [N/16][p_rows][3][16] for the next GEMM (N % 16 == 0).  Either may be NULL, not both. */
+typedef struct svl_pgemm_desc {
+  const void* A;        /* planes [K/16][a_rows][3][16] bf16 */
+  const void* B;        /* planes [K/16][b_rows][3][16] bf16, b_rows >= N */
+  int64_t a_rows, b_rows;
+  int m_off, M, N, K;
+  float* C;
+  int64_t ldc;
+  void* planes_out;
+  int64_t p_rows;
+  const float* bias;
+  int act;
+  float* preact;
+  const float* resid;
+  int64_t ldr;
+  int accumulate;
+} svl_pgemm_desc;
+int64_t svl_planes_bytes(int64_t rows, int K);
+int svl_split_planes_bf16x3(const float* x, int64_t ld, int64_t k_stride, int64_t rows, int K, void* planes,
+                            int64_t planes_rows, int64_t row_off, svl_stream_t stream);
+int svl_gemm_planes_f32(const svl_pgemm_desc* d, svl_stream_t stream);
 /* Weight gradient of a narrow (Co = 32 / 64) 3x3 / stride 1 / pad 1 convolution over NHWC activations with an optional
  * second concat source (read at image img / rep): slabs[g][co][tap * (C1 + C2) + ci] for g < groups (forward-pack
  * layout per slab); the caller sums the slabs (svl_reduce_slabs_f32).  Replaces the conv2d weight-gradient of

@@ -41,6 +41,14 @@ class GemmDesc(C.Structure):
                 ("accumulate", C.c_int)]
 
 
+class PGemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("a_rows", C.c_int64), ("b_rows", C.c_int64),
+                ("m_off", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("planes_out", C.c_void_p), ("p_rows", C.c_int64),
+                ("bias", C.c_void_p), ("act", C.c_int), ("preact", C.c_void_p), ("resid", C.c_void_p),
+                ("ldr", C.c_int64), ("accumulate", C.c_int)]
+
+
 class CeDesc(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("B", C.c_int), ("N", C.c_int), ("HW", C.c_int64),
                 ("target", C.c_void_p), ("use_ignore_t", C.c_int), ("conf", C.c_void_p), ("ign", C.c_void_p),
@@ -64,6 +72,9 @@ SIGNATURES = {
     "svl_set_gemm_emulation": (_I, [_I]),
     "svl_get_gemm_emulation": (_I, []),
     "svl_set_conv_tiled": (_I, [_I]),
+    "svl_planes_bytes": (_L, [_L, _I]),
+    "svl_split_planes_bf16x3": (_I, [_P, _L, _L, _L, _I, _P, _L, _L, _P]),
+    "svl_gemm_planes_f32": (_I, [C.POINTER(PGemmDesc), _P]),
     "svl_conv3x3_wgrad_tiled_groups": (_I, [_I, _I, _I, _I, _I]),
     "svl_conv3x3_wgrad_tiled": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _P]),
     "svl_reduce_slabs_f32": (_I, [_P, _P, _I, _L, _I, _P]),

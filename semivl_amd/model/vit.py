@@ -103,7 +103,7 @@ def block_forward(x, p, heads, eps, Bn, T, want_v, skip_x, save):
         vo = ops.linear(vproj, p["wout"], p["bout"], resid=x)  # out_proj(v) + x   (maskclip_vit.py:115-117)
         y2v, st2v = ops.layernorm_fwd(vo, p["ln2w"], p["ln2b"], eps)
         hv_pre = ops.empty(y2v.shape[0], p["w1"].shape[0], device=x.device) if save is not None else None
-        hv = ops.linear(y2v, p["w1"], p["b1"], act=ops.ACT_GELU, preact=hv_pre)
+        hv = ops.linear(y2v, p["w1"], p["b1"], act=ops.ACT_GELU, preact=hv_pre, planes_only=True)  # only feeds FFN-2
         v = ops.linear(hv, p["w2"], p["b2"], resid=vo)
         if save is not None:
             save.update(vo=vo, st2v=st2v, hv_pre=hv_pre)
@@ -116,7 +116,7 @@ def block_forward(x, p, heads, eps, Bn, T, want_v, skip_x, save):
         x2 = ops.linear(o, p["wout"], p["bout"], resid=x)
         y2, st2 = ops.layernorm_fwd(x2, p["ln2w"], p["ln2b"], eps)
         h_pre = ops.empty(y2.shape[0], p["w1"].shape[0], device=x.device) if save is not None else None
-        h = ops.linear(y2, p["w1"], p["b1"], act=ops.ACT_GELU, preact=h_pre)
+        h = ops.linear(y2, p["w1"], p["b1"], act=ops.ACT_GELU, preact=h_pre, planes_only=True)
         xo = ops.linear(h, p["w2"], p["b2"], resid=x2)
         if save is not None:
             save.update(o=o, P=P, x2=x2, st2=st2, h_pre=h_pre)
@@ -135,7 +135,8 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False):
     wout_parts = []  # (dy, input) pairs contributing to out_proj wgrad
 
     def ffn_ln_bwd(dout, pre_ln_in, st2, h_pre, tag):
-        dhp = ops.matmul_nn(dout, p["w2"], dact=ops.ACT_MUL_DGELU, z=h_pre)  # (dout W2) * GELU'(h_pre), one pass
+        # (dout W2) * GELU'(h_pre), one pass; with frozen FFN weights its only consumer is the next GEMM (bf16 planes)
+        dhp = ops.matmul_nn(dout, p["w2"], dact=ops.ACT_MUL_DGELU, z=h_pre, planes_only=not train_ffn_ln)
         dy2 = ops.matmul_nn(dhp, p["w1"])
         if train_ffn_ln:
             # recompute h = gelu(h_pre) and y2 = LN(pre_ln_in) for the weight grads (cheap vs. saving them)

@@ -124,12 +124,130 @@ def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld
     return g
 
 
+# ------------------------------------------------------------------------------------------------ pre-split bf16x3 operands
+class Planes:
+    """An fp32 matrix [rows, K] held as three bf16 planes x = x0 + x1 + x2 in the k-group-blocked layout of
+    csrc/gemm_planes.hip ([K/16][rows][3][16]); the operand format of svl_gemm_planes_f32."""
+    __slots__ = ("buf", "rows", "K")
+
+    def __init__(self, rows, K, device=None, buf=None):
+        assert K % 16 == 0
+        self.rows, self.K = rows, K
+        self.buf = buf if buf is not None else torch.empty(K // 16 * rows * 48, dtype=torch.bfloat16,
+                                                           device=device if device is not None else torch.cuda.current_device())
+
+    @property
+    def shape(self):
+        return (self.rows, self.K)
+
+
+def split_planes(x2d, out=None, row_off=0, transpose=False):
+    """fp32 [rows, K] -> Planes (one HBM pass: 4 B read + 6 B written per element).  transpose=True splits x2d^T (used
+    once per weight for the input-gradient GEMMs)."""
+    assert x2d.dim() == 2 and x2d.dtype == torch.float32
+    if transpose:
+        K, rows = x2d.shape
+        assert x2d.stride(1) == 1
+        ld, ks = 1, x2d.stride(0)
+    else:
+        rows, K = x2d.shape
+        assert x2d.stride(1) == 1
+        ld, ks = x2d.stride(0), 1
+    if out is None:
+        out = Planes(rows, K, device=x2d.device)
+    assert out.K == K and out.rows >= row_off + rows
+    L.check(L.load().svl_split_planes_bf16x3(_p(x2d), ld, ks, rows, K, _p(out.buf), out.rows, row_off, _st()),
+            "svl_split_planes_bf16x3")
+    return out
+
+
+WEIGHT_EPOCH = 0          # bumped by FusedAdamW.step(): its kernel rewrites the parameter arena behind torch's back
+_WPLANES = {}
+
+
+def weights_changed():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def weight_planes(W, transpose=False):
+    """Planes of a weight matrix (or of a row slice of one), split ONCE and cached: frozen weights for the life of the
+    process (keyed on storage + torch version counter), trainable ones until the next optimizer step."""
+    base = W._base if W._base is not None else W
+    if not isinstance(base, torch.nn.Parameter):      # not a parameter: no identity to key a cache on
+        return split_planes(W.detach(), transpose=transpose)
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transpose)
+    ver = (base._version, WEIGHT_EPOCH if base.requires_grad else 0)
+    hit = _WPLANES.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    pl = split_planes(W.detach(), transpose=transpose)
+    if len(_WPLANES) > 4096:
+        _WPLANES.clear()
+    _WPLANES[key] = (ver, pl)
+    return pl
+
+
+def planes_eligible(M, N, K):
+    """The pre-split path serves what the in-register emulation served (large dense GEMMs) when K is a whole number of
+    MFMA k-groups."""
+    return get_gemm_emulation() == 6 and PLANES_PATH and M >= 256 and N >= 96 and K >= 64 and K % 16 == 0
+
+
+# Opt-in (SVL_GEMM_PLANES=1): measured on MI355X the pre-split kernel runs the six-product scheme at the SAME matrix-pipe
+# rate as the in-register split kernel (~1.0 PF bf16 = 165-180 TF fp32-equivalent at 128x128 tiles; both are bound by the
+# per-K-step barrier / LDS-latency structure, not by the split's VALU work), and its extra pass over the activations
+# makes the step 3.5 % slower (598 vs 578 ms, DESIGN.md §7) -- so the in-register kernel stays the default of mode 6.
+PLANES_PATH = bool(os.environ.get("SVL_GEMM_PLANES"))
+
+
+def pgemm(A, B, M, N, out=None, planes_out=None, bias=None, act=ACT_NONE, preact=None, resid=None, accumulate=False,
+          m_off=0):
+    """out[M, N] (fp32, row-major, optional) and / or planes_out (Planes [M, N], optional) = epi(A @ B^T)."""
+    K = A.K
+    assert B.K == K and A.rows >= m_off + M and B.rows >= N
+    d = L.PGemmDesc()
+    d.A, d.B, d.a_rows, d.b_rows = _p(A.buf), _p(B.buf), A.rows, B.rows
+    d.m_off, d.M, d.N, d.K = m_off, M, N, K
+    if out is not None:
+        assert out.stride(1) == 1
+        d.C, d.ldc = _p(out), out.stride(0)
+    elif preact is not None:
+        d.ldc = preact.stride(0)
+    if planes_out is not None:
+        d.planes_out, d.p_rows = _p(planes_out.buf), planes_out.rows
+    d.bias, d.act, d.preact = _p(bias), act, _p(preact)
+    if resid is not None:
+        assert resid.stride(1) == 1
+        d.resid, d.ldr = _p(resid), resid.stride(0)
+    d.accumulate = 1 if accumulate else 0
+    e0 = _prof_begin()
+    L.check(L.load().svl_gemm_planes_f32(C.byref(d), _st()), "svl_gemm_planes_f32")
+    _prof_end("gemm", e0, 2.0 * M * N * K, ("planes", M, N, K, 1))
+
+
 # ------------------------------------------------------------------------------------------------ dense helpers
-def linear(x, W, bias=None, act=ACT_NONE, resid=None, out=None, accumulate=False, preact=None):
-    """out[M,N] = act(x[M,K] @ W[N,K]^T + bias) + resid   (torch F.linear layout)."""
+def linear(x, W, bias=None, act=ACT_NONE, resid=None, out=None, accumulate=False, preact=None, planes_only=False):
+    """out[M,N] = act(x[M,K] @ W[N,K]^T + bias) + resid   (torch F.linear layout).  `x` may be a Planes object (the
+    previous GEMM's / producer's pre-split output).  planes_only=True returns the result as Planes instead of fp32 when
+    the pre-split path is active (else the fp32 tensor): for values whose only consumer is the next GEMM."""
     M, K = x.shape
     N = W.shape[0]
-    assert W.shape[1] == K and x.stride(1) == 1 and W.is_contiguous()
+    assert W.shape[1] == K and W.stride(1) == 1
+    if isinstance(x, Planes) or planes_eligible(M, N, K):
+        xa = x if isinstance(x, Planes) else split_planes(x)
+        wb = weight_planes(W)
+        if preact is not None:
+            assert out is None or preact.stride(0) == out.stride(0)
+        if planes_only and N % 16 == 0 and out is None and not accumulate:
+            po = Planes(M, N, device=xa.buf.device)
+            pgemm(xa, wb, M, N, None, po, bias, act, preact, resid)
+            return po
+        if out is None:
+            out = empty(M, N, device=xa.buf.device)
+        pgemm(xa, wb, M, N, out, None, bias, act, preact, resid, accumulate)
+        return out
+    assert x.stride(1) == 1 and W.is_contiguous()
     if out is None:
         out = empty(M, N, device=x.device)
     gemm(A_KC, B_KC, M, N, K, Op(x, x.stride(0)), Op(W, K), out, ldc_m=out.stride(0), bias=bias, act=act,
@@ -144,12 +262,27 @@ def copy2d(src, s_off, sgrp, src_go, src_ld, dst, d_off, dgrp, dst_go, dst_ld, r
                                     1 if accumulate else 0, _st()), "svl_copy2d_f32")
 
 
-def matmul_nn(a, b, out=None, accumulate=False, dact=ACT_NONE, z=None):
+def matmul_nn(a, b, out=None, accumulate=False, dact=ACT_NONE, z=None, planes_only=False):
     """out[M,N] = a[M,K] @ b[K,N]  (dgrad: dY @ W with W [out,in]).  `dact` = ACT_MUL_DGELU / ACT_MUL_DRELU multiplies
-    the result by the activation derivative at the saved pre-activation `z` [M,N] in the epilogue."""
+    the result by the activation derivative at the saved pre-activation `z` [M,N] in the epilogue.  `a` may be Planes;
+    planes_only as in linear()."""
     M, K = a.shape
     N = b.shape[1]
-    assert b.shape[0] == K and a.stride(1) == 1 and b.stride(1) == 1
+    assert b.shape[0] == K and b.stride(1) == 1
+    if isinstance(a, Planes) or planes_eligible(M, N, K):
+        xa = a if isinstance(a, Planes) else split_planes(a)
+        wb = weight_planes(b, transpose=True)       # B^T planes: rows = N (input features), k = K (output features)
+        if dact != ACT_NONE:
+            assert z is not None and z.shape == (M, N) and z.stride(1) == 1 and not accumulate
+        if planes_only and N % 16 == 0 and out is None and not accumulate:
+            po = Planes(M, N, device=xa.buf.device)
+            pgemm(xa, wb, M, N, None, po, None, dact, None, z if dact != ACT_NONE else None)
+            return po
+        if out is None:
+            out = empty(M, N, device=xa.buf.device)
+        pgemm(xa, wb, M, N, out, None, None, dact, None, z if dact != ACT_NONE else None, accumulate)
+        return out
+    assert a.stride(1) == 1
     if out is None:
         out = empty(M, N, device=a.device)
     if dact != ACT_NONE:

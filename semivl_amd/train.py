@@ -273,6 +273,7 @@ class FusedAdamW:
         ops.adamw_step(self.p, self.g, self.m, self.v, self.seg_off, self.seg_lr, self.seg_wd, len(self.groups),
                        self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale, self.ema,
                        self.ema_decay)
+        ops.weights_changed()    # cached bf16 planes of the trainable weights are stale now (ops.weight_planes)
 
     def state_dict(self):
         """torch.optim.AdamW layout (`semivl.py:428` stores `optimizer.state_dict()`): one param group per tensor, in

@@ -98,12 +98,14 @@ def emu_mode():
     def use(mode):
         ops.set_gemm_emulation(mode)
 
+    keep = ops.PLANES_PATH
     yield use
     ops.set_gemm_emulation(0)
+    ops.PLANES_PATH = keep
 
 
 def _relerr(y, ref):
-    return float((y.double() - ref).norm() / ref.norm())
+    return float((y.detach().double() - ref.detach()).norm() / ref.detach().norm())
 
 
 @pytest.mark.parametrize("M,N,K", [(1025, 768, 768), (2050, 768, 3072), (333, 200, 97), (4100, 2304, 768),
@@ -149,6 +151,89 @@ def test_gemm_bf16_split_emulation_special_values(dev, emu_mode):
     assert _relerr(ops.linear(xs, ws), ref) < 2e-6
     x[::2] = 0
     assert torch.equal(ops.linear(x, w), (x.double() @ w.double().t()).float())
+
+
+def _unpack_planes(pl):
+    """Planes -> three fp32 [rows, K] tensors (layout [K/16][rows][3][16])."""
+    v = pl.buf.view(pl.K // 16, pl.rows, 3, 16).float()
+    return [v[:, :, i, :].permute(1, 0, 2).reshape(pl.rows, pl.K) for i in range(3)]
+
+
+def test_split_planes_is_an_exact_three_term_split(dev):
+    from semivl_amd import ops
+    x = rnd(1000, 208, dev=dev, seed=61) * torch.logspace(-20, 20, 208, device=dev)
+    x[5] = 0
+    p0, p1, p2 = _unpack_planes(ops.split_planes(x))
+    assert torch.equal(p0, x.bfloat16().float())                       # RNE leading term
+    assert torch.equal(p1, (x - p0).bfloat16().float()) and torch.equal(p2, (x - p0 - p1).bfloat16().float())
+    resid = (x.double() - p0.double() - p1.double() - p2.double()).abs()
+    assert (resid <= 2.0 ** -24 * x.abs().double() + 1e-45).all()     # 24 mantissa bits carried
+    # transposed split (weights for the input-gradient GEMMs) and writing at a row offset of a larger buffer
+    w = rnd(96, 160, dev=dev, seed=62)
+    t0, _, _ = _unpack_planes(ops.split_planes(w, transpose=True))
+    assert torch.equal(t0, w.t().bfloat16().float())
+    big = ops.Planes(3000, 208, device=dev)
+    ops.split_planes(x, out=big, row_off=1500)
+    b0, _, _ = _unpack_planes(big)
+    assert torch.equal(b0[1500:2500], p0)
+
+
+@pytest.mark.parametrize("M,N,K", [(8 * 1025, 768, 768), (1300, 3072, 768), (2050, 768, 3072), (260, 96, 64),
+                                   (4 * 1025, 2304, 768)])
+def test_gemm_planes_path(dev, emu_mode, M, N, K):
+    """The pre-split form of mode 6 (csrc/gemm_planes.hip): error vs fp64 at or below the fp32 MFMA chain's for the
+    forward and input-gradient layouts, ragged token counts (M = 8 x 1025: helper-stream fork), every epilogue option,
+    results handed over as planes (FFN-1 -> FFN-2, dGELU dgrad -> dgrad), determinism, and identity with the in-register
+    split kernel (same arithmetic, same product order)."""
+    from semivl_amd import ops
+    x, b, r = rnd(M, K, dev=dev, seed=71), rnd(N, dev=dev), rnd(M, N, dev=dev)
+    w = torch.nn.Parameter(rnd(N, K, dev=dev) * 0.05)
+    dy = rnd(M, N, dev=dev)
+    ref_nt, ref_nn = x.double() @ w.double().t(), dy.double() @ w.double()
+    emu_mode(0)
+    e0 = (_relerr(ops.linear(x, w), ref_nt), _relerr(ops.matmul_nn(dy, w), ref_nn))
+    emu_mode(6)
+    ops.PLANES_PATH = True          # (opt-in path: the in-register split kernel is mode 6's default)
+    assert ops.planes_eligible(M, N, K)
+    y, dx = ops.linear(x, w), ops.matmul_nn(dy, w)
+    assert _relerr(y, ref_nt) <= 1.5 * e0[0] + 1e-8 and _relerr(dx, ref_nn) <= 1.5 * e0[1] + 1e-8, (e0, _relerr(y, ref_nt))
+    assert torch.equal(y, ops.linear(x, w)), "deterministic"
+    ops.PLANES_PATH = False
+    y_inreg = ops.linear(x, w)
+    ops.PLANES_PATH = True
+    assert torch.equal(y, y_inreg), "pre-split and in-register split must be the same arithmetic"
+    # epilogue: bias + GELU + saved pre-activation, residual, accumulate, GELU' product
+    pre = torch.empty_like(r)
+    g = ops.linear(x, w, b, act=ops.ACT_GELU, preact=pre)
+    close(pre, x @ w.t() + b, what="preact", atol=2e-5 * math.sqrt(K))
+    close(g, F.gelu(x @ w.t() + b), what="gelu", atol=2e-5 * math.sqrt(K))
+    close(ops.linear(x, w, b, resid=r), x @ w.t() + b + r, what="resid", atol=2e-5 * math.sqrt(K))
+    acc = r.clone()
+    ops.linear(x, w, out=acc, accumulate=True)
+    close(acc, r + x @ w.t(), what="accumulate", atol=2e-5 * math.sqrt(K))
+    z = rnd(M, K, dev=dev, seed=72)
+    zt = z.clone().requires_grad_(True)
+    F.gelu(zt).backward(torch.ones_like(zt))
+    close(ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z), (dy @ w) * zt.grad, what="dgelu", atol=2e-5 * math.sqrt(N))
+    # results handed over as planes: the three terms of the fp32 result, consumed by the next GEMM
+    w2 = torch.nn.Parameter(rnd(128, N, dev=dev) * 0.05)
+    hp = ops.linear(x, w, b, act=ops.ACT_GELU, planes_only=True)
+    assert isinstance(hp, ops.Planes) and hp.shape == (M, N)
+    p0, p1, p2 = _unpack_planes(hp)
+    assert torch.equal(p0, g.bfloat16().float()) and torch.equal(p1, (g - p0).bfloat16().float())
+    out2 = ops.linear(hp, w2)
+    assert torch.equal(out2, ops.linear(g, w2))
+    w3 = torch.nn.Parameter(rnd(K, 128, dev=dev) * 0.05)
+    dhp = ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z, planes_only=True)
+    assert isinstance(dhp, ops.Planes) and dhp.shape == (M, K)
+    assert torch.equal(ops.matmul_nn(dhp, w3), ops.matmul_nn(ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z), w3))
+    # weight cache: a parameter update behind torch's back (the fused AdamW kernel) is announced with weights_changed()
+    ops.fill(w.data[0], 0.0)
+    stale = ops.linear(x, w)
+    ops.weights_changed()
+    fresh = ops.linear(x, w)
+    assert torch.equal(stale, y) and not torch.equal(fresh[:, 0], y[:, 0]) and float(fresh[:, 0].abs().max()) == 0.0
+    ops.PLANES_PATH = False
 
 
 @pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (3, 17, 4), (1, 64, 2)])
