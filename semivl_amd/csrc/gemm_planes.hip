@@ -96,14 +96,19 @@ __device__ __forceinline__ void split3(const float (&x)[4], bf16x4& h0, bf16x4& 
 // pre-split and the in-register kernel both sat at 165-175 TF at 128x128).  256x256 (262 FLOP per L2 byte) halves that;
 // 256x128 serves N = 768 / 2304, whose 256-wide tilings would leave a partial last round of the grid.  The large tiles
 // run 4 waves of (BM/2)x(BN/2) at ONE block per CU with the 512-register budget (accumulators 128 / 256 registers).
-template <int BM, int BN>
+// BK = 16, two LDS buffers, one barrier per step (the classic double buffer), or BK = 32 with ONE LDS buffer and two
+// barriers per step: a block then alternates a compute phase (48 MFMAs per wave) and a short refill phase, and the two
+// blocks resident on a CU interleave them -- the matrix pipe of a SIMD is fed by one block's wave while the other's
+// refills -- at half the barriers per k of the BK = 16 form (whose per-step overhead, not bandwidth, was the limiter).
+template <int BM, int BN, int BK, int NBUF>
 __device__ __forceinline__ void gemm_planes_body(const PlanesP& p, __bf16* sm) {
-  constexpr int LDR = 24;                               // bf16 elements per LDS row (48 B)
+  constexpr int KG = BK / 16;                           // MFMA k-groups per K step
+  constexpr int LDR = BK == 16 ? 24 : 40;               // bf16 elements per LDS row (48 / 80 B: conflict-free b128 reads)
   constexpr int PLA = BM * LDR + 16, PLB = BN * LDR + 16;   // plane strides (elements): 32 B skew between planes
   constexpr int OPA = 3 * PLA, OPB = 3 * PLB;           // one operand, three planes
   constexpr int BUF = OPA + OPB;                        // A + B of one K step
   constexpr int TM = BM / 64, TN = BN / 64;             // 32x32 MFMA tiles per wave (wave grid 2 x 2)
-  constexpr int CA = BM * 6 / 256, CB = BN * 6 / 256;   // 16-byte chunks per thread and K step
+  constexpr int CA = BM * 6 * KG / 256, CB = BN * 6 * KG / 256;   // 16-byte chunks per thread and K step
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
@@ -117,31 +122,31 @@ __device__ __forceinline__ void gemm_planes_body(const PlanesP& p, __bf16* sm) {
   tile_to_mn(p, tile, tm_i, tn_i);
   const int m0 = p.m_off + tm_i * BM, n0 = tn_i * BN;
   const int m_end = p.m_off + p.M;
-  const int nk = p.K >> 4;
+  const int nk = p.K / BK;
 
-  // staging: chunk c = tid + 256 i of the tile's BM*6 (BN*6) 16-byte chunks; row = c / 6, (plane, k-half) = c % 6.
+  // staging: chunk c = tid + 256 i of the tile's 16-byte chunks; row = c / (6 KG), then (k-group, plane, k-half).
   // Everything is a compile-time-indexed register (static_for): a run-time index would demote it to scratch.
-  const long ka_step = p.a_rows * (REC / 8), kb_step = p.b_rows * (REC / 8);   // u32x4 units per k-group
+  const long ka_step = p.a_rows * (REC / 8) * KG, kb_step = p.b_rows * (REC / 8) * KG;   // u32x4 units per K step
   const u32x4* ga[CA];
   const u32x4* gb[CB];
   int sa[CA], sb[CB];
   static_for<0, CA>([&](auto I) {
     constexpr int i = decltype(I)::value;
     const int c = tid + 256 * i;
-    const int row = c / 6, w = c - row * 6;
+    const int row = c / (6 * KG), w2 = c - row * (6 * KG), kg = w2 / 6, w = w2 - kg * 6;
     const long ra = min((long)(m0 + row), (long)(m_end - 1));   // rows past the edge: clamped, never stored
-    ga[i] = reinterpret_cast<const u32x4*>(p.A) + ra * (REC / 8) + w;
-    sa[i] = (w >> 1) * PLA + row * LDR + (w & 1) * 8;
+    ga[i] = reinterpret_cast<const u32x4*>(p.A) + ((long)kg * p.a_rows + ra) * (REC / 8) + w;
+    sa[i] = (w >> 1) * PLA + row * LDR + kg * 16 + (w & 1) * 8;
   });
   static_for<0, CB>([&](auto I) {
     constexpr int i = decltype(I)::value;
     const int c = tid + 256 * i;
-    const int row = c / 6, w = c - row * 6;
+    const int row = c / (6 * KG), w2 = c - row * (6 * KG), kg = w2 / 6, w = w2 - kg * 6;
     const long rb = min((long)(n0 + row), (long)(p.N - 1));
-    gb[i] = reinterpret_cast<const u32x4*>(p.B) + rb * (REC / 8) + w;
-    sb[i] = OPA + (w >> 1) * PLB + row * LDR + (w & 1) * 8;
+    gb[i] = reinterpret_cast<const u32x4*>(p.B) + ((long)kg * p.b_rows + rb) * (REC / 8) + w;
+    sb[i] = OPA + (w >> 1) * PLB + row * LDR + kg * 16 + (w & 1) * 8;
   });
-  u32x4 xa0[CA], xb0[CB], xa1[CA], xb1[CB];
+  u32x4 xa0[CA], xb0[CB], xa1[NBUF == 2 ? CA : 1], xb1[NBUF == 2 ? CB : 1];
   auto gload = [&](u32x4 (&xa)[CA], u32x4 (&xb)[CB], int t) __attribute__((always_inline)) {
     if (t < nk) {
       const long oa = (long)t * ka_step, ob = (long)t * kb_step;
@@ -166,49 +171,71 @@ __device__ __forceinline__ void gemm_planes_body(const PlanesP& p, __bf16* sm) {
   const int fa = (wr * (BM / 2) + l31) * LDR + 8 * hi, fb = OPA + (wc * (BN / 2) + l31) * LDR + 8 * hi;
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const __bf16* S = sm + buf * BUF;
-    bf16x8 a[3][TM], b[3][TN];
-    static_for<0, 3>([&](auto P) {
-      constexpr int pl = decltype(P)::value;
-      static_for<0, TM>([&](auto I) {
-        a[pl][decltype(I)::value] = *reinterpret_cast<const bf16x8*>(S + fa + pl * PLA + decltype(I)::value * 32 * LDR);
-      });
-      static_for<0, TN>([&](auto J) {
-        b[pl][decltype(J)::value] = *reinterpret_cast<const bf16x8*>(S + fb + pl * PLB + decltype(J)::value * 32 * LDR);
-      });
-    });
-    // transposed accumulators: D(n, m) += B-fragment x A-fragment; smallest cross terms first; consecutive MFMAs go to
-    // different accumulators (dependent ones are TM * TN instructions apart)
-    static_for<0, 6>([&](auto T) {
-      constexpr int t = decltype(T)::value;
-      constexpr int PA = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;     // (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
-      constexpr int PB = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
-      static_for<0, TM>([&](auto I) {
+    static_for<0, KG>([&](auto G) {
+      constexpr int kg = decltype(G)::value;
+      bf16x8 a[3][TM], b[3][TN];
+      static_for<0, 3>([&](auto P) {
+        constexpr int pl = decltype(P)::value;
+        static_for<0, TM>([&](auto I) {
+          a[pl][decltype(I)::value] =
+              *reinterpret_cast<const bf16x8*>(S + fa + pl * PLA + decltype(I)::value * 32 * LDR + kg * 16);
+        });
         static_for<0, TN>([&](auto J) {
-          constexpr int i = decltype(I)::value, j = decltype(J)::value;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB][j], a[PA][i], acc[i][j], 0, 0, 0);
+          b[pl][decltype(J)::value] =
+              *reinterpret_cast<const bf16x8*>(S + fb + pl * PLB + decltype(J)::value * 32 * LDR + kg * 16);
+        });
+      });
+      // transposed accumulators: D(n, m) += B-fragment x A-fragment; smallest cross terms first; consecutive MFMAs go
+      // to different accumulators (dependent ones are TM * TN instructions apart)
+      static_for<0, 6>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        constexpr int PA = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;     // (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+        constexpr int PB = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+        static_for<0, TM>([&](auto I) {
+          static_for<0, TN>([&](auto J) {
+            constexpr int i = decltype(I)::value, j = decltype(J)::value;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB][j], a[PA][i], acc[i][j], 0, 0, 0);
+          });
         });
       });
     });
   };
 
-  // data of step s lives in register set s & 1, then in LDS buffer s & 1; loads run two steps ahead of their LDS store
-  gload(xa0, xb0, 0);
-  gload(xa1, xb1, 1);
-  if (nk > 0) sstore(xa0, xb0, 0);
-  gload(xa0, xb0, 2);
-  __syncthreads();
-  int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    compute(0);
-    sstore(xa1, xb1, 1);
-    gload(xa1, xb1, t + 3);
+  if constexpr (NBUF == 2) {
+    // data of step s lives in register set s & 1, then in LDS buffer s & 1; loads run two steps ahead of their LDS store
+    gload(xa0, xb0, 0);
+    gload(xa1, xb1, 1);
+    if (nk > 0) sstore(xa0, xb0, 0);
+    gload(xa0, xb0, 2);
     __syncthreads();
-    compute(1);
-    if (t + 2 < nk) sstore(xa0, xb0, 0);
-    gload(xa0, xb0, t + 4);
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      compute(0);
+      sstore(xa1, xb1, 1);
+      gload(xa1, xb1, t + 3);
+      __syncthreads();
+      compute(1);
+      if (t + 2 < nk) sstore(xa0, xb0, 0);
+      gload(xa0, xb0, t + 4);
+      __syncthreads();
+    }
+    if (t < nk) compute(0);
+  } else {
+    // one LDS buffer: compute | barrier | refill (registers loaded during the compute phase) + next loads | barrier
+    gload(xa0, xb0, 0);
+    if (nk > 0) sstore(xa0, xb0, 0);
+    gload(xa0, xb0, 1);
     __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      compute(0);
+      if (t + 1 < nk) {
+        __syncthreads();
+        sstore(xa0, xb0, 0);
+        gload(xa0, xb0, t + 2);
+        __syncthreads();
+      }
+    }
   }
-  if (t < nk) compute(0);
 
   // ---- epilogue: acc[i][j][r] = C(m, n), m = m0 + wr*BM/2 + i*32 + l31, n = n0 + wc*BN/2 + j*32 + 8*(r>>2) + 4*hi + (r&3)
   const bool vec = (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
@@ -294,20 +321,26 @@ __device__ __forceinline__ void gemm_planes_body(const PlanesP& p, __bf16* sm) {
   });
 }
 
-template <int BM, int BN>
-constexpr int planes_lds_elems() { return 2 * (3 * (BM * 24 + 16) + 3 * (BN * 24 + 16)); }
+template <int BM, int BN, int BK, int NBUF>
+constexpr int planes_lds_elems() {
+  return NBUF * (3 * (BM * (BK == 16 ? 24 : 40) + 16) + 3 * (BN * (BK == 16 ? 24 : 40) + 16));
+}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel_128x128(const PlanesP p) {
-  __shared__ __attribute__((aligned(16))) __bf16 sm[planes_lds_elems<128, 128>()];
-  gemm_planes_body<128, 128>(p, sm);
+  __shared__ __attribute__((aligned(16))) __bf16 sm[planes_lds_elems<128, 128, 16, 2>()];
+  gemm_planes_body<128, 128, 16, 2>(p, sm);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel_128x128_k32(const PlanesP p) {
+  __shared__ __attribute__((aligned(16))) __bf16 sm[planes_lds_elems<128, 128, 32, 1>()];
+  gemm_planes_body<128, 128, 32, 1>(p, sm);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_planes_kernel_256x128(const PlanesP p) {
   extern __shared__ __attribute__((aligned(16))) __bf16 smd[];
-  gemm_planes_body<256, 128>(p, smd);
+  gemm_planes_body<256, 128, 16, 2>(p, smd);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_planes_kernel_256x256(const PlanesP p) {
   extern __shared__ __attribute__((aligned(16))) __bf16 smd[];
-  gemm_planes_body<256, 256>(p, smd);
+  gemm_planes_body<256, 256, 16, 2>(p, smd);
 }
 
 // fp32 [rows, K] (element (r, k) at x[r * ld + k * ks]) -> planes[K/16][rows][3][16].  Thread = (row, pair of k-groups):
@@ -375,7 +408,7 @@ bool attr_needed(std::atomic<uint64_t>& mask) {
   return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
 }
 
-template <int BM, int BN, typename K>
+template <int BM, int BN, int BK, int NBUF, typename K>
 int launch_tile(PlanesP q, K kern, hipStream_t st) {
   q.tiles_m = (q.M + BM - 1) / BM;
   q.tiles_n = (q.N + BN - 1) / BN;
@@ -386,7 +419,7 @@ int launch_tile(PlanesP q, K kern, hipStream_t st) {
     svl_set_error("svl_gemm_planes_f32: bad tile count %ld", tiles);
     return SVL_ERR_INVALID_ARG;
   }
-  constexpr size_t lds = (size_t)planes_lds_elems<BM, BN>() * 2;
+  constexpr size_t lds = (size_t)planes_lds_elems<BM, BN, BK, NBUF>() * 2;
   if constexpr (BM == 128) {
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), 0, st, q);
   } else {
@@ -403,7 +436,8 @@ int launch_tile(PlanesP q, K kern, hipStream_t st) {
 // Tile choice: the largest tile whose grid is a whole number of rounds of resident blocks (256 CUs x 1 block for the
 // 256-row tiles, x 2 for 128x128), falling back to the shape that wastes the least of its last round.
 int launch(const PlanesP& q, hipStream_t st) {
-  static const int force = getenv("SVL_PLANES_TILE") ? atoi(getenv("SVL_PLANES_TILE")) : 0;   // 1: 128x128, 2: 256x128, 3: 256x256
+  // 1: 128x128 BK 16; 2: 256x128; 3: 256x256; 4: 128x128 BK 32 (single LDS buffer)
+  static const int force = getenv("SVL_PLANES_TILE") ? atoi(getenv("SVL_PLANES_TILE")) : 0;
   auto waste = [&](int bm, int bn, int resident) {
     const long tiles = (long)((q.M + bm - 1) / bm) * ((q.N + bn - 1) / bn);
     const long rounds = (tiles + resident - 1) / resident;
@@ -420,9 +454,11 @@ int launch(const PlanesP& q, hipStream_t st) {
       pick = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
     }
   }
-  if (pick == 3) return launch_tile<256, 256>(q, gemm_planes_kernel_256x256, st);
-  if (pick == 2) return launch_tile<256, 128>(q, gemm_planes_kernel_256x128, st);
-  return launch_tile<128, 128>(q, gemm_planes_kernel_128x128, st);
+  if (pick == 4 && (q.K % 32) != 0) pick = 1;
+  if (pick == 4) return launch_tile<128, 128, 32, 1>(q, gemm_planes_kernel_128x128_k32, st);
+  if (pick == 3) return launch_tile<256, 256, 16, 2>(q, gemm_planes_kernel_256x256, st);
+  if (pick == 2) return launch_tile<256, 128, 16, 2>(q, gemm_planes_kernel_256x128, st);
+  return launch_tile<128, 128, 16, 2>(q, gemm_planes_kernel_128x128, st);
 }
 
 }  // namespace

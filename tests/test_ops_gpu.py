@@ -201,7 +201,9 @@ def test_gemm_planes_path(dev, emu_mode, M, N, K):
     ops.PLANES_PATH = False
     y_inreg = ops.linear(x, w)
     ops.PLANES_PATH = True
-    assert torch.equal(y, y_inreg), "pre-split and in-register split must be the same arithmetic"
+    # (svl_gemm_f32 runs the < 256 leftover rows of a ragged token count on the exact fp32 kernel: compare the aligned part)
+    ma = M if M < 8192 else M // 128 * 128
+    assert torch.equal(y[:ma], y_inreg[:ma]), "pre-split and in-register split must be the same arithmetic"
     # epilogue: bias + GELU + saved pre-activation, residual, accumulate, GELU' product
     pre = torch.empty_like(r)
     g = ops.linear(x, w, b, act=ops.ACT_GELU, preact=pre)
@@ -224,9 +226,10 @@ def test_gemm_planes_path(dev, emu_mode, M, N, K):
     out2 = ops.linear(hp, w2)
     assert torch.equal(out2, ops.linear(g, w2))
     w3 = torch.nn.Parameter(rnd(K, 128, dev=dev) * 0.05)
-    dhp = ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z, planes_only=True)
-    assert isinstance(dhp, ops.Planes) and dhp.shape == (M, K)
-    assert torch.equal(ops.matmul_nn(dhp, w3), ops.matmul_nn(ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z), w3))
+    if ops.planes_eligible(M, K, N):
+        dhp = ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z, planes_only=True)
+        assert isinstance(dhp, ops.Planes) and dhp.shape == (M, K)
+        assert torch.equal(ops.matmul_nn(dhp, w3), ops.matmul_nn(ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z), w3))
     # weight cache: a parameter update behind torch's back (the fused AdamW kernel) is announced with weights_changed()
     ops.fill(w.data[0], 0.0)
     stale = ops.linear(x, w)
