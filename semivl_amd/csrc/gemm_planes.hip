@@ -19,8 +19,8 @@
 // what the three bf16 MFMA fragments of lane (row, k-half) read.
 //
 // Structure: 256 threads = 4 waves of 64x64 in a 128x128 tile, K step 16 (one MFMA k-group), 24 MFMAs per wave and step
-// (768 matrix-pipe cycles) against 12 ds_read_b128; LDS rows are 48 B apart (conflict-free b128 reads), planes 32 B
-// skewed (conflict-free b128 writes of the 6 chunks of a record); two LDS buffers, global loads two steps ahead in two
+// (768 matrix-pipe cycles) against 12 ds_read_b128; LDS rows are 48 B apart (conflict-free b128 reads and, with 16-lane groups
+// writing one plane slot of 16 consecutive rows, conflict-free b128 writes); two LDS buffers, global loads two steps ahead in two
 // register sets, one barrier per step, 2 blocks per CU.  The accumulators are kept TRANSPOSED (the MFMA is issued as
 // B-fragment x A-fragment): a lane then owns 4 runs of 4 consecutive n of ONE row m, so the epilogue reads / writes 16 B
 // per lane (bias, erf-GELU, saved pre-activation, residual, GELU'(z) product) and can emit its result directly as bf16
@@ -104,7 +104,7 @@ template <int BM, int BN, int BK, int NBUF>
 __device__ __forceinline__ void gemm_planes_body(const PlanesP& p, __bf16* sm) {
   constexpr int KG = BK / 16;                           // MFMA k-groups per K step
   constexpr int LDR = BK == 16 ? 24 : 40;               // bf16 elements per LDS row (48 / 80 B: conflict-free b128 reads)
-  constexpr int PLA = BM * LDR + 16, PLB = BN * LDR + 16;   // plane strides (elements): 32 B skew between planes
+  constexpr int PLA = BM * LDR, PLB = BN * LDR;   // plane strides (elements)
   constexpr int OPA = 3 * PLA, OPB = 3 * PLB;           // one operand, three planes
   constexpr int BUF = OPA + OPB;                        // A + B of one K step
   constexpr int TM = BM / 64, TN = BN / 64;             // 32x32 MFMA tiles per wave (wave grid 2 x 2)
@@ -130,28 +130,33 @@ __device__ __forceinline__ void gemm_planes_body(const PlanesP& p, __bf16* sm) {
   const u32x4* ga[CA];
   const u32x4* gb[CB];
   int sa[CA], sb[CB];
+  // Lane -> chunk map: a group of 16 consecutive lanes takes ONE (k-group, plane, k-half) slot of 16 consecutive rows, so
+  // its ds_write_b128 hits 16 distinct 4-bank windows (rows are 48 / 80 B apart) -- chunk-linear lanes (6 chunks of a row,
+  // then the next row) collided 2-way (PMC: SQ_LDS_BANK_CONFLICT = 1/3 of the LDS-active cycles); the four groups of a
+  // wave instruction take consecutive slots, i.e. 64 contiguous bytes of each row's record on the global side.
   static_for<0, CA>([&](auto I) {
     constexpr int i = decltype(I)::value;
-    const int c = tid + 256 * i;
-    const int row = c / (6 * KG), w2 = c - row * (6 * KG), kg = w2 / 6, w = w2 - kg * 6;
+    const int g = (i * 4 + wave) * 4 + (lane >> 4);
+    const int rb = g / (6 * KG), w2 = g - rb * (6 * KG), kg = w2 / 6, w = w2 - kg * 6;
+    const int row = rb * 16 + (lane & 15);
     const long ra = min((long)(m0 + row), (long)(m_end - 1));   // rows past the edge: clamped, never stored
     ga[i] = reinterpret_cast<const u32x4*>(p.A) + ((long)kg * p.a_rows + ra) * (REC / 8) + w;
     sa[i] = (w >> 1) * PLA + row * LDR + kg * 16 + (w & 1) * 8;
   });
   static_for<0, CB>([&](auto I) {
     constexpr int i = decltype(I)::value;
-    const int c = tid + 256 * i;
-    const int row = c / (6 * KG), w2 = c - row * (6 * KG), kg = w2 / 6, w = w2 - kg * 6;
-    const long rb = min((long)(n0 + row), (long)(p.N - 1));
-    gb[i] = reinterpret_cast<const u32x4*>(p.B) + ((long)kg * p.b_rows + rb) * (REC / 8) + w;
+    const int g = (i * 4 + wave) * 4 + (lane >> 4);
+    const int rb = g / (6 * KG), w2 = g - rb * (6 * KG), kg = w2 / 6, w = w2 - kg * 6;
+    const int row = rb * 16 + (lane & 15);
+    const long rb_ = min((long)(n0 + row), (long)(p.N - 1));
+    gb[i] = reinterpret_cast<const u32x4*>(p.B) + ((long)kg * p.b_rows + rb_) * (REC / 8) + w;
     sb[i] = OPA + (w >> 1) * PLB + row * LDR + kg * 16 + (w & 1) * 8;
   });
   u32x4 xa0[CA], xb0[CB], xa1[NBUF == 2 ? CA : 1], xb1[NBUF == 2 ? CB : 1];
   auto gload = [&](u32x4 (&xa)[CA], u32x4 (&xb)[CB], int t) __attribute__((always_inline)) {
-    if (t < nk) {
-      const long oa = (long)t * ka_step, ob = (long)t * kb_step;
-      static_for<0, CA>([&](auto I) { xa[decltype(I)::value] = ga[decltype(I)::value][oa]; });
-      static_for<0, CB>([&](auto I) { xb[decltype(I)::value] = gb[decltype(I)::value][ob]; });
+    if (t < nk) {   // steps are requested in increasing order: the pointers walk along K
+      static_for<0, CA>([&](auto I) { xa[decltype(I)::value] = *ga[decltype(I)::value]; ga[decltype(I)::value] += ka_step; });
+      static_for<0, CB>([&](auto I) { xb[decltype(I)::value] = *gb[decltype(I)::value]; gb[decltype(I)::value] += kb_step; });
     }
   };
   auto sstore = [&](const u32x4 (&xa)[CA], const u32x4 (&xb)[CB], int buf) __attribute__((always_inline)) {
@@ -323,7 +328,7 @@ __device__ __forceinline__ void gemm_planes_body(const PlanesP& p, __bf16* sm) {
 
 template <int BM, int BN, int BK, int NBUF>
 constexpr int planes_lds_elems() {
-  return NBUF * (3 * (BM * (BK == 16 ? 24 : 40) + 16) + 3 * (BN * (BK == 16 ? 24 : 40) + 16));
+  return NBUF * 3 * (BM + BN) * (BK == 16 ? 24 : 40);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel_128x128(const PlanesP p) {
