@@ -1,0 +1,189 @@
+"""CPU: COMPUTE through the C-ABI without a GPU -- the CPU reference backend (oracle/cabi_cpu.c, same header, same
+argument conventions as libsemivl_hip.so) against PyTorch / the oracle on the host; the `-m gpu` half holds the HIP
+library against this second implementation of the same entry points (integer outputs bit-exact)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cabi_cpu as K
+
+
+def _case(B=2, N=21, H=24, W=20, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    logits = (torch.randn(B, N, H, W, generator=g) * 3).contiguous()
+    target = torch.randint(0, N, (B, H, W), generator=g)
+    target[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    conf = torch.rand(B, H, W, generator=g)
+    ign = torch.zeros(B, H, W, dtype=torch.int64)
+    ign[:, -5:] = 255
+    mc = torch.randint(0, N, (B, H, W), generator=g)
+    mc[torch.rand(B, H, W, generator=g) < 0.5] = 255
+    return logits, target, conf, ign, mc
+
+
+def test_cpu_backend_exports_the_header_signatures():
+    lib = K.load()
+    assert lib.svl_version() >= 200
+    assert lib.svl_fill_f32(None, 0.0, 0, None) == -1        # same error convention as the HIP library
+    buf = C.create_string_buffer(64)
+    lib.svl_last_error(buf, 64)
+    assert b"svl_fill_f32" in buf.value
+
+
+def test_cpu_softmax_max_and_cutmix():
+    lib = K.load()
+    logits, target, conf, ign, _ = _case()
+    B, N, H, W = logits.shape
+    x = logits.numpy()
+    cf, lab = np.zeros((B, H, W), np.float32), np.zeros((B, H, W), np.int64)
+    K.check(lib.svl_softmax_max_f32(K.ptr(x), B, N, H * W, K.ptr(cf), K.ptr(lab), None))
+    rc, rl = logits.softmax(1).max(1)
+    assert np.array_equal(lab, rl.numpy()) and np.abs(cf - rc.numpy()).max() < 1e-6
+    t = np.zeros((1, N, 8), np.float32)                     # ties -> lowest index
+    l2, c2 = np.zeros((1, 8), np.int64), np.zeros((1, 8), np.float32)
+    K.check(lib.svl_softmax_max_f32(K.ptr(t), 1, N, 8, K.ptr(c2), K.ptr(l2), None))
+    assert (l2 == 0).all()
+    box = (torch.rand(B, H, W) < 0.3).float().numpy()
+    a, b_ = target.numpy(), (target.numpy() + 1) % 7
+    out = np.zeros_like(a)
+    K.check(lib.svl_cutmix_i64(K.ptr(out), K.ptr(a), K.ptr(b_), K.ptr(box), B, H * W, None))
+    assert np.array_equal(out, np.where(box == 1, b_, a))
+    cnt = np.zeros(1, np.int64)
+    K.check(lib.svl_count_valid_i64(K.ptr(a), a.size, K.ptr(cnt), None))
+    assert cnt[0] == (a != 255).sum()
+
+
+@pytest.mark.parametrize("all_pixels", [False, True])
+def test_cpu_ce_fused_matches_autograd(all_pixels):
+    """Forward sums and d(loss)/d(logits) of the fused CE entry point == torch autograd of the reference expressions
+    (semivl.py:275-310: CE(reduction='none') * confidence gate + mc CE(ignore 255))."""
+    logits, target, conf, ign, mc = _case(seed=3)
+    gs = np.array([0.37, 0.11], np.float32)
+    sums, dl = K.ce_fused(logits.numpy(), target.clamp(max=20).numpy(), False, conf.numpy(), ign.numpy(), 0.6, mc.numpy(),
+                          gs, all_pixels)
+    lt = logits.clone().requires_grad_(True)
+    tgt = target.clamp(max=20)
+    ce = F.cross_entropy(lt, tgt, reduction="none")
+    valid = ign != 255
+    w = torch.ones_like(conf) if all_pixels else ((conf >= 0.6) & valid).float()
+    ce_m = F.cross_entropy(lt, mc, ignore_index=255, reduction="none")
+    (gs[0] * (w * ce).sum() + gs[1] * ce_m.sum()).backward()
+    assert abs(sums[0] - (w * ce).sum().item()) < 1e-3 * max(1.0, abs(sums[0]))
+    assert abs(sums[1] - ce_m.sum().item()) < 1e-3 * max(1.0, abs(sums[1]))
+    assert abs(sums[2] - (conf * valid).sum().item()) < 1e-3 and sums[3] == valid.sum().item()
+    assert np.abs(dl - lt.grad.numpy()).max() < 1e-5
+    # labeled branch: ignore_index 255 on the target, no confidence maps
+    sums_x, dl_x = K.ce_fused(logits.numpy(), target.numpy(), True, gscale=np.array([0.5, 0.0], np.float32))
+    lt2 = logits.clone().requires_grad_(True)
+    lx = F.cross_entropy(lt2, target, ignore_index=255, reduction="sum")
+    (0.5 * lx).backward()
+    assert abs(sums_x[0] - lx.item()) < 1e-3 * abs(lx.item()) and sums_x[3] == (target != 255).sum().item()
+    assert np.abs(dl_x - lt2.grad.numpy()).max() < 1e-5
+
+
+def test_cpu_loss_assembly_matches_oracle_formula():
+    from oracle import semivl_oracle as O
+    lib = K.load()
+    logits, target, conf, ign, mc = _case(seed=5)
+    lam = 0.07
+    numel = float(ign.numel())
+    counts = np.array([(target != 255).sum(), (ign != 255).sum(), (ign != 255).sum(), (ign != 255).sum()], np.int64)
+    gs = np.zeros((4, 2), np.float32)
+    K.check(lib.svl_semivl_gscale(K.ptr(counts), numel, lam, None, K.ptr(gs), None))
+    assert math.isclose(gs[0, 0], 0.5 / counts[0], rel_tol=1e-6) and math.isclose(gs[3, 1], 0.5 * lam / numel, rel_tol=1e-6)
+    sums = np.zeros((4, 4), np.float64)
+    sums[0], _ = K.ce_fused(logits.numpy(), target.numpy(), True)
+    tg = target.clamp(max=20)
+    for i in (1, 2, 3):
+        sums[i], _ = K.ce_fused(logits.numpy(), tg.numpy(), False, conf.numpy(), ign.numpy(), 0.6, mc.numpy())
+    out = np.zeros(8, np.float32)
+    K.check(lib.svl_semivl_loss(K.ptr(sums), numel, lam, None, K.ptr(out), None))
+    ce = F.cross_entropy(logits, tg, reduction="none")
+    lu = O.confidence_weighted_loss(ce, conf, ign, "pixelwise", 0.6)
+    lmc = O.compute_mc_loss(logits, mc, ign)
+    lx = F.cross_entropy(logits, target, ignore_index=255)
+    ref = (lx + lu * 0.25 + lu * 0.25 + lu * 0.5) / 2.0 + lmc * 0.25 * lam + lmc * 0.25 * lam + lmc * 0.5 * lam
+    assert abs(out[0] - ref.item()) < 1e-5 and abs(out[1] - lx.item()) < 1e-5 and abs(out[5] - lmc.item()) < 1e-6
+    # pixelavg factor (train_utils.py:43-46)
+    f = np.zeros(1, np.float64)
+    ws = np.zeros(int(lib.svl_conf_avg_ws_doubles(2)), np.float64)
+    K.check(lib.svl_conf_avg_factor(K.ptr(conf.numpy()), K.ptr(ign.numpy()), 2, ign[0].numel(), K.ptr(f), K.ptr(ws), None))
+    v = (ign != 255)
+    assert abs(f[0] - ((conf * v).sum((1, 2)) / v.sum((1, 2))).sum().item()) < 1e-6
+
+
+def test_cpu_maskclip_labels_iou_hist_adamw():
+    from oracle import eval_oracle as E
+    lib = K.load()
+    g = torch.Generator().manual_seed(9)
+    B, NC, h, S = 2, 12, 8, 64
+    emb = F.normalize(torch.randn(B, 16, h, h, generator=g), dim=1)
+    text = F.normalize(torch.randn(NC, 16, generator=g), dim=1)
+    dense = F.conv2d(emb, text[:, :, None, None]).contiguous()
+    offs = np.array([0, 5, 7, 12], np.int32)
+    agg = np.zeros((B, 3, h, h), np.float32)
+    K.check(lib.svl_concept_max_f32(K.ptr(dense.numpy()), B, NC, h * h, K.ptr(offs), 3, K.ptr(agg), None))
+    ref_agg = torch.stack([dense[:, offs[i]:offs[i + 1]].max(1).values for i in range(3)], 1)
+    assert np.array_equal(agg, ref_agg.numpy())
+    prob = (100.0 * F.interpolate(ref_agg, size=(S, S), mode="bilinear", align_corners=False)).softmax(1)
+    cert, pred = prob.max(1)
+    ref = pred.clone()
+    ref[cert < 0.9] = 255
+    out = np.zeros((B, S, S), np.int64)
+    K.check(lib.svl_maskclip_labels(K.ptr(agg), B, 3, h, h, S, S, 100.0, 0.9, None, K.ptr(out), None))
+    t2 = prob.topk(2, 1).values
+    near = (((cert - 0.9).abs() < 1e-5) | ((t2[:, 0] - t2[:, 1]) < 1e-5)).numpy()
+    assert not ((out != ref.numpy()) & ~near).any()
+    # intersectionAndUnion
+    pr, tg = torch.randint(0, 5, (3000,), generator=g), torch.randint(0, 5, (3000,), generator=g)
+    tg[::7] = 255
+    hist = np.zeros(15, np.int64)
+    K.check(lib.svl_iou_hist_i64(K.ptr(pr.numpy()), K.ptr(tg.numpy()), 3000, 5, 255, K.ptr(hist), None))
+    i, u, t = E.intersection_and_union(pr.numpy(), tg.numpy(), 5, 255)
+    assert np.array_equal(hist[:5], i) and np.array_equal(hist[5:10] + hist[10:] - hist[:5], u) and np.array_equal(hist[10:], t)
+    # AdamW on a two-segment arena
+    n = 500
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([dict(params=[ref_p], lr=1e-3, weight_decay=0.01)])
+    p, m, v = p0.numpy().copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    off, lr, wd = np.array([0, 200, n], np.int64), np.full(2, 1e-3, np.float32), np.full(2, 0.01, np.float32)
+    for step in (1, 2, 3):
+        gr = torch.randn(n, generator=g)
+        ref_p.grad = gr.clone()
+        opt.step()
+        K.check(lib.svl_adamw_step(K.ptr(p), K.ptr(gr.numpy()), K.ptr(m), K.ptr(v), K.ptr(off), K.ptr(lr), K.ptr(wd), 2, n,
+                                   0.9, 0.999, 1e-8, step, 1.0, None, 0.0, None))
+        assert np.abs(p - ref_p.detach().numpy()).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_library_agrees_with_cpu_backend_on_the_same_inputs(dev):
+    """Two implementations of the same entry points (HIP kernels vs plain C): integer outputs identical, fp32 outputs to
+    rounding."""
+    from semivl_amd import ops
+    lib = K.load()
+    logits, target, conf, ign, mc = _case(B=2, N=21, H=64, W=48, seed=11)
+    B, N, H, W = logits.shape
+    cf, lab = np.zeros((B, H, W), np.float32), np.zeros((B, H, W), np.int64)
+    K.check(lib.svl_softmax_max_f32(K.ptr(logits.numpy()), B, N, H * W, K.ptr(cf), K.ptr(lab), None))
+    gcf, glab = ops.softmax_max(logits.to(dev))
+    assert np.array_equal(glab.cpu().numpy(), lab) and np.abs(gcf.cpu().numpy() - cf).max() < 1e-6
+    gs = torch.tensor([0.37, 0.11])
+    tg = target.clamp(max=20)
+    sums, dl = K.ce_fused(logits.numpy(), tg.numpy(), False, conf.numpy(), ign.numpy(), 0.6, mc.numpy(), gs.numpy())
+    gdl = torch.empty_like(logits, device=dev)
+    gsums = ops.ce_fused(logits.to(dev), tg.to(dev), False, conf=conf.to(dev), ign=ign.to(dev), conf_thresh=0.6,
+                         mc=mc.to(dev), dlogits=gdl, gscale=gs.to(dev))
+    assert np.abs(gsums.cpu().numpy() - sums).max() < 1e-3 * max(1.0, np.abs(sums).max()) and gsums[3].item() == sums[3]
+    assert np.abs(gdl.cpu().numpy() - dl).max() < 1e-6
+    pr, tt = torch.randint(0, 21, (B, H, W)), target
+    hist = np.zeros(63, np.int64)
+    K.check(lib.svl_iou_hist_i64(K.ptr(pr.numpy()), K.ptr(tt.numpy()), pr.numel(), 21, 255, K.ptr(hist), None))
+    gh = ops.zeros(63, dtype=torch.int64, device=dev)
+    ops.iou_hist(pr.to(dev), tt.to(dev), 21, 255, gh)
+    assert np.array_equal(gh.cpu().numpy(), hist)
