@@ -130,7 +130,7 @@ def cpu_baseline(crop, nclass, warm, timed):
 
     cores = physical_cores()
     runs, total = {}, 0.0
-    for threads, (w_, t_) in ((min(32, cores), (warm, timed)), (cores, (1, 1))):
+    for threads, (w_, t_) in ((min(32, cores), (warm, timed)), (cores, (0, 1))):   # all-cores run: one (warm-cache) step
         if threads in runs:
             continue
         med, spent = run(threads, w_, t_)

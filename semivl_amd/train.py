@@ -8,6 +8,8 @@ Mirrors (same names / argument meaning):
   semivl.py:139-140            DistributedDataParallel -> GradAllReducer (RCCL all-reduce of the flat grad arena)
 """
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -54,6 +56,8 @@ def _cat2(a, b):
     return out
 
 
+_SIDE = {}     # device -> second stream for the gradient-free passes of the step
+
 LOSS_NAMES = ("loss", "loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "loss_mc_s2", "loss_mc_fp")
 
 
@@ -87,9 +91,20 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     if getattr(model, "decode_head", None) is not None:
         model.decode_head._bwd_ranges = None
     # pseudo labels + MaskCLIP guidance (model.eval(): the side encoder's BatchNorm uses its running statistics here,
-    # semivl.py:228-244; nothing else on the path depends on the mode)
+    # semivl.py:228-244; nothing else on the path depends on the mode).  Both passes are gradient-free and independent of
+    # the two student forwards below: they are enqueued on a second stream (event-forked from / joined back into the
+    # caller's stream), so their kernels fill the partial last rounds of the student's grids instead of queueing behind
+    # them.  Not with a conv_encoder: its eval-mode BatchNorm reads the running statistics the train-mode pass updates.
+    side = None
+    if img_x.is_cuda and cfg.get("overlap_streams", True) and getattr(model, "conv_encoder", None) is None:
+        side = _SIDE.get(dev)
+        if side is None:
+            side = _SIDE[dev] = torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev) if img_x.is_cuda else None
     model.eval()
-    with torch.no_grad():
+    if side is not None:
+        side.wait_stream(main)
+    with torch.no_grad(), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
         pred_w_other = model(b["img_w_other"])
         conf_w_other, mask_w_other = ops.softmax_max(pred_w_other)
         if not return_aux:
@@ -122,6 +137,10 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     pred_w, pred_x, pred_w_fp = preds4[:B], preds4[B:2 * B], preds4[2 * B:]
     pred_s1, pred_s2 = preds_s[:B], preds_s[B:]
     conf_w, mask_w = ops.softmax_max(pred_w.detach())
+    if side is not None:        # join: the label maps of the side stream are consumed from here on
+        main.wait_stream(side)
+        for t_ in (conf_w_other, mask_w_other, mclip_all):
+            t_.record_stream(main)
     # CutMix labels
     mw1, mw2 = cutmix_mask(mask_w, mask_w_other, mix1), cutmix_mask(mask_w, mask_w_other, mix2)
     cw1, cw2 = cutmix_mask(conf_w, conf_w_other, mix1), cutmix_mask(conf_w, conf_w_other, mix2)

@@ -146,8 +146,9 @@ def test_hip_evaluate_through_vlm_matches_reference_fixture(dev, mode):
     hip.load_state_dict(fixture_state(z, c, hip), strict=True)
     hip.to(dev).eval()
     cfg = dict(crop_size=c["S"], stride=c["stride"], nclass=21)
-    with torch.no_grad():
-        pred, final = predict(hip, img.to(dev), mask.to(dev), mode, cfg, return_logits=True)
+    with torch.no_grad():   # one image at a time, exactly as evaluate() feeds the model (rounding depends on the batch shape)
+        outs = [predict(hip, img[i:i + 1].to(dev), mask[i:i + 1].to(dev), mode, cfg, return_logits=True) for i in range(2)]
+    pred, final = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     ref = z[f"final_s4/{mode}"]
     err = np.abs(final[:, :, ::4, ::4].cpu().numpy() - ref).max()
     assert err < (1e-3 if mode != "sliding_window" else 1e-5), err      # logits 1e-3; probabilities (sum of <= 4 softmaxes)
