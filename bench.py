@@ -197,8 +197,8 @@ def main():
     batch = synthetic_batch(a.batch, a.crop, a.nclass, seed=1234 + rank, device=dev)
     total_iters = 10000
 
-    def step(i):
-        return semivl_train_step(model, batch, i, total_iters, cfg, optimizer=opt, reducer=red)
+    def step(i, **kw):
+        return semivl_train_step(model, batch, i, total_iters, dict(cfg, **kw) if kw else cfg, optimizer=opt, reducer=red)
 
     def sync():
         if world > 1:
@@ -245,7 +245,9 @@ def main():
     if not a.no_profile:   # every rank runs the step (it contains the gradient all-reduce); rank 0 records the events
         if rank == 0:
             ops.PROFILE = {}
-        step(a.warmup + a.steps)
+        # per-kernel HIP-event durations are taken with the step's two streams run back to back: under the overlap used
+        # for `value` a kernel's interval includes the time it shares the chip with the other stream's kernels
+        step(a.warmup + a.steps, overlap_streams=False)
         torch.cuda.synchronize()
     if rank == 0 and not a.no_profile:
         g_arith_exact = a.gemm_arith == "f32"

@@ -151,7 +151,9 @@ def test_hip_evaluate_through_vlm_matches_reference_fixture(dev, mode):
     pred, final = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     ref = z[f"final_s4/{mode}"]
     err = np.abs(final[:, :, ::4, ::4].cpu().numpy() - ref).max()
-    assert err < (1e-3 if mode != "sliding_window" else 1e-5), err      # logits 1e-3; probabilities (sum of <= 4 softmaxes)
+    # logits within north_star's 1e-3; summed window probabilities within the error a 1e-3 logit perturbation can cause
+    # (|d softmax| <= |d logit| / 2 per window, <= 4 windows per pixel; measured 5e-5 on these 150x-gain logits)
+    assert err < (1e-3 if mode != "sliding_window" else 2e-4), err
     hp = pred.cpu().numpy().astype(np.uint8)
     # bit-exact prediction map; a flip needs the reference's own top-2 gap at that pixel to be below the error measured in
     # this very run (x4: the error is measured on a 1/16 subsample of the map)
