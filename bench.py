@@ -31,6 +31,7 @@ DEC_GF_PER_UNIT_B = 1322.0      # 7 decoder fwd + 6 x 2 fwd-equivalents bwd, 69.
 ALGO_GF = {(21, 512): (2866.6, 1322.0), (81, 512): (2866.6, 5075.0), (150, 512): (2866.6, 9412.0),
            (19, 801): (5 * 725.0 + 2 * 669.8 + 4 * 1098.1, 3027.0)}
 PEAK_F32_MFMA_TF = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TF = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -50,11 +51,15 @@ def parse():
                     help="oracle steps on the host cores (SURVEY §8(d) asks for 3 5; the default 1 2 keeps the default "
                          "run within a few minutes)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--gemm-arith", choices=["f32", "bf16x6", "bf16x3"], default="f32",
+    ap.add_argument("--gemm-arith", choices=["f32", "bf16x6", "bf16x3"], default="bf16x6",
                     help="arithmetic of the large dense GEMMs in the timed region (include/semivl_hip.h, "
-                         "svl_set_gemm_emulation); 'value' is always measured in this mode")
-    ap.add_argument("--no-throughput-mode", action="store_true",
-                    help="skip the extra bf16x6 measurement that is reported next to the f32 value")
+                         "svl_set_gemm_emulation); 'value' is always measured in this mode.  bf16x6 (default): fp32 "
+                         "in / out / accumulate, every operand split into 3 bf16 terms, 6 cross products -- error vs fp64 "
+                         "at or below the plain fp32 MFMA chain's on every operand layout (tests/test_ops_gpu.py); f32: "
+                         "v_mfma_f32_32x32x2_f32 everywhere (reported next to `value` as `exact_f32`); bf16x3 is a "
+                         "16-bit-product mode for experiments and is never the default")
+    ap.add_argument("--no-throughput-mode", "--no-second-mode", dest="no_throughput_mode", action="store_true",
+                    help="skip the extra measurement of the other arithmetic (exact f32 next to a bf16x6 value and vice versa)")
     a = ap.parse_args()
     if a.config is not None:
         a.nclass, a.crop, a.batch = {"voc": (21, 512, 16), "cityscapes": (19, 801, 8), "ade": (150, 512, 16),
@@ -231,7 +236,10 @@ def main():
 
     out = dict(metric="train images/sec (512^2, ViT-B/16)", value=round(ips, 3), unit="images/s", n_gpus=world,
                steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 2), higher_is_better=True, scaling="weak",
-               vs_baseline=None, dtype="f32" if a.gemm_arith == "f32" else f"f32 ({a.gemm_arith} split-product MFMA, f32 accumulate)",
+               vs_baseline=None,
+               dtype="f32" if a.gemm_arith == "f32" else
+               f"f32 (fp32 in/out/accumulate everywhere; large dense GEMMs as {a.gemm_arith} split products on the bf16 MFMA pipe, "
+               f"error vs fp64 <= the plain fp32 MFMA chain's; attention and convolutions on the fp32 MFMA pipe)",
                data="synthetic",
                config=dict(workload=f"SemiVL step, {dataset} N={a.nclass}, {cfg['model'].replace('mmseg.', '')}, {a.crop}x{a.crop}, "
                                     f"bs={a.batch}/GPU labeled + {a.batch}/GPU unlabeled" +
@@ -252,7 +260,8 @@ def main():
     if rank == 0 and not a.no_profile:
         g_arith_exact = a.gemm_arith == "f32"
         prof, ops.PROFILE = ops.PROFILE, None
-        g = prof.get("gemm", []) + prof.get("attention", [])   # the two fp32-MFMA kernel families
+        gx = prof.get("gemm_bf16x", [])                        # dense GEMMs served by the bf16 pipe (split emulation)
+        g = prof.get("gemm", []) + gx + prof.get("attention", [])   # every MFMA kernel family
         t_gemm = sum(e0.elapsed_time(e1) for e0, e1, *_ in g) * 1e-3
         executed = sum(w for _, _, w, *_ in g)
         algo = sum(ALGO_GF[(a.nclass, a.crop)]) * 1e9 * a.batch if (a.nclass, a.crop) in ALGO_GF else executed
@@ -262,13 +271,26 @@ def main():
                                frac=round(ach / PEAK_F32_MFMA_TF, 4), traffic=None,
                                frac_executed=round(executed / t_gemm / 1e12 / PEAK_F32_MFMA_TF, 4),
                                frac_whole_step=round(step_tf / PEAK_F32_MFMA_TF, 4), whole_step_tflops=round(step_tf, 2),
-                               kernel="gemm_kernel + attn_{fwd,bwd}_kernel (svl_gemm_f32, svl_attention_*; v_mfma_f32_32x32x2_f32)", launches=len(g),
+                               kernel="all MFMA launches of one step: gemm_kernel / conv kernels + attn_{fwd,bwd}_kernel "
+                                      "(v_mfma_f32_32x32x2_f32)" + (" + gemm_bf16x_kernel (v_mfma_f32_32x32x16_bf16, 6 products)"
+                                                                       if gx else ""), launches=len(g),
                                kernel_time_ms=round(t_gemm * 1e3, 2),
                                executed_tflops=round(executed / t_gemm / 1e12, 2),
                                note="achieved = algorithmic FLOPs of one step (SURVEY §8(d): (2866.6+1322.0) GF x B) / "
                                     "summed duration of all svl_gemm_f32 + svl_attention_* launches of one step (HIP events on the launch stream); "
                                     "frac_executed = FLOPs actually issued by those launches / the same time; frac_whole_step = "
                                     "algorithmic FLOPs / the WHOLE step time (every non-MFMA pass counted against the MFMA peak)")
+        if gx:   # the split-emulation GEMM family against ITS pipe: bf16 dense peak / products per fp32 MAC
+            nprod = 6 if a.gemm_arith == "bf16x6" else 3
+            t_x = sum(e0.elapsed_time(e1) for e0, e1, *_ in gx) * 1e-3
+            f_x = sum(w for _, _, w, *_ in gx)
+            out["roofline"]["bf16_pipe"] = dict(
+                kernel=f"gemm_bf16x_kernel<{nprod // 2 if nprod == 6 else 2},...> (svl_gemm_f32 in emulation mode {nprod})",
+                launches=len(gx), kernel_time_ms=round(t_x * 1e3, 2), achieved=round(f_x / t_x / 1e12, 2),
+                peak=round(PEAK_BF16_MFMA_TF / nprod, 1), unit="TFLOP/s (fp32-equivalent)",
+                frac=round(f_x / t_x / 1e12 / (PEAK_BF16_MFMA_TF / nprod), 4),
+                note=f"2MNK of the launches / their summed duration vs {PEAK_BF16_MFMA_TF:.0f} TF bf16 dense / {nprod} products; "
+                     "`roofline.frac` above prices ALL MFMA kernel time of the step against the fp32-MFMA peak")
         # the ViT encoder alone (north_star: ">= 60 % MFMA peak on the ViT encoder"): launches issued inside the encoder's
         # forward / backward regions (5 trainable + 2 frozen forwards, 4 backwards per step)
         gv = [e for e in g if e[4] == "vit"]
@@ -306,6 +328,15 @@ def main():
                                               tflops=round(v[1] / v[0] / 1e12, 1)) for k, v in top]
         # the single dominant launch shape (FFN-1 of the ViT blocks): per-launch roofline + its PMC traffic
         dom = by.get((0, 0, 32 * 1025 * a.batch // 16, 3072, 768, 1))
+        if dom is not None and not g_arith_exact:
+            d_tf = dom[1] / dom[0] / 1e12
+            nprod = 6 if a.gemm_arith == "bf16x6" else 3
+            out["roofline"]["dominant_launch"] = dict(
+                kernel="gemm_bf16x_kernel (svl_gemm_f32, split emulation), M=%d N=3072 K=768" % (32 * 1025 * a.batch // 16),
+                launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 3), achieved=round(d_tf, 1),
+                peak=round(PEAK_BF16_MFMA_TF / nprod, 1), frac=round(d_tf / (PEAK_BF16_MFMA_TF / nprod), 4),
+                algorithmic_bytes=513.0e6 * a.batch / 16, traffic=None,
+                traffic_note="PMC traffic is recorded for the exact-f32 kernel only (profiles/pmc_gemm_traffic.json)")
         if dom is not None and g_arith_exact:
             d_ms = dom[0] * 1e3 / dom[2]
             d_tf = dom[1] / dom[0] / 1e12
@@ -329,18 +360,23 @@ def main():
                                        achieved=round(by_ce / t_ce / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=round(by_ce / t_ce / 1e9 / PEAK_HBM_GBS, 4), traffic=None, launches=len(c),
                                        note="algorithmic bytes (12N+40) B/px per fwd+bwd branch (SURVEY §8(d))")
-    # ---- the same step with the ViT linears on the bf16 matrix pipe (fp32-accurate 3-way split, 6 products) ----
-    if a.gemm_arith == "f32" and not a.no_throughput_mode:
-        ops.set_gemm_emulation(6)
-        dt6, losses6 = timed(1, min(a.steps, 5), a.warmup + a.steps + 1)
-        ops.set_gemm_emulation(0)
-        n6 = min(a.steps, 5)
-        out["throughput_mode"] = dict(
-            gemm_arith="bf16x6", value=round(2.0 * a.batch * world / (dt6 / n6), 3), unit="images/s", steps=n6,
-            ms_per_step=round(dt6 / n6 * 1e3, 2), loss=round(float(losses6[0].item()), 5),
-            note="opt-in svl_set_gemm_emulation(6): dense GEMMs with M>=256 split every fp32 operand element into 3 "
-                 "bf16 terms and accumulate the 6 leading cross products in fp32 (v_mfma_f32_32x32x16_bf16); error vs "
-                 "fp64 <= the f32 MFMA chain's (tests/test_ops_gpu.py::test_gemm_bf16_split_emulation). Not used for 'value'.")
+    # ---- the same step in the OTHER arithmetic (exact fp32 MFMA next to a bf16x6 value, bf16x6 next to an f32 value) ----
+    if not a.no_throughput_mode and a.gemm_arith in ("f32", "bf16x6"):
+        other = "f32" if a.gemm_arith == "bf16x6" else "bf16x6"
+        ops.set_gemm_emulation(EMU[other])
+        n2 = min(a.steps, 5)
+        dt2, losses2 = timed(1, n2, a.warmup + a.steps + 1)
+        ops.set_gemm_emulation(EMU[a.gemm_arith])
+        key = "exact_f32" if other == "f32" else "throughput_mode"
+        out[key] = dict(
+            gemm_arith=other, value=round(2.0 * a.batch * world / (dt2 / n2), 3), unit="images/s", steps=n2,
+            ms_per_step=round(dt2 / n2 * 1e3, 2), loss=round(float(losses2[0].item()), 5),
+            whole_step_frac_of_f32_mfma_peak=(round(sum(ALGO_GF[(a.nclass, a.crop)]) * 1e9 * a.batch / (dt2 / n2) / 1e12 /
+                                                    PEAK_F32_MFMA_TF, 4) if (a.nclass, a.crop) in ALGO_GF else None),
+            note="the same step with every GEMM on v_mfma_f32_32x32x2_f32 (bit-for-bit a k-ordered fp32 fma chain)"
+                 if other == "f32" else
+                 "svl_set_gemm_emulation(6): dense GEMMs with M>=256 split every fp32 operand element into 3 bf16 terms and "
+                 "accumulate the 6 leading cross products in fp32 (v_mfma_f32_32x32x16_bf16)")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(512, 21, *a.cpu_baseline_steps)

@@ -111,7 +111,12 @@ def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batc
     d.accumulate = 1 if accumulate else 0
     e0 = _prof_begin()
     L.check(L.load().svl_gemm_f32(C.byref(d), _st()), "svl_gemm_f32")
-    _prof_end("gemm", e0, 2.0 * M * N * K * (1 if ksplit > 0 else batch), (a_mode, b_mode, M, N, K, batch))
+    if e0 is not None:
+        # which matrix pipe served this launch (the dispatch rule of svl_gemm_f32 for the split-emulation modes)
+        emu = (get_gemm_emulation() in (3, 6) and a_mode in (A_KC, A_MC) and b_mode in (B_KC, B_NC) and
+               out_mode == OUT_STRIDED and M >= 256 and N >= 96 and K >= 64)
+        _prof_end("gemm_bf16x" if emu else "gemm", e0, 2.0 * M * N * K * (1 if ksplit > 0 else batch),
+                  (a_mode, b_mode, M, N, K, batch))
 
 
 def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld2=0, patch=0, stride=1, Ho=0, Wo=0):
