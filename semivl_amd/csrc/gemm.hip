@@ -990,13 +990,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // (the k-contiguous row order 0,2,4,6,1,3,5,7 per 8 rows keeps the 8 B LDS stores of 16 consecutive lanes on
   //  disjoint banks with the 48 B row stride)
   const int kc_row = ((tid >> 2) & ~7) | (((tid >> 2) & 3) << 1) | ((tid >> 4) & 1);
-  const int a_row = A_RM ? (tid & 127) : kc_row, a_ko = A_RM ? 8 * (tid >> 7) : 4 * (tid & 3);
+  constexpr bool A_CV = A_RM == 2;   // A operand = NHWC implicit im2col (k-contiguous pieces of 4 inside one tap)
+  constexpr int A_ST = A_RM == 1 ? 1 : 0;   // LDS store shape of the A pieces
+  const int a_row = A_RM == 1 ? (tid & 127) : kc_row, a_ko = A_RM == 1 ? 8 * (tid >> 7) : 4 * (tid & 3);
   const int b_row = B_RM ? (tid & 127) : kc_row, b_ko = B_RM ? 8 * (tid >> 7) : 4 * (tid & 3);
   // rows past the edge are clamped: they only feed accumulators whose outputs are never stored
   const long a_r = min(m0 + a_row, p.M - 1), b_r = min(n0 + b_row, p.N - 1);
   const long a_r2 = min(m0 + a_row + 64, p.M - 1), b_r2 = min(n0 + b_row + 64, p.N - 1);
-  const long a_ks = A_RM ? (long)p.A.ld : 1, b_ks = B_RM ? (long)p.B.ld : 1;
-  const float* pa = A + (A_RM ? a_r : a_r * p.A.ld) + (long)(kbeg + a_ko) * a_ks;
+  const long a_ks = A_RM == 1 ? (long)p.A.ld : 1, b_ks = B_RM ? (long)p.B.ld : 1;
+  const float* pa = A_CV ? A : A + (A_RM == 1 ? a_r : a_r * p.A.ld) + (long)(kbeg + a_ko) * a_ks;
+  // conv operand: the two pixels of this thread's pieces and the running (tap, channel) position of its 4 k's; every A
+  // load below is "the next K step" (the loads are requested in increasing step order exactly once)
+  ConvSt cs0, cs1;
+  if constexpr (A_CV) {
+    conv_split_pixel(p.cv, (int)a_r, cs0);
+    conv_split_pixel(p.cv, (int)a_r2, cs1);
+    conv_split_k(p.cv, kbeg + a_ko, cs0);
+    cs1.ti = cs0.ti; cs1.tj = cs0.tj; cs1.ci = cs0.ci;
+  }
+  auto aload_conv = [&](EmuRaw& x) __attribute__((always_inline)) {
+    const float4 lo = conv_load_st(p.A, p.cv, cs0), hi = conv_load_st(p.A, p.cv, cs1);
+    x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = lo.z; x.v[3] = lo.w;
+    x.v[4] = hi.x; x.v[5] = hi.y; x.v[6] = hi.z; x.v[7] = hi.w;
+    conv_advance_k<BKE>(p.cv, cs0);
+    cs1.ti = cs0.ti; cs1.tj = cs0.tj; cs1.ci = cs0.ci;
+  };
   const float* pb = B + (B_RM ? b_r : b_r * p.B.ld) + (long)(kbeg + b_ko) * b_ks;
   const long a_d2 = A_RM ? 0 : (a_r2 - a_r) * p.A.ld, b_d2 = B_RM ? 0 : (b_r2 - b_r) * p.B.ld;  // second-row offsets
   const bool a_vec = p.A.vec, b_vec = p.B.vec;
@@ -1017,18 +1035,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (t < nfull) {
       const float* qa = pa + (long)t * BKE * a_ks;
       const float* qb = pb + (long)t * BKE * b_ks;
-      emu_gload<A_RM>(xa, qa, qa + a_d2, a_ks, a_vec);
+      if constexpr (A_CV) aload_conv(xa);            // (K % 16 == 0 for this mode: every step is a full one)
+      else emu_gload<A_RM>(xa, qa, qa + a_d2, a_ks, a_vec);
       emu_gload<B_RM>(xb, qb, qb + b_d2, b_ks, b_vec);
     } else if (t < nk) {
       const int rem = klen - t * BKE;
       const float* qa = pa + (long)t * BKE * a_ks;
       const float* qb = pb + (long)t * BKE * b_ks;
-      emu_gload_tail<A_RM>(xa, qa, qa + a_d2, a_ks, rem - a_ko);
+      emu_gload_tail<A_ST>(xa, qa, qa + a_d2, a_ks, rem - a_ko);
       emu_gload_tail<B_RM>(xb, qb, qb + b_d2, b_ks, rem - b_ko);
     }
   };
   auto sstore = [&](const EmuRaw& xa, const EmuRaw& xb, int buf) {
-    emu_split_store<NS, A_RM>(sm + buf * BUF + a_st, APL, 64 * LDR, xa);
+    emu_split_store<NS, A_ST>(sm + buf * BUF + a_st, APL, 64 * LDR, xa);
     emu_split_store<NS, B_RM>(sm + buf * BUF + b_st, BPL, 64 * LDR, xb);
   };
   const int fa = (wr * WTM + l31) * LDR + 8 * hi, fb = NS * APL + (wc * WTN + l31) * LDR + 8 * hi;
@@ -1075,7 +1094,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // inside the wave; the LDS stores of an operand follow the slice that completes it.
     constexpr int NT = NS * (NS + 1) / 2, NMF = 4 * NT, NSL = 16 * NS / 2;  // products, MFMAs, (pair, plane) slices
     auto fast_step = [&](EmuRaw& la, EmuRaw& lb, EmuRaw& ca, EmuRaw& cb, int buf) {
-      emu_gload<A_RM>(la, qa, qa + a_d2, a_ks, true);
+      if constexpr (A_CV) aload_conv(la);
+      else emu_gload<A_RM>(la, qa, qa + a_d2, a_ks, true);
       emu_gload<B_RM>(lb, qb, qb + b_d2, b_ks, true);
       qa += a_step;
       qb += b_step;
@@ -1118,7 +1138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
           if constexpr (q == 3 && pl == NS - 1) {          // operand complete: store its planes
             __bf16* dst = D + (isb ? b_st : a_st);
-            constexpr int rm = isb ? B_RM : A_RM;
+            constexpr int rm = isb ? B_RM : A_ST;
             constexpr int pstride = isb ? BPL : APL;
 #pragma unroll
             for (int p2 = 0; p2 < NS; ++p2) {
@@ -1194,7 +1214,8 @@ int launch_emu(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
   q.band_n = svl_band_n(q.tiles_n);
   const long tiles = (long)((p.M + 127) / 128) * q.tiles_n;
   dim3 grid((unsigned)tiles, 1, (unsigned)batch);
-  if (a_rm == 0 && b_rm == 0) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 0>), grid, dim3(256), 0, st, q);
+  if (a_rm == 2) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 2, 0>), grid, dim3(256), 0, st, q);
+  else if (a_rm == 0 && b_rm == 0) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 0>), grid, dim3(256), 0, st, q);
   else if (a_rm == 0 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 1>), grid, dim3(256), 0, st, q);
   else if (a_rm == 1 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 1>), grid, dim3(256), 0, st, q);
   else hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 0>), grid, dim3(256), 0, st, q);
@@ -1359,7 +1380,15 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     emu_mode = env_int("SVL_GEMM_EMU", 0);
     g_emu_mode.store(emu_mode, std::memory_order_relaxed);
   }
+  static const int emu_conv = getenv("SVL_GEMM_EMU_NO_CONV") ? 0 : 1;
   auto launch = [&](const GemmP& q) -> int {
+    // implicit-GEMM convolutions (NHWC im2col on the fly, forward and mirrored-tap input gradient) join the split
+    // emulation when every 4-k piece stays inside one tap (channels % 4) and K is a whole number of 16-deep steps
+    if ((emu_mode == 3 || emu_mode == 6) && am == SVL_A_CONV && bm == SVL_B_KCONTIG && d->out_mode == SVL_OUT_STRIDED &&
+        d->batch == 1 && d->ksplit == 0 && q.M >= 256 && q.N >= 96 && q.K >= 64 && (q.K % 16) == 0 && q.A.vec && q.B.vec &&
+        emu_conv) {
+      return emu_mode == 6 ? launch_emu<3>(q, 2, 0, 1, st) : launch_emu<2>(q, 2, 0, 1, st);
+    }
     if ((emu_mode == 3 || emu_mode == 6) && (am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) &&
         (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && q.M >= 256 && q.N >= 96 &&
         q.K >= 64) {

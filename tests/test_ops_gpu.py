@@ -316,6 +316,42 @@ def test_conv_fwd_dgrad_wgrad(dev, Ci, Co, k, dil, H):
     close(ops.unpack_conv_wgrad(dwf, Co, Ci, k, k), gw, atol=3e-5 * math.sqrt(n * H * W), what="conv wgrad")
 
 
+@pytest.mark.parametrize("Ci,Co,k,dil,H,n", [(128, 128, 3, 1, 16, 3), (128, 128, 3, 6, 32, 2), (128, 128, 3, 18, 32, 2),
+                                             (64, 96, 3, 1, 20, 2), (128, 160, 3, 12, 24, 1)])
+def test_conv_split_emulation(dev, emu_mode, Ci, Co, k, dil, H, n):
+    """Implicit-GEMM convolutions (forward and mirrored-tap input gradient, dilated, halo taps, ragged row tiles) in the
+    bf16x6 split emulation: error vs fp64 at or below the fp32 MFMA chain's; bf16x3 within 2^-16-ish."""
+    from semivl_amd import ops
+    W = H
+    pad = dil * (k - 1) // 2
+    x, w = rnd(n, Ci, H, W, dev=dev, seed=16), rnd(Co, Ci, k, k, dev=dev, scale=0.1)
+    dy = rnd(n, Co, H, W, dev=dev)
+    ref_y = F.conv2d(x.double(), w.double(), padding=pad, dilation=dil)
+    xd = x.double().requires_grad_(True)
+    (ref_dx,) = torch.autograd.grad(F.conv2d(xd, w.double(), padding=pad, dilation=dil), xd, dy.double())
+    wf, wd = ops.pack_conv_w(w)
+    xs, dys = nhwc(x), nhwc(dy)
+    err = {}
+    for mode in (0, 6, 3):
+        emu_mode(mode)
+        y = ops.conv_fwd(xs, Ci, n, H, W, Ci, wf, Co, k, k, dil, pad)
+        dx = ops.conv_dgrad(dys, Co, n, H, W, Co, wd, Ci, k, k, dil, pad)
+        err[mode] = (_relerr(nchw(y, n, H, W), ref_y), _relerr(nchw(dx, n, H, W), ref_dx))
+    for i in (0, 1):
+        assert err[6][i] <= 1.5 * err[0][i] + 1e-8, err
+        assert err[3][i] <= 2e-5, err
+    emu_mode(6)
+    b = rnd(Co, dev=dev)
+    r = rnd(n * H * W, Co, dev=dev)
+    y = ops.conv_fwd(xs, Ci, n, H, W, Ci, wf, Co, k, k, dil, pad, bias=b, act=ops.ACT_RELU)
+    close(nchw(y, n, H, W), F.relu(F.conv2d(x, w, b, padding=pad, dilation=dil)), atol=2e-5 * math.sqrt(Ci * k * k) + 1e-5,
+          what="bias+relu")
+    acc = r.clone()
+    ops.conv_dgrad(dys, Co, n, H, W, Co, wd, Ci, k, k, dil, pad, out=acc, ldo=Ci, accumulate=True) if Ci == Co else None
+    assert torch.equal(ops.conv_fwd(xs, Ci, n, H, W, Ci, wf, Co, k, k, dil, pad),
+                       ops.conv_fwd(xs, Ci, n, H, W, Ci, wf, Co, k, k, dil, pad)), "deterministic"
+
+
 @pytest.mark.parametrize("C,H", [(32, 40), (16, 24)])
 def test_conv_cout1_thin_kernels(dev, C, H):
     from semivl_amd import ops
