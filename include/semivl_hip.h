@@ -323,6 +323,9 @@ int svl_eltwise_f32(int mode, const float* a, const float* b, float* out, int64_
 int svl_chanmask_f32(const float* x, const float* mask, float scale, int64_t rows, int rows_per_img, int C,
                      float* out, svl_stream_t stream);
 int svl_fill_f32(float* p, float v, int64_t n, svl_stream_t stream);
+/* y = ((x * k[0][c] + k[1][c]) - k[2][c]) / k[3][c] on NCHW planes (planes = B * C, k4 = float[4][C] device): the loader
+ * (ImageNet) -> CLIP statistics re-normalisation of VLM.renormalize_img_for_clip (model/vlm.py:69-78), same op order. */
+int svl_affine_planes_f32(const float* x, int64_t planes, int C, int64_t HW, const float* k4, float* y, svl_stream_t stream);
 /* Strided row copy / gather / scatter / broadcast of `rows` rows of C floats:
  *   dst[(i / dgrp)*dst_go + (i % dgrp)*dst_ld + c] (=|+=) src[(i / sgrp)*src_go + (i % sgrp)*src_ld + c]
  * (token slicing x[:, 1:], cls-row scatter, torch.cat into channel slices, batch broadcast, strided grad adds). */

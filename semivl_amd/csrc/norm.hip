@@ -327,6 +327,15 @@ __global__ void copy2d_kernel(const float* __restrict__ src, long sgrp, long src
     *d = accumulate ? (*d + v) : v;
   }
 }
+// y[b, c, p] = ((x * k0[c] + k1[c]) - k2[c]) / k3[c] on NCHW planes (vlm.py:69-78, same operation order)
+__global__ void affine_planes_kernel(const float* __restrict__ x, long planes, int C, long HW, const float* __restrict__ k,
+                                     float* __restrict__ y) {
+  const long n = planes * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    y[i] = ((x[i] * k[c] + k[C + c]) - k[2 * C + c]) / k[3 * C + c];
+  }
+}
 __global__ void fill_kernel(float* p, float v, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -344,12 +353,26 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __res
   const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
   const long img = blockIdx.x;
   const float* xi = x + img * HW * ldx;
-  double s = 0.0, q = 0.0;
-  for (long p = pr; p < HW; p += PR) {
-    const float4 v = *reinterpret_cast<const float4*>(xi + p * ldx + 4 * cq);
-    s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-    q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  // four independent accumulator pairs: four 16 B loads in flight per thread (with one, the loop ran at the pace of a
+  // load -> dependent double add chain: 3.1 TB/s); fixed combination order, still deterministic
+  double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+  long p = pr;
+  for (; p + 3 * PR < HW; p += 4 * PR) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xi + (p + u * PR) * ldx + 4 * cq);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s4[u] += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+      q4[u] += ((double)v[u].x * v[u].x + (double)v[u].y * v[u].y) + ((double)v[u].z * v[u].z + (double)v[u].w * v[u].w);
+    }
   }
+  for (; p < HW; p += PR) {
+    const float4 v = *reinterpret_cast<const float4*>(xi + p * ldx + 4 * cq);
+    s4[0] += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    q4[0] += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+  const double s = (s4[0] + s4[1]) + (s4[2] + s4[3]), q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
   sh_s[threadIdx.x] = s;
   sh_q[threadIdx.x] = q;
   __syncthreads();
@@ -414,12 +437,8 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float* __
   const int g = (4 * cq) / cg;
   const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
   double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-  for (long p = pr; p < HW; p += PR) {
-    const long pix = img * HW + p;
-    float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + 4 * cq);
-    const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + 4 * cq);
+  auto body = [&](float4 d, const float4 v, const float4 o) {
     if (relu) {
-      const float4 o = *reinterpret_cast<const float4*>(y + pix * ldy + 4 * cq);
       if (!(o.x > 0.f)) d.x = 0.f;
       if (!(o.y > 0.f)) d.y = 0.f;
       if (!(o.z > 0.f)) d.z = 0.f;
@@ -430,6 +449,24 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float* __
     b[1] += (double)d.y * ((v.y - mean) * rstd);
     b[2] += (double)d.z * ((v.z - mean) * rstd);
     b[3] += (double)d.w * ((v.w - mean) * rstd);
+  };
+  const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+  long p = pr;
+  for (; p + PR < HW; p += 2 * PR) {   // two pixels per trip: six 16 B loads in flight per thread before the first use
+    const long p0 = img * HW + p, p1 = p0 + PR;
+    const float4 d0 = *reinterpret_cast<const float4*>(dy + p0 * lddy + 4 * cq);
+    const float4 d1 = *reinterpret_cast<const float4*>(dy + p1 * lddy + 4 * cq);
+    const float4 v0 = *reinterpret_cast<const float4*>(x + p0 * ldx + 4 * cq);
+    const float4 v1 = *reinterpret_cast<const float4*>(x + p1 * ldx + 4 * cq);
+    const float4 o0 = relu ? *reinterpret_cast<const float4*>(y + p0 * ldy + 4 * cq) : one;
+    const float4 o1 = relu ? *reinterpret_cast<const float4*>(y + p1 * ldy + 4 * cq) : one;
+    body(d0, v0, o0);
+    body(d1, v1, o1);
+  }
+  for (; p < HW; p += PR) {
+    const long pix = img * HW + p;
+    body(*reinterpret_cast<const float4*>(dy + pix * lddy + 4 * cq), *reinterpret_cast<const float4*>(x + pix * ldx + 4 * cq),
+         relu ? *reinterpret_cast<const float4*>(y + pix * ldy + 4 * cq) : one);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -626,6 +663,14 @@ extern "C" int svl_chanmask_f32(const float* x, const float* mask, float scale, 
   hipLaunchKernelGGL(chanmask_kernel, dim3(grid_for(rows * C, 4)), dim3(256), 0, (hipStream_t)stream, x, mask, scale,
                      (long)rows, rows_per_img, C, out);
   SVL_LAUNCH_CHECK("svl_chanmask_f32");
+  return SVL_OK;
+}
+extern "C" int svl_affine_planes_f32(const float* x, int64_t planes, int C, int64_t HW, const float* k4, float* y,
+                                     svl_stream_t stream) {
+  SVL_CHECK_ARG(x && y && k4 && planes > 0 && C > 0 && HW > 0 && planes % C == 0, "svl_affine_planes_f32: bad args");
+  hipLaunchKernelGGL(affine_planes_kernel, dim3(grid_for(planes * HW, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)planes, C, (long)HW, k4, y);
+  SVL_LAUNCH_CHECK("svl_affine_planes_f32");
   return SVL_OK;
 }
 extern "C" int svl_fill_f32(float* p, float v, int64_t n, svl_stream_t stream) {

@@ -108,6 +108,7 @@ SIGNATURES = {
     "svl_eltwise_f32": (_I, [_I, _P, _P, _P, _L, _P]),
     "svl_chanmask_f32": (_I, [_P, _P, _F, _L, _I, _I, _P, _P]),
     "svl_fill_f32": (_I, [_P, _F, _L, _P]),
+    "svl_affine_planes_f32": (_I, [_P, _L, _I, _L, _P, _P, _P]),
     "svl_copy2d_f32": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _P]),
     "svl_groupnorm_fwd": (_I, [_P, _L, _P, _P, _F, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),

@@ -372,6 +372,16 @@ def fill(t, v):
     return t
 
 
+def affine_planes(x, k4):
+    """((x * k4[0][c] + k4[1][c]) - k4[2][c]) / k4[3][c] on an NCHW tensor (k4 [4, C] on the device)."""
+    x = x.contiguous()
+    Bn, Cc = x.shape[:2]
+    y = torch.empty_like(x)
+    L.check(L.load().svl_affine_planes_f32(_p(x), Bn * Cc, Cc, x[0, 0].numel(), _p(k4), _p(y), _st()),
+            "svl_affine_planes_f32")
+    return y
+
+
 def chanmask(x, mask, scale, rows_per_img, out=None):
     rows, Cc = x.shape
     if out is None:
