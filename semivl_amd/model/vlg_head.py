@@ -394,7 +394,8 @@ def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv):
     Cu = up.up.weight.shape[1]
     Cs = skip.shape[1]
     dev = x.device
-    wp_ = up.up.weight.permute(2, 3, 1, 0).reshape(4 * Cu, Cin).contiguous()  # n = (a, b, co)
+    wp_ = ops.cached_pack(up.up.weight, "convT_fwd",
+                          lambda w_: w_.permute(2, 3, 1, 0).reshape(4 * Cu, Cin).contiguous())  # n = (a, b, co)
     u = ops.empty(imgs * 4 * h * w, Cu, device=dev)
     ops.convT2x_fwd(x, Cin, imgs, h, w, Cin, wp_, Cu, up.up.bias, u, Cu)
     sup = ops.empty(b * 4 * h * w, Cs, device=dev)
@@ -422,7 +423,7 @@ def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
     gc.put(up.up.bias, lambda d, acc: ops.colsum(dcat, out=d, accumulate=acc, C_=Cu, ld=ld))
     dwb = ops.convT2x_wgrad(sv["x"], Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
     gc.put_tensor(up.up.weight, dwb.view(Cin, 2, 2, Cu).permute(0, 3, 1, 2).contiguous())
-    wb = up.up.weight.permute(0, 2, 3, 1).reshape(Cin, 4 * Cu).contiguous()
+    wb = ops.cached_pack(up.up.weight, "convT_bwd", lambda w_: w_.permute(0, 2, 3, 1).reshape(Cin, 4 * Cu).contiguous())
     dx = ops.convT2x_dgrad(dcat, ld, imgs, h, w, Cu, wb, Cin)
     return dx, dskip
 
@@ -556,7 +557,7 @@ def _head_backward_core(m, sv, dlogits, gc):
         gc.put(m.conv1.bias, lambda d, acc: ops.colsum(dx1, out=d, accumulate=acc))
         dw1 = ops.conv_wgrad(dx1, Ch, sv["sim"], 1, imgs, h, w, 1, Ch, k1, k1, 1, (k1 - 1) // 2)
         gc.put_tensor(m.conv1.weight, ops.unpack_conv_wgrad(dw1, Ch, 1, k1, k1))
-        wtap = m.conv1.weight.view(Ch, k1 * k1).t().contiguous()  # [tap, co]
+        wtap = ops.cached_pack(m.conv1.weight, "tap", lambda w_: w_.view(Ch, k1 * k1).t().contiguous())  # [tap, co]
         dsim = ops.conv_cin1_dgrad(dx1, Ch, imgs, h, w, Ch, wtap, k1, k1, 1, (k1 - 1) // 2)  # [(b n) hw, 1]
         # ---- cosine sim: demb_n[b,p,c] = sum_n dsim[b,n,p] textn[n,c]
         dembn = ops.empty(b * HW, Ce, device=dev)

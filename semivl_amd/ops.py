@@ -544,12 +544,35 @@ def seqattn_bwd(dout, qkv, probs, groups, inner, seq, heads, outer_stride, inner
 
 
 # ------------------------------------------------------------------------------------------------ convolutions (NHWC, stride 1)
+_PACKS = {}
+
+
+def cached_pack(W, tag, fn):
+    """A re-laid-out copy of a weight (conv operand packs, ConvTranspose packs), built ONCE per parameter version: frozen
+    weights for the life of the process, trainable ones until the next optimizer step (`weights_changed`).  Keeps the
+    ~130 weight-sized permute kernels per step (and their launches) off the hot path.  Non-parameters are not cached."""
+    base = W._base if W._base is not None else W
+    if not isinstance(base, torch.nn.Parameter):
+        return fn(W.detach())
+    key = (W.data_ptr(), tuple(W.shape), tag)
+    ver = (base._version, WEIGHT_EPOCH if base.requires_grad else 0)
+    hit = _PACKS.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    out = fn(W.detach())
+    if len(_PACKS) > 4096:
+        _PACKS.clear()
+    _PACKS[key] = (ver, out)
+    return out
+
+
 def pack_conv_w(W):
-    """[Co, Ci, kh, kw] -> forward pack [Co, (kh kw) Ci] and dgrad pack [Ci, (kh kw) Co] (weight-sized permutes)."""
-    Co, Ci, kh, kw = W.shape
-    wf = W.permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci).contiguous()
-    wd = W.permute(1, 2, 3, 0).reshape(Ci, kh * kw * Co).contiguous()
-    return wf, wd
+    """[Co, Ci, kh, kw] -> forward pack [Co, (kh kw) Ci] and dgrad pack [Ci, (kh kw) Co] (weight-sized permutes, cached)."""
+    def build(w):
+        Co, Ci, kh, kw = w.shape
+        return (w.permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci).contiguous(),
+                w.permute(1, 2, 3, 0).reshape(Ci, kh * kw * Co).contiguous())
+    return cached_pack(W, "conv", build)
 
 
 def unpack_conv_wgrad(dwf, Co, Ci, kh, kw):
