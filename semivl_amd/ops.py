@@ -6,6 +6,7 @@ path is issued through libsemivl_hip.so.  All tensors are fp32 CUDA(HIP) tensors
 import ctypes as C
 import os
 import math
+import weakref
 
 import torch
 
@@ -184,12 +185,12 @@ def weight_planes(W, transpose=False):
     key = (W.data_ptr(), tuple(W.shape), W.stride(0), transpose)
     ver = (base._version, WEIGHT_EPOCH if base.requires_grad else 0)
     hit = _WPLANES.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and hit[2]() is base:    # (a freed parameter's address may be handed out again)
         return hit[1]
     pl = split_planes(W.detach(), transpose=transpose)
     if len(_WPLANES) > 4096:
         _WPLANES.clear()
-    _WPLANES[key] = (ver, pl)
+    _WPLANES[key] = (ver, pl, weakref.ref(base))
     return pl
 
 
@@ -557,12 +558,12 @@ def cached_pack(W, tag, fn):
     key = (W.data_ptr(), tuple(W.shape), tag)
     ver = (base._version, WEIGHT_EPOCH if base.requires_grad else 0)
     hit = _PACKS.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
+    if hit is not None and hit[0] == ver and hit[2]() is base:    # weak reference: the address of a freed parameter of an
+        return hit[1]                                              # earlier model may be handed out again by the allocator
     out = fn(W.detach())
     if len(_PACKS) > 4096:
         _PACKS.clear()
-    _PACKS[key] = (ver, out)
+    _PACKS[key] = (ver, out, weakref.ref(base))
     return out
 
 
