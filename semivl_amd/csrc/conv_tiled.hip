@@ -6,6 +6,7 @@
 // taps read it with immediate offsets, the slab's 9 x 16 x N weights sit next to it, and a wave runs 72 x N/32 MFMAs
 // between barriers.  fp32 v_mfma_f32_32x32x2_f32 as everywhere else (A = pixels x channels, B = channels x outputs).
 #include "conv_tiled.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -143,6 +144,185 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same tiling with the bf16 split emulation of gemm.hip (svl_set_gemm_emulation(6): every fp32 value = 3 bf16 terms,
+// the 6 leading cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate -- error vs fp64 at or below the fp32 chain's).
+// A 16-channel slab is exactly one MFMA k-group: per tap a wave reads 3 A fragments (its 32 pixels, shifted by the tap) and
+// 3 TN B fragments (the tap's weights) and issues 6 TN MFMAs -- 54 TN per slab against 72 TN of the twice-as-long fp32
+// instruction.  Values are split ONCE when a slab is staged (the halo tile serves 9 taps, the weights 4 waves).
+// LDS rows are 32 B (16 bf16) with the two 16 B halves swapped on bit 3 of the row index: any 16 consecutive rows (pixels
+// of a patch row, output channels) then cover all 64 banks once -- conflict-free ds_read_b128 without padding, which keeps
+// the image at 17 + 55 KB (N = 64): two blocks per CU.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3x4(const float4 v, bf16x4& h0, bf16x4& h1, bf16x4& h2) {
+  float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = x[j];
+    h0[j] = (__bf16)t;
+    t -= (float)h0[j];
+    h1[j] = (__bf16)t;
+    t -= (float)h1[j];
+    h2[j] = (__bf16)t;
+  }
+}
+// element offset of channel quad q (channels 4q..4q+3) of row `row` inside a plane of 16-channel rows
+__device__ __forceinline__ int swz(int row, int q) { return row * 16 + ((((q >> 1) ^ (row >> 3)) & 1) << 3) + ((q & 1) << 2); }
+
+template <int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_tiled_bf16x_kernel(const ConvTiledP p, int tiles_x, int tiles_y) {
+  constexpr int N = 32 * TN;
+  constexpr int XP = (NPIX * 4 + 255) / 256;        // input float4 pieces per thread (3)
+  constexpr int WP = (9 * N * 4 + 255) / 256;       // weight float4 pieces per thread (5 / 9)
+  constexpr int XPL = NPIX * 16, WPL = 9 * N * 16;  // plane strides (bf16 elements)
+  __shared__ __attribute__((aligned(16))) __bf16 xs[3 * XPL];
+  __shared__ __attribute__((aligned(16))) __bf16 ws[3 * WPL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  int t = blockIdx.x;
+  const int txi = t % tiles_x;
+  t /= tiles_x;
+  const int tyi = t % tiles_y, img = t / tiles_y;
+  const int y0 = tyi * PH, x0 = txi * PW;
+  const int Ct = p.C1 + p.C2, nslab = Ct / SLAB;
+  const int nwp = 9 * N * 4;
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float4 rx[XP];
+  float4 rw[WP];
+  auto gload = [&](int s) __attribute__((always_inline)) {
+    const int c0 = s * SLAB;
+    const bool first = c0 < p.C1;
+    const float* base = first ? p.src1 + ((long)img * p.H) * p.W * p.ld1 + c0
+                              : p.src2 + ((long)(img / p.rep) * p.H) * p.W * p.ld2 + (c0 - p.C1);
+    const long ld = first ? p.ld1 : p.ld2;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int f = tid + 256 * i;
+      const int pix = f >> 2, q = f & 3;
+      const int iy = pix / IW, ix = pix - iy * IW;
+      const int y = y0 - 1 + iy, x = x0 - 1 + ix;
+      rx[i] = (f < NPIX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W)
+                  ? *reinterpret_cast<const float4*>(base + ((long)y * p.W + x) * ld + 4 * q)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int f = tid + 256 * i;                 // quad fastest: 4 lanes cover the 64 contiguous bytes of one (co, tap)
+      const int q = f & 3, rest = f >> 2, co = rest % N, tap = rest / N;
+      rw[i] = f < nwp ? *reinterpret_cast<const float4*>(p.w + (long)co * p.K + tap * Ct + c0 + 4 * q)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int f = tid + 256 * i;
+      if (f < NPIX * 4) {
+        bf16x4 h0, h1, h2;
+        split3x4(rx[i], h0, h1, h2);
+        const int o = swz(f >> 2, f & 3);
+        *reinterpret_cast<bf16x4*>(xs + o) = h0;
+        *reinterpret_cast<bf16x4*>(xs + XPL + o) = h1;
+        *reinterpret_cast<bf16x4*>(xs + 2 * XPL + o) = h2;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int f = tid + 256 * i;
+      if (f < nwp) {
+        const int q = f & 3, rest = f >> 2, co = rest % N, tap = rest / N;
+        bf16x4 h0, h1, h2;
+        split3x4(rw[i], h0, h1, h2);
+        const int o = swz(tap * N + co, q);        // (N is a multiple of 8: bit 3 of the row index is bit 3 of co)
+        *reinterpret_cast<bf16x4*>(ws + o) = h0;
+        *reinterpret_cast<bf16x4*>(ws + WPL + o) = h1;
+        *reinterpret_cast<bf16x4*>(ws + 2 * WPL + o) = h2;
+      }
+    }
+  };
+
+  const int pr = wave * 2 + (l31 >> 4), pc = l31 & 15;   // this lane's A-operand pixel inside the patch
+  gload(0);
+  sstore();
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) gload(s + 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = p.sign * (tap / 3 - 1), dx = p.sign * (tap % 3 - 1);
+      const int pa = (pr + 1 + dy) * IW + (pc + 1 + dx);
+      const int oa = pa * 16 + (((hi ^ (pa >> 3)) & 1) << 3);
+      bf16x8 a[3], b[3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(xs + pl * XPL + oa);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int rb = tap * N + 32 * j + l31;
+        const int ob = rb * 16 + (((hi ^ (rb >> 3)) & 1) << 3);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[pl][j] = *reinterpret_cast<const bf16x8*>(ws + pl * WPL + ob);
+      }
+      // smallest cross terms first: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+#define SVL_CT(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB][j], acc[j], 0, 0, 0);
+      SVL_CT(2, 0)
+      SVL_CT(0, 2)
+      SVL_CT(1, 1)
+      SVL_CT(1, 0)
+      SVL_CT(0, 1)
+      SVL_CT(0, 0)
+#undef SVL_CT
+    }
+    __syncthreads();
+    if (s + 1 < nslab) {
+      sstore();
+      __syncthreads();
+    }
+  }
+  // epilogue: identical to the fp32 kernel's (column = output channel, row = pixel of the wave)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = l31 + 32 * j;
+    const float bv = p.bias ? p.bias[co] : 0.f;
+    float* ob = p.out + (long)img * p.H * p.W * p.ldo + co;
+    float v[16];
+    long off[16];
+    bool ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int y = y0 + wave * 2 + (i >> 4), x = x0 + (i & 15);
+      ok[r] = y < p.H && x < p.W;
+      off[r] = ((long)y * p.W + x) * p.ldo;
+      v[r] = acc[j][r] + bv;
+    }
+    if (p.act == SVL_ACT_GELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+    } else if (p.act == SVL_ACT_RELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (p.accumulate) {
+      float prev[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[r] = ok[r] ? ob[off[r]] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += prev[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) ob[off[r]] = v[r];
+  }
+}
+
 }  // namespace
 
 bool svl_conv3x3_tiled_eligible(const ConvTiledP& p) {
@@ -159,7 +339,11 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st) {
   const int tx = (p.W + PW - 1) / PW, ty = (p.H + PH - 1) / PH;
   const long blocks = (long)p.imgs * tx * ty;
   SVL_CHECK_ARG(blocks < (1L << 31), "svl_conv3x3_tiled: grid too large");
-  if (p.N == 32) hipLaunchKernelGGL(conv3x3_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
+  static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
+  if (emu_ok && svl_get_gemm_emulation() == 6) {   // the split emulation covers the narrow convolutions too
+    if (p.N == 32) hipLaunchKernelGGL(conv3x3_tiled_bf16x_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
+    else hipLaunchKernelGGL(conv3x3_tiled_bf16x_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
+  } else if (p.N == 32) hipLaunchKernelGGL(conv3x3_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   else hipLaunchKernelGGL(conv3x3_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   SVL_LAUNCH_CHECK("svl_gemm_f32 (tiled 3x3 conv)");
   return SVL_OK;

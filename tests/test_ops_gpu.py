@@ -864,6 +864,43 @@ def test_tiled_narrow_conv3x3(dev, b, N, H, W, C1, C2, Co):
     assert torch.equal(o1, o2), "tiled wgrad must be deterministic"
 
 
+@pytest.mark.parametrize("b,N,H,W,C1,C2,Co", [(2, 6, 32, 48, 48, 16, 32), (2, 4, 40, 56, 96, 32, 64), (1, 3, 72, 80, 64, 0, 64),
+                                              (3, 8, 19, 37, 16, 16, 32)])
+def test_tiled_narrow_conv3x3_split_emulation(dev, emu_mode, b, N, H, W, C1, C2, Co):
+    """conv3x3_tiled_bf16x_kernel (mode 6: forward and mirrored-tap input gradient of the narrow 3x3 convolutions on the
+    bf16 pipe): error vs fp64 at or below the fp32 tiled kernel's; two concat sources, ragged patches, bias / ReLU /
+    accumulate epilogue; deterministic."""
+    from semivl_amd import ops
+    imgs = b * N
+    x1 = rnd(imgs, H, W, C1, dev=dev, seed=61)
+    x2 = rnd(b, H, W, C2, dev=dev, seed=62) if C2 else None
+    w = rnd(Co, C1 + C2, 3, 3, dev=dev, seed=63) * 0.1
+    dy = rnd(imgs, H, W, Co, dev=dev, seed=64)
+    wf, wd = ops.pack_conv_w(w)
+    xin = (x1 if not C2 else torch.cat([x1, x2.repeat_interleave(N, 0)], -1)).permute(0, 3, 1, 2).double().requires_grad_(True)
+    ref = F.conv2d(xin, w.double(), padding=1)
+    (gx,) = torch.autograd.grad(ref, xin, dy.permute(0, 3, 1, 2).double())
+    ref, gx = ref.permute(0, 2, 3, 1), gx.permute(0, 2, 3, 1)
+    kw = dict(src2=x2.view(-1, C2) if C2 else None, ld2=C2, C2=C2, rep=N)
+    err = {}
+    for mode in (0, 6):
+        emu_mode(mode)
+        y = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, **kw)
+        dx = ops.conv_dgrad(dy.view(-1, Co), Co, imgs, H, W, Co, wd, C1 + C2, 3, 3, 1, 1)
+        err[mode] = (_relerr(y.view(imgs, H, W, Co), ref), _relerr(dx.view(imgs, H, W, C1 + C2), gx))
+    assert err[6][0] <= 1.5 * err[0][0] + 1e-8 and err[6][1] <= 1.5 * err[0][1] + 1e-8, err
+    emu_mode(6)
+    bias = rnd(Co, dev=dev)
+    y = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, bias=bias, act=ops.ACT_RELU, **kw)
+    close(y.view(imgs, H, W, Co), F.relu(ref.float() + bias), atol=2e-4, what="bias+relu")
+    acc = rnd(imgs * H * W, C1 + C2, dev=dev, seed=65)
+    want = acc + gx.float().reshape(-1, C1 + C2)
+    ops.conv_dgrad(dy.view(-1, Co), Co, imgs, H, W, Co, wd, C1 + C2, 3, 3, 1, 1, out=acc, ldo=C1 + C2, accumulate=True)
+    close(acc, want, atol=2e-4, what="accumulate")
+    y2 = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, bias=bias, act=ops.ACT_RELU, **kw)
+    assert torch.equal(y, y2), "deterministic"
+
+
 # ------------------------------------------------------------------------------------------------ ABI contract: re-entrancy
 def test_two_streams_own_their_helper_contexts(dev):
     """include/semivl_hip.h: calls on different caller streams never share a helper stream or an event.  Ragged-M GEMMs
