@@ -174,3 +174,22 @@ def test_warmup_then_poly_lr():
     o.poly_lr(50, 100, warmup_iters=10)                          # :343-345
     assert math.isclose(o.groups[0]["lr"], 1e-3 * 0.5 ** 0.9)
     assert torch.allclose(o.seg_lr, torch.tensor([g["lr"] for g in o.groups]))
+
+
+def test_head_chunk_plan():
+    """Sample chunks of the class-batched decoder (memory plan): live ranges announced by the step are kept apart from the
+    dead samples, chunks never exceed the class-image budget, and the plan tiles the batch exactly."""
+    from types import SimpleNamespace
+    from semivl_amd.model.vlg_head import _chunk_plan
+    m = SimpleNamespace(chunk_class_images=1344, _bwd_ranges={48: [(16, 48)]})
+    assert _chunk_plan(m, 48, 21) == [(0, 16, False), (16, 48, True)]            # VOC B=16: exactly the round-1 launches
+    plan = _chunk_plan(m, 48, 150)                                               # ADE: 8 samples (1200 class-images) per chunk
+    assert plan == [(0, 8, False), (8, 16, False), (16, 24, True), (24, 32, True), (32, 40, True), (40, 48, True)]
+    assert _chunk_plan(m, 32, 150) == [(0, 8, True), (8, 16, True), (16, 24, True), (24, 32, True)]   # no entry: all live
+    m2 = SimpleNamespace(chunk_class_images=100, _bwd_ranges={10: [(2, 5), (7, 10)]})
+    plan = _chunk_plan(m2, 10, 81)                                               # budget below one sample: one sample per chunk
+    assert [c[:2] for c in plan] == [(i, i + 1) for i in range(10)]
+    assert [c[2] for c in plan] == [False, False, True, True, True, False, False, True, True, True]
+    m3 = SimpleNamespace(chunk_class_images=1344, _bwd_ranges=None)
+    plan = _chunk_plan(m3, 7, 300)                                               # 4 samples fit: balanced 4 + 3, not 4 + 4 - 1
+    assert plan == [(0, 4, True), (4, 7, True)]
