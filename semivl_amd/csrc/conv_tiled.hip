@@ -171,12 +171,16 @@ __device__ __forceinline__ void split3x4(const float4 v, bf16x4& h0, bf16x4& h1,
 // element offset of channel quad q (channels 4q..4q+3) of row `row` inside a plane of 16-channel rows
 __device__ __forceinline__ int swz(int row, int q) { return row * 16 + ((((q >> 1) ^ (row >> 3)) & 1) << 3) + ((q & 1) << 2); }
 
-template <int TN>
+// PT = 32-pixel tiles per wave: PT = 2 (a 16 x 16 patch per block) doubles the MFMA work per staged weight fragment and
+// per barrier -- used for N = 32, where one tile per wave left only 54 MFMAs between two barriers (119-133 TF vs 167-171
+// at N = 64).
+template <int TN, int PT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_tiled_bf16x_kernel(const ConvTiledP p, int tiles_x, int tiles_y) {
   constexpr int N = 32 * TN;
-  constexpr int XP = (NPIX * 4 + 255) / 256;        // input float4 pieces per thread (3)
+  constexpr int PHT = PH * PT, IHT = PHT + 2, NPX = IHT * IW;   // patch rows, halo rows, staged pixels
+  constexpr int XP = (NPX * 4 + 255) / 256;         // input float4 pieces per thread (3 / 6)
   constexpr int WP = (9 * N * 4 + 255) / 256;       // weight float4 pieces per thread (5 / 9)
-  constexpr int XPL = NPIX * 16, WPL = 9 * N * 16;  // plane strides (bf16 elements)
+  constexpr int XPL = NPX * 16, WPL = 9 * N * 16;   // plane strides (bf16 elements)
   __shared__ __attribute__((aligned(16))) __bf16 xs[3 * XPL];
   __shared__ __attribute__((aligned(16))) __bf16 ws[3 * WPL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -184,15 +188,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int txi = t % tiles_x;
   t /= tiles_x;
   const int tyi = t % tiles_y, img = t / tiles_y;
-  const int y0 = tyi * PH, x0 = txi * PW;
+  const int y0 = tyi * PHT, x0 = txi * PW;
   const int Ct = p.C1 + p.C2, nslab = Ct / SLAB;
   const int nwp = 9 * N * 4;
 
-  f32x16 acc[TN];
+  f32x16 acc[PT][TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+  for (int u = 0; u < PT; ++u)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][j][r] = 0.f;
 
   float4 rx[XP];
   float4 rw[WP];
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int pix = f >> 2, q = f & 3;
       const int iy = pix / IW, ix = pix - iy * IW;
       const int y = y0 - 1 + iy, x = x0 - 1 + ix;
-      rx[i] = (f < NPIX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W)
+      rx[i] = (f < NPX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W)
                   ? *reinterpret_cast<const float4*>(base + ((long)y * p.W + x) * ld + 4 * q)
                   : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int f = tid + 256 * i;
-      if (f < NPIX * 4) {
+      if (f < NPX * 4) {
         bf16x4 h0, h1, h2;
         split3x4(rx[i], h0, h1, h2);
         const int o = swz(f >> 2, f & 3);
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
 
-  const int pr = wave * 2 + (l31 >> 4), pc = l31 & 15;   // this lane's A-operand pixel inside the patch
+  const int pr = wave * 2 * PT + (l31 >> 4), pc = l31 & 15;   // this lane's A-operand pixel of its first tile
   gload(0);
   sstore();
   __syncthreads();
@@ -257,11 +263,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = p.sign * (tap / 3 - 1), dx = p.sign * (tap % 3 - 1);
-      const int pa = (pr + 1 + dy) * IW + (pc + 1 + dx);
-      const int oa = pa * 16 + (((hi ^ (pa >> 3)) & 1) << 3);
-      bf16x8 a[3], b[3][TN];
+      bf16x8 a[3][PT], b[3][TN];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(xs + pl * XPL + oa);
+      for (int u = 0; u < PT; ++u) {
+        const int pa = (pr + 2 * u + 1 + dy) * IW + (pc + 1 + dx);
+        const int oa = pa * 16 + (((hi ^ (pa >> 3)) & 1) << 3);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl][u] = *reinterpret_cast<const bf16x8*>(xs + pl * XPL + oa);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int rb = tap * N + 32 * j + l31;
@@ -270,8 +279,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int pl = 0; pl < 3; ++pl) b[pl][j] = *reinterpret_cast<const bf16x8*>(ws + pl * WPL + ob);
       }
       // smallest cross terms first: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
-#define SVL_CT(PA, PB) \
-  _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB][j], acc[j], 0, 0, 0);
+#define SVL_CT(PA, PB)                                                                     \
+  _Pragma("unroll") for (int u = 0; u < PT; ++u) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[u][j] = \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][u], b[PB][j], acc[u][j], 0, 0, 0);
       SVL_CT(2, 0)
       SVL_CT(0, 2)
       SVL_CT(1, 1)
@@ -288,6 +298,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // epilogue: identical to the fp32 kernel's (column = output channel, row = pixel of the wave)
 #pragma unroll
+  for (int u = 0; u < PT; ++u)
+#pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = l31 + 32 * j;
     const float bv = p.bias ? p.bias[co] : 0.f;
@@ -298,10 +310,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int y = y0 + wave * 2 + (i >> 4), x = x0 + (i & 15);
+      const int y = y0 + wave * 2 * PT + 2 * u + (i >> 4), x = x0 + (i & 15);
       ok[r] = y < p.H && x < p.W;
       off[r] = ((long)y * p.W + x) * p.ldo;
-      v[r] = acc[j][r] + bv;
+      v[r] = acc[u][j][r] + bv;
     }
     if (p.act == SVL_ACT_GELU) {
 #pragma unroll
@@ -340,9 +352,13 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st) {
   const long blocks = (long)p.imgs * tx * ty;
   SVL_CHECK_ARG(blocks < (1L << 31), "svl_conv3x3_tiled: grid too large");
   static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
+  static const int pt2 = getenv("SVL_CONV_TILED_PT1") ? 0 : 1;
   if (emu_ok && svl_get_gemm_emulation() == 6) {   // the split emulation covers the narrow convolutions too
-    if (p.N == 32) hipLaunchKernelGGL(conv3x3_tiled_bf16x_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
-    else hipLaunchKernelGGL(conv3x3_tiled_bf16x_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
+    if (p.N == 32 && pt2 && p.H >= 2 * PH) {        // 16 x 16 patches: two pixel tiles per wave
+      const int ty2 = (p.H + 2 * PH - 1) / (2 * PH);
+      hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 2>), dim3((unsigned)((long)p.imgs * tx * ty2)), dim3(256), 0, st, p, tx, ty2);
+    } else if (p.N == 32) hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
+    else hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   } else if (p.N == 32) hipLaunchKernelGGL(conv3x3_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   else hipLaunchKernelGGL(conv3x3_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   SVL_LAUNCH_CHECK("svl_gemm_f32 (tiled 3x3 conv)");
