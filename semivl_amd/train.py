@@ -94,21 +94,24 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     # semivl.py:228-244; nothing else on the path depends on the mode).  Both passes are gradient-free and independent of
     # the two student forwards below: they are enqueued on a second stream (event-forked from / joined back into the
     # caller's stream), so their kernels fill the partial last rounds of the student's grids instead of queueing behind
-    # them.  Not with a conv_encoder: its eval-mode BatchNorm reads the running statistics the train-mode pass updates.
+    # them.  With a conv_encoder only the frozen-CLIP guidance moves over: the pseudo-label pass reads, in eval mode, the
+    # BatchNorm running statistics that the train-mode forwards update, so it stays in program order on the main stream.
     side = None
-    if img_x.is_cuda and cfg.get("overlap_streams", True) and getattr(model, "conv_encoder", None) is None:
+    if img_x.is_cuda and cfg.get("overlap_streams", True):
         side = _SIDE.get(dev)
         if side is None:
             side = _SIDE[dev] = torch.cuda.Stream(dev)
     main = torch.cuda.current_stream(dev) if img_x.is_cuda else None
+    pl_side = side if getattr(model, "conv_encoder", None) is None else None
     model.eval()
     if side is not None:
         side.wait_stream(main)
-    with torch.no_grad(), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+    with torch.no_grad(), (torch.cuda.stream(pl_side) if pl_side is not None else contextlib.nullcontext()):
         pred_w_other = model(b["img_w_other"])
         conf_w_other, mask_w_other = ops.softmax_max(pred_w_other)
         if not return_aux:
             del pred_w_other
+    with torch.no_grad(), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
         mclip_all = model.forward_maskclip(_cat2(img_w, b["img_w_other"]), cfg.get("mcc_conf_thresh", 0.9),
                                            ignore_mask=_cat2i(ign, ign_o))
         mclip, mclip_other = mclip_all[:B], mclip_all[B:]
@@ -139,7 +142,7 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     conf_w, mask_w = ops.softmax_max(pred_w.detach())
     if side is not None:        # join: the label maps of the side stream are consumed from here on
         main.wait_stream(side)
-        for t_ in (conf_w_other, mask_w_other, mclip_all):
+        for t_ in ((conf_w_other, mask_w_other, mclip_all) if pl_side is not None else (mclip_all,)):
             t_.record_stream(main)
     # CutMix labels
     mw1, mw2 = cutmix_mask(mask_w, mask_w_other, mix1), cutmix_mask(mask_w, mask_w_other, mix2)
