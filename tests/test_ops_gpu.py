@@ -282,6 +282,40 @@ def test_fused_attention(dev, Bn, T, H):
     assert torch.equal(out, o2) and torch.equal(dqkv, ops.attention_bwd(do, qkv.detach(), out, lse, Bn, T, H))
 
 
+@pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 17, 4), (2, 129, 3), (1, 161, 1), (1, 97, 2)])
+def test_fused_attention_split_emulation(dev, Bn, T, H):
+    """svl_set_gemm_emulation(6) covers the attention products: the error vs fp64 stays at the level of the exact fp32
+    kernels' (bound: 1.5 x theirs + 1e-6), on the same ragged / spiky cases, and the result is deterministic."""
+    from semivl_amd import ops
+    D, E = 64, 64 * H
+    qkv = rnd(Bn * T, 3 * E, dev=dev, seed=51)
+    qkv[:, :2 * E] *= 2.0
+    if T > 40:
+        qkv.view(Bn, T, 3 * E)[0, T - 3, E:E + 64] = 6.0 * qkv.view(Bn, T, 3 * E)[0, 5, 0:64]
+    do = rnd(Bn * T, E, dev=dev)
+    qd = qkv.double().requires_grad_(True)
+    q, k, v = [t.reshape(Bn, T, H, D).transpose(1, 2) for t in qd.view(Bn, T, 3 * E).split(E, dim=2)]
+    sc = (q * D ** -0.5) @ k.transpose(-1, -2)
+    ref = (sc.softmax(-1) @ v).transpose(1, 2).reshape(Bn * T, E)
+    (g,) = torch.autograd.grad(ref, qd, do.double())
+    res = {}
+    try:
+        for mode in (0, 6):
+            ops.set_gemm_emulation(mode)
+            out, lse = ops.attention_fwd(qkv, Bn, T, H)
+            dqkv = ops.attention_bwd(do, qkv, out, lse, Bn, T, H)
+            res[mode] = (float((out.double() - ref).abs().max()), float((dqkv.double() - g).abs().max()),
+                         float((lse.view(Bn, H, T).double() - torch.logsumexp(sc, -1)).abs().max()))
+            o2, l2 = ops.attention_fwd(qkv, Bn, T, H)
+            assert torch.equal(out, o2) and torch.equal(lse, l2)
+            assert torch.equal(dqkv, ops.attention_bwd(do, qkv, out, lse, Bn, T, H))
+    finally:
+        ops.set_gemm_emulation(0)
+    lse_ulp = 1.2e-7 * float(torch.logsumexp(sc, -1).abs().max())     # LSE itself is O(100) on the spiky rows
+    for e0, e6, what, slack in zip(res[0], res[6], ("out", "dqkv", "lse"), (1e-6, 1e-6, 2 * lse_ulp)):
+        assert e6 <= 1.5 * e0 + slack, (what, e0, e6)
+
+
 # ------------------------------------------------------------------------------------------------ conv family
 def nhwc(x):  # NCHW -> [N*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()

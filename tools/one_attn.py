@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from semivl_amd import ops
 dev = torch.device("cuda:0")
+ops.set_gemm_emulation(int(os.environ.get("EMU", "0")))   # 6: the bf16 x 6 kernels
 Bn, T, H = 32, 1025, 12
 torch.manual_seed(0)
 qkv = torch.randn(Bn * T, 3 * H * 64, device=dev)
