@@ -239,7 +239,8 @@ def main():
                vs_baseline=None,
                dtype="f32" if a.gemm_arith == "f32" else
                f"f32 (fp32 in/out/accumulate everywhere; large dense GEMMs as {a.gemm_arith} split products on the bf16 MFMA pipe, "
-               f"error vs fp64 <= the plain fp32 MFMA chain's; attention and convolutions on the fp32 MFMA pipe)",
+               f"error vs fp64 <= the plain fp32 MFMA chain's: the dense GEMMs, the fused ViT attention and the >= 32-channel "
+               f"convolutions' forward / input gradient; the remaining MFMA kernels on the fp32 pipe)",
                data="synthetic",
                config=dict(workload=f"SemiVL step, {dataset} N={a.nclass}, {cfg['model'].replace('mmseg.', '')}, {a.crop}x{a.crop}, "
                                     f"bs={a.batch}/GPU labeled + {a.batch}/GPU unlabeled" +
@@ -260,7 +261,7 @@ def main():
     if rank == 0 and not a.no_profile:
         g_arith_exact = a.gemm_arith == "f32"
         prof, ops.PROFILE = ops.PROFILE, None
-        gx = prof.get("gemm_bf16x", [])                        # dense GEMMs served by the bf16 pipe (split emulation)
+        gx = prof.get("gemm_bf16x", []) + prof.get("attention_bf16x", [])   # launches served by the bf16 pipe (split emulation)
         g = prof.get("gemm", []) + gx + prof.get("attention", [])   # every MFMA kernel family
         t_gemm = sum(e0.elapsed_time(e1) for e0, e1, *_ in g) * 1e-3
         executed = sum(w for _, _, w, *_ in g)
@@ -272,7 +273,7 @@ def main():
                                frac_executed=round(executed / t_gemm / 1e12 / PEAK_F32_MFMA_TF, 4),
                                frac_whole_step=round(step_tf / PEAK_F32_MFMA_TF, 4), whole_step_tflops=round(step_tf, 2),
                                kernel="all MFMA launches of one step: gemm_kernel / conv kernels + attn_{fwd,bwd}_kernel "
-                                      "(v_mfma_f32_32x32x2_f32)" + (" + gemm_bf16x_kernel (v_mfma_f32_32x32x16_bf16, 6 products)"
+                                      "(v_mfma_f32_32x32x2_f32)" + (" + gemm_bf16x_kernel / attn_*_x6_kernel (v_mfma_f32_32x32x16_bf16, 6 products)"
                                                                        if gx else ""), launches=len(g),
                                kernel_time_ms=round(t_gemm * 1e3, 2),
                                executed_tflops=round(executed / t_gemm / 1e12, 2),
@@ -285,7 +286,8 @@ def main():
             t_x = sum(e0.elapsed_time(e1) for e0, e1, *_ in gx) * 1e-3
             f_x = sum(w for _, _, w, *_ in gx)
             out["roofline"]["bf16_pipe"] = dict(
-                kernel=f"gemm_bf16x_kernel<{nprod // 2 if nprod == 6 else 2},...> (svl_gemm_f32 in emulation mode {nprod})",
+                kernel=f"gemm_bf16x_kernel<{nprod // 2 if nprod == 6 else 2},...> (svl_gemm_f32 in emulation mode {nprod})"
+                       + (" + attn_{fwd,bwd_dq,bwd_dkv}_x6_kernel" if prof.get("attention_bf16x") else ""),
                 launches=len(gx), kernel_time_ms=round(t_x * 1e3, 2), achieved=round(f_x / t_x / 1e12, 2),
                 peak=round(PEAK_BF16_MFMA_TF / nprod, 1), unit="TFLOP/s (fp32-equivalent)",
                 frac=round(f_x / t_x / 1e12 / (PEAK_BF16_MFMA_TF / nprod), 4),

@@ -135,12 +135,15 @@ typedef struct svl_gemm_desc {
 
 int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream);
 
-/* Process-wide (relaxed-atomic, read once per svl_gemm_f32 call) arithmetic mode of the LARGE dense GEMMs (M >= 256, N >= 96, K >= 64, dense operand modes):
+/* Process-wide (relaxed-atomic, read once per call) arithmetic mode of the LARGE dense GEMMs (M >= 256, N >= 96, K >= 64, dense operand modes):
  *   0  v_mfma_f32_32x32x2_f32, exact fp32 fma chain (default);
  *   6  fp32-accurate emulation on the bf16 matrix pipe: every operand element is split into 3 bf16 terms and the 6
- *      leading cross products are accumulated in fp32 (error <= the fp32 path's, 2.7x the MFMA rate);
- *   3  2-term split, 3 products (~16 mantissa bits, 5.3x the MFMA rate).
- * Initial value: environment variable SVL_GEMM_EMU (0 if unset).  Inputs, outputs and accumulation stay fp32. */
+ *      leading cross products are accumulated in fp32 (error <= the fp32 path's, 2.7x the MFMA rate).  Mode 6 also
+ *      covers svl_attention_{fwd,bwd} (all five products of the fused attention; S is recomputed bit-identically in
+ *      the backward) and the forward / input gradient of the spatially tiled 3x3 convolutions;
+ *   3  2-term split, 3 products (~16 mantissa bits, 5.3x the MFMA rate); dense GEMMs only.
+ * Initial value: environment variable SVL_GEMM_EMU (0 if unset).  Inputs, outputs and accumulation stay fp32.
+ * A/B switches (read once per process): SVL_ATTN_NO_EMU, SVL_CONV_TILED_NO_EMU keep those kernels on the fp32 pipe. */
 int svl_set_gemm_emulation(int mode);
 int svl_get_gemm_emulation(void);
 /* 1 (default): narrow (N = 32 / 64) 3x3 stride-1 convolutions run on the spatially tiled kernel; 0: implicit GEMM only.
@@ -344,6 +347,7 @@ int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx
                       float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream);
 
 /* Fused (flash-style) multi-head self-attention of the ViT blocks, head dim 64, softmax scale 64^-0.5, fp32 MFMA
+ * (or the bf16 x 6 split emulation with fp32 accumulation under svl_set_gemm_emulation(6): same error level vs fp64)
  * (nn.MultiheadAttention inside mmcv's wrapper, maskclip_vit.py:77-84,141).  qkv [B*T, 3E] = in-proj output
  * (q | k | v, E = 64*H); out [B*T, E]; lse [B*H*T] (log-sum-exp per query, saved for backward; may be NULL).
  * Backward: dqkv [B*T, 3E] fully written; dsum_ws is a [B*H*T] float workspace.  Deterministic. */

@@ -933,7 +933,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_x6_kernel(const AttnP p) {
   const int k0 = blockIdx.x * FQ + wave * 32;
   const int kj = k0 + l31, kc = min(kj, p.T - 1);
   const bool wave_active = k0 < p.T;
-  const bool key_ok = kj < p.T;
   const float* image = p.qkv + (long)b * p.T * p.ld;
   const float* dimage = p.dout + (long)b * p.T * p.E;
   bf16x8 kf[3][4], vf[3][4];
@@ -1025,7 +1024,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_x6_kernel(const AttnP p) {
           const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float pv = key_ok ? exp_sub2(sa[r0 + i], lq[i]) : 0.f;
+            const float pv = exp_sub2(sa[r0 + i], lq[i]);   // (a lane past T works on a copy of key T - 1; never stored)
             xp[4 * g + i] = pv;
             xs[4 * g + i] = pv * (dp[r0 + i] - dq[i]);
           }

@@ -930,6 +930,13 @@ __device__ __forceinline__ void emu_gload_tail(EmuRaw& r, const float* ptr, cons
   }
 }
 
+// Split on PAIRS, explicitly: one v_cvt_pk_bf16_f32 per pair and plane (the packed word is stored as is), a shift / an
+// and to read the two bf16 back as floats, two scalar subtractions -- 5.5 VALU per element.  The loop is issue-bound
+// (a 32x32x16 MFMA occupies the pipe for ~8 issue slots), and v_pk_add_f32 costs more there than two v_sub_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int NS, int RM>
 __device__ __forceinline__ void emu_split_store(__bf16* dst, int plane_stride, int row2_off, const EmuRaw& r) {
   float x[8];
@@ -937,17 +944,22 @@ __device__ __forceinline__ void emu_split_store(__bf16* dst, int plane_stride, i
   for (int j = 0; j < 8; ++j) x[j] = r.v[j];
 #pragma unroll
   for (int pl = 0; pl < NS; ++pl) {
-    bf16x8 h;
+    u32x4 w;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      h[j] = (__bf16)x[j];
-      if (pl + 1 < NS) x[j] -= (float)h[j];
+    for (int jp = 0; jp < 4; ++jp) {
+      const f32x2 pr = {x[2 * jp], x[2 * jp + 1]};
+      const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+      w[jp] = u;
+      if (pl + 1 < NS) {
+        x[2 * jp] -= __builtin_bit_cast(float, u << 16);   // (gemm.o is built with -fno-slp-vectorize: scalar v_sub_f32)
+        x[2 * jp + 1] -= __builtin_bit_cast(float, u & 0xffff0000u);
+      }
     }
     if (RM == 0) {
-      *reinterpret_cast<bf16x4*>(dst + pl * plane_stride) = __builtin_shufflevector(h, h, 0, 1, 2, 3);
-      *reinterpret_cast<bf16x4*>(dst + pl * plane_stride + row2_off) = __builtin_shufflevector(h, h, 4, 5, 6, 7);
+      *reinterpret_cast<u32x2*>(dst + pl * plane_stride) = u32x2{w[0], w[1]};
+      *reinterpret_cast<u32x2*>(dst + pl * plane_stride + row2_off) = u32x2{w[2], w[3]};
     } else {
-      *reinterpret_cast<bf16x8*>(dst + pl * plane_stride) = h;
+      *reinterpret_cast<u32x4*>(dst + pl * plane_stride) = w;
     }
   }
 }

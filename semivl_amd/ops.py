@@ -461,6 +461,13 @@ def groupnorm_bwd(dy, lddy, x, ldx, y, ldy, stats, gamma, imgs, HW, Cc, G, relu,
 
 
 # ------------------------------------------------------------------------------------------------ ViT attention (fused, D = 64)
+def _attn_family():
+    """Profile family of the attention launches: the bf16 x 6 kernels serve them in emulation mode 6 (attention.hip)."""
+    if PROFILE is None:
+        return "attention"
+    return "attention_bf16x" if (get_gemm_emulation() == 6 and not os.environ.get("SVL_ATTN_NO_EMU")) else "attention"
+
+
 def attention_fwd(qkv, Bn, T, H, want_lse=True):
     """Flash-style fused attention: qkv [Bn*T, 3E] -> (out [Bn*T, E], lse [Bn*H*T] or None)."""
     E = H * 64
@@ -468,7 +475,7 @@ def attention_fwd(qkv, Bn, T, H, want_lse=True):
     lse = empty(Bn * H * T, device=qkv.device) if want_lse else None
     e0 = _prof_begin()
     L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _st()), "svl_attention_fwd")
-    _prof_end("attention", e0, 4.0 * Bn * H * T * T * 64, ("fwd", Bn, T, H))
+    _prof_end(_attn_family(), e0, 4.0 * Bn * H * T * T * 64, ("fwd", Bn, T, H))
     return out, lse
 
 
@@ -478,7 +485,7 @@ def attention_bwd(dout, qkv, out, lse, Bn, T, H):
     e0 = _prof_begin()
     L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv), _st()),
             "svl_attention_bwd")
-    _prof_end("attention", e0, 14.0 * Bn * H * T * T * 64, ("bwd", Bn, T, H))
+    _prof_end(_attn_family(), e0, 14.0 * Bn * H * T * T * 64, ("bwd", Bn, T, H))
     return dqkv
 
 
