@@ -504,6 +504,204 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 pipe (svl_set_gemm_emulation(6): 3 bf16 terms per value, 6 cross products, fp32
+// accumulate -- error vs fp64 at or below the fp32 kernel's).  The MFMA k index is the PIXEL, and the bf16 MFMA wants 8
+// consecutive k per lane, so both operands are staged TRANSPOSED: dy^T [co][64 px] and x^T [ci][6 halo rows x 24 px
+// slots] (thread = one channel x 8 consecutive pixels: 8 channel-coalesced dword loads, split, one ds_write_b128 per
+// plane; rows padded to an odd number of 16 B slots: conflict-free reads and writes).  A patch is 4 rows x 16 px; one
+// MFMA k-step = one patch row (lane half hi = pixels 8 hi .. 8 hi + 7).  The tap shift: ty selects the halo row, tx
+// (0, 1, 2) slides the 8-pixel window -- tx = 0 is the aligned 16 B slot, tx = 2 is the same words one register over
+// (plus one dword of the next slot), tx = 1 is four v_alignbit_b32 per plane.  So a wave owns ONE (tile, ty) pair and
+// its three tx accumulators share every LDS read: 6 waves = 2 co tiles x 3 ty (Co = 64, 32-channel slab) or 2 ci tiles x
+// 3 ty (Co = 32, 64-channel slab; Ct = 32 stays on the fp32 kernel).
+constexpr int WPH = 4, WIH = WPH + 2;
+constexpr int DCH = 2 * WPH, DRS = (DCH + 1) * 8;      // dy^T: 8 slots per row, row stride 9 slots (bf16 elements)
+constexpr int XCH = 3 * WIH, XRS = (XCH + 1) * 8;      // x^T: 18 slots per row, row stride 19 slots
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3w(const float (&v)[8], u32x4_t (&h)[3]) {   // 5.5 VALU per element, pairs packed
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = v[j];
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      const f32x2_t pr = {x[2 * jp], x[2 * jp + 1]};
+      const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_t));
+      h[pl][jp] = u;
+      if (pl < 2) {
+        x[2 * jp] -= __builtin_bit_cast(float, u << 16);
+        x[2 * jp + 1] -= __builtin_bit_cast(float, u & 0xffff0000u);
+      }
+    }
+}
+
+// <MT, NT> = (2, 1): Co = 64, slab of 32 input channels, wave = (co tile, ty); (1, 2): Co = 32, slab of 64 input
+// channels, wave = (ci tile, ty).  Either way a block issues 4 k-steps x 18 tiles x 6 products per patch.
+template <int MT, int NT>
+__global__ __launch_bounds__(384) void conv3x3_wgrad_tiled_bf16x_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
+  static_assert(MT * NT == 2, "six waves = two tiles x three tap rows");
+  constexpr int Co = 32 * MT, SL = 32 * NT;
+  constexpr int DPL = Co * DRS, XPL = SL * XRS;          // plane strides (elements)
+  constexpr int NDC = DCH * Co, NXC = XCH * SL;           // thread-chunks per patch
+  constexpr int ND = (NDC + 383) / 384, NX = (NXC + 383) / 384;
+  __shared__ __attribute__((aligned(16))) __bf16 dsT[3 * DPL];
+  __shared__ __attribute__((aligned(16))) __bf16 xsT[3 * XPL];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x, slab = blockIdx.y, ngrp = gridDim.x;
+  const int c0 = slab * SL, Ct = p.C1 + p.C2;
+  const int npatch = p.imgs * tiles_x * tiles_y;
+  const int mt = MT == 2 ? (wave & 1) : 0, nt = NT == 2 ? (wave & 1) : 0, ty = wave >> 1;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // staging assignment (fixed per thread): ND dy chunks (channel dco, slot dch) and NX x chunks (channel xci, slot xch)
+  float rd[ND][8], rx[NX][8];
+  int dco[ND], dch[ND], xci[NX], xch[NX], xdiv[NX];
+  bool dok[ND], xok[NX];
+  const float* xsrc[NX];  // channel column of this thread's x chunks in its concat source (selected ONCE: the loads stay
+  long xld[NX];           // unconditional -- a per-lane choice of source inside the loop turns every load into a branch)
+#pragma unroll
+  for (int z = 0; z < ND; ++z) {
+    const int f = tid + 384 * z;
+    dok[z] = f < NDC;
+    dco[z] = f % Co; dch[z] = dok[z] ? f / Co : 0;
+  }
+#pragma unroll
+  for (int z = 0; z < NX; ++z) {
+    const int f = tid + 384 * z;
+    xok[z] = f < NXC;
+    xci[z] = f % SL; xch[z] = xok[z] ? f / SL : 0;
+    const bool second = c0 + xci[z] >= p.C1;
+    xsrc[z] = second ? p.src2 + (c0 + xci[z] - p.C1) : p.src1 + (c0 + xci[z]);
+    xld[z] = second ? p.ld2 : p.ld1;
+    xdiv[z] = second ? p.rep : 1;
+  }
+  // gload = unconditional loads at clamped coordinates, nothing else: the zeroing of out-of-image pixels happens in
+  // sstore, on the far side of the compute phase and its barrier (a select next to the load makes the compiler sink the
+  // load under the condition -- one exec-masked branch and one s_waitcnt per element).
+  auto coords = [&](int pi, int& img, int& y0, int& x0) {
+    int t = pi;
+    const int txi = t % tiles_x;
+    t /= tiles_x;
+    const int tyi = t % tiles_y;
+    img = t / tiles_y;
+    y0 = tyi * WPH; x0 = txi * PW;
+  };
+  auto gload = [&](int pi) {
+    int img, y0, x0;
+    coords(pi, img, y0, x0);
+#pragma unroll
+    for (int z = 0; z < ND; ++z) {
+      const int y = y0 + (dch[z] >> 1), xb = x0 + 8 * (dch[z] & 1);
+      const float* q = p.dy + (((long)img * p.H + min(y, p.H - 1)) * p.W) * p.lddy + dco[z];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rd[z][j] = q[(long)min(xb + j, p.W - 1) * p.lddy];
+    }
+#pragma unroll
+    for (int z = 0; z < NX; ++z) {
+      const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
+      const int yc = min(max(y0 - 1 + hr, 0), p.H - 1), xb = x0 - 1 + 8 * cg;
+      const float* q = xsrc[z] + (((long)(img / xdiv[z]) * p.H + yc) * p.W) * xld[z];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rx[z][j] = q[(long)min(max(xb + j, 0), p.W - 1) * xld[z]];
+    }
+  };
+  auto sstore = [&](int pi) {
+    int img, y0, x0;
+    coords(pi, img, y0, x0);
+#pragma unroll
+    for (int z = 0; z < ND; ++z) {
+      u32x4_t h[3];
+      const int y = y0 + (dch[z] >> 1), xb = x0 + 8 * (dch[z] & 1);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (y < p.H && xb + j < p.W) ? rd[z][j] : 0.f;
+      split3w(v, h);
+      if (dok[z]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4_t*>(dsT + pl * DPL + dco[z] * DRS + dch[z] * 8) = h[pl];
+      }
+    }
+#pragma unroll
+    for (int z = 0; z < NX; ++z) {
+      u32x4_t h[3];
+      const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
+      const int y = y0 - 1 + hr, xb = x0 - 1 + 8 * cg;
+      const bool rowok = y >= 0 && y < p.H;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (rowok && xb + j >= 0 && xb + j < p.W && 8 * cg + j < IW) ? rx[z][j] : 0.f;
+      split3w(v, h);
+      if (xok[z]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4_t*>(xsT + pl * XPL + xci[z] * XRS + xch[z] * 8) = h[pl];
+      }
+    }
+  };
+
+  int pi = g;
+  if (pi < npatch) {
+    gload(pi);
+    sstore(pi);
+  }
+  __syncthreads();
+  const __bf16* da = dsT + (l31 + 32 * mt) * DRS + hi * 8;
+  const __bf16* xb_ = xsT + (l31 + 32 * nt) * XRS + (ty * 3 + hi) * 8;
+  for (; pi < npatch; pi += ngrp) {
+    const bool more = pi + ngrp < npatch;
+    if (more) gload(pi + ngrp);
+#pragma unroll
+    for (int r = 0; r < WPH; ++r) {
+      bf16x8 a[3], b0[3], b1[3], b2[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        a[pl] = *reinterpret_cast<const bf16x8*>(da + pl * DPL + 2 * r * 8);
+        const __bf16* q = xb_ + pl * XPL + 3 * r * 8;
+        const u32x4_t w = *reinterpret_cast<const u32x4_t*>(q);
+        const unsigned w4 = *reinterpret_cast<const unsigned*>(q + 8);
+        b0[pl] = __builtin_bit_cast(bf16x8, w);
+        const u32x4_t s1 = {__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                            __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};
+        const u32x4_t s2 = {w[1], w[2], w[3], w4};
+        b1[pl] = __builtin_bit_cast(bf16x8, s1);
+        b2[pl] = __builtin_bit_cast(bf16x8, s2);
+      }
+      // smallest cross terms first; the three tx accumulators alternate (dependent MFMAs are 3 apart)
+#define SVL_W6(PA, PB)                                                                               \
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b0[PB], acc[0], 0, 0, 0);                      \
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b1[PB], acc[1], 0, 0, 0);                      \
+  acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b2[PB], acc[2], 0, 0, 0);
+      SVL_W6(2, 0) SVL_W6(0, 2) SVL_W6(1, 1) SVL_W6(1, 0) SVL_W6(0, 1) SVL_W6(0, 0)
+#undef SVL_W6
+    }
+    __syncthreads();
+    if (more) {
+      sstore(pi + ngrp);
+      __syncthreads();
+    }
+  }
+  // C layout: row i = co (within the tile), column = lane = ci; tap = 3 ty + tx
+  float* out = p.slabs + (long)g * Co * 9 * Ct;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      out[(long)co * 9 * Ct + (3 * ty + t) * Ct + c0 + 32 * nt + l31] = acc[t][r];
+    }
+}
+
 }  // namespace
 
 extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, int Co) {
@@ -511,6 +709,9 @@ extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, in
   const int nslab = Ct / 32;
   // measured: Co = 64 is best with one full round of its 2 resident blocks per CU, Co = 32 with 1.5x that
   long g = (Co > 32 ? 512 : 768) / (nslab < 1 ? 1 : nslab);
+  // (the bf16 x 6 kernel of Co = 32 works on 64-channel slabs: one round of 2 blocks per CU; any value is valid for
+  //  either kernel, the switch is only read here to size the grid well)
+  if (Co == 32 && Ct % 64 == 0 && svl_get_gemm_emulation() == 6 && !getenv("SVL_CONV_TILED_NO_EMU")) g = 512 / (Ct / 64);
   if (g < 1) g = 1;
   if (g > npatch) g = npatch;
   return (int)g;
@@ -533,7 +734,12 @@ extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, co
   const int tx = (W + PW - 1) / PW, ty = (H + PH - 1) / PH;
   dim3 grid((unsigned)groups, (unsigned)(Ct / 32));
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<1, 32>), grid, dim3(256), 0, st, p, tx, ty);
+  static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
+  if (emu_ok && svl_get_gemm_emulation() == 6 && (Co == 64 || Ct % 64 == 0)) {   // the split emulation covers the weight gradient too
+    const int ty4 = (H + WPH - 1) / WPH;
+    if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(384), 0, st, p, tx, ty4);
+    else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<2, 1>), grid, dim3(384), 0, st, p, tx, ty4);
+  } else if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<1, 32>), grid, dim3(256), 0, st, p, tx, ty);
   else hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<2, 32>), grid, dim3(256), 0, st, p, tx, ty);
   SVL_LAUNCH_CHECK("svl_conv3x3_wgrad_tiled");
   return SVL_OK;

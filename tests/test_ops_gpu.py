@@ -912,8 +912,9 @@ def test_tiled_narrow_conv3x3_split_emulation(dev, emu_mode, b, N, H, W, C1, C2,
     dy = rnd(imgs, H, W, Co, dev=dev, seed=64)
     wf, wd = ops.pack_conv_w(w)
     xin = (x1 if not C2 else torch.cat([x1, x2.repeat_interleave(N, 0)], -1)).permute(0, 3, 1, 2).double().requires_grad_(True)
-    ref = F.conv2d(xin, w.double(), padding=1)
-    (gx,) = torch.autograd.grad(ref, xin, dy.permute(0, 3, 1, 2).double())
+    wdbl = w.double().requires_grad_(True)
+    ref = F.conv2d(xin, wdbl, padding=1)
+    gx, gw = torch.autograd.grad(ref, [xin, wdbl], dy.permute(0, 3, 1, 2).double())
     ref, gx = ref.permute(0, 2, 3, 1), gx.permute(0, 2, 3, 1)
     kw = dict(src2=x2.view(-1, C2) if C2 else None, ld2=C2, C2=C2, rep=N)
     err = {}
@@ -921,8 +922,12 @@ def test_tiled_narrow_conv3x3_split_emulation(dev, emu_mode, b, N, H, W, C1, C2,
         emu_mode(mode)
         y = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, **kw)
         dx = ops.conv_dgrad(dy.view(-1, Co), Co, imgs, H, W, Co, wd, C1 + C2, 3, 3, 1, 1)
-        err[mode] = (_relerr(y.view(imgs, H, W, Co), ref), _relerr(dx.view(imgs, H, W, C1 + C2), gx))
+        dwf = ops.conv_wgrad(dy.view(-1, Co), Co, x1.view(-1, C1), C1, imgs, H, W, C1, Co, 3, 3, 1, 1, **kw)
+        dw = ops.unpack_conv_wgrad(dwf, Co, C1 + C2, 3, 3)
+        assert torch.equal(dwf, ops.conv_wgrad(dy.view(-1, Co), Co, x1.view(-1, C1), C1, imgs, H, W, C1, Co, 3, 3, 1, 1, **kw))
+        err[mode] = (_relerr(y.view(imgs, H, W, Co), ref), _relerr(dx.view(imgs, H, W, C1 + C2), gx), _relerr(dw, gw))
     assert err[6][0] <= 1.5 * err[0][0] + 1e-8 and err[6][1] <= 1.5 * err[0][1] + 1e-8, err
+    assert err[6][2] <= 1.5 * err[0][2] + 1e-8, err      # weight gradient (conv3x3_wgrad_tiled_bf16x_kernel)
     emu_mode(6)
     bias = rnd(Co, dev=dev)
     y = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, bias=bias, act=ops.ACT_RELU, **kw)
