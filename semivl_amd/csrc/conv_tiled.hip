@@ -544,7 +544,7 @@ __device__ __forceinline__ void split3w(const float (&v)[8], u32x4_t (&h)[3]) { 
 // <MT, NT> = (2, 1): Co = 64, slab of 32 input channels, wave = (co tile, ty); (1, 2): Co = 32, slab of 64 input
 // channels, wave = (ci tile, ty).  Either way a block issues 4 k-steps x 18 tiles x 6 products per patch.
 template <int MT, int NT>
-__global__ __launch_bounds__(384) void conv3x3_wgrad_tiled_bf16x_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_wgrad_tiled_bf16x_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
   static_assert(MT * NT == 2, "six waves = two tiles x three tap rows");
   constexpr int Co = 32 * MT, SL = 32 * NT;
   constexpr int DPL = Co * DRS, XPL = SL * XRS;          // plane strides (elements)
@@ -565,17 +565,26 @@ __global__ __launch_bounds__(384) void conv3x3_wgrad_tiled_bf16x_kernel(const Wg
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // staging assignment (fixed per thread): ND dy chunks (channel dco, slot dch) and NX x chunks (channel xci, slot xch)
+  // staging assignment (fixed per thread): ND dy chunks (channel dco, slot dch) and NX x chunks (channel xci, slot xch).
+  // Addressing is the expensive part of a transposed staging (one dword per lane and load), so everything that does not
+  // change from patch to patch is hoisted: byte offset inside the IMAGE = thread constant + (y0 W + x0) ld (+ j ld),
+  // clamped into the image (reads past an edge land on a neighbouring pixel and are zeroed in sstore), added to the
+  // image's base pointer.
   float rd[ND][8], rx[NX][8];
   int dco[ND], dch[ND], xci[NX], xch[NX], xdiv[NX];
   bool dok[ND], xok[NX];
-  const float* xsrc[NX];  // channel column of this thread's x chunks in its concat source (selected ONCE: the loads stay
-  long xld[NX];           // unconditional -- a per-lane choice of source inside the loop turns every load into a branch)
+  int dtc[ND], dmax[ND], xtp[NX], xch4[NX], xmax[NX], xld4[NX];
+  const char* xsrc[NX];   // (channel 0 of) this thread's concat source -- selected ONCE: a per-lane choice of source inside
+                          // the loop would turn every load into a branch
+  long ximg[NX];          // bytes per image of that source
+  const int dld4 = (int)p.lddy * 4;
 #pragma unroll
   for (int z = 0; z < ND; ++z) {
     const int f = tid + 384 * z;
     dok[z] = f < NDC;
     dco[z] = f % Co; dch[z] = dok[z] ? f / Co : 0;
+    dtc[z] = ((dch[z] >> 1) * p.W + 8 * (dch[z] & 1)) * dld4 + dco[z] * 4;
+    dmax[z] = (p.H * p.W - 1) * dld4 + dco[z] * 4;
   }
 #pragma unroll
   for (int z = 0; z < NX; ++z) {
@@ -583,11 +592,16 @@ __global__ __launch_bounds__(384) void conv3x3_wgrad_tiled_bf16x_kernel(const Wg
     xok[z] = f < NXC;
     xci[z] = f % SL; xch[z] = xok[z] ? f / SL : 0;
     const bool second = c0 + xci[z] >= p.C1;
-    xsrc[z] = second ? p.src2 + (c0 + xci[z] - p.C1) : p.src1 + (c0 + xci[z]);
-    xld[z] = second ? p.ld2 : p.ld1;
+    xsrc[z] = reinterpret_cast<const char*>(second ? p.src2 : p.src1);
+    xld4[z] = (int)(second ? p.ld2 : p.ld1) * 4;
     xdiv[z] = second ? p.rep : 1;
+    ximg[z] = (long)p.H * p.W * xld4[z];
+    xch4[z] = (second ? c0 + xci[z] - p.C1 : c0 + xci[z]) * 4;
+    const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
+    xtp[z] = (hr - 1) * p.W + 8 * cg - 1;                      // pixel offset of element 0 from the patch origin
+    xmax[z] = (p.H * p.W - 1) * xld4[z] + xch4[z];
   }
-  // gload = unconditional loads at clamped coordinates, nothing else: the zeroing of out-of-image pixels happens in
+  // gload = unconditional loads at clamped addresses, nothing else: the zeroing of out-of-image pixels happens in
   // sstore, on the far side of the compute phase and its barrier (a select next to the load makes the compiler sink the
   // load under the condition -- one exec-masked branch and one s_waitcnt per element).
   auto coords = [&](int pi, int& img, int& y0, int& x0) {
@@ -601,32 +615,41 @@ __global__ __launch_bounds__(384) void conv3x3_wgrad_tiled_bf16x_kernel(const Wg
   auto gload = [&](int pi) {
     int img, y0, x0;
     coords(pi, img, y0, x0);
+    const int spix = y0 * p.W + x0;
+    const char* dimg = reinterpret_cast<const char*>(p.dy) + (long)img * p.H * p.W * dld4;
 #pragma unroll
     for (int z = 0; z < ND; ++z) {
-      const int y = y0 + (dch[z] >> 1), xb = x0 + 8 * (dch[z] & 1);
-      const float* q = p.dy + (((long)img * p.H + min(y, p.H - 1)) * p.W) * p.lddy + dco[z];
+      const int o0 = dtc[z] + spix * dld4;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) rd[z][j] = q[(long)min(xb + j, p.W - 1) * p.lddy];
+      for (int j = 0; j < 8; ++j) rd[z][j] = *reinterpret_cast<const float*>(dimg + (unsigned)min(o0 + j * dld4, dmax[z]));
     }
 #pragma unroll
     for (int z = 0; z < NX; ++z) {
-      const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
-      const int yc = min(max(y0 - 1 + hr, 0), p.H - 1), xb = x0 - 1 + 8 * cg;
-      const float* q = xsrc[z] + (((long)(img / xdiv[z]) * p.H + yc) * p.W) * xld[z];
+      const char* ximgp = xsrc[z] + (long)(img / xdiv[z]) * ximg[z];
+      int o = (spix + xtp[z]) * xld4[z] + xch4[z];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) rx[z][j] = q[(long)min(max(xb + j, 0), p.W - 1) * xld[z]];
+      for (int j = 0; j < 8; ++j) {
+        rx[z][j] = *reinterpret_cast<const float*>(ximgp + (unsigned)min(max(o, xch4[z]), xmax[z]));
+        o += xld4[z];
+      }
     }
   };
   auto sstore = [&](int pi) {
     int img, y0, x0;
     coords(pi, img, y0, x0);
+    // patches whose halo lies inside the image need no zeroing at all (uniform branch)
+    const bool inner = y0 >= 1 && y0 + WPH + 1 <= p.H && x0 >= 1 && x0 + PW + 1 <= p.W;
 #pragma unroll
     for (int z = 0; z < ND; ++z) {
       u32x4_t h[3];
-      const int y = y0 + (dch[z] >> 1), xb = x0 + 8 * (dch[z] & 1);
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (y < p.H && xb + j < p.W) ? rd[z][j] : 0.f;
+      for (int j = 0; j < 8; ++j) v[j] = rd[z][j];
+      if (!inner) {
+        const int y = y0 + (dch[z] >> 1), xb = x0 + 8 * (dch[z] & 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (y < p.H && xb + j < p.W) ? v[j] : 0.f;
+      }
       split3w(v, h);
       if (dok[z]) {
 #pragma unroll
@@ -636,13 +659,17 @@ __global__ __launch_bounds__(384) void conv3x3_wgrad_tiled_bf16x_kernel(const Wg
 #pragma unroll
     for (int z = 0; z < NX; ++z) {
       u32x4_t h[3];
-      const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
-      const int y = y0 - 1 + hr, xb = x0 - 1 + 8 * cg;
-      const bool rowok = y >= 0 && y < p.H;
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (rowok && xb + j >= 0 && xb + j < p.W && 8 * cg + j < IW) ? rx[z][j] : 0.f;
-      split3w(v, h);
+      for (int j = 0; j < 8; ++j) v[j] = rx[z][j];
+      if (!inner) {
+        const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
+        const int y = y0 - 1 + hr, xb = x0 - 1 + 8 * cg;
+        const bool rowok = y >= 0 && y < p.H;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (rowok && xb + j >= 0 && xb + j < p.W) ? v[j] : 0.f;
+      }
+      split3w(v, h);     // (halo columns 18..23 of a row are staged but never read: finite neighbours, no mask needed)
       if (xok[z]) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4_t*>(xsT + pl * XPL + xci[z] * XRS + xch[z] * 8) = h[pl];
@@ -668,8 +695,11 @@ __global__ __launch_bounds__(384) void conv3x3_wgrad_tiled_bf16x_kernel(const Wg
       for (int pl = 0; pl < 3; ++pl) {
         a[pl] = *reinterpret_cast<const bf16x8*>(da + pl * DPL + 2 * r * 8);
         const __bf16* q = xb_ + pl * XPL + 3 * r * 8;
-        const u32x4_t w = *reinterpret_cast<const u32x4_t*>(q);
-        const unsigned w4 = *reinterpret_cast<const unsigned*>(q + 8);
+        // two whole 16 B slots, made opaque: left alone the compiler re-reads the shifted words one dword at a time, and
+        // dword reads of 32 rows whose stride is a multiple of 16 B are 4-way bank conflicts (PMC: 56 % of the LDS cycles)
+        u32x4_t w = *reinterpret_cast<const u32x4_t*>(q), wn = *reinterpret_cast<const u32x4_t*>(q + 8);
+        asm("" : "+v"(w), "+v"(wn));
+        const unsigned w4 = wn[0];
         b0[pl] = __builtin_bit_cast(bf16x8, w);
         const u32x4_t s1 = {__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
                             __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};

@@ -1515,8 +1515,13 @@ extern "C" int svl_set_conv_tiled(int on) {
   return SVL_OK;
 }
 extern "C" int svl_get_gemm_emulation(void) {
-  const int m = g_emu_mode.load(std::memory_order_relaxed);
-  return m < 0 ? 0 : m;
+  int m = g_emu_mode.load(std::memory_order_relaxed);
+  if (m < 0) {   // first use: the environment decides (the attention / tiled-conv dispatch may ask before any GEMM ran)
+    m = env_int("SVL_GEMM_EMU", 0);
+    if (m != 3 && m != 6) m = 0;
+    g_emu_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
 }
 
 extern "C" int svl_reduce_slabs_f32(float* out, const float* slabs, int nslab, int64_t count, int accumulate,

@@ -3,7 +3,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from semivl_amd import ops
 dev = torch.device("cuda:0")
-C, Co, Hh, imgs = int(os.environ.get("ONE_C", 32)), int(os.environ.get("ONE_CO", 32)), 128, 336
+ops.set_gemm_emulation(int(os.environ.get("EMU", "0")))   # 6: the bf16 x 6 kernels
+C, Co, Hh, imgs = int(os.environ.get("ONE_C", 32)), int(os.environ.get("ONE_CO", 32)), int(os.environ.get("ONE_HW", 128)), int(os.environ.get("ONE_IMGS", 336))
 x = torch.randn(imgs * Hh * Hh, C, device=dev)
 w = torch.randn(Co, C, 3, 3, device=dev)
 wf, wd = ops.pack_conv_w(w)
