@@ -555,6 +555,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = blockIdx.x, slab = blockIdx.y, ngrp = gridDim.x;
+  const int cz = Co * blockIdx.z;                         // Co = 128 layers: two launches' worth of 64 output channels
   const int c0 = slab * SL, Ct = p.C1 + p.C2;
   const int npatch = p.imgs * tiles_x * tiles_y;
   const int mt = MT == 2 ? (wave & 1) : 0, nt = NT == 2 ? (wave & 1) : 0, ty = wave >> 1;
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int img, y0, x0;
     coords(pi, img, y0, x0);
     const int spix = y0 * p.W + x0;
-    const char* dimg = reinterpret_cast<const char*>(p.dy) + (long)img * p.H * p.W * dld4;
+    const char* dimg = reinterpret_cast<const char*>(p.dy + cz) + (long)img * p.H * p.W * dld4;
 #pragma unroll
     for (int z = 0; z < ND; ++z) {
       const int o0 = dtc[z] + spix * dld4;
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   }
   // C layout: row i = co (within the tile), column = lane = ci; tap = 3 ty + tx
-  float* out = p.slabs + (long)g * Co * 9 * Ct;
+  float* out = p.slabs + ((long)g * Co * gridDim.z + cz) * 9 * Ct;
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -742,6 +743,7 @@ extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, in
   // (the bf16 x 6 kernel of Co = 32 works on 64-channel slabs: one round of 2 blocks per CU; any value is valid for
   //  either kernel, the switch is only read here to size the grid well)
   if (Co == 32 && Ct % 64 == 0 && svl_get_gemm_emulation() == 6 && !getenv("SVL_CONV_TILED_NO_EMU")) g = 512 / (Ct / 64);
+  if (Co == 128) g = 256 / (nslab < 1 ? 1 : nslab);
   if (g < 1) g = 1;
   if (g > npatch) g = npatch;
   return (int)g;
@@ -751,7 +753,10 @@ extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, co
                                        const float* src2, int64_t ld2, int C2, int rep, int imgs, int H, int W,
                                        float* slabs, int groups, svl_stream_t stream) {
   auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-  SVL_CHECK_ARG(dy && src1 && slabs && (Co == 32 || Co == 64) && C1 > 0 && C1 % 4 == 0 && C2 >= 0 && C2 % 4 == 0 &&
+  static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
+  const bool emu6 = emu_ok && svl_get_gemm_emulation() == 6;
+  // Co = 128 exists on the bf16 x 6 kernel only (two blocks of 64 output channels per patch group)
+  SVL_CHECK_ARG(dy && src1 && slabs && (Co == 32 || Co == 64 || (Co == 128 && emu6)) && C1 > 0 && C1 % 4 == 0 && C2 >= 0 && C2 % 4 == 0 &&
                     (C1 + C2) % 32 == 0 &&
                     lddy % 4 == 0 && ld1 % 4 == 0 && a16(dy) && a16(src1) && imgs > 0 && H >= PH && W >= PW &&
                     groups >= 1 && (C2 == 0 || (src2 && rep >= 1 && ld2 % 4 == 0 && a16(src2))),
@@ -764,11 +769,10 @@ extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, co
   const int tx = (W + PW - 1) / PW, ty = (H + PH - 1) / PH;
   dim3 grid((unsigned)groups, (unsigned)(Ct / 32));
   hipStream_t st = (hipStream_t)stream;
-  static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
-  if (emu_ok && svl_get_gemm_emulation() == 6 && (Co == 64 || Ct % 64 == 0)) {   // the split emulation covers the weight gradient too
+  if (emu6 && (Co >= 64 || Ct % 64 == 0)) {   // the split emulation covers the weight gradient too
     const int ty4 = (H + WPH - 1) / WPH;
     if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(384), 0, st, p, tx, ty4);
-    else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<2, 1>), grid, dim3(384), 0, st, p, tx, ty4);
+    else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<2, 1>), dim3((unsigned)groups, (unsigned)(Ct / 32), (unsigned)(Co / 64)), dim3(384), 0, st, p, tx, ty4);
   } else if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<1, 32>), grid, dim3(256), 0, st, p, tx, ty);
   else hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<2, 32>), grid, dim3(256), 0, st, p, tx, ty);
   SVL_LAUNCH_CHECK("svl_conv3x3_wgrad_tiled");

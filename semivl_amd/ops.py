@@ -626,7 +626,8 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
     Ho, Wo = conv_out_size(H, W, KH, KW, dil, pad, stride) if stride != 1 else (H, W)
     Kpix = imgs * Ho * Wo
     N = KH * KW * (C1 + C2)
-    if (CONV_TILED and KH == 3 and KW == 3 and dil == 1 and pad == 1 and stride == 1 and Co in (32, 64) and
+    co_ok = Co in (32, 64) or (Co == 128 and get_gemm_emulation() == 6 and not os.environ.get("SVL_CONV_TILED_NO_EMU"))
+    if (CONV_TILED and KH == 3 and KW == 3 and dil == 1 and pad == 1 and stride == 1 and co_ok and
             C1 % 4 == 0 and C2 % 4 == 0 and (C1 + C2) % 32 == 0 and H >= 8 and W >= 16 and Kpix >= 16384 and lddy % 4 == 0 and ldx % 4 == 0 and
             (C2 == 0 or ld2 % 4 == 0)):
         # narrow layers: spatially tiled weight-gradient kernel (conv_tiled.hip), slabs reduced in fixed order

@@ -899,7 +899,7 @@ def test_tiled_narrow_conv3x3(dev, b, N, H, W, C1, C2, Co):
 
 
 @pytest.mark.parametrize("b,N,H,W,C1,C2,Co", [(2, 6, 32, 48, 48, 16, 32), (2, 4, 40, 56, 96, 32, 64), (1, 3, 72, 80, 64, 0, 64),
-                                              (3, 8, 19, 37, 16, 16, 32)])
+                                              (3, 8, 19, 37, 16, 16, 32), (2, 8, 32, 32, 96, 32, 128), (1, 5, 61, 70, 32, 0, 32)])
 def test_tiled_narrow_conv3x3_split_emulation(dev, emu_mode, b, N, H, W, C1, C2, Co):
     """conv3x3_tiled_bf16x_kernel (mode 6: forward and mirrored-tap input gradient of the narrow 3x3 convolutions on the
     bf16 pipe): error vs fp64 at or below the fp32 tiled kernel's; two concat sources, ragged patches, bias / ReLU /
