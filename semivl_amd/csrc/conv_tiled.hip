@@ -543,29 +543,32 @@ __device__ __forceinline__ void split3w(const float (&v)[8], u32x4_t (&h)[3]) { 
 
 // <MT, NT> = (2, 1): Co = 64, slab of 32 input channels, wave = (co tile, ty); (1, 2): Co = 32, slab of 64 input
 // channels, wave = (ci tile, ty).  Either way a block issues 4 k-steps x 18 tiles x 6 products per patch.
+// Twelve waves per block: waves 0..5 are CONSUMERS (LDS fragments + MFMAs of patch i out of buffer i & 1), waves 6..11 are
+// PRODUCERS (loads of patch i + 2, split + store of patch i + 1 into the other buffer) -- one barrier per patch, and on
+// every SIMD the matrix pipe and the VALU / memory pipes are fed by different waves at the same time.  (With six waves
+// doing both in turn, two barriers per patch, the kernel sat at 30 % MFMA-busy with 43 % of the wave time waiting.)
 template <int MT, int NT>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_wgrad_tiled_bf16x_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
-  static_assert(MT * NT == 2, "six waves = two tiles x three tap rows");
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_wgrad_tiled_bf16x_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
+  static_assert(MT * NT == 2, "six consumer waves = two tiles x three tap rows");
   constexpr int Co = 32 * MT, SL = 32 * NT;
   constexpr int DPL = Co * DRS, XPL = SL * XRS;          // plane strides (elements)
   constexpr int NDC = DCH * Co, NXC = XCH * SL;           // thread-chunks per patch
   constexpr int ND = (NDC + 383) / 384, NX = (NXC + 383) / 384;
-  __shared__ __attribute__((aligned(16))) __bf16 dsT[3 * DPL];
-  __shared__ __attribute__((aligned(16))) __bf16 xsT[3 * XPL];
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int BUFE = 3 * (DPL + XPL);                   // one buffer: dy^T planes, then x^T planes
+  __shared__ __attribute__((aligned(16))) __bf16 smw[2 * BUFE];
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool producer = wave_all >= 6;
+  const int tid = threadIdx.x - (producer ? 384 : 0), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = producer ? wave_all - 6 : wave_all;
   const int g = blockIdx.x, slab = blockIdx.y, ngrp = gridDim.x;
   const int cz = Co * blockIdx.z;                         // Co = 128 layers: two launches' worth of 64 output channels
   const int c0 = slab * SL, Ct = p.C1 + p.C2;
   const int npatch = p.imgs * tiles_x * tiles_y;
   const int mt = MT == 2 ? (wave & 1) : 0, nt = NT == 2 ? (wave & 1) : 0, ty = wave >> 1;
 
-  f32x16 acc[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
+  // The two roles run SEPARATE loops with the same number of barriers (one before the first patch, one per patch), so that
+  // neither role's registers are live in the other's loop.
+  if (producer) {
   // staging assignment (fixed per thread): ND dy chunks (channel dco, slot dch) and NX x chunks (channel xci, slot xch).
   // Addressing is the expensive part of a transposed staging (one dword per lane and load), so everything that does not
   // change from patch to patch is hoisted: byte offset inside the IMAGE = thread constant + (y0 W + x0) ld (+ j ld),
@@ -635,7 +638,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
     }
   };
-  auto sstore = [&](int pi) {
+  auto sstore = [&](int pi, int buf) {
+    __bf16* dsT = smw + buf * BUFE;
+    __bf16* xsT = dsT + 3 * DPL;
     int img, y0, x0;
     coords(pi, img, y0, x0);
     // patches whose halo lies inside the image need no zeroing at all (uniform branch)
@@ -678,49 +683,61 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   };
 
-  int pi = g;
-  if (pi < npatch) {
-    gload(pi);
-    sstore(pi);
+    int pi = g;
+    if (pi < npatch) {
+      gload(pi);
+      sstore(pi, 0);
+      if (pi + ngrp < npatch) gload(pi + ngrp);
+    }
+    __syncthreads();
+    for (int it = 0; pi < npatch; pi += ngrp, ++it) {
+      if (pi + ngrp < npatch) sstore(pi + ngrp, (it + 1) & 1);       // (loaded during the previous patch)
+      if (pi + 2 * ngrp < npatch) gload(pi + 2 * ngrp);
+      __syncthreads();
+    }
+    return;
   }
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int fa = (l31 + 32 * mt) * DRS + hi * 8, fb = 3 * DPL + (l31 + 32 * nt) * XRS + (ty * 3 + hi) * 8;
   __syncthreads();
-  const __bf16* da = dsT + (l31 + 32 * mt) * DRS + hi * 8;
-  const __bf16* xb_ = xsT + (l31 + 32 * nt) * XRS + (ty * 3 + hi) * 8;
-  for (; pi < npatch; pi += ngrp) {
-    const bool more = pi + ngrp < npatch;
-    if (more) gload(pi + ngrp);
+  for (int it = 0, pi = g; pi < npatch; pi += ngrp, ++it) {
+    {
+      const __bf16* da = smw + (it & 1) * BUFE + fa;
+      const __bf16* xb_ = smw + (it & 1) * BUFE + fb;
 #pragma unroll
-    for (int r = 0; r < WPH; ++r) {
-      bf16x8 a[3], b0[3], b1[3], b2[3];
+      for (int r = 0; r < WPH; ++r) {
+        bf16x8 a[3], b0[3], b1[3], b2[3];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        a[pl] = *reinterpret_cast<const bf16x8*>(da + pl * DPL + 2 * r * 8);
-        const __bf16* q = xb_ + pl * XPL + 3 * r * 8;
-        // two whole 16 B slots, made opaque: left alone the compiler re-reads the shifted words one dword at a time, and
-        // dword reads of 32 rows whose stride is a multiple of 16 B are 4-way bank conflicts (PMC: 56 % of the LDS cycles)
-        u32x4_t w = *reinterpret_cast<const u32x4_t*>(q), wn = *reinterpret_cast<const u32x4_t*>(q + 8);
-        asm("" : "+v"(w), "+v"(wn));
-        const unsigned w4 = wn[0];
-        b0[pl] = __builtin_bit_cast(bf16x8, w);
-        const u32x4_t s1 = {__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
-                            __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};
-        const u32x4_t s2 = {w[1], w[2], w[3], w4};
-        b1[pl] = __builtin_bit_cast(bf16x8, s1);
-        b2[pl] = __builtin_bit_cast(bf16x8, s2);
-      }
-      // smallest cross terms first; the three tx accumulators alternate (dependent MFMAs are 3 apart)
+        for (int pl = 0; pl < 3; ++pl) {
+          a[pl] = *reinterpret_cast<const bf16x8*>(da + pl * DPL + 2 * r * 8);
+          const __bf16* q = xb_ + pl * XPL + 3 * r * 8;
+          // two whole 16 B slots, made opaque: left alone the compiler re-reads the shifted words one dword at a time, and
+          // dword reads of 32 rows whose stride is a multiple of 16 B are 4-way bank conflicts (PMC: 56 % of the LDS cycles)
+          u32x4_t w = *reinterpret_cast<const u32x4_t*>(q), wn = *reinterpret_cast<const u32x4_t*>(q + 8);
+          asm("" : "+v"(w), "+v"(wn));
+          const unsigned w4 = wn[0];
+          b0[pl] = __builtin_bit_cast(bf16x8, w);
+          const u32x4_t s1 = {__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                              __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};
+          const u32x4_t s2 = {w[1], w[2], w[3], w4};
+          b1[pl] = __builtin_bit_cast(bf16x8, s1);
+          b2[pl] = __builtin_bit_cast(bf16x8, s2);
+        }
+        // smallest cross terms first; the three tx accumulators alternate (dependent MFMAs are 3 apart)
 #define SVL_W6(PA, PB)                                                                               \
   acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b0[PB], acc[0], 0, 0, 0);                      \
   acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b1[PB], acc[1], 0, 0, 0);                      \
   acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b2[PB], acc[2], 0, 0, 0);
-      SVL_W6(2, 0) SVL_W6(0, 2) SVL_W6(1, 1) SVL_W6(1, 0) SVL_W6(0, 1) SVL_W6(0, 0)
+        SVL_W6(2, 0) SVL_W6(0, 2) SVL_W6(1, 1) SVL_W6(1, 0) SVL_W6(0, 1) SVL_W6(0, 0)
 #undef SVL_W6
+      }
     }
     __syncthreads();
-    if (more) {
-      sstore(pi + ngrp);
-      __syncthreads();
-    }
   }
   // C layout: row i = co (within the tile), column = lane = ci; tap = 3 ty + tx
   float* out = p.slabs + ((long)g * Co * gridDim.z + cz) * 9 * Ct;
@@ -740,10 +757,13 @@ extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, in
   const int nslab = Ct / 32;
   // measured: Co = 64 is best with one full round of its 2 resident blocks per CU, Co = 32 with 1.5x that
   long g = (Co > 32 ? 512 : 768) / (nslab < 1 ? 1 : nslab);
-  // (the bf16 x 6 kernel of Co = 32 works on 64-channel slabs: one round of 2 blocks per CU; any value is valid for
-  //  either kernel, the switch is only read here to size the grid well)
-  if (Co == 32 && Ct % 64 == 0 && svl_get_gemm_emulation() == 6 && !getenv("SVL_CONV_TILED_NO_EMU")) g = 512 / (Ct / 64);
-  if (Co == 128) g = 256 / (nslab < 1 ? 1 : nslab);
+  // the bf16 x 6 kernel: twelve-wave blocks with double-buffered LDS, ONE block per CU -> one round of 256 blocks (any
+  // value is valid for either kernel; the arithmetic switch is only read here to size the grid well)
+  if (svl_get_gemm_emulation() == 6 && !getenv("SVL_CONV_TILED_NO_EMU")) {
+    if (Co == 32 && Ct % 64 == 0) g = 256 / (Ct / 64);
+    if (Co == 64) g = 256 / (nslab < 1 ? 1 : nslab);
+  }
+  if (Co == 128) g = 128 / (nslab < 1 ? 1 : nslab);
   if (g < 1) g = 1;
   if (g > npatch) g = npatch;
   return (int)g;
@@ -771,8 +791,8 @@ extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, co
   hipStream_t st = (hipStream_t)stream;
   if (emu6 && (Co >= 64 || Ct % 64 == 0)) {   // the split emulation covers the weight gradient too
     const int ty4 = (H + WPH - 1) / WPH;
-    if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(384), 0, st, p, tx, ty4);
-    else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<2, 1>), dim3((unsigned)groups, (unsigned)(Ct / 32), (unsigned)(Co / 64)), dim3(384), 0, st, p, tx, ty4);
+    if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(768), 0, st, p, tx, ty4);
+    else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<2, 1>), dim3((unsigned)groups, (unsigned)(Ct / 32), (unsigned)(Co / 64)), dim3(768), 0, st, p, tx, ty4);
   } else if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<1, 32>), grid, dim3(256), 0, st, p, tx, ty);
   else hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<2, 32>), grid, dim3(256), 0, st, p, tx, ty);
   SVL_LAUNCH_CHECK("svl_conv3x3_wgrad_tiled");
