@@ -188,7 +188,10 @@ int svl_gemm_planes_f32(const svl_pgemm_desc* d, svl_stream_t stream);
 /* Weight gradient of a narrow (Co = 32 / 64) 3x3 / stride 1 / pad 1 convolution over NHWC activations with an optional
  * second concat source (read at image img / rep): slabs[g][co][tap * (C1 + C2) + ci] for g < groups (forward-pack
  * layout per slab); the caller sums the slabs (svl_reduce_slabs_f32).  Replaces the conv2d weight-gradient of
- * vlg_head.py:121-127 (Up.conv) for the layers whose implicit-GEMM form is im2col-address bound.  C1, C2 % 4 == 0, (C1 + C2) % 32 == 0. */
+ * vlg_head.py:121-127 (Up.conv) for the layers whose implicit-GEMM form is im2col-address bound.  C1, C2 % 4 == 0, (C1 + C2) % 32 == 0.
+ * Under svl_set_gemm_emulation(6) the bf16 x 6 kernel serves Co = 64, Co = 32 with (C1 + C2) % 64 == 0, and additionally
+ * Co = 128 (an error in mode 0); svl_conv3x3_wgrad_tiled_groups sizes `groups` for the kernel the current mode selects
+ * (any groups >= 1 is valid for either). */
 int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, int Co);
 int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, const float* src1, int64_t ld1, int C1,
                             const float* src2, int64_t ld2, int C2, int rep, int imgs, int H, int W, float* slabs,

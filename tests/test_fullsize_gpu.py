@@ -154,6 +154,8 @@ def test_fullsize_step_large_class_counts(dev, nclass, dataset):
     masks = fp_masks_for((768, 768, 512), seed=nclass)
     loss, aux = oracle_step(orc, cfg, batch, masks, 0.0)
     check_step(dev, cfg, hip, orc, batch, masks, loss, aux)
+    # the arithmetic bench.py measures by default (GEMMs, attention, tiled / ASPP convolutions as bf16 x 6 split products)
+    check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=6)
     hip.decode_head.chunk_class_images = 1344
 
 
@@ -177,10 +179,13 @@ def test_fullsize_cityscapes_recipe(dev):
     batch = O.synthetic_batch(1, 801, 19, seed=119)
     masks = fp_masks_for((768, 512, 256), seed=19)     # dropout2d call order: [v4, emb, conv feature]
     loss, aux = oracle_step(orc, cfg, batch, masks, cfg["conf_thresh"])
-    check_step(dev, cfg, hip, orc, batch, masks, loss, aux, noisy=("conv_encoder", "skip_proj.1", "up2"))
-    for (n, bo), (_, bh) in zip(sorted(orc.named_buffers()), sorted(hip.named_buffers())):
-        if "conv_encoder" in n:   # SyncBN running statistics after the train-mode passes
-            assert (bh.cpu().float() - bo.float()).abs().max().item() < 1e-4 * max(1.0, bo.float().abs().max().item()), n
+    start = {k: v.clone() for k, v in hip.state_dict().items()}
+    for gemm_mode in (0, 6):   # 6 = the arithmetic bench.py measures by default; T = 2602 tokens: a ragged last attention block
+        hip.load_state_dict(start, strict=True)
+        check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=gemm_mode, noisy=("conv_encoder", "skip_proj.1", "up2"))
+        for (n, bo), (_, bh) in zip(sorted(orc.named_buffers()), sorted(hip.named_buffers())):
+            if "conv_encoder" in n:   # SyncBN running statistics after the train-mode passes
+                assert (bh.cpu().float() - bo.float()).abs().max().item() < 1e-4 * max(1.0, bo.float().abs().max().item()), n
 
 
 def test_fullsize_ade150_head_forward(dev):
