@@ -152,12 +152,13 @@ def cpu_baseline(crop, nclass, warm, timed):
                        f"{total:.0f} s of CPU work")
 
 
-def pmc_traffic_record(batch):
-    """HBM-side bytes of the dominant launch from a committed rocprofv3 --pmc record (profiles/pmc_gemm_traffic.json,
-    written by tools/pmc_traffic.sh): used only when it was measured on the SAME kernel source (sha256 of gemm.hip)."""
+def pmc_traffic_record(batch, name="pmc_gemm_traffic.json"):
+    """HBM-side bytes of the dominant launch from a committed rocprofv3 --pmc record (profiles/pmc_gemm_traffic.json for
+    the exact kernel, pmc_gemm_traffic_bf16x6.json for the split-emulation kernel; written by tools/pmc_traffic.sh):
+    used only when it was measured on the SAME kernel source (sha256 of gemm.hip)."""
     import hashlib
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_gemm_traffic.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         sha = hashlib.sha256(open(os.path.join(ROOT, "semivl_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
         if rec.get("gemm_hip_sha16") == sha and rec.get("M") == 32 * 1025 * batch // 16:
             return rec["traffic_bytes"], rec.get("note", "")
@@ -337,8 +338,13 @@ def main():
                 kernel="gemm_bf16x_kernel (svl_gemm_f32, split emulation), M=%d N=3072 K=768" % (32 * 1025 * a.batch // 16),
                 launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 3), achieved=round(d_tf, 1),
                 peak=round(PEAK_BF16_MFMA_TF / nprod, 1), frac=round(d_tf / (PEAK_BF16_MFMA_TF / nprod), 4),
-                algorithmic_bytes=513.0e6 * a.batch / 16, traffic=None,
-                traffic_note="PMC traffic is recorded for the exact-f32 kernel only (profiles/pmc_gemm_traffic.json)")
+                algorithmic_bytes=513.0e6 * a.batch / 16)
+            if nprod == 6:
+                traffic, tnote = pmc_traffic_record(a.batch, "pmc_gemm_traffic_bf16x6.json")
+                out["roofline"]["dominant_launch"].update(traffic=traffic, traffic_note=tnote)
+                out["roofline"]["traffic"] = traffic
+            else:
+                out["roofline"]["dominant_launch"].update(traffic=None, traffic_note="no PMC record for the x3 kernel")
         if dom is not None and g_arith_exact:
             d_ms = dom[0] * 1e3 / dom[2]
             d_tf = dom[1] / dom[0] / 1e12
