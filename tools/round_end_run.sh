@@ -2,11 +2,11 @@
 cd $GRAFT_REPO_ROOT
 T=${TAG:-r2g}
 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -25 > gpurun_out/${T}_pytest.log
-python bench.py --steps 10 --warmup 3 > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
-for c in cityscapes ade coco; do python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${T}_bench_$c.json 2>/dev/null; done
 SVL_GEMM_EMU=0 bash tools/pmc_traffic.sh tools/one_gemm.py gemm_kernel > gpurun_out/${T}_pmc_traffic.txt 2>&1
 SVL_GEMM_EMU=6 bash tools/pmc_traffic.sh tools/one_gemm.py gemm_bf16x >> gpurun_out/${T}_pmc_traffic.txt 2>&1
 mkdir -p profiles && cp gpurun_out/pmc_gemm_traffic.json gpurun_out/pmc_gemm_traffic_bf16x6.json profiles/   # (so that the bench lines below can quote them)
+python bench.py --steps 10 --warmup 3 > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
+for c in cityscapes ade coco; do python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${T}_bench_$c.json 2>/dev/null; done
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-throughput-mode --gemm-arith f32 > gpurun_out/${T}_bench_exact_f32.json 2>/dev/null
 for m in bf16x6 f32; do
   cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$m -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode --gemm-arith $m > $GRAFT_REPO_ROOT/gpurun_out/${T}_bench_under_rocprof_$m.json 2>/dev/null
