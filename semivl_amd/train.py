@@ -132,7 +132,7 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         head._bwd_ranges = {3 * B: [(B, 3 * B)]}
         if cfg.get("head_chunk_class_images"):
             head.chunk_class_images = int(cfg["head_chunk_class_images"])
-        frac = cfg.get("act_mem_fraction", 0.62)
+        frac = cfg.get("act_mem_fraction", 0.70)
         head.act_limit_bytes = (None if frac is None or not img_x.is_cuda else
                                 int(frac * torch.cuda.get_device_properties(dev).total_memory))
     preds4 = model(_cat2(img_w, img_x), need_fp=True, fp_masks=fp_masks, split_fp=False, fp_range=(0, B))
