@@ -99,10 +99,10 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(const SeqP p) {
   const int N = p.seq, E = p.heads * D;
   float* Ks = sm;
   float* Vs = Ks + N * LDK;
-  float* wbuf = Vs + N * LDK;  // per wave: do[64] + dsrow[N]
+  float* wbuf = Vs + N * LDK;  // per wave: do[64] + dsrow[N] (+ a second [N] for phase 2)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
-  float* dorow = wbuf + wave * (D + N);
+  float* dorow = wbuf + wave * (D + 2 * N);
   float* dsrow = dorow + D;
 
   for (int i = tid; i < N * D; i += 256) {
@@ -150,18 +150,37 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(const SeqP p) {
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();  // dscores of this (g,h) written by this block only; workgroup-scope visibility suffices
+  // Phase 2 out of LDS: K and V are no longer needed, their tiles take Q and dO (each read N times below); the column
+  // j of dS and P (stride N in memory) is gathered once per key into a per-wave buffer.  (Reading all four operands
+  // from global memory inside the i loop made this phase 7x the forward's time at N = 150.)
+  for (int i = tid; i < N * D; i += 256) {
+    const int j = i >> 6, d = i & 63;
+    const long row = tok_row(p, g, j);
+    Ks[j * LDK + d] = p.qkv[row * (3 * E) + h * D + d];
+    Vs[j * LDK + d] = p.dout[row * E + h * D + d];
+  }
+  __syncthreads();
+  float* cds = dsrow;          // [N]  (this wave's buffers from phase 1 are free now)
+  float* cpr = dsrow + N;      // [N]
   for (int j = wave; j < N; j += 4) {
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int i = lane + 64 * t;
+      if (i < N) {
+        cds[i] = p.dscores[pbase + (long)i * N + j];
+        cpr[i] = p.probs[pbase + (long)i * N + j];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
     float dk = 0.f, dv = 0.f;
     for (int i = 0; i < N; ++i) {
-      const long row = tok_row(p, g, i);
-      const float ds = p.dscores[pbase + (long)i * N + j];
-      const float pv = p.probs[pbase + (long)i * N + j];
-      dk += ds * p.qkv[row * (3 * E) + h * D + lane];
-      dv += pv * p.dout[row * E + h * D + lane];
+      dk += cds[i] * Ks[i * LDK + lane];
+      dv += cpr[i] * Vs[i * LDK + lane];
     }
     const long rowj = tok_row(p, g, j);
     p.dqkv[rowj * (3 * E) + E + h * D + lane] = dk * p.scale;
     p.dqkv[rowj * (3 * E) + 2 * E + h * D + lane] = dv;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -175,7 +194,7 @@ int fill(const svl_seqattn_desc* d, SeqP& p, const char* who) {
   p.scale = 0.125f;  // 64^-0.5, applied to q like nn.MultiheadAttention
   return SVL_OK;
 }
-size_t lds_bytes(int N) { return (size_t)(2 * N * LDK + 4 * (D + N)) * sizeof(float); }
+size_t lds_bytes(int N) { return (size_t)(2 * N * LDK + 4 * (D + 2 * N)) * sizeof(float); }
 
 }  // namespace
 
