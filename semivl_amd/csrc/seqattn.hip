@@ -99,10 +99,10 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(const SeqP p) {
   const int N = p.seq, E = p.heads * D;
   float* Ks = sm;
   float* Vs = Ks + N * LDK;
-  float* wbuf = Vs + N * LDK;  // per wave: do[64] + dsrow[N] (+ a second [N] for phase 2)
+  float* wbuf = Vs + N * LDK;  // per wave: do[64] + dsrow[N]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
-  float* dorow = wbuf + wave * (D + 2 * N);
+  float* dorow = wbuf + wave * (D + N);
   float* dsrow = dorow + D;
 
   for (int i = tid; i < N * D; i += 256) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(const SeqP p) {
   }
   __syncthreads();  // dscores of this (g,h) written by this block only; workgroup-scope visibility suffices
   // Phase 2 out of LDS: K and V are no longer needed, their tiles take Q and dO (each read N times below); the column
-  // j of dS and P (stride N in memory) is gathered once per key into a per-wave buffer.  (Reading all four operands
+  // j of dS and P (stride N in memory) is gathered once per key into registers.  (Reading all four operands
   // from global memory inside the i loop made this phase 7x the forward's time at N = 150.)
   for (int i = tid; i < N * D; i += 256) {
     const int j = i >> 6, d = i & 63;
@@ -160,27 +160,29 @@ __global__ __launch_bounds__(256) void seqattn_bwd_kernel(const SeqP p) {
     Vs[j * LDK + d] = p.dout[row * E + h * D + d];
   }
   __syncthreads();
-  float* cds = dsrow;          // [N]  (this wave's buffers from phase 1 are free now)
-  float* cpr = dsrow + N;      // [N]
   for (int j = wave; j < N; j += 4) {
+    float cds[MAXT], cpr[MAXT];   // column j of dS and P: lane l holds queries l, l + 64, l + 128
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       const int i = lane + 64 * t;
-      if (i < N) {
-        cds[i] = p.dscores[pbase + (long)i * N + j];
-        cpr[i] = p.probs[pbase + (long)i * N + j];
-      }
+      cds[t] = i < N ? p.dscores[pbase + (long)i * N + j] : 0.f;
+      cpr[t] = i < N ? p.probs[pbase + (long)i * N + j] : 0.f;
     }
-    __builtin_amdgcn_wave_barrier();
     float dk = 0.f, dv = 0.f;
-    for (int i = 0; i < N; ++i) {
-      dk += cds[i] * Ks[i * LDK + lane];
-      dv += cpr[i] * Vs[i * LDK + lane];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int n = min(N - 64 * t, 64);
+      for (int il = 0; il < n; ++il) {   // il is wave-uniform: v_readlane_b32 broadcasts the column entry (no LDS buffer,
+        const int i = 64 * t + il;       // which keeps the block at 79.5 KiB for N = 150 -- two blocks per CU)
+        const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cds[t]), il));
+        const float pv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cpr[t]), il));
+        dk += ds * Ks[i * LDK + lane];
+        dv += pv * Vs[i * LDK + lane];
+      }
     }
     const long rowj = tok_row(p, g, j);
     p.dqkv[rowj * (3 * E) + E + h * D + lane] = dk * p.scale;
     p.dqkv[rowj * (3 * E) + 2 * E + h * D + lane] = dv;
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -194,7 +196,7 @@ int fill(const svl_seqattn_desc* d, SeqP& p, const char* who) {
   p.scale = 0.125f;  // 64^-0.5, applied to q like nn.MultiheadAttention
   return SVL_OK;
 }
-size_t lds_bytes(int N) { return (size_t)(2 * N * LDK + 4 * (D + 2 * N)) * sizeof(float); }
+size_t lds_bytes(int N) { return (size_t)(2 * N * LDK + 4 * (D + N)) * sizeof(float); }
 
 }  // namespace
 
