@@ -241,7 +241,7 @@ def main():
                dtype="f32" if a.gemm_arith == "f32" else
                f"f32 (fp32 in/out/accumulate everywhere; large dense GEMMs as {a.gemm_arith} split products on the bf16 MFMA pipe, "
                f"error vs fp64 <= the plain fp32 MFMA chain's: the dense GEMMs, the fused ViT attention and the >= 32-channel "
-               f"convolutions' forward / input gradient; the remaining MFMA kernels on the fp32 pipe)",
+               f"convolutions' forward / input gradient and the tiled 3x3 weight gradient; the remaining MFMA kernels on the fp32 pipe)",
                data="synthetic",
                config=dict(workload=f"SemiVL step, {dataset} N={a.nclass}, {cfg['model'].replace('mmseg.', '')}, {a.crop}x{a.crop}, "
                                     f"bs={a.batch}/GPU labeled + {a.batch}/GPU unlabeled" +
