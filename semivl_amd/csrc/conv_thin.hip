@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const float* __rest
   }
 }
 
-// slab[blk][tap*C + c] = sum over the block's pixel chunk of dy[pix] * x[pix + off(tap)][c]   (3x3 only: 9 taps)
+// slab[blk][tap*C + c] = sum over pixels of dy[pix] * x[pix + off(tap)][c]   (3x3 only: 9 taps).  A block owns a chunk
+// of INPUT pixels q: x[q] (the wide operand) is loaded ONCE and meets the nine dy[q - off(tap)] (one float each, the
+// same address for all channel lanes of a pixel) -- the first version walked output pixels and fetched x nine times
+// per pixel (1.06 TB/s of unique bytes).  The pixel coordinates advance by add-and-carry, no divisions in the loop.
 __global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                long ldx, int H, int W, int C, int dil, int pad,
                                                                long npix, long pix_per_block, float* __restrict__ slabs) {
@@ -56,18 +59,23 @@ __global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(const float* __re
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
-  for (long p = p0 + pr; p < p1; p += PR) {
-    const float g = dy[p];
-    const int ow = (int)(p % W);
-    const int oh = (int)((p / W) % H);
+  long q = p0 + pr;
+  int iw = (int)(q % W), ih = (int)((q / W) % H);
+  const int stepw = PR % W, steph = PR / W;
+  for (; q < p1; q += PR) {
+    const float4 v = *reinterpret_cast<const float4*>(x + q * ldx + 4 * cq);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int ih = oh + (t / 3) * dil - pad, iw = ow + (t % 3) * dil - pad;
-      if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
-        const float4 v = *reinterpret_cast<const float4*>(x + (p + (long)((t / 3) * dil - pad) * W + ((t % 3) * dil - pad)) * ldx + 4 * cq);
-        acc[t].x += g * v.x; acc[t].y += g * v.y; acc[t].z += g * v.z; acc[t].w += g * v.w;
-      }
+      const int dh = (t / 3) * dil - pad, dw = (t % 3) * dil - pad;
+      const int oh = ih - dh, ow = iw - dw;               // the output pixel whose tap t reads input pixel q
+      const bool ok = oh >= 0 && oh < H && ow >= 0 && ow < W;
+      const float g = dy[ok ? q - (long)dh * W - dw : q];
+      const float gm = ok ? g : 0.f;
+      acc[t].x += gm * v.x; acc[t].y += gm * v.y; acc[t].z += gm * v.z; acc[t].w += gm * v.w;
     }
+    iw += stepw; ih += steph;
+    if (iw >= W) { iw -= W; ++ih; }
+    if (ih >= H) ih -= H;
   }
   const int NW = 9 * C;
 #pragma unroll
