@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(const float* __re
     }
     iw += stepw; ih += steph;
     if (iw >= W) { iw -= W; ++ih; }
-    if (ih >= H) ih -= H;
+    while (ih >= H) ih -= H;   // PR / W may exceed H on tiny maps (PR up to 256): a single subtraction is not enough
   }
   const int NW = 9 * C;
 #pragma unroll

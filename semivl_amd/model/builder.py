@@ -134,8 +134,8 @@ class VLM(nn.Module):
             lm, ls = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
             cm, cs = (torch.tensor([0.48145466, 0.4578275, 0.40821073]),
                       torch.tensor([0.26862954, 0.26130258, 0.27577711]))
-            self._dev_cache[k] = torch.stack((ls, lm, cm, cs)).contiguous().to(img.device)   # [4, 3]
-        return ops.affine_planes(img, self._dev_cache[k])      # (img * ls + lm - cm) / cs, one pass
+            self._dev_cache[k] = ops.StreamCached(torch.stack((ls, lm, cm, cs)).contiguous().to(img.device))   # [4, 3]
+        return ops.affine_planes(img, self._dev_cache[k].get())      # (img * ls + lm - cm) / cs, one pass
 
     def freeze(self, model, exclude_keys=None):  # vlm.py:80-88
         for n, m in model.named_parameters():
@@ -152,8 +152,8 @@ class VLM(nn.Module):
     def _on(self, name, t, device):
         key = (name, str(device))
         if key not in self._dev_cache:
-            self._dev_cache[key] = t.to(device)
-        return self._dev_cache[key]
+            self._dev_cache[key] = ops.StreamCached(t.to(device))   # built on whichever stream asks first (train.py)
+        return self._dev_cache[key].get()
 
     def text_feat(self, device):
         return self._on("text", self._text_feat, device)

@@ -360,8 +360,9 @@ class MaskClipVisionTransformer(nn.Module):
         if key not in cache:
             with torch.no_grad():
                 eye = torch.eye(ph * pw, device=self.pos_embed.device).view(ph * pw, 1, ph, pw)
-                cache[key] = F.interpolate(eye, size=hw, mode="bicubic", align_corners=False).view(ph * pw, -1).t().contiguous()
-        return cache[key]
+                cache[key] = ops.StreamCached(
+                    F.interpolate(eye, size=hw, mode="bicubic", align_corners=False).view(ph * pw, -1).t().contiguous())
+        return cache[key].get()
 
     def forward_tokens(self, img, need_global=False):
         """Returns (feat_tokens list of [B, P, C] tensors, global or None) on the autograd graph."""

@@ -171,6 +171,44 @@ WEIGHT_EPOCH = 0          # bumped by FusedAdamW.step(): its kernel rewrites the
 _WPLANES = {}
 
 
+class StreamCached:
+    """A cached device value (tensor, tuple of tensors, Planes) together with the event that completes it on the stream
+    that BUILT it.  The step runs its gradient-free passes on a second stream (train.py): whichever stream first needs a
+    re-laid-out weight builds it, and a later hit from the OTHER stream must (1) wait for that build and (2) tell the
+    caching allocator that the block is in use there -- without this a lagging side stream leaves the main stream
+    convolving with a half-written (or, after an optimizer step, stale) pack."""
+    __slots__ = ("val", "ev", "seen")
+
+    def __init__(self, val):
+        self.val, self.ev, self.seen = val, None, None
+        if torch.cuda.is_available():
+            s = torch.cuda.current_stream()
+            self.ev = torch.cuda.Event()
+            self.ev.record(s)
+            self.seen = {s.cuda_stream}
+
+    @staticmethod
+    def _tensors(v):
+        if isinstance(v, torch.Tensor):
+            yield v
+        elif isinstance(v, (tuple, list)):
+            for x in v:
+                yield from StreamCached._tensors(x)
+        elif hasattr(v, "buf"):
+            yield v.buf
+
+    def get(self):
+        if self.ev is not None:
+            s = torch.cuda.current_stream()
+            if s.cuda_stream not in self.seen:
+                s.wait_event(self.ev)
+                for t in self._tensors(self.val):
+                    if t.is_cuda:
+                        t.record_stream(s)
+                self.seen.add(s.cuda_stream)
+        return self.val
+
+
 def weights_changed():
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
@@ -186,11 +224,11 @@ def weight_planes(W, transpose=False):
     ver = (base._version, WEIGHT_EPOCH if base.requires_grad else 0)
     hit = _WPLANES.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is base:    # (a freed parameter's address may be handed out again)
-        return hit[1]
+        return hit[1].get()
     pl = split_planes(W.detach(), transpose=transpose)
     if len(_WPLANES) > 4096:
         _WPLANES.clear()
-    _WPLANES[key] = (ver, pl, weakref.ref(base))
+    _WPLANES[key] = (ver, StreamCached(pl), weakref.ref(base))
     return pl
 
 
@@ -566,11 +604,11 @@ def cached_pack(W, tag, fn):
     ver = (base._version, WEIGHT_EPOCH if base.requires_grad else 0)
     hit = _PACKS.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is base:    # weak reference: the address of a freed parameter of an
-        return hit[1]                                              # earlier model may be handed out again by the allocator
+        return hit[1].get()                                        # earlier model may be handed out again by the allocator
     out = fn(W.detach())
     if len(_PACKS) > 4096:
         _PACKS.clear()
-    _PACKS[key] = (ver, out, weakref.ref(base))
+    _PACKS[key] = (ver, StreamCached(out), weakref.ref(base))      # stream-aware: see StreamCached
     return out
 
 

@@ -90,6 +90,8 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     cutmix_img_(img_s2, b["img_s2_other"], mix2)
     if getattr(model, "decode_head", None) is not None:
         model.decode_head._bwd_ranges = None
+    if reducer is not None:
+        reducer.begin()
     # pseudo labels + MaskCLIP guidance (model.eval(): the side encoder's BatchNorm uses its running statistics here,
     # semivl.py:228-244; nothing else on the path depends on the mode).  Both passes are gradient-free and independent of
     # the two student forwards below: they are enqueued on a second stream (event-forked from / joined back into the
@@ -445,6 +447,15 @@ class GradAllReducer:
     def broadcast_params(self, src=0):
         if self.world > 1:
             dist.broadcast(self.opt.p, src, group=self.group)
+
+    def begin(self):
+        """Start of a step: forget whatever a previous, aborted step left behind -- a
+        backward that raised, or a grad-enabled forward that never ran its backward, would otherwise carry `expected` /
+        `done` counts into this step and fire a bucket before its last contribution (or never fire it early).
+        semivl_train_step calls it before the first grad-enabled forward (the forwards register their `expect`s)."""
+        self._works, self._fired = [], set()
+        self._complete = [0] * len(self.buckets)
+        self._expected, self._done = {}, {}
 
     def finish(self):
         """After backward: every gradient in the arena, every bucket reduced, compute stream ordered after them."""

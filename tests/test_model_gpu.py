@@ -164,6 +164,38 @@ def test_step_is_deterministic(dev):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_step_with_a_lagging_side_stream(dev):
+    """The gradient-free passes run on a second stream and are the FIRST users of the head's weight packs after an
+    optimizer step (ops.cached_pack / weight_planes build them there).  With the side stream held back by a long sleep
+    kernel the main stream must still wait for those builds (ops.StreamCached): two optimizer steps with the side stream
+    lagging == the same two steps with everything on one stream, bit for bit."""
+    from semivl_amd import train as T
+    from semivl_amd.train import semivl_train_step, FusedAdamW
+    z, c = load_fixture("tiny")
+    res = []
+    for lag in (False, True):
+        hip = build_hip(c)
+        hip.load_state_dict(fixture_state(z, c, hip), strict=True)
+        hip.to(dev)
+        opt = FusedAdamW(hip, dict(type="AdamW", lr=1e-3, weight_decay=0.01,
+                                   paramwise_cfg=dict(custom_keys=dict(backbone=dict(lr_mult=0.1), head=dict(lr_mult=10.0)))))
+        cfg = dict(CFG, conf_thresh=0.05, overlap_streams=lag)
+        out = []
+        for it in range(2):
+            if lag:
+                side = T._SIDE.get(torch.device(dev)) or T._SIDE.setdefault(torch.device(dev), torch.cuda.Stream(dev))
+                with torch.cuda.stream(side):
+                    torch.cuda._sleep(int(2e8))          # ~0.1 s: the side stream starts the step far behind
+            losses = semivl_train_step(hip, to_dev(fixture_batch(z, c), dev), it, 10, cfg, optimizer=opt,
+                                       fp_masks=[m.to(dev) for m in fixture_fp_masks(z, c)])
+            out.append(losses.clone())
+        torch.cuda.synchronize()
+        res.append((out, opt.p.clone()))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b), (a, b)
+    assert torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("B,S", [(2, 65), (1, 96)])
 def test_conv_encoder_matches_oracle(dev, B, S):
     """ResNetV1c stem + layer1 (the skr04 `conv_encoder`): forward, running statistics, every parameter gradient and
