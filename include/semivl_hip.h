@@ -151,23 +151,30 @@ int svl_get_gemm_emulation(void);
 int svl_set_conv_tiled(int on);
 
 /* ------------------------------------------------------------------------------------------------
- * fp32-accurate GEMM with PRE-SPLIT operands (the fast form of emulation mode 6; csrc/gemm_planes.hip).
- * An fp32 matrix X [rows, K] (K % 16 == 0) is held as three bf16 "planes" x = x0 + x1 + x2 in the k-group-blocked
- * layout planes[K/16][rows][3][16] (96-byte records; svl_planes_bytes(rows, K) bytes, 16-byte aligned).  Weights are
- * split once, activations once by their producer; the GEMM then runs loads + v_mfma_f32_32x32x16_bf16 only (6 cross
- * products, fp32 accumulate).  Replaces F.linear / its input gradient on the ViT linears (maskclip_vit.py:110-144 via
- * mmcv MultiheadAttention / FFN) when svl_set_gemm_emulation(6) is active.
+ * fp32-accurate GEMM with PRE-SPLIT, fragment-packed operands (the fast form of emulation mode 6; csrc/gemm_planes.hip).
+ * An fp32 matrix X [rows, K] (K % 16 == 0) is held as three bf16 "planes" x = x0 + x1 + x2, packed in the register image
+ * of the MFMA operand fragments: for k-group kg = k / 16, row block rb = row / 32 and plane pl one 1 KiB chunk
+ *     planes[((kg * rows_padded / 32 + rb) * 3 + pl) * 1024 + (h * 32 + row % 32) * 16 .. + 16)
+ * holds, for h = 0 / 1, the 8 bf16 values of row `row` at k = kg * 16 + 4 h + {0, 1, 2, 3, 8, 9, 10, 11}.  rows_padded =
+ * svl_planes_rows(rows) (a multiple of 256: tiles read whole 256-row bands; the padding is never stored from);
+ * svl_planes_bytes(rows, K) bytes, 1 KiB aligned.  Weights are packed once per parameter version, activations by their
+ * producer (svl_layernorm_* planes outputs, the previous GEMM's epilogue, svl_split_planes_bf16x3 as the generic pass);
+ * the GEMM then runs LDS-DMA + ds_read_b128 + v_mfma_f32_32x32x16_bf16 only (6 cross products, fp32 accumulate).
+ * Replaces F.linear / its input gradient on the ViT linears (maskclip_vit.py:110-144 via mmcv MultiheadAttention / FFN)
+ * when svl_set_gemm_emulation(6) is active.
  *   svl_split_planes_bf16x3   element (r, k) read at x[r * ld + k * k_stride] (k_stride 1: row-major; ld 1 + k_stride =
  *                             leading dim: the transpose of a row-major matrix), written to rows [row_off, row_off+rows)
- *                             of a plane buffer with planes_rows rows
- *   svl_gemm_planes_f32       C[m, n] = epi(sum_k A[m, k] B[n, k]) for rows m in [m_off, m_off + M): bias[n], act
- *                             (svl_act: GELU / RELU; MUL_DGELU / MUL_DRELU multiply by the activation derivative at
- *                             resid = saved pre-activation), preact (pre-activation copy out), resid (added), accumulate
- *                             (into C); outputs: C fp32 row-major (ldc) and / or planes_out = the result split into
- *                             planes [N/16][p_rows][3][16] for the next GEMM (N % 16 == 0).  Either may be NULL, not both. */
+ *                             of a plane buffer with planes_rows (% 256 == 0) rows; row_off % 32 == 0; the rest of the
+ *                             last 32-row block is zero-filled
+ *   svl_gemm_planes_f32       C[m, n] = epi(sum_k A[m, k] B[n, k]) for rows m in [m_off, m_off + M) (m_off % 32 == 0):
+ *                             bias[n], act (svl_act: GELU / RELU; MUL_DGELU / MUL_DRELU multiply by the activation
+ *                             derivative at resid = saved pre-activation), preact (pre-activation copy out), resid
+ *                             (added), accumulate (into C); outputs: C fp32 row-major (ldc) and / or planes_out = the
+ *                             result as packed planes [M, N] (p_rows % 256 == 0 rows, N % 16 == 0) for the next GEMM.
+ *                             Either may be NULL, not both. */
 typedef struct svl_pgemm_desc {
-  const void* A;        /* planes [K/16][a_rows][3][16] bf16 */
-  const void* B;        /* planes [K/16][b_rows][3][16] bf16, b_rows >= N */
+  const void* A;        /* packed planes of [a_rows, K], a_rows % 256 == 0 */
+  const void* B;        /* packed planes of [b_rows, K], b_rows % 256 == 0, b_rows >= N */
   int64_t a_rows, b_rows;
   int m_off, M, N, K;
   float* C;
@@ -181,6 +188,7 @@ typedef struct svl_pgemm_desc {
   int64_t ldr;
   int accumulate;
 } svl_pgemm_desc;
+int64_t svl_planes_rows(int64_t rows);             /* rows rounded up to the 256-row band a tile reads */
 int64_t svl_planes_bytes(int64_t rows, int K);
 int svl_split_planes_bf16x3(const float* x, int64_t ld, int64_t k_stride, int64_t rows, int K, void* planes,
                             int64_t planes_rows, int64_t row_off, svl_stream_t stream);
@@ -297,12 +305,22 @@ int svl_iou_hist_i64(const int64_t* pred, const int64_t* target, int64_t n, int 
 /* LayerNorm over the last dim C of x [rows, C]; stats [rows, 2] = (mean, rstd). */
 int svl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
                       float* y, float* stats, svl_stream_t stream);
+/* The same with the result ALSO (y != NULL) or ONLY (y == NULL) emitted as packed bf16x3 planes, the A operand of the
+ * following svl_gemm_planes_f32 (C % 16 == 0; planes_rows % 256 == 0 rows in the plane buffer, rows start at 0):
+ * LN1 -> qkv and LN2 -> FFN-1 of every ViT block (maskclip_vit.py:120-144). */
+int svl_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
+                             float* y, float* stats, void* planes, int64_t planes_rows, svl_stream_t stream);
 /* dx = LN backward (+ dx_add if non-NULL, fused residual-grad add). If dgamma_part != NULL also writes
  * per-block partial sums dgamma_part/dbeta_part [nparts, C] (nparts = svl_layernorm_bwd_parts(rows)). */
 int svl_layernorm_bwd_parts(int64_t rows);
 int svl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int64_t rows,
                       int C, const float* dx_add, float* dx, float* dgamma_part, float* dbeta_part,
                       svl_stream_t stream);
+/* ... with dx additionally emitted as packed planes (planes may be NULL): the A operand of the input-gradient GEMM that
+ * consumes it (d out_proj, d FFN-2 of the block below). */
+int svl_layernorm_bwd_planes(const float* dy, const float* x, const float* stats, const float* gamma, int64_t rows,
+                             int C, const float* dx_add, float* dx, float* dgamma_part, float* dbeta_part, void* planes,
+                             int64_t planes_rows, svl_stream_t stream);
 
 /* Row softmax in place over the first `cols` entries of rows with stride ld: p = softmax(scale * s).
  * Entries [cols, ld) are zeroed. */

@@ -1,30 +1,42 @@
-// fp32-accurate GEMM on the bf16 matrix pipe with PRE-SPLIT operands (gfx950 / CDNA4).
+// fp32-accurate GEMM on the bf16 matrix pipe with PRE-SPLIT, FRAGMENT-PACKED operands (gfx950 / CDNA4).
 //
 //   C(m, n) = epilogue( sum_k A(m, k) * B(n, k) ),   A, B given as 3 bf16 "planes" each.
 //
-// Arithmetic (same as gemm.hip's in-register split emulation, svl_set_gemm_emulation(6)): every fp32 operand element x
-// is the exact sum x0 + x1 + x2 (+ a residual below 2^-24 |x|) of three bf16 terms x0 = bf16(x), x1 = bf16(x - x0),
-// x2 = bf16(x - x0 - x1); bf16 x bf16 products are exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, and the six
-// leading cross products (a2 b0, a0 b2, a1 b1, a1 b0, a0 b1, a0 b0 -- smallest first) carry 24 mantissa bits of every
-// a * b: the error against fp64 is at or below the plain fp32 MFMA chain's (tests/test_ops_gpu.py).
+// Arithmetic (svl_set_gemm_emulation(6)): every fp32 operand element x is the exact sum x0 + x1 + x2 (+ a residual
+// below 2^-24 |x|) of three bf16 terms x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); bf16 x bf16 products are
+// exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, and the six leading cross products (a2 b0, a0 b2, a1 b1,
+// a1 b0, a0 b1, a0 b0 -- smallest first) carry 24 mantissa bits of every a * b: the error against fp64 is at or below
+// the plain fp32 MFMA chain's (tests/test_ops_gpu.py).
 //
-// Why pre-split: in the in-register variant every tile re-splits its A panel once per column tile and its B panel once
-// per row tile (~5.5 VALU instructions per staged value: the kernel sat at 45 % MFMA-busy, VALU-bound).  Weights are
-// split once (frozen ones once per process, trainable ones once per optimizer step) and activations once by their
-// producer (split pass, LayerNorm, or the previous GEMM's epilogue), so the inner loop here is loads + MFMAs only.
+// Operand format ("packed planes"): for k-group kg = k / 16, row block rb = row / 32 and plane pl, ONE 1 KiB chunk
+//     P[(kg * RB + rb) * 3 + pl][lane][8]  (bf16),   lane = h * 32 + row % 32,
+// holds, for lane-half h, the 8 k's  kg*16 + 4h + {0,1,2,3, 8,9,10,11}  of that row: exactly the register image of one
+// MFMA 32x32x16 operand fragment (lane = row, 8 consecutive registers-halves = its k's; the k order inside a group is free
+// as long as A and B agree).  Consequences:
+//   * a tile's K step is one contiguous run of chunks in memory; it is copied global -> LDS by global_load_lds_dwordx4
+//     (1 KiB per wave instruction, fully coalesced, no VGPR round trip, no address arithmetic beyond an SGPR bump);
+//   * the LDS image IS the fragment: every operand read is one ds_read_b128 at base + lane * 16 -- conflict-free by
+//     construction, no padding, no swizzle;
+//   * with transposed accumulators (MFMA issued as B-fragment x A-fragment) a lane of the epilogue owns, per 16 output
+//     columns, exactly the 8 values of ITS lane slot of the next GEMM's A chunk, so a GEMM emits its result as packed
+//     planes with one coalesced 1 KiB store per (row block, k-group, plane).
+// Weights are packed once per parameter version, activations by their producer (LayerNorm, the previous GEMM's
+// epilogue, svl_split_planes_bf16x3 as the generic pass), so the main loop is LDS-DMA + ds_read_b128 + MFMA only.
 //
-// Plane layout ("k-group blocked"): planes[K/16][rows][3][16] bf16 -- the 3 x 32 B of one (row, 16-k group) are one 96 B
-// record and the 128 rows x 96 B of a tile's K step are ONE contiguous 12 KiB run: global -> LDS staging is 3 fully
-// coalesced dwordx4 loads per thread per operand, no address arithmetic beyond a pointer bump, and a record is exactly
-// what the three bf16 MFMA fragments of lane (row, k-half) read.
-//
-// Structure: 256 threads = 4 waves of 64x64 in a 128x128 tile, K step 16 (one MFMA k-group), 24 MFMAs per wave and step
-// (768 matrix-pipe cycles) against 12 ds_read_b128; LDS rows are 48 B apart (conflict-free b128 reads and, with 16-lane groups
-// writing one plane slot of 16 consecutive rows, conflict-free b128 writes); two LDS buffers, global loads two steps ahead in two
-// register sets, one barrier per step, 2 blocks per CU.  The accumulators are kept TRANSPOSED (the MFMA is issued as
-// B-fragment x A-fragment): a lane then owns 4 runs of 4 consecutive n of ONE row m, so the epilogue reads / writes 16 B
-// per lane (bias, erf-GELU, saved pre-activation, residual, GELU'(z) product) and can emit its result directly as bf16
-// planes for the next GEMM (8 B per plane and run) instead of fp32.
+// Kernel structure (256 x BN tile, BN = 256 or 128; 512 threads = 8 waves; one block per CU):
+//   * waves 0-3 (group 0) own tile rows 0-127, waves 4-7 (group 1) rows 128-255; wave w and w + 4 share a SIMD.
+//   * the two groups run ONE BARRIER INTERVAL APART: while a group issues its 48 (24) MFMAs of a k-group -- a pure
+//     matrix-pipe phase of 1536 (768) cycles -- its SIMD partner reads the fragments of ITS next k-group from LDS
+//     (18 / 15 ds_read_b128), issues its share of the LDS-DMA for the k-group two ahead and parks at the barrier.  The
+//     matrix pipe of every SIMD is always owned by exactly one wave; nothing but MFMAs is issued between two barriers
+//     by the computing wave.  (The round-2 kernels ran all waves in lockstep -- read, compute, refill -- and sat at
+//     ~1.0 PF whatever the tile: MI355X_MICROARCH.md "Two waves per SIMD".)
+//   * three LDS stages of 48 / 36 KiB; LDS-DMA stays in flight across barriers: a wave waits with a COUNTED vmcnt for
+//     the k-group it issued two intervals earlier, one interval before anybody reads it.
+// Barrier B_n ends interval I_n.  Group 0: mem(kg) in I_{2kg+1}, mfma(kg) in I_{2kg+2}; group 1 one interval later.
+// Stage kg % 3 is read in I_{2kg+1} (g0) and I_{2kg+2} (g1) and refilled for kg + 3 from I_{2kg+3} on (WAR safe: both
+// groups drained their reads with lgkmcnt(0) before B_{2kg+2}); its LDS-DMA was issued in I_{2kg-3} / I_{2kg-2} and waited
+// for (vmcnt) before B_{2kg-1} / B_{2kg}, i.e. at least one barrier before the first read (RAW safe).
 #include "svl_common.h"
 #include <atomic>
 #include <type_traits>
@@ -32,10 +44,11 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a class: not promoted to registers)
 
-constexpr int REC = 48;   // bf16 elements per (row, k-group) record: 3 planes x 16
+constexpr int BM = 256;
+constexpr int CH = 1024;        // bytes of one (k-group, row block, plane) chunk
+constexpr int NSTAGE = 3;
 
 template <int I, int N_, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -46,42 +59,42 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 struct PlanesP {
-  const __bf16* A;
-  const __bf16* B;
-  long a_rows, b_rows;      // rows of the A / B plane buffers (record index = kg * rows + row)
-  int m_off, M, N, K;       // this launch computes rows [m_off, m_off + M)
+  const char* A;            // first chunk of row block 0, k-group 0
+  const char* B;
+  long a_ks, b_ks;          // bytes between k-groups (rows_padded * 96)
+  int M, N, K;              // M valid rows from A's row block 0
   float* C;
   long ldc;
-  __bf16* P;                // planes out [N/16][p_rows][3][16] or null
-  long p_rows;
+  char* P;                  // packed planes out (row block 0, k-group 0 of the result) or null
+  long p_ks;
   const float* bias;
   int act;
   float* preact;
   const float* resid;
   long ldr;
   int accumulate;
-  int tiles_m, tiles_n, band_n;
+  int tiles_n, full_m, tail_rows;   // full_m = M / 256 row bands; tail_rows = M % 256
+  int rcnt[8], fstart[8];   // per XCD x (blocks with id % 8 == x): ragged-band tiles it takes first, first full tile of its chunk
 };
 
-__device__ __forceinline__ void tile_to_mn(const PlanesP& p, int tile, int& tm, int& tn) {
-  if (p.band_n >= p.tiles_n) {
-    tn = tile % p.tiles_n;
-    tm = tile / p.tiles_n;
-    return;
-  }
-  const int per_band = p.tiles_m * p.band_n;
-  const int nb = (p.tiles_n + p.band_n - 1) / p.band_n;
-  const int band = min(tile / per_band, nb - 1);
-  const int r = tile - band * per_band;
-  const int wb = band == nb - 1 ? p.tiles_n - band * p.band_n : p.band_n;
-  tm = r / wb;
-  tn = band * p.band_n + (r - tm * wb);
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// x = x0 + x1 + x2: the three bf16 planes of 4 values
-__device__ __forceinline__ void split3(const float (&x)[4], bf16x4& h0, bf16x4& h1, bf16x4& h2) {
+template <int N_>
+__device__ __forceinline__ void wait_vm() {
+  if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N_ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else static_assert(N_ < 0, "unsupported vmcnt");
+}
+
+// x = x0 + x1 + x2: the three bf16 planes of 8 values
+__device__ __forceinline__ void split3x8(const float (&x)[8], bf16x8& h0, bf16x8& h1, bf16x8& h2) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 8; ++j) {
     float v = x[j];
     h0[j] = (__bf16)v;
     v -= (float)h0[j];
@@ -91,78 +104,87 @@ __device__ __forceinline__ void split3(const float (&x)[4], bf16x4& h0, bf16x4& 
   }
 }
 
-// Tile shapes: the six-product scheme moves 96 B per (row, k-group) through L2 for 6 x 32 k-MACs per output column, so a
-// 128x128 tile needs ~19 TB/s of L2 -> CU traffic at the matrix pipe's peak and is L2-bound at ~40 % of it (measured: the
-// pre-split and the in-register kernel both sat at 165-175 TF at 128x128).  256x256 (262 FLOP per L2 byte) halves that;
-// 256x128 serves N = 768 / 2304, whose 256-wide tilings would leave a partial last round of the grid.  The large tiles
-// run 4 waves of (BM/2)x(BN/2) at ONE block per CU with the 512-register budget (accumulators 128 / 256 registers).
-// BK = 16, two LDS buffers, one barrier per step (the classic double buffer), or BK = 32 with ONE LDS buffer and two
-// barriers per step: a block then alternates a compute phase (48 MFMAs per wave) and a short refill phase, and the two
-// blocks resident on a CU interleave them -- the matrix pipe of a SIMD is fed by one block's wave while the other's
-// refills -- at half the barriers per k of the BK = 16 form (whose per-step overhead, not bandwidth, was the limiter).
-template <int BM, int BN, int BK, int NBUF>
-__device__ __forceinline__ void gemm_planes_body(const PlanesP& p, __bf16* sm) {
-  constexpr int KG = BK / 16;                           // MFMA k-groups per K step
-  constexpr int LDR = BK == 16 ? 24 : 40;               // bf16 elements per LDS row (48 / 80 B: conflict-free b128 reads)
-  constexpr int PLA = BM * LDR, PLB = BN * LDR;   // plane strides (elements)
-  constexpr int OPA = 3 * PLA, OPB = 3 * PLB;           // one operand, three planes
-  constexpr int BUF = OPA + OPB;                        // A + B of one K step
-  constexpr int TM = BM / 64, TN = BN / 64;             // 32x32 MFMA tiles per wave (wave grid 2 x 2)
-  constexpr int CA = BM * 6 * KG / 256, CB = BN * 6 * KG / 256;   // 16-byte chunks per thread and K step
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int wr = wave >> 1, wc = wave & 1;
-  int tile;
-  {  // XCD-aware bijective remap: consecutive tiles of the (banded) order stay on one XCD
-    const int lin = (int)blockIdx.x, nt = (int)gridDim.x;
-    const int xcd = lin & 7, q = nt >> 3, r = nt & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+// Block -> tile.  Blocks go to XCD (id % 8) and, inside an XCD, to CUs in id order as CUs free up.  Every XCD first takes
+// its share of the RAGGED row band's tiles (M % 256 rows: they are short, so their CUs simply start the next tile
+// early and the grid stays a whole number of rounds), then a contiguous chunk of the full tiles in n-fastest order:
+// concurrent tiles of an XCD share A row bands / B column bands in that XCD's L2.
+// (Tried and dropped: cutting the first 32 tiles of every XCD in two row parts of s / 8 and (8 - s) / 8 so that its CUs
+// run 1/8 of a tile apart and their store bursts do not coincide -- partial tiles keep only one wave group busy and
+// cost more than the de-synchronised epilogues gain: +5...7 % on the ViT shapes.)
+struct TileRef { int m0, rows, tn; };
+__device__ __forceinline__ TileRef tile_of_block(const PlanesP& p) {
+  const int lin = (int)blockIdx.x, x = lin & 7, idx = lin >> 3;
+  TileRef t;
+  const int rc = p.rcnt[x];
+  if (idx < rc) {
+    t.m0 = p.full_m * BM;
+    t.rows = p.tail_rows;
+    t.tn = idx * 8 + x;
+  } else {
+    const int f = p.fstart[x] + idx - rc;
+    const int tm = f / p.tiles_n;
+    t.tn = f - tm * p.tiles_n;
+    t.m0 = tm * BM;
+    t.rows = BM;
   }
-  int tm_i, tn_i;
-  tile_to_mn(p, tile, tm_i, tn_i);
-  const int m0 = p.m_off + tm_i * BM, n0 = tn_i * BN;
-  const int m_end = p.m_off + p.M;
-  const int nk = p.K / BK;
+  return t;
+}
 
-  // staging: chunk c = tid + 256 i of the tile's 16-byte chunks; row = c / (6 KG), then (k-group, plane, k-half).
-  // Everything is a compile-time-indexed register (static_for): a run-time index would demote it to scratch.
-  const long ka_step = p.a_rows * (REC / 8) * KG, kb_step = p.b_rows * (REC / 8) * KG;   // u32x4 units per K step
-  const u32x4* ga[CA];
-  const u32x4* gb[CB];
-  int sa[CA], sb[CB];
-  // Lane -> chunk map: a group of 16 consecutive lanes takes ONE (k-group, plane, k-half) slot of 16 consecutive rows, so
-  // its ds_write_b128 hits 16 distinct 4-bank windows (rows are 48 / 80 B apart) -- chunk-linear lanes (6 chunks of a row,
-  // then the next row) collided 2-way (PMC: SQ_LDS_BANK_CONFLICT = 1/3 of the LDS-active cycles); the four groups of a
-  // wave instruction take consecutive slots, i.e. 64 contiguous bytes of each row's record on the global side.
-  static_for<0, CA>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    const int g = (i * 4 + wave) * 4 + (lane >> 4);
-    const int rb = g / (6 * KG), w2 = g - rb * (6 * KG), kg = w2 / 6, w = w2 - kg * 6;
-    const int row = rb * 16 + (lane & 15);
-    const long ra = min((long)(m0 + row), (long)(m_end - 1));   // rows past the edge: clamped, never stored
-    ga[i] = reinterpret_cast<const u32x4*>(p.A) + ((long)kg * p.a_rows + ra) * (REC / 8) + w;
-    sa[i] = (w >> 1) * PLA + row * LDR + kg * 16 + (w & 1) * 8;
-  });
-  static_for<0, CB>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    const int g = (i * 4 + wave) * 4 + (lane >> 4);
-    const int rb = g / (6 * KG), w2 = g - rb * (6 * KG), kg = w2 / 6, w = w2 - kg * 6;
-    const int row = rb * 16 + (lane & 15);
-    const long rb_ = min((long)(n0 + row), (long)(p.N - 1));
-    gb[i] = reinterpret_cast<const u32x4*>(p.B) + ((long)kg * p.b_rows + rb_) * (REC / 8) + w;
-    sb[i] = OPA + (w >> 1) * PLB + row * LDR + kg * 16 + (w & 1) * 8;
-  });
-  u32x4 xa0[CA], xb0[CB], xa1[NBUF == 2 ? CA : 1], xb1[NBUF == 2 ? CB : 1];
-  auto gload = [&](u32x4 (&xa)[CA], u32x4 (&xb)[CB], int t) __attribute__((always_inline)) {
-    if (t < nk) {   // steps are requested in increasing order: the pointers walk along K
-      static_for<0, CA>([&](auto I) { xa[decltype(I)::value] = *ga[decltype(I)::value]; ga[decltype(I)::value] += ka_step; });
-      static_for<0, CB>([&](auto I) { xb[decltype(I)::value] = *gb[decltype(I)::value]; gb[decltype(I)::value] += kb_step; });
-    }
+enum { EPI_LIGHT = 0, EPI_GELU = 1, EPI_DGELU = 2 };   // epilogue flavour compiled in (the erf code is large)
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
+  extern __shared__ __attribute__((aligned(1024))) char sm[];
+  constexpr int TM = 4, TN = BN / 128;                 // 32x32 MFMA blocks per wave: wave tile 128 x (BN / 4)
+  constexpr int NCHA = BM / 32 * 3, NCHB = BN / 32 * 3, NCH = NCHA + NCHB;   // chunks of one stage (A then B)
+  constexpr int STAGE = NCH * CH;
+  constexpr int CPW = (NCH + 7) / 8;                   // LDS-DMA instructions per wave and k-group (upper bound)
+  constexpr bool EVEN = NCH % 8 == 0;                  // every wave issues CPW; else waves >= NCH % 8 issue CPW - 1
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3;
+
+  const TileRef tr = tile_of_block(p);
+  const int m0 = tr.m0, n0 = tr.tn * BN, mvalid = tr.rows;
+  const int nblk = (mvalid + 31) >> 5;                 // row blocks of A this tile needs
+  // valid 32-row blocks of this wave (wave-uniform): partial tiles skip the MFMAs of row blocks past their edge
+  const int vb = min(TM, max(0, nblk - grp * TM));
+
+  const char* a_src = p.A + (long)(m0 >> 5) * (3 * CH) + lane * 16;
+  const char* b_src = p.B + (long)tr.tn * (NCHB * CH) + lane * 16;
+  const int nk = p.K >> 4;
+
+  // chunk sources of this wave inside a k-group (wave-uniform byte offsets); A chunks of row blocks the tile does not
+  // need are redirected to row block 0 (same instruction count -- the vmcnt bookkeeping is static -- and no read past the
+  // operand's last row band)
+  auto issue = [&](int kg, int st) __attribute__((always_inline)) {
+    const char* ak = a_src + (long)kg * p.a_ks;
+    const char* bk = b_src + (long)kg * p.b_ks;
+    char* dst = sm + st * STAGE;
+    static_for<0, CPW>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const int c = wave + 8 * i;
+      if (EVEN || i + 1 < CPW || c < NCH) {
+        const char* s;
+        if constexpr (8 * i + 7 < NCHA) {
+          const int rb = c / 3;
+          s = ak + (rb < nblk ? c : c - 3 * rb) * CH;
+        } else {
+          static_assert(8 * i >= NCHA, "A / B chunk boundary must fall on a multiple of 8");
+          s = bk + (c - NCHA) * CH;
+        }
+        glds16(s, dst + c * CH);
+      }
+    });
   };
-  auto sstore = [&](const u32x4 (&xa)[CA], const u32x4 (&xb)[CB], int buf) __attribute__((always_inline)) {
-    __bf16* D = sm + buf * BUF;
-    static_for<0, CA>([&](auto I) { *reinterpret_cast<u32x4*>(D + sa[decltype(I)::value]) = xa[decltype(I)::value]; });
-    static_for<0, CB>([&](auto I) { *reinterpret_cast<u32x4*>(D + sb[decltype(I)::value]) = xb[decltype(I)::value]; });
+  const bool short_wave = !EVEN && wave >= NCH % 8;
+  auto wait_older = [&]() __attribute__((always_inline)) {   // all but the k-group issued last have landed
+    if constexpr (EVEN) wait_vm<CPW>();
+    else {
+      if (short_wave) wait_vm<CPW - 1>();
+      else wait_vm<CPW>();
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -173,236 +195,259 @@ __device__ __forceinline__ void gemm_planes_body(const PlanesP& p, __bf16* sm) {
     });
   });
 
-  const int fa = (wr * (BM / 2) + l31) * LDR + 8 * hi, fb = OPA + (wc * (BN / 2) + l31) * LDR + 8 * hi;
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const __bf16* S = sm + buf * BUF;
-    static_for<0, KG>([&](auto G) {
-      constexpr int kg = decltype(G)::value;
-      bf16x8 a[3][TM], b[3][TN];
-      static_for<0, 3>([&](auto P) {
-        constexpr int pl = decltype(P)::value;
-        static_for<0, TM>([&](auto I) {
-          a[pl][decltype(I)::value] =
-              *reinterpret_cast<const bf16x8*>(S + fa + pl * PLA + decltype(I)::value * 32 * LDR + kg * 16);
-        });
-        static_for<0, TN>([&](auto J) {
-          b[pl][decltype(J)::value] =
-              *reinterpret_cast<const bf16x8*>(S + fb + pl * PLB + decltype(J)::value * 32 * LDR + kg * 16);
-        });
-      });
-      // transposed accumulators: D(n, m) += B-fragment x A-fragment; smallest cross terms first; consecutive MFMAs go
-      // to different accumulators (dependent ones are TM * TN instructions apart)
-      static_for<0, 6>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        constexpr int PA = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;     // (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
-        constexpr int PB = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
-        static_for<0, TM>([&](auto I) {
+  // fragment addresses inside a stage: A row block (grp * 4 + i), B row block (wq * TN + j)
+  const int fa = lane * 16 + grp * (TM * 3 * CH);
+  const int fb = lane * 16 + NCHA * CH + wq * (TN * 3 * CH);
+
+  issue(0, 0);
+  if (nk > 1) {
+    issue(1, 1);
+    wait_older();
+  } else {
+    wait_vm<0>();
+  }
+  __builtin_amdgcn_s_barrier();                 // B_0: k-group 0 is in LDS for everybody
+  if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto kloop = [&](auto FULLT) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(FULLT)::value;
+    bf16x8 a[3][TM], b[3][TN];
+    int st = 0;
+    for (int kg = 0; kg < nk; ++kg) {
+      // ---------------- memory phase: fragments of this k-group, LDS-DMA of k-group kg + 2
+      const char* S = sm + st * STAGE;
+      {
+        static_for<0, 3>([&](auto P) {
+          constexpr int pl = decltype(P)::value;
           static_for<0, TN>([&](auto J) {
-            constexpr int i = decltype(I)::value, j = decltype(J)::value;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB][j], a[PA][i], acc[i][j], 0, 0, 0);
+            b[pl][decltype(J)::value] = *reinterpret_cast<const bf16x8*>(S + fb + (decltype(J)::value * 3 + pl) * CH);
           });
         });
-      });
-    });
-  };
-
-  if constexpr (NBUF == 2) {
-    // data of step s lives in register set s & 1, then in LDS buffer s & 1; loads run two steps ahead of their LDS store
-    gload(xa0, xb0, 0);
-    gload(xa1, xb1, 1);
-    if (nk > 0) sstore(xa0, xb0, 0);
-    gload(xa0, xb0, 2);
-    __syncthreads();
-    int t = 0;
-    for (; t + 1 < nk; t += 2) {
-      compute(0);
-      sstore(xa1, xb1, 1);
-      gload(xa1, xb1, t + 3);
-      __syncthreads();
-      compute(1);
-      if (t + 2 < nk) sstore(xa0, xb0, 0);
-      gload(xa0, xb0, t + 4);
-      __syncthreads();
-    }
-    if (t < nk) compute(0);
-  } else {
-    // one LDS buffer: compute | barrier | refill (registers loaded during the compute phase) + next loads | barrier
-    gload(xa0, xb0, 0);
-    if (nk > 0) sstore(xa0, xb0, 0);
-    gload(xa0, xb0, 1);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-      compute(0);
-      if (t + 1 < nk) {
-        __syncthreads();
-        sstore(xa0, xb0, 0);
-        gload(xa0, xb0, t + 2);
-        __syncthreads();
+        static_for<0, 3>([&](auto P) {
+          constexpr int pl = decltype(P)::value;
+          static_for<0, TM>([&](auto I) {
+            a[pl][decltype(I)::value] = *reinterpret_cast<const bf16x8*>(S + fa + (decltype(I)::value * 3 + pl) * CH);
+          });
+        });
       }
+      if (kg + 2 < nk) {
+        int st2 = st + 2;
+        if (st2 >= NSTAGE) st2 -= NSTAGE;
+        issue(kg + 2, st2);
+        wait_older();                             // k-group kg + 1 (this wave's part) has landed
+      } else {
+        wait_vm<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- matrix phase: transposed accumulators D(n, m) += B-fragment x A-fragment, smallest cross terms
+      // first; consecutive MFMAs go to different accumulators
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (FULL) {
+        static_for<0, 6>([&](auto T) {
+          constexpr int t = decltype(T)::value;
+          constexpr int PA = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;     // (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+          constexpr int PB = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+          static_for<0, TM>([&](auto I) {
+            static_for<0, TN>([&](auto J) {
+              constexpr int i = decltype(I)::value, j = decltype(J)::value;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB][j], a[PA][i], acc[i][j], 0, 0, 0);
+            });
+          });
+        });
+      } else {   // partial tile: row blocks past the edge are skipped (vb is wave-uniform)
+        static_for<0, TM>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          if (i < vb) {
+            static_for<0, 6>([&](auto T) {
+              constexpr int t = decltype(T)::value;
+              constexpr int PA = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+              constexpr int PB = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+              static_for<0, TN>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB][j], a[PA][i], acc[i][j], 0, 0, 0);
+              });
+            });
+          }
+        });
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      st = st + 1 == NSTAGE ? 0 : st + 1;
     }
-  }
+  };
+  // two instances of the whole loop (not a branch inside it: the accumulators would be merged through copies)
+  if (vb == TM) kloop(std::true_type{});
+  else kloop(std::false_type{});
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two groups match: every LDS read is done
 
-  // ---- epilogue: acc[i][j][r] = C(m, n), m = m0 + wr*BM/2 + i*32 + l31, n = n0 + wc*BN/2 + j*32 + 8*(r>>2) + 4*hi + (r&3)
-  const bool vec = (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
-  static_for<0, TM>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    const int m = m0 + wr * (BM / 2) + i * 32 + l31;
+  // ---- epilogue.  acc[i][j][r] = C(m, n), m = m0 + grp*128 + i*32 + l31, n = nw + j*32 + 8*(r>>2) + 4*hi + (r&3).  The
+  // arithmetic runs in this layout (a lane owns 4-runs of ONE row: bias / saved pre-activation are 16 B reads, and per 16
+  // columns its 8 values are exactly its lane slot of the next GEMM's A chunk: packed planes leave as 1 KiB stores).
+  // fp32 outputs (C, preact) go through a per-wave LDS transpose so that every store instruction writes whole 128 /
+  // 256-byte row segments (measured: 32-byte segments straight from the accumulator layout write at 2.8 TB/s, full
+  // lines at 4.6 TB/s).
+  constexpr int WC = TN * 32;                      // columns of a wave
+  constexpr int RS = WC * 4 + 16;                  // LDS row stride of the transpose buffer (bytes)
+  constexpr int LPR = WC / 4;                      // lanes per row in the row-major readback (16 B each)
+  constexpr int RPI = 64 / LPR;                    // rows per store instruction
+  char* wl = sm + wave * (32 * RS);
+  const int nw = n0 + wq * WC;
+  const bool vec = (p.ldc % 4 == 0) && (reinterpret_cast<uintptr_t>(p.C) % 16 == 0) &&
+                   (reinterpret_cast<uintptr_t>(p.preact) % 16 == 0);
+  const bool rvec = p.resid && (p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.resid) % 16 == 0);
+  const int rr = lane / LPR, rc4 = (lane % LPR) * 4;   // row-major readback: row rr (+ RPI per step), columns rc4..+3
+
+  // the wave's 32 x WC block `o` (acc layout) -> dst rows, coalesced; acc_in: C += o
+  auto store_rows = [&](float* dst, const f32x16 (&o)[TN], int mloc, bool accumulate) __attribute__((always_inline)) {
     static_for<0, TN>([&](auto J) {
       constexpr int j = decltype(J)::value;
       static_for<0, 4>([&](auto G) {
         constexpr int g = decltype(G)::value;
-        const int n = n0 + wc * (BN / 2) + j * 32 + 8 * g + 4 * hi;
-        if (m < m_end && n < p.N) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-          const int nv = min(4, p.N - n);
-          if (p.bias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += e < nv ? p.bias[n + e] : 0.f;
-          }
-          const long co = (long)m * p.ldc + n;
-          float rv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.resid) {
-            const float* rp = p.resid + (long)m * p.ldr + n;
-            if (vec && nv == 4) {
-              const float4 q = *reinterpret_cast<const float4*>(rp);
-              rv[0] = q.x; rv[1] = q.y; rv[2] = q.z; rv[3] = q.w;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) rv[e] = e < nv ? rp[e] : 0.f;
-            }
-          }
-          if (p.preact) {
-            float* pp = p.preact + co;
-            if (vec && nv == 4) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) if (e < nv) pp[e] = v[e];
-            }
-          }
-          if (p.act == SVL_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-          } else if (p.act == SVL_ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (p.resid) {
-            if (p.act == SVL_ACT_MUL_DGELU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(rv[e]);
-            } else if (p.act == SVL_ACT_MUL_DRELU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += rv[e];
-            }
-          }
-          if (p.C) {
-            float* cp = p.C + co;
-            if (p.accumulate) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) if (e < nv) v[e] += cp[e];
-            }
-            if (vec && nv == 4) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) if (e < nv) cp[e] = v[e];
-            }
-          }
-          if (p.P) {   // the result as the A planes of the next GEMM: record (n / 16, m), 8 B per plane at k offset n % 16
-            bf16x4 h0, h1, h2;
-            split3(v, h0, h1, h2);
-            __bf16* rec = p.P + ((long)(n >> 4) * p.p_rows + m) * REC + (n & 15);
-            *reinterpret_cast<bf16x4*>(rec) = h0;
-            *reinterpret_cast<bf16x4*>(rec + 16) = h1;
-            *reinterpret_cast<bf16x4*>(rec + 32) = h2;
-          }
-        }
+        f32x4 q = {o[j][4 * g], o[j][4 * g + 1], o[j][4 * g + 2], o[j][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(wl + l31 * RS + (j * 32 + 8 * g + 4 * hi) * 4) = q;
       });
     });
+    // (same wave wrote and reads: DS operations of a wave execute in order, no barrier)
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int row = it * RPI + rr;
+      const f32x4 q = *reinterpret_cast<const f32x4*>(wl + row * RS + rc4 * 4);
+      const int n = nw + rc4;
+      if (mloc + row < mvalid && n < p.N) {
+        float* d = dst + (long)(m0 + mloc + row) * p.ldc + n;
+        if (vec && n + 4 <= p.N) {
+          f32x4 v = q;
+          if (accumulate) v += *reinterpret_cast<const f32x4*>(d);
+          *reinterpret_cast<f32x4*>(d) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) d[e] = accumulate ? d[e] + q[e] : q[e];
+        }
+      }
+    }
+  };
+
+  static_for<0, TM>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    const int mloc = grp * 128 + i * 32;
+    if (mloc < mvalid) {
+      const int m = m0 + mloc + l31;
+      const bool mok = mloc + l31 < mvalid;
+      // 1. bias
+      if (p.bias) {
+        static_for<0, TN>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          static_for<0, 4>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            const int n = nw + j * 32 + 8 * g + 4 * hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += n + e < p.N ? p.bias[n + e] : 0.f;
+          });
+        });
+      }
+      // 2. pre-activation copy
+      if (p.preact) store_rows(p.preact, acc[i], mloc, false);
+      // 3. activation / residual / derivative product
+      static_for<0, TN>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        static_for<0, 4>([&](auto G) {
+          constexpr int g = decltype(G)::value;
+          const int n = nw + j * 32 + 8 * g + 4 * hi;
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.resid && mok && n < p.N) {
+            const float* rp = p.resid + (long)m * p.ldr + n;
+            if (rvec && n + 4 <= p.N) {
+              const f32x4 q = *reinterpret_cast<const f32x4*>(rp);
+              rv[0] = q[0]; rv[1] = q[1]; rv[2] = q[2]; rv[3] = q[3];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) rv[e] = n + e < p.N ? rp[e] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][4 * g + e];
+            if constexpr (EPI == EPI_GELU) v = gelu_erf(v) + rv[e];
+            else if constexpr (EPI == EPI_DGELU) v *= gelu_erf_grad(rv[e]);
+            else {
+              if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
+              if (p.act == SVL_ACT_MUL_DRELU) v = rv[e] > 0.f ? v : 0.f;
+              else v += rv[e];
+            }
+            acc[i][j][4 * g + e] = v;
+          }
+        });
+      });
+      // 4. outputs
+      if (p.C) store_rows(p.C, acc[i], mloc, p.accumulate != 0);
+      if (p.P) {
+        static_for<0, TN>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          static_for<0, 2>([&](auto G2) {
+            constexpr int g2 = decltype(G2)::value;
+            const int nb = nw + j * 32 + 16 * g2;
+            if (nb < p.N) {   // (columns past N / rows past the edge land in padding nobody reads)
+              float o8[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o8[e] = acc[i][j][8 * g2 + e];
+              bf16x8 h0, h1, h2;
+              split3x8(o8, h0, h1, h2);
+              char* q = p.P + (long)(nb >> 4) * p.p_ks + (long)((m0 + mloc) >> 5) * (3 * CH) + lane * 16;
+              *reinterpret_cast<bf16x8*>(q) = h0;
+              *reinterpret_cast<bf16x8*>(q + CH) = h1;
+              *reinterpret_cast<bf16x8*>(q + 2 * CH) = h2;
+            }
+          });
+        });
+      }
+    }
   });
 }
 
-template <int BM, int BN, int BK, int NBUF>
-constexpr int planes_lds_elems() {
-  return NBUF * 3 * (BM + BN) * (BK == 16 ? 24 : 40);
-}
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel_128x128(const PlanesP p) {
-  __shared__ __attribute__((aligned(16))) __bf16 sm[planes_lds_elems<128, 128, 16, 2>()];
-  gemm_planes_body<128, 128, 16, 2>(p, sm);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_planes_kernel_128x128_k32(const PlanesP p) {
-  __shared__ __attribute__((aligned(16))) __bf16 sm[planes_lds_elems<128, 128, 32, 1>()];
-  gemm_planes_body<128, 128, 32, 1>(p, sm);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_planes_kernel_256x128(const PlanesP p) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 smd[];
-  gemm_planes_body<256, 128, 16, 2>(p, smd);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_planes_kernel_256x256(const PlanesP p) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 smd[];
-  gemm_planes_body<256, 256, 16, 2>(p, smd);
-}
-
-// fp32 [rows, K] (element (r, k) at x[r * ld + k * ks]) -> planes[K/16][rows][3][16].  Thread = (row, pair of k-groups):
-// 128 B contiguous read (ks == 1), 2 x 96 B contiguous writes; consecutive lanes = consecutive rows, so a wave writes
-// 6 KiB runs.  ks != 1 (transposed weights, split once) falls back to scalar reads.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long ld, long ks, long rows, int K,
-                                                           __bf16* __restrict__ planes, long p_rows, long row_off) {
+// fp32 [rows, K] (element (r, k) at x[r * ld + k * ks]) -> packed planes.  Thread = (row, k-group, lane half): 2 x 16 B read,
+// 3 x 16 B written; the 32 rows of a block give 512 B contiguous per (k-group, half, plane).  Rows in [rows, rows_pad)
+// of the last row block are written as zeros (finite padding).
+__global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ x, long ld, long ks, long rows, int K,
+                                                          char* __restrict__ planes, long p_ks, long row_off) {
   const long nkg = K >> 4;
-  const long npair = (nkg + 1) >> 1;
-  const long total = rows * npair;
+  const long rows32 = (rows + 31) & ~31L;
+  const long total = rows32 * nkg * 2;
+  const bool fast = ks == 1 && (ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i % rows, kp = i / rows;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const long kg = 2 * kp + h;
-      if (kg >= nkg) break;
-      float v[16];
-      const float* src = x + r * ld + kg * 16 * ks;
-      if (ks == 1 && (ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 f = reinterpret_cast<const float4*>(src)[q];
-          v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
-        }
+    // i = ((rb * nkg + kg) * 2 + h) * 32 + r31: a wave covers one (rb, kg) pair = one chunk triple
+    const int r31 = (int)(i & 31), h = (int)((i >> 5) & 1);
+    const long t = i >> 6;
+    const long kg = t % nkg, rb = t / nkg;
+    const long r = rb * 32 + r31;
+    float v[8];
+    if (r < rows) {
+      const float* src = x + r * ld + (kg * 16 + 4 * h) * ks;
+      if (fast) {
+        const float4 f0 = *reinterpret_cast<const float4*>(src), f1 = *reinterpret_cast<const float4*>(src + 8);
+        v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
       } else {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = src[q * ks];
+        for (int q = 0; q < 4; ++q) { v[q] = src[q * ks]; v[4 + q] = src[(8 + q) * ks]; }
       }
-      bf16x8 o[6];   // record order: plane 0 (k 0..7, 8..15), plane 1, plane 2
+    } else {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float t = v[q];
-        const __bf16 a0 = (__bf16)t;
-        t -= (float)a0;
-        const __bf16 a1 = (__bf16)t;
-        t -= (float)a1;
-        const __bf16 a2 = (__bf16)t;
-        o[q >> 3][q & 7] = a0;
-        o[2 + (q >> 3)][q & 7] = a1;
-        o[4 + (q >> 3)][q & 7] = a2;
-      }
-      bf16x8* dst = reinterpret_cast<bf16x8*>(planes + (kg * p_rows + row_off + r) * REC);
-#pragma unroll
-      for (int q = 0; q < 6; ++q) dst[q] = o[q];
+      for (int q = 0; q < 8; ++q) v[q] = 0.f;
     }
+    bf16x8 h0, h1, h2;
+    split3x8(v, h0, h1, h2);
+    const long rr = row_off + r;
+    char* q = planes + kg * p_ks + (rr >> 5) * (3 * CH) + (h * 32 + (int)(rr & 31)) * 16;
+    *reinterpret_cast<bf16x8*>(q) = h0;
+    *reinterpret_cast<bf16x8*>(q + CH) = h1;
+    *reinterpret_cast<bf16x8*>(q + 2 * CH) = h2;
   }
-}
-
-std::atomic<int> g_band{-1};
-int band_n(int tiles_n) {
-  int band = g_band.load(std::memory_order_relaxed);
-  if (band < 0) {
-    band = getenv("SVL_GEMM_BAND") ? atoi(getenv("SVL_GEMM_BAND")) : 8;
-    if (band < 0) band = 0;
-    g_band.store(band, std::memory_order_relaxed);
-  }
-  return (band <= 0 || tiles_n <= band) ? tiles_n : band;
 }
 
 // hipFuncSetAttribute is per device: one bit per device ordinal and kernel
@@ -413,76 +458,74 @@ bool attr_needed(std::atomic<uint64_t>& mask) {
   return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
 }
 
-template <int BM, int BN, int BK, int NBUF, typename K>
-int launch_tile(PlanesP q, K kern, hipStream_t st) {
-  q.tiles_m = (q.M + BM - 1) / BM;
-  q.tiles_n = (q.N + BN - 1) / BN;
-  q.band_n = band_n(q.tiles_n) * 128 / BN;     // bands of ~1024 columns
-  if (q.band_n < 1) q.band_n = 1;
-  const long tiles = (long)q.tiles_m * q.tiles_n;
-  if (tiles <= 0 || tiles > 0x7fffffffL) {
-    svl_set_error("svl_gemm_planes_f32: bad tile count %ld", tiles);
-    return SVL_ERR_INVALID_ARG;
-  }
-  constexpr size_t lds = (size_t)planes_lds_elems<BM, BN, BK, NBUF>() * 2;
-  if constexpr (BM == 128) {
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), 0, st, q);
-  } else {
-    static std::atomic<uint64_t> mask{0};
-    if (attr_needed(mask))
-      SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, q);
-  }
+template <int BN, int EPI>
+int launch_kernel(const PlanesP& q, long blocks, hipStream_t st) {
+  constexpr size_t lds = (size_t)NSTAGE * ((BM + BN) / 32 * 3) * CH;
+  static std::atomic<uint64_t> mask{0};
+  if (attr_needed(mask))
+    SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6p_kernel<BN, EPI>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((gemm_x6p_kernel<BN, EPI>), dim3((unsigned)blocks), dim3(512), lds, st, q);
   SVL_LAUNCH_CHECK("svl_gemm_planes_f32");
   return SVL_OK;
 }
 
-// Tile choice: the largest tile whose grid is a whole number of rounds of resident blocks (256 CUs x 1 block for the
-// 256-row tiles, x 2 for 128x128), falling back to the shape that wastes the least of its last round.
-int launch(const PlanesP& q, hipStream_t st) {
-  // 1: 128x128 BK 16; 2: 256x128; 3: 256x256; 4: 128x128 BK 32 (single LDS buffer)
-  static const int force = getenv("SVL_PLANES_TILE") ? atoi(getenv("SVL_PLANES_TILE")) : 0;
-  auto waste = [&](int bm, int bn, int resident) {
-    const long tiles = (long)((q.M + bm - 1) / bm) * ((q.N + bn - 1) / bn);
-    const long rounds = (tiles + resident - 1) / resident;
-    return (double)(rounds * resident) / (double)tiles;      // >= 1: executed / useful block slots
-  };
-  int pick = force;
-  if (!pick) {
-    if (q.M < 1024 || q.N < 128) pick = 1;
-    else {
-      // relative cost model: slots wasted x per-FLOP efficiency of the shape (L2 traffic: 128x128 is L2-bound)
-      const double c3 = q.N >= 256 ? waste(256, 256, 256) * 1.00 : 1e9;
-      const double c2 = waste(256, 128, 256) * 1.12;
-      const double c1 = waste(128, 128, 512) * 1.55;
-      pick = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
-    }
+template <int BN>
+int launch_tile(PlanesP q, hipStream_t st) {
+  q.tiles_n = (q.N + BN - 1) / BN;
+  q.full_m = q.M / BM;
+  q.tail_rows = q.M % BM;
+  const long nf = (long)q.full_m * q.tiles_n, nr = q.tail_rows ? q.tiles_n : 0, total = nf + nr;
+  if (total <= 0 || total > 0x7fffffffL) {
+    svl_set_error("svl_gemm_planes_f32: bad tile count %ld", total);
+    return SVL_ERR_INVALID_ARG;
   }
-  if (pick == 4 && (q.K % 32) != 0) pick = 1;
-  if (pick == 4) return launch_tile<128, 128, 32, 1>(q, gemm_planes_kernel_128x128_k32, st);
-  if (pick == 3) return launch_tile<256, 256, 16, 2>(q, gemm_planes_kernel_256x256, st);
-  if (pick == 2) return launch_tile<256, 128, 16, 2>(q, gemm_planes_kernel_256x128, st);
-  return launch_tile<128, 128, 16, 2>(q, gemm_planes_kernel_128x128, st);
+  long fs = 0;
+  for (int x = 0; x < 8; ++x) {   // XCD x runs the blocks with id % 8 == x
+    const long blocks = (total - x + 7) / 8, rag = nr > x ? (nr - x + 7) / 8 : 0;
+    q.rcnt[x] = (int)rag;
+    q.fstart[x] = (int)fs;
+    fs += blocks - rag;
+  }
+  const long grid = total;
+  if (q.act == SVL_ACT_GELU) return launch_kernel<BN, EPI_GELU>(q, grid, st);
+  if (q.act == SVL_ACT_MUL_DGELU) return launch_kernel<BN, EPI_DGELU>(q, grid, st);
+  return launch_kernel<BN, EPI_LIGHT>(q, grid, st);
+}
+
+// Tile choice: 256 x 256 unless 256 x 128 wastes less of the last round of the grid (256 CUs x 1 block; the ragged row
+// band's tiles are short and come first, so only the full tiles count) -- N = 768 / 2304 at M = 32768.
+int launch(const PlanesP& q, hipStream_t st) {
+  static const int force = getenv("SVL_PLANES_TILE") ? atoi(getenv("SVL_PLANES_TILE")) : 0;
+  auto cost = [&](int bn) {
+    const long tiles = (long)(q.M / BM) * ((q.N + bn - 1) / bn);
+    const long rounds = tiles > 0 ? (tiles + 255) / 256 : 1;
+    return (double)rounds * bn * (bn == 128 ? 1.06 : 1.0);     // time ~ rounds x tile width (x the narrow tile's overhead)
+  };
+  int bn = force ? force : (q.N <= 128 || cost(128) < cost(256) ? 128 : 256);
+  if (bn == 128) return launch_tile<128>(q, st);
+  return launch_tile<256>(q, st);
 }
 
 }  // namespace
 
+extern "C" int64_t svl_planes_rows(int64_t rows) { return rows <= 0 ? -1 : (rows + 255) / 256 * 256; }
+
 extern "C" int64_t svl_planes_bytes(int64_t rows, int K) {
   if (rows <= 0 || K <= 0 || (K & 15)) return -1;
-  return (int64_t)(K >> 4) * rows * REC * 2;
+  return (int64_t)(K >> 4) * svl_planes_rows(rows) * 96;
 }
 
 extern "C" int svl_split_planes_bf16x3(const float* x, int64_t ld, int64_t k_stride, int64_t rows, int K, void* planes,
                                        int64_t planes_rows, int64_t row_off, svl_stream_t stream) {
   SVL_CHECK_ARG(x && planes && rows > 0 && K > 0 && (K & 15) == 0 && k_stride >= 1 && planes_rows >= row_off + rows &&
-                    row_off >= 0,
-                "svl_split_planes_bf16x3: bad args (K must be a multiple of 16)");
-  const long total = rows * (((long)(K >> 4) + 1) >> 1);
+                    row_off >= 0 && (planes_rows & 255) == 0 && (row_off & 31) == 0,
+                "svl_split_planes_bf16x3: bad args (K %% 16, planes_rows %% 256, row_off %% 32 must be 0)");
+  const long total = ((rows + 31) & ~31L) * (K >> 4) * 2;
   long grid = (total + 255) / 256;
   if (grid > 256 * 64) grid = 256 * 64;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (long)ld,
-                     (long)k_stride, (long)rows, K, (__bf16*)planes, (long)planes_rows, (long)row_off);
+  hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, (long)ld,
+                     (long)k_stride, (long)rows, K, (char*)planes, (long)planes_rows * 96, (long)row_off);
   SVL_LAUNCH_CHECK("svl_split_planes_bf16x3");
   return SVL_OK;
 }
@@ -490,40 +533,30 @@ extern "C" int svl_split_planes_bf16x3(const float* x, int64_t ld, int64_t k_str
 extern "C" int svl_gemm_planes_f32(const svl_pgemm_desc* d, svl_stream_t stream) {
   SVL_CHECK_ARG(d, "svl_gemm_planes_f32: null desc");
   SVL_CHECK_ARG(d->A && d->B && d->M > 0 && d->N > 0 && d->K > 0 && (d->K & 15) == 0 && d->m_off >= 0 &&
+                    (d->m_off & 31) == 0 && (d->a_rows & 255) == 0 && (d->b_rows & 255) == 0 &&
                     d->a_rows >= d->m_off + d->M && d->b_rows >= d->N,
-                "svl_gemm_planes_f32: bad operands (K %% 16 == 0, plane buffers must cover the rows)");
+                "svl_gemm_planes_f32: bad operands (K %% 16 == 0, m_off %% 32 == 0, plane buffers padded to 256 rows)");
   SVL_CHECK_ARG(d->C || d->planes_out, "svl_gemm_planes_f32: no output");
-  SVL_CHECK_ARG(!d->planes_out || ((d->N & 15) == 0 && d->p_rows >= d->m_off + d->M),
-                "svl_gemm_planes_f32: planes_out needs N %% 16 == 0 and p_rows >= rows");
+  SVL_CHECK_ARG(!d->planes_out || ((d->N & 15) == 0 && (d->p_rows & 255) == 0 && d->p_rows >= d->m_off + d->M),
+                "svl_gemm_planes_f32: planes_out needs N %% 16 == 0 and p_rows (%% 256 == 0) >= rows");
   SVL_CHECK_ARG(d->act >= SVL_ACT_NONE && d->act <= SVL_ACT_MUL_DRELU, "svl_gemm_planes_f32: bad act");
   SVL_CHECK_ARG(!(d->act == SVL_ACT_MUL_DGELU || d->act == SVL_ACT_MUL_DRELU) || d->resid,
                 "svl_gemm_planes_f32: MUL_D* needs the saved pre-activation in resid");
   SVL_CHECK_ARG(!d->accumulate || d->C, "svl_gemm_planes_f32: accumulate needs C");
+  // a tile reads whole 256-row bands of A from m_off on: the buffer must hold them (allocation padding, never stored)
+  SVL_CHECK_ARG(d->a_rows - d->m_off >= (int64_t)(d->M + 255) / 256 * 256 || (d->m_off % 256) == 0,
+                "svl_gemm_planes_f32: A plane buffer too short for the last row band");
   PlanesP p;
-  p.A = (const __bf16*)d->A; p.B = (const __bf16*)d->B;
-  p.a_rows = d->a_rows; p.b_rows = d->b_rows;
-  p.m_off = d->m_off; p.M = d->M; p.N = d->N; p.K = d->K;
-  p.C = d->C; p.ldc = d->ldc;
-  p.P = (__bf16*)d->planes_out; p.p_rows = d->p_rows;
-  p.bias = d->bias; p.act = d->act; p.preact = d->preact; p.resid = d->resid; p.ldr = d->ldr;
+  const long mo = d->m_off;
+  p.A = (const char*)d->A + (mo >> 5) * (3 * CH);
+  p.B = (const char*)d->B;
+  p.a_ks = d->a_rows * 96; p.b_ks = d->b_rows * 96;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.C = d->C ? d->C + mo * d->ldc : nullptr; p.ldc = d->ldc;
+  p.P = d->planes_out ? (char*)d->planes_out + (mo >> 5) * (3 * CH) : nullptr; p.p_ks = d->p_rows * 96;
+  p.bias = d->bias; p.act = d->act;
+  p.preact = d->preact ? d->preact + mo * d->ldc : nullptr;
+  p.resid = d->resid ? d->resid + mo * d->ldr : nullptr; p.ldr = d->ldr;
   p.accumulate = d->accumulate;
-  hipStream_t st = (hipStream_t)stream;
-  // Ragged token counts (M = images x 1025 = 128 k + r): the r leftover rows would add a whole round of the grid; they
-  // run as a second one-row-tile launch on the helper stream, concurrent with the aligned part (as in svl_gemm_f32).
-  static const int fork = getenv("SVL_GEMM_NO_FORK") ? 0 : 1;
-  if (fork && d->M >= 8192 && (d->M % 256) != 0) {
-    PlanesP mainp = p, rem = p;
-    mainp.M = (d->M / 256) * 256;
-    rem.m_off = p.m_off + mainp.M;
-    rem.M = d->M - mainp.M;
-    hipStream_t aux = nullptr;
-    int rc = svl_fork(st, &aux);
-    if (rc != SVL_OK) return rc;
-    rc = launch(rem, aux);
-    if (rc != SVL_OK) return rc;
-    rc = launch(mainp, st);
-    if (rc != SVL_OK) return rc;
-    return svl_join(st);
-  }
-  return launch(p, st);
+  return launch(p, (hipStream_t)stream);
 }

@@ -19,7 +19,8 @@ inline int grid_for(long n, int per_thread = 1) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, long rows, int C,
-                                                            float* __restrict__ y, float* __restrict__ stats) {
+                                                            float* __restrict__ y, float* __restrict__ stats,
+                                                            char* __restrict__ planes, long p_ks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C4 = C >> 2;
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.y = (v.y - mean) * rstd * g.y + b.y;
       o.z = (v.z - mean) * rstd * g.z + b.z;
       o.w = (v.w - mean) * rstd * g.w + b.w;
-      yr[i] = o;
+      if (y) yr[i] = o;
+      if (planes) svl_store_planes_f4(planes, p_ks, r, i, o.x, o.y, o.z, o.w);   // the following GEMM's A operand
     }
     if (lane == 0) {
       stats[2 * r] = mean;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, long rows, int C,
                                                             const float* __restrict__ dx_add, float* __restrict__ dx,
                                                             float* __restrict__ dg_part, float* __restrict__ db_part,
-                                                            long rows_per_block) {
+                                                            long rows_per_block, char* __restrict__ planes, long p_ks) {
   __shared__ float sh[2][4][LN_MAXV * 256];  // [dg|db][wave][column]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C4 = C >> 2;
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         oxr[i] = o;
+        if (planes) svl_store_planes_f4(planes, p_ks, r, i, o.x, o.y, o.z, o.w);   // dx as the next dgrad GEMM's A operand
       }
     }
   }
@@ -550,14 +553,23 @@ inline bool gn_shape_ok(int C, int G) {
 
 }  // namespace
 
-extern "C" int svl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
-                                 float* y, float* stats, svl_stream_t stream) {
-  SVL_CHECK_ARG(x && gamma && beta && y && stats && rows > 0 && C > 0 && C % 4 == 0, "svl_layernorm_fwd: bad args");
+extern "C" int svl_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, float eps, int64_t rows,
+                                        int C, float* y, float* stats, void* planes, int64_t planes_rows,
+                                        svl_stream_t stream) {
+  SVL_CHECK_ARG(x && gamma && beta && (y || planes) && stats && rows > 0 && C > 0 && C % 4 == 0,
+                "svl_layernorm_fwd: bad args");
+  SVL_CHECK_ARG(!planes || (C % 16 == 0 && planes_rows >= rows && planes_rows % 256 == 0),
+                "svl_layernorm_fwd_planes: C %% 16 == 0 and planes_rows (%% 256 == 0) >= rows");
   const int grid = (int)((rows + 3) / 4 > 4096 * 4 ? 4096 * 4 : (rows + 3) / 4);
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
-                     (long)rows, C, y, stats);
+                     (long)rows, C, y, stats, (char*)planes, (long)planes_rows * 96);
   SVL_LAUNCH_CHECK("svl_layernorm_fwd");
   return SVL_OK;
+}
+extern "C" int svl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
+                                 float* y, float* stats, svl_stream_t stream) {
+  SVL_CHECK_ARG(y, "svl_layernorm_fwd: bad args");
+  return svl_layernorm_fwd_planes(x, gamma, beta, eps, rows, C, y, stats, nullptr, 0, stream);
 }
 
 extern "C" int svl_layernorm_bwd_parts(int64_t rows) {
@@ -570,13 +582,20 @@ extern "C" int svl_layernorm_bwd_parts(int64_t rows) {
 extern "C" int svl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int64_t rows,
                                  int C, const float* dx_add, float* dx, float* dgamma_part, float* dbeta_part,
                                  svl_stream_t stream) {
+  return svl_layernorm_bwd_planes(dy, x, stats, gamma, rows, C, dx_add, dx, dgamma_part, dbeta_part, nullptr, 0, stream);
+}
+extern "C" int svl_layernorm_bwd_planes(const float* dy, const float* x, const float* stats, const float* gamma,
+                                        int64_t rows, int C, const float* dx_add, float* dx, float* dgamma_part,
+                                        float* dbeta_part, void* planes, int64_t planes_rows, svl_stream_t stream) {
   SVL_CHECK_ARG(dy && x && stats && gamma && dx && rows > 0 && C > 0 && C % 4 == 0 && C <= 1024,
                 "svl_layernorm_bwd: bad args (C=%d)", C);
+  SVL_CHECK_ARG(!planes || (C % 16 == 0 && planes_rows >= rows && planes_rows % 256 == 0),
+                "svl_layernorm_bwd_planes: C %% 16 == 0 and planes_rows (%% 256 == 0) >= rows");
   SVL_CHECK_ARG((dgamma_part == nullptr) == (dbeta_part == nullptr), "svl_layernorm_bwd: dgamma/dbeta go together");
   const int nparts = svl_layernorm_bwd_parts(rows);
   const long rpb = (rows + nparts - 1) / nparts;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma,
-                     (long)rows, C, dx_add, dx, dgamma_part, dbeta_part, rpb);
+                     (long)rows, C, dx_add, dx, dgamma_part, dbeta_part, rpb, (char*)planes, (long)planes_rows * 96);
   SVL_LAUNCH_CHECK("svl_layernorm_bwd");
   return SVL_OK;
 }

@@ -72,6 +72,7 @@ SIGNATURES = {
     "svl_set_gemm_emulation": (_I, [_I]),
     "svl_get_gemm_emulation": (_I, []),
     "svl_set_conv_tiled": (_I, [_I]),
+    "svl_planes_rows": (_L, [_L]),
     "svl_planes_bytes": (_L, [_L, _I]),
     "svl_split_planes_bf16x3": (_I, [_P, _L, _L, _L, _I, _P, _L, _L, _P]),
     "svl_gemm_planes_f32": (_I, [C.POINTER(PGemmDesc), _P]),
@@ -97,8 +98,10 @@ SIGNATURES = {
     "svl_concept_max_f32": (_I, [_P, _I, _I, _L, _P, _I, _P, _P]),
     "svl_iou_hist_i64": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "svl_layernorm_fwd": (_I, [_P, _P, _P, _F, _L, _I, _P, _P, _P]),
+    "svl_layernorm_fwd_planes": (_I, [_P, _P, _P, _F, _L, _I, _P, _P, _P, _L, _P]),
     "svl_layernorm_bwd_parts": (_I, [_L]),
     "svl_layernorm_bwd": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P]),
+    "svl_layernorm_bwd_planes": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _L, _P]),
     "svl_softmax_rows_fwd": (_I, [_P, _L, _I, _L, _F, _P]),
     "svl_softmax_rows_bwd": (_I, [_P, _P, _L, _I, _L, _F, _P]),
     "svl_l2norm_fwd": (_I, [_P, _L, _I, _F, _P, _P, _P]),

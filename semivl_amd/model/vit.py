@@ -86,25 +86,41 @@ def sink_grad(param, grad_fn, shape=None):
 
 # ------------------------------------------------------------------------------------------------ block forward / backward
 def block_forward(x, p, heads, eps, Bn, T, want_v, skip_x, save):
-    """x [Bn*T, E] -> (x_out or None, v or None).  `save` is a dict to stash what backward needs (or None)."""
+    """x [Bn*T, E] -> (x_out or None, v or None).  `save` is a dict to stash what backward needs (or None).
+    Under the packed-planes GEMM path (ops.planes_eligible) every A operand is produced directly in that format: both
+    LayerNorms and the FFN-1 epilogue emit planes (ln2's output and gelu(h) exist ONLY as planes), the attention output
+    and the v slice of qkv take the generic split pass."""
     E = x.shape[1]
     D = E // heads
-    y1, st1 = ops.layernorm_fwd(x, p["ln1w"], p["ln1b"], eps)
+    pp = ops.planes_eligible(x.shape[0], E, E)
+    if pp:   # y1 in fp32 is only read by the in_proj weight gradient
+        y1, st1, y1a = ops.layernorm_fwd(x, p["ln1w"], p["ln1b"], eps, planes=True, want_y=save is not None)
+    else:
+        y1, st1 = ops.layernorm_fwd(x, p["ln1w"], p["ln1b"], eps)
+        y1a = y1
     if skip_x:
-        vproj = ops.linear(y1, p["win"][2 * E:], p["bin"][2 * E:])
+        vproj = ops.linear(y1a, p["win"][2 * E:], p["bin"][2 * E:])
         qkv = None
     else:
-        qkv = ops.linear(y1, p["win"], p["bin"])
+        qkv = ops.linear(y1a, p["win"], p["bin"])
         vproj = qkv[:, 2 * E:]
     v = None
     if save is not None:
         save.update(x=x, y1=y1, st1=st1, qkv=qkv, vproj=vproj, want_v=want_v, skip_x=skip_x, eps=eps)
+
+    def ffn(pre, want_pre):
+        """pre + FFN(LN2(pre)); returns (out, ln2 stats, saved pre-activation or None)."""
+        if pp:
+            _, st2_, y2a = ops.layernorm_fwd(pre, p["ln2w"], p["ln2b"], eps, planes=True, want_y=False)
+        else:
+            y2a, st2_ = ops.layernorm_fwd(pre, p["ln2w"], p["ln2b"], eps)
+        h_pre_ = ops.empty(pre.shape[0], p["w1"].shape[0], device=x.device) if want_pre else None
+        h_ = ops.linear(y2a, p["w1"], p["b1"], act=ops.ACT_GELU, preact=h_pre_, planes_only=True)   # only feeds FFN-2
+        return ops.linear(h_, p["w2"], p["b2"], resid=pre), st2_, h_pre_
+
     if want_v:
-        vo = ops.linear(vproj, p["wout"], p["bout"], resid=x)  # out_proj(v) + x   (maskclip_vit.py:115-117)
-        y2v, st2v = ops.layernorm_fwd(vo, p["ln2w"], p["ln2b"], eps)
-        hv_pre = ops.empty(y2v.shape[0], p["w1"].shape[0], device=x.device) if save is not None else None
-        hv = ops.linear(y2v, p["w1"], p["b1"], act=ops.ACT_GELU, preact=hv_pre, planes_only=True)  # only feeds FFN-2
-        v = ops.linear(hv, p["w2"], p["b2"], resid=vo)
+        vo = ops.linear(ops.split_planes(vproj) if pp else vproj, p["wout"], p["bout"], resid=x)  # out_proj(v) + x   (maskclip_vit.py:115-117)
+        v, st2v, hv_pre = ffn(vo, save is not None)
         if save is not None:
             save.update(vo=vo, st2v=st2v, hv_pre=hv_pre)
     xo = None
@@ -113,30 +129,31 @@ def block_forward(x, p, heads, eps, Bn, T, want_v, skip_x, save):
             o, P = ops.attention_fwd(qkv, Bn, T, heads, want_lse=save is not None)  # P := log-sum-exp rows
         else:  # generic head dim: batched-GEMM attention with materialised probabilities
             o, P = ops.vit_attention_fwd(qkv, Bn, T, heads, D)
-        x2 = ops.linear(o, p["wout"], p["bout"], resid=x)
-        y2, st2 = ops.layernorm_fwd(x2, p["ln2w"], p["ln2b"], eps)
-        h_pre = ops.empty(y2.shape[0], p["w1"].shape[0], device=x.device) if save is not None else None
-        h = ops.linear(y2, p["w1"], p["b1"], act=ops.ACT_GELU, preact=h_pre, planes_only=True)
-        xo = ops.linear(h, p["w2"], p["b2"], resid=x2)
+        x2 = ops.linear(ops.split_planes(o) if pp else o, p["wout"], p["bout"], resid=x)
+        xo, st2, h_pre = ffn(x2, save is not None)
         if save is not None:
             save.update(o=o, P=P, x2=x2, st2=st2, h_pre=h_pre)
     return xo, v
 
 
-def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False):
-    """Returns (dx_in, grads dict).  Attention projections are the trainable part of the backbone (vlm.py:66-67);
-    `train_ffn_ln` additionally produces FFN / LN weight grads (decoder's SemanticTransformer)."""
+def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False, dxo_p=None):
+    """Returns (dx_in, dx_in planes or None, grads dict).  Attention projections are the trainable part of the backbone
+    (vlm.py:66-67); `train_ffn_ln` additionally produces FFN / LN weight grads (decoder's SemanticTransformer).
+    `dxo_p`: dxo as packed planes when the block above already produced them (its LN1 backward)."""
     x, y1 = s["x"], s["y1"]
     E = x.shape[1]
     D = E // heads
+    pp = ops.planes_eligible(x.shape[0], E, E)
     g = {}
     dx_res = None
     dqkv = None
     wout_parts = []  # (dy, input) pairs contributing to out_proj wgrad
 
-    def ffn_ln_bwd(dout, pre_ln_in, st2, h_pre, tag):
+    def ffn_ln_bwd(dout, dout_p, pre_ln_in, st2, h_pre, tag):
+        """-> (d pre_ln_in, the same as planes or None)"""
         # (dout W2) * GELU'(h_pre), one pass; with frozen FFN weights its only consumer is the next GEMM (bf16 planes)
-        dhp = ops.matmul_nn(dout, p["w2"], dact=ops.ACT_MUL_DGELU, z=h_pre, planes_only=not train_ffn_ln)
+        a_ = dout_p if dout_p is not None else dout
+        dhp = ops.matmul_nn(a_, p["w2"], dact=ops.ACT_MUL_DGELU, z=h_pre, planes_only=not train_ffn_ln)
         dy2 = ops.matmul_nn(dhp, p["w1"])
         if train_ffn_ln:
             # recompute h = gelu(h_pre) and y2 = LN(pre_ln_in) for the weight grads (cheap vs. saving them)
@@ -146,15 +163,17 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False):
             g.setdefault("b2", []).append(dout)
             g.setdefault("w1", []).append((dhp, y2))
             g.setdefault("b1", []).append(dhp)
-            dxx, dg_, db_ = ops.layernorm_bwd(dy2, pre_ln_in, st2, p["ln2w"], dx_add=dout, want_wgrad=True)
-            g.setdefault("ln2w", []).append(dg_)
-            g.setdefault("ln2b", []).append(db_)
-            return dxx
-        return ops.layernorm_bwd(dy2, pre_ln_in, st2, p["ln2w"], dx_add=dout)
+            r_ = ops.layernorm_bwd(dy2, pre_ln_in, st2, p["ln2w"], dx_add=dout, want_wgrad=True, planes=pp)
+            g.setdefault("ln2w", []).append(r_[1])
+            g.setdefault("ln2b", []).append(r_[2])
+            return r_[0], (r_[3] if pp else None)
+        if pp:
+            return ops.layernorm_bwd(dy2, pre_ln_in, st2, p["ln2w"], dx_add=dout, planes=True)
+        return ops.layernorm_bwd(dy2, pre_ln_in, st2, p["ln2w"], dx_add=dout), None
 
     if not s["skip_x"] and dxo is not None:
-        dx2 = ffn_ln_bwd(dxo, s["x2"], s["st2"], s["h_pre"], "x")
-        do = ops.matmul_nn(dx2, p["wout"])
+        dx2, dx2p = ffn_ln_bwd(dxo, dxo_p, s["x2"], s["st2"], s["h_pre"], "x")
+        do = ops.matmul_nn(dx2p if dx2p is not None else dx2, p["wout"])
         wout_parts.append((dx2, s["o"]))
         if D == 64:
             dqkv = ops.attention_bwd(do, s["qkv"], s["o"], s["P"], Bn, T, heads)
@@ -163,8 +182,8 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False):
         dx_res = dx2
     dvproj = None
     if s["want_v"] and dv is not None:
-        dvo = ffn_ln_bwd(dv, s["vo"], s["st2v"], s["hv_pre"], "v")
-        dvproj = ops.matmul_nn(dvo, p["wout"])
+        dvo, dvop = ffn_ln_bwd(dv, None, s["vo"], s["st2v"], s["hv_pre"], "v")
+        dvproj = ops.matmul_nn(dvop if dvop is not None else dvo, p["wout"])
         wout_parts.append((dvo, s["vproj"]))
         dx_res = dvo if dx_res is None else ops.add(dx_res, dvo)
     if dqkv is not None and dvproj is not None:
@@ -179,13 +198,15 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False):
         g["in_v"] = (dvproj, y1)
         dy1 = ops.matmul_nn(dvproj, p["win"][2 * E:])
     else:
-        return dx_res, g
+        return dx_res, None, g
     if train_ffn_ln:
         dx_in, dg_, db_ = ops.layernorm_bwd(dy1, x, s["st1"], p["ln1w"], dx_add=dx_res, want_wgrad=True)
         g["ln1w"], g["ln1b"] = dg_, db_
-    else:
-        dx_in = ops.layernorm_bwd(dy1, x, s["st1"], p["ln1w"], dx_add=dx_res)
-    return dx_in, g
+        return dx_in, None, g
+    if pp:   # the block below consumes dx_in as the A operand of its d FFN-2 GEMM
+        dx_in, dx_in_p = ops.layernorm_bwd(dy1, x, s["st1"], p["ln1w"], dx_add=dx_res, planes=True)
+        return dx_in, dx_in_p, g
+    return ops.layernorm_bwd(dy1, x, s["st1"], p["ln1w"], dx_add=dx_res), None, g
 
 
 def attn_wgrads(p_mod, g, E):
@@ -532,12 +553,12 @@ class _EncoderFn(torch.autograd.Function):
             ops.copy2d(d, 0, NP, NP * E, E, full, E, NP, T * E, E, B * NP, E)
             dvs[li] = full if dvs.get(li) is None else ops.add(dvs[li], full)
         # ---- blocks, last to first
-        dx = None
+        dx = dxp = None
         grads = {}
         for i in range(L - 1, -1, -1):
             layer = m.layers[i]
             sv = s["layers"][i]
-            dx, g = block_backward(dx, dvs.get(i), layer.plist(), sv, m.num_heads, B, T)
+            dx, dxp, g = block_backward(dx, dvs.get(i), layer.plist(), sv, m.num_heads, B, T, dxo_p=dxp)
             wg = attn_wgrads(layer, g, E)
             a = layer.attn.attn
             grads[id(a.in_proj_weight)], grads[id(a.in_proj_bias)] = wg["win"], wg["bin"]

@@ -131,20 +131,31 @@ def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld
 
 
 # ------------------------------------------------------------------------------------------------ pre-split bf16x3 operands
+def planes_rows(rows):
+    return (rows + 255) // 256 * 256
+
+
 class Planes:
-    """An fp32 matrix [rows, K] held as three bf16 planes x = x0 + x1 + x2 in the k-group-blocked layout of
-    csrc/gemm_planes.hip ([K/16][rows][3][16]); the operand format of svl_gemm_planes_f32."""
-    __slots__ = ("buf", "rows", "K")
+    """An fp32 matrix [rows, K] held as three bf16 planes x = x0 + x1 + x2 in the fragment-packed layout of
+    csrc/gemm_planes.hip (1 KiB chunks per (k-group, 32-row block, plane); include/semivl_hip.h): the operand format of
+    svl_gemm_planes_f32.  The buffer holds `prow` = rows rounded up to 256 rows (tiles read whole row bands)."""
+    __slots__ = ("buf", "rows", "K", "prow")
 
     def __init__(self, rows, K, device=None, buf=None):
         assert K % 16 == 0
-        self.rows, self.K = rows, K
-        self.buf = buf if buf is not None else torch.empty(K // 16 * rows * 48, dtype=torch.bfloat16,
+        self.rows, self.K, self.prow = rows, K, planes_rows(rows)
+        self.buf = buf if buf is not None else torch.empty(K // 16 * self.prow * 48, dtype=torch.bfloat16,
                                                            device=device if device is not None else torch.cuda.current_device())
 
     @property
     def shape(self):
         return (self.rows, self.K)
+
+    def kslice(self, k0, k1):
+        """Columns [k0, k1) (multiples of 16) as a Planes view: k-groups are the outermost index of the layout."""
+        assert k0 % 16 == 0 and k1 % 16 == 0 and 0 <= k0 < k1 <= self.K
+        per = self.prow * 48
+        return Planes(self.rows, k1 - k0, buf=self.buf[k0 // 16 * per:k1 // 16 * per])
 
 
 def split_planes(x2d, out=None, row_off=0, transpose=False):
@@ -161,8 +172,8 @@ def split_planes(x2d, out=None, row_off=0, transpose=False):
         ld, ks = x2d.stride(0), 1
     if out is None:
         out = Planes(rows, K, device=x2d.device)
-    assert out.K == K and out.rows >= row_off + rows
-    L.check(L.load().svl_split_planes_bf16x3(_p(x2d), ld, ks, rows, K, _p(out.buf), out.rows, row_off, _st()),
+    assert out.K == K and out.rows >= row_off + rows and row_off % 32 == 0
+    L.check(L.load().svl_split_planes_bf16x3(_p(x2d), ld, ks, rows, K, _p(out.buf), out.prow, row_off, _st()),
             "svl_split_planes_bf16x3")
     return out
 
@@ -233,16 +244,15 @@ def weight_planes(W, transpose=False):
 
 
 def planes_eligible(M, N, K):
-    """The pre-split path serves what the in-register emulation served (large dense GEMMs) when K is a whole number of
-    MFMA k-groups."""
-    return get_gemm_emulation() == 6 and PLANES_PATH and M >= 256 and N >= 96 and K >= 64 and K % 16 == 0
+    """The pre-split path serves the large dense GEMMs of emulation mode 6 (the ViT linears: K, N in {768, 2304, 3072})
+    when K is a whole number of MFMA k-groups; narrower ones (the decoder's K = 128 ... 512 per-pixel linears) stay on the
+    in-register split kernel, where a separate split pass over A would cost more than it saves."""
+    return get_gemm_emulation() == 6 and PLANES_PATH and M >= 256 and N >= 256 and K >= 512 and K % 16 == 0
 
 
-# Opt-in (SVL_GEMM_PLANES=1): measured on MI355X the pre-split kernel runs the six-product scheme at the SAME matrix-pipe
-# rate as the in-register split kernel (~1.0 PF bf16 = 165-180 TF fp32-equivalent at 128x128 tiles; both are bound by the
-# per-K-step barrier / LDS-latency structure, not by the split's VALU work), and its extra pass over the activations
-# makes the step 3.5 % slower (598 vs 578 ms, DESIGN.md §7) -- so the in-register kernel stays the default of mode 6.
-PLANES_PATH = bool(os.environ.get("SVL_GEMM_PLANES"))
+# Mode 6 runs its dense GEMMs on the packed-planes kernel (csrc/gemm_planes.hip: LDS-DMA + MFMA only in the main loop);
+# SVL_GEMM_NO_PLANES=1 keeps the in-register split kernel of gemm.hip for A/B runs.
+PLANES_PATH = not os.environ.get("SVL_GEMM_NO_PLANES")
 
 
 def pgemm(A, B, M, N, out=None, planes_out=None, bias=None, act=ACT_NONE, preact=None, resid=None, accumulate=False,
@@ -251,7 +261,7 @@ def pgemm(A, B, M, N, out=None, planes_out=None, bias=None, act=ACT_NONE, preact
     K = A.K
     assert B.K == K and A.rows >= m_off + M and B.rows >= N
     d = L.PGemmDesc()
-    d.A, d.B, d.a_rows, d.b_rows = _p(A.buf), _p(B.buf), A.rows, B.rows
+    d.A, d.B, d.a_rows, d.b_rows = _p(A.buf), _p(B.buf), A.prow, B.prow
     d.m_off, d.M, d.N, d.K = m_off, M, N, K
     if out is not None:
         assert out.stride(1) == 1
@@ -259,7 +269,7 @@ def pgemm(A, B, M, N, out=None, planes_out=None, bias=None, act=ACT_NONE, preact
     elif preact is not None:
         d.ldc = preact.stride(0)
     if planes_out is not None:
-        d.planes_out, d.p_rows = _p(planes_out.buf), planes_out.rows
+        d.planes_out, d.p_rows = _p(planes_out.buf), planes_out.prow
     d.bias, d.act, d.preact = _p(bias), act, _p(preact)
     if resid is not None:
         assert resid.stride(1) == 1
@@ -267,7 +277,7 @@ def pgemm(A, B, M, N, out=None, planes_out=None, bias=None, act=ACT_NONE, preact
     d.accumulate = 1 if accumulate else 0
     e0 = _prof_begin()
     L.check(L.load().svl_gemm_planes_f32(C.byref(d), _st()), "svl_gemm_planes_f32")
-    _prof_end("gemm", e0, 2.0 * M * N * K, ("planes", M, N, K, 1))
+    _prof_end("gemm_bf16x", e0, 2.0 * M * N * K, ("planes", M, N, K, 1))
 
 
 # ------------------------------------------------------------------------------------------------ dense helpers
@@ -431,16 +441,25 @@ def chanmask(x, mask, scale, rows_per_img, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ normalisation
-def layernorm_fwd(x, gamma, beta, eps):
+def layernorm_fwd(x, gamma, beta, eps, planes=False, want_y=True):
+    """y = LN(x), stats.  planes=True additionally returns the result as packed Planes (the next GEMM's A operand);
+    want_y=False then skips the fp32 copy (returns None for it)."""
     rows, Cc = x.shape
-    y = torch.empty_like(x)
     stats = empty(rows, 2, device=x.device)
-    L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),
-            "svl_layernorm_fwd")
-    return y, stats
+    if not planes:
+        y = torch.empty_like(x)
+        L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),
+                "svl_layernorm_fwd")
+        return y, stats
+    y = torch.empty_like(x) if want_y else None
+    pl = Planes(rows, Cc, device=x.device)
+    L.check(L.load().svl_layernorm_fwd_planes(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats),
+                                              _p(pl.buf), pl.prow, _st()), "svl_layernorm_fwd_planes")
+    return y, stats, pl
 
 
-def layernorm_bwd(dy, x, stats, gamma, dx_add=None, want_wgrad=False):
+def layernorm_bwd(dy, x, stats, gamma, dx_add=None, want_wgrad=False, planes=False):
+    """dx (+ dgamma, dbeta).  planes=True: dx is additionally emitted as packed Planes (appended to the result)."""
     rows, Cc = x.shape
     dx = torch.empty_like(x)
     lib = L.load()
@@ -449,11 +468,14 @@ def layernorm_bwd(dy, x, stats, gamma, dx_add=None, want_wgrad=False):
         nparts = lib.svl_layernorm_bwd_parts(rows)
         dgp = empty(nparts, Cc, device=x.device)
         dbp = empty(nparts, Cc, device=x.device)
-    L.check(lib.svl_layernorm_bwd(_p(dy), _p(x), _p(stats), _p(gamma), rows, Cc, _p(dx_add), _p(dx), _p(dgp), _p(dbp),
-                                  _st()), "svl_layernorm_bwd")
-    if want_wgrad:
-        return dx, colsum(dgp), colsum(dbp)
-    return dx
+    pl = Planes(rows, Cc, device=x.device) if planes else None
+    L.check(lib.svl_layernorm_bwd_planes(_p(dy), _p(x), _p(stats), _p(gamma), rows, Cc, _p(dx_add), _p(dx), _p(dgp),
+                                         _p(dbp), _p(pl.buf) if planes else None, pl.prow if planes else 0, _st()),
+            "svl_layernorm_bwd")
+    res = (dx, colsum(dgp), colsum(dbp)) if want_wgrad else (dx,)
+    if planes:
+        res = res + (pl,)
+    return res if len(res) > 1 else res[0]
 
 
 def softmax_rows_fwd(s, rows, cols, ld, scale):

@@ -154,9 +154,18 @@ def test_gemm_bf16_split_emulation_special_values(dev, emu_mode):
 
 
 def _unpack_planes(pl):
-    """Planes -> three fp32 [rows, K] tensors (layout [K/16][rows][3][16])."""
-    v = pl.buf.view(pl.K // 16, pl.rows, 3, 16).float()
-    return [v[:, :, i, :].permute(1, 0, 2).reshape(pl.rows, pl.K) for i in range(3)]
+    """Planes -> three fp32 [rows, K] tensors.  Packed layout (include/semivl_hip.h): chunk ((kg * prow/32 + rb) * 3 + pl)
+    of 512 bf16 = [lane = h * 32 + r % 32][e], k = kg * 16 + 4 h + (e < 4 ? e : e + 4)."""
+    v = pl.buf.view(pl.K // 16, pl.prow // 32, 3, 2, 32, 8).float()        # kg, rb, plane, h, r31, e
+    kk = torch.tensor([[4 * h + (e if e < 4 else e + 4) for e in range(8)] for h in range(2)], device=v.device)
+    out = []
+    for i in range(3):
+        t = v[:, :, i]                                                     # kg, rb, h, r31, e
+        full = torch.empty(pl.K // 16, pl.prow // 32, 32, 16, device=v.device)
+        for h in range(2):
+            full[:, :, :, kk[h]] = t[:, :, h]
+        out.append(full.permute(1, 2, 0, 3).reshape(pl.prow, pl.K)[:pl.rows])
+    return out
 
 
 def test_split_planes_is_an_exact_three_term_split(dev):
@@ -168,23 +177,49 @@ def test_split_planes_is_an_exact_three_term_split(dev):
     assert torch.equal(p1, (x - p0).bfloat16().float()) and torch.equal(p2, (x - p0 - p1).bfloat16().float())
     resid = (x.double() - p0.double() - p1.double() - p2.double()).abs()
     assert (resid <= 2.0 ** -24 * x.abs().double() + 1e-45).all()     # 24 mantissa bits carried
-    # transposed split (weights for the input-gradient GEMMs) and writing at a row offset of a larger buffer
+    # transposed split (weights for the input-gradient GEMMs), a strided source, writing at a row offset of a larger
+    # buffer, and a column slice of a plane buffer (k-groups are the outermost index)
     w = rnd(96, 160, dev=dev, seed=62)
     t0, _, _ = _unpack_planes(ops.split_planes(w, transpose=True))
     assert torch.equal(t0, w.t().bfloat16().float())
+    s0, _, _ = _unpack_planes(ops.split_planes(x[:, 48:112]))
+    assert torch.equal(s0, p0[:, 48:112])
     big = ops.Planes(3000, 208, device=dev)
-    ops.split_planes(x, out=big, row_off=1500)
+    ops.split_planes(x, out=big, row_off=1504)
     b0, _, _ = _unpack_planes(big)
-    assert torch.equal(b0[1500:2500], p0)
+    assert torch.equal(b0[1504:2504], p0)
+    k0, _, _ = _unpack_planes(big.kslice(64, 160))
+    assert torch.equal(k0[1504:2504], p0[:, 64:160])
+
+
+def test_layernorm_emits_planes(dev):
+    """LN forward / backward with the result additionally (or only) as packed planes == split_planes of the fp32 result."""
+    from semivl_amd import ops
+    rows, Cc = 1025 * 2, 768
+    x, g, b = rnd(rows, Cc, dev=dev, seed=63), 1 + 0.1 * rnd(Cc, dev=dev), 0.1 * rnd(Cc, dev=dev)
+    y_ref, st_ref = ops.layernorm_fwd(x, g, b, 1e-6)
+    y, st, pl = ops.layernorm_fwd(x, g, b, 1e-6, planes=True)
+    assert torch.equal(y, y_ref) and torch.equal(st, st_ref)
+    for got, want in zip(_unpack_planes(pl), _unpack_planes(ops.split_planes(y_ref))):
+        assert torch.equal(got, want)
+    y_none, _, pl2 = ops.layernorm_fwd(x, g, b, 1e-6, planes=True, want_y=False)
+    assert y_none is None and torch.equal(_unpack_planes(pl2)[1], _unpack_planes(pl)[1])
+    dy, add = rnd(rows, Cc, dev=dev), rnd(rows, Cc, dev=dev)
+    dx_ref = ops.layernorm_bwd(dy, x, st, g, dx_add=add)
+    dx, dxp = ops.layernorm_bwd(dy, x, st, g, dx_add=add, planes=True)
+    assert torch.equal(dx, dx_ref)
+    for got, want in zip(_unpack_planes(dxp), _unpack_planes(ops.split_planes(dx_ref))):
+        assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("M,N,K", [(8 * 1025, 768, 768), (1300, 3072, 768), (2050, 768, 3072), (260, 96, 64),
-                                   (4 * 1025, 2304, 768)])
+                                   (4 * 1025, 2304, 768), (16 * 1025, 3072, 768)])
 def test_gemm_planes_path(dev, emu_mode, M, N, K):
     """The pre-split form of mode 6 (csrc/gemm_planes.hip): error vs fp64 at or below the fp32 MFMA chain's for the
-    forward and input-gradient layouts, ragged token counts (M = 8 x 1025: helper-stream fork), every epilogue option,
-    results handed over as planes (FFN-1 -> FFN-2, dGELU dgrad -> dgrad), determinism, and identity with the in-register
-    split kernel (same arithmetic, same product order)."""
+    forward and input-gradient layouts, ragged token counts (M = 8 x 1025: a short row band whose tiles are scheduled
+    first), both tile widths, every epilogue option, results handed over as planes (FFN-1 -> FFN-2, dGELU dgrad -> dgrad),
+    determinism, and agreement with the in-register split kernel (same six products; the k order inside an MFMA k-group
+    differs, so the last bit may)."""
     from semivl_amd import ops
     x, b, r = rnd(M, K, dev=dev, seed=71), rnd(N, dev=dev), rnd(M, N, dev=dev)
     w = torch.nn.Parameter(rnd(N, K, dev=dev) * 0.05)
@@ -193,50 +228,57 @@ def test_gemm_planes_path(dev, emu_mode, M, N, K):
     emu_mode(0)
     e0 = (_relerr(ops.linear(x, w), ref_nt), _relerr(ops.matmul_nn(dy, w), ref_nn))
     emu_mode(6)
-    ops.PLANES_PATH = True          # (opt-in path: the in-register split kernel is mode 6's default)
-    assert ops.planes_eligible(M, N, K)
-    y, dx = ops.linear(x, w), ops.matmul_nn(dy, w)
+    xa, dya = ops.split_planes(x), ops.split_planes(dy)     # explicit planes: served by the planes kernel at any size
+    y, dx = ops.linear(xa, w), ops.matmul_nn(dya, w)
     assert _relerr(y, ref_nt) <= 1.5 * e0[0] + 1e-8 and _relerr(dx, ref_nn) <= 1.5 * e0[1] + 1e-8, (e0, _relerr(y, ref_nt))
-    assert torch.equal(y, ops.linear(x, w)), "deterministic"
-    ops.PLANES_PATH = False
-    y_inreg = ops.linear(x, w)
-    ops.PLANES_PATH = True
-    # (svl_gemm_f32 runs the < 256 leftover rows of a ragged token count on the exact fp32 kernel: compare the aligned part)
-    ma = M if M < 8192 else M // 128 * 128
-    assert torch.equal(y[:ma], y_inreg[:ma]), "pre-split and in-register split must be the same arithmetic"
+    assert torch.equal(y, ops.linear(xa, w)), "deterministic"
+    if ops.planes_eligible(M, N, K):
+        assert torch.equal(y, ops.linear(x, w)), "fp32 inputs of eligible shapes take the same path (split pass first)"
+    saved, ops.PLANES_PATH = ops.PLANES_PATH, False
+    try:
+        y_inreg = ops.linear(x, w)
+    finally:
+        ops.PLANES_PATH = saved
+    assert (y - y_inreg).abs().max().item() <= 4e-6 * ref_nt.abs().max().item()
     # epilogue: bias + GELU + saved pre-activation, residual, accumulate, GELU' product
     pre = torch.empty_like(r)
-    g = ops.linear(x, w, b, act=ops.ACT_GELU, preact=pre)
+    g = ops.linear(xa, w, b, act=ops.ACT_GELU, preact=pre)
     close(pre, x @ w.t() + b, what="preact", atol=2e-5 * math.sqrt(K))
     close(g, F.gelu(x @ w.t() + b), what="gelu", atol=2e-5 * math.sqrt(K))
-    close(ops.linear(x, w, b, resid=r), x @ w.t() + b + r, what="resid", atol=2e-5 * math.sqrt(K))
+    close(ops.linear(xa, w, b, resid=r), x @ w.t() + b + r, what="resid", atol=2e-5 * math.sqrt(K))
+    close(ops.linear(xa, w, b, act=ops.ACT_RELU), F.relu(x @ w.t() + b), what="relu", atol=2e-5 * math.sqrt(K))
     acc = r.clone()
-    ops.linear(x, w, out=acc, accumulate=True)
+    ops.linear(xa, w, out=acc, accumulate=True)
     close(acc, r + x @ w.t(), what="accumulate", atol=2e-5 * math.sqrt(K))
     z = rnd(M, K, dev=dev, seed=72)
     zt = z.clone().requires_grad_(True)
     F.gelu(zt).backward(torch.ones_like(zt))
-    close(ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z), (dy @ w) * zt.grad, what="dgelu", atol=2e-5 * math.sqrt(N))
+    close(ops.matmul_nn(dya, w, dact=ops.ACT_MUL_DGELU, z=z), (dy @ w) * zt.grad, what="dgelu", atol=2e-5 * math.sqrt(N))
+    # a row range of a plane buffer (m_off) and a strided fp32 output
+    if M >= 512:
+        wide = ops.empty(M, N + 8, device=dev)
+        ops.pgemm(xa, ops.weight_planes(w), M - 256, N, out=wide[:, 4:4 + N], m_off=256)   # (C is addressed by absolute row)
+        assert torch.equal(wide[256:, 4:4 + N], y[256:])
     # results handed over as planes: the three terms of the fp32 result, consumed by the next GEMM
     w2 = torch.nn.Parameter(rnd(128, N, dev=dev) * 0.05)
-    hp = ops.linear(x, w, b, act=ops.ACT_GELU, planes_only=True)
+    hp = ops.linear(xa, w, b, act=ops.ACT_GELU, planes_only=True)
     assert isinstance(hp, ops.Planes) and hp.shape == (M, N)
     p0, p1, p2 = _unpack_planes(hp)
     assert torch.equal(p0, g.bfloat16().float()) and torch.equal(p1, (g - p0).bfloat16().float())
-    out2 = ops.linear(hp, w2)
-    assert torch.equal(out2, ops.linear(g, w2))
+    assert torch.equal(p2, (g - p0 - p1).bfloat16().float())
+    assert torch.equal(ops.linear(hp, w2), ops.linear(ops.split_planes(g), w2))
     w3 = torch.nn.Parameter(rnd(K, 128, dev=dev) * 0.05)
-    if ops.planes_eligible(M, K, N):
-        dhp = ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z, planes_only=True)
-        assert isinstance(dhp, ops.Planes) and dhp.shape == (M, K)
-        assert torch.equal(ops.matmul_nn(dhp, w3), ops.matmul_nn(ops.matmul_nn(dy, w, dact=ops.ACT_MUL_DGELU, z=z), w3))
+    dhp = ops.matmul_nn(dya, w, dact=ops.ACT_MUL_DGELU, z=z, planes_only=True)
+    assert isinstance(dhp, ops.Planes) and dhp.shape == (M, K)
+    dh = ops.matmul_nn(dya, w, dact=ops.ACT_MUL_DGELU, z=z)
+    assert torch.equal(ops.matmul_nn(dhp, w3), ops.matmul_nn(ops.split_planes(dh), w3))
     # weight cache: a parameter update behind torch's back (the fused AdamW kernel) is announced with weights_changed()
     ops.fill(w.data[0], 0.0)
-    stale = ops.linear(x, w)
+    stale = ops.linear(xa, w)
     ops.weights_changed()
-    fresh = ops.linear(x, w)
+    fresh = ops.linear(xa, w)
     assert torch.equal(stale, y) and not torch.equal(fresh[:, 0], y[:, 0]) and float(fresh[:, 0].abs().max()) == 0.0
-    ops.PLANES_PATH = False
+
 
 
 @pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (3, 17, 4), (1, 64, 2)])

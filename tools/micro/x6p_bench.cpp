@@ -1,0 +1,110 @@
+// Stand-alone check + timing of svl_gemm_planes_f32 through the C-ABI (no Python): packs random fp32 operands, runs the
+// GEMM, compares sampled outputs against fp64 on the host, times it with HIP events.
+//   hipcc --offload-arch=gfx950 -O2 tools/micro/x6p_bench.cpp -Iinclude -Lsemivl_amd -lsemivl_hip -Wl,-rpath,$PWD/semivl_amd -o tools/micro/x6p_bench
+//   tools/micro/x6p_bench M N K [iters] [mode]     mode: 0 plain C, 1 bias+GELU+preact+planes_out, 2 resid add, 3 planes_out only
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "semivl_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+#define SV(x) do { int r_ = (x); if (r_ != 0) { char b_[512]; svl_last_error(b_, sizeof b_); printf("svl error %d: %s (line %d)\n", r_, b_, __LINE__); exit(1); } } while (0)
+
+static inline float bf16_to_f(unsigned short h) { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static unsigned long long rng = 88172645463325252ull;
+static inline float urand() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (float)((rng >> 40) * (1.0 / 16777216.0)) * 2.f - 1.f; }
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 32800, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
+  const int iters = argc > 4 ? atoi(argv[4]) : 20, mode = argc > 5 ? atoi(argv[5]) : 0;
+  const long Mp = svl_planes_rows(M), Np = svl_planes_rows(N);
+  std::vector<float> hA((size_t)M * K), hB((size_t)N * K), hbias(N), hres;
+  for (auto& v : hA) v = urand();
+  for (auto& v : hB) v = urand() * 0.05f;
+  for (auto& v : hbias) v = urand() * 0.1f;
+  float *dA, *dB, *dC, *dbias, *dpre = nullptr, *dres = nullptr;
+  void *pA, *pB, *pO = nullptr;
+  CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+  CK(hipMalloc(&dbias, N * 4));
+  CK(hipMalloc(&pA, svl_planes_bytes(M, K))); CK(hipMalloc(&pB, svl_planes_bytes(N, K)));
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dbias, hbias.data(), N * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(pA, 0, svl_planes_bytes(M, K))); CK(hipMemset(pB, 0, svl_planes_bytes(N, K)));
+  SV(svl_split_planes_bf16x3(dA, K, 1, M, K, pA, Mp, 0, nullptr));
+  SV(svl_split_planes_bf16x3(dB, K, 1, N, K, pB, Np, 0, nullptr));
+  if (mode == 1) CK(hipMalloc(&dpre, (size_t)M * N * 4));
+  if (mode == 1 || mode == 3) { CK(hipMalloc(&pO, svl_planes_bytes(M, N))); CK(hipMemset(pO, 0, svl_planes_bytes(M, N))); }
+  if (mode == 2) {
+    hres.resize((size_t)M * N);
+    for (auto& v : hres) v = urand();
+    CK(hipMalloc(&dres, hres.size() * 4));
+    CK(hipMemcpy(dres, hres.data(), hres.size() * 4, hipMemcpyHostToDevice));
+  }
+  CK(hipMemset(dC, 0xff, (size_t)M * N * 4));
+  svl_pgemm_desc d;
+  memset(&d, 0, sizeof d);
+  d.A = pA; d.B = pB; d.a_rows = Mp; d.b_rows = Np; d.m_off = 0; d.M = M; d.N = N; d.K = K;
+  d.C = mode == 3 ? nullptr : dC; d.ldc = N;
+  if (mode == 1) { d.bias = dbias; d.act = SVL_ACT_GELU; d.preact = dpre; }
+  if (mode == 1 || mode == 3) { d.planes_out = pO; d.p_rows = Mp; }
+  if (mode == 2) { d.resid = dres; d.ldr = N; d.bias = dbias; }
+  SV(svl_gemm_planes_f32(&d, nullptr));
+  CK(hipDeviceSynchronize());
+  // ---- check
+  std::vector<float> hC((size_t)M * N);
+  CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<unsigned short> hP;
+  if (pO) { hP.resize(svl_planes_bytes(M, N) / 2); CK(hipMemcpy(hP.data(), pO, hP.size() * 2, hipMemcpyDeviceToHost)); }
+  std::vector<float> hpre;
+  if (dpre) { hpre.resize((size_t)M * N); CK(hipMemcpy(hpre.data(), dpre, hpre.size() * 4, hipMemcpyDeviceToHost)); }
+  double worst = 0, worst_p = 0, worst_pre = 0, scale = 0;
+  long bad = 0;
+  const int ns = 6000;
+  for (int s = 0; s < ns; ++s) {
+    long m, n;
+    if (s < 64) { m = M - 1 - (s & 31); n = (s * 97) % N; }            // ragged band
+    else if (s < 128) { m = (s * 131) % M; n = N - 1 - (s & 31); }      // last columns
+    else { m = (long)((urand() * 0.5 + 0.5) * M) % M; n = (long)((urand() * 0.5 + 0.5) * N) % N; }
+    double acc = 0;
+    for (int k = 0; k < K; ++k) acc += (double)hA[m * K + k] * (double)hB[n * K + k];
+    double pre = acc, ref = acc;
+    if (mode == 1) { pre = acc + hbias[n]; ref = 0.5 * pre * (1.0 + erf(pre * 0.70710678118654752440)); }
+    if (mode == 2) ref = acc + hbias[n] + hres[m * N + n];
+    scale = fmax(scale, fabs(ref));
+    if (mode != 3) {
+      const double e = fabs((double)hC[m * N + n] - ref);
+      if (!(e <= 1e-3)) ++bad;
+      worst = fmax(worst, e);
+    }
+    if (dpre) worst_pre = fmax(worst_pre, fabs((double)hpre[m * N + n] - pre));
+    if (pO) {   // unpack: chunk (kg = n / 16, rb = m / 32, plane), lane = h * 32 + m % 32, element e
+      const long kg = n >> 4, rb = m >> 5;
+      const int kk = (int)(n & 15), h = (kk >> 2) & 1, e = (kk & 3) + ((kk >> 3) << 2);
+      double v = 0;
+      for (int pl = 0; pl < 3; ++pl)
+        v += bf16_to_f(hP[((kg * (Mp / 32) + rb) * 3 + pl) * 512 + (h * 32 + (m & 31)) * 8 + e]);
+      worst_p = fmax(worst_p, fabs(v - ref));
+    }
+  }
+  printf("M %d N %d K %d mode %d: max |err| C %.3e  preact %.3e  planes %.3e  (max |ref| %.3f, bad %ld / %d)\n", M, N, K, mode,
+         worst, worst_pre, worst_p, scale, bad, ns);
+  // ---- time
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) SV(svl_gemm_planes_f32(&d, nullptr));
+  CK(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) SV(svl_gemm_planes_f32(&d, nullptr));
+  CK(hipEventRecord(e1, nullptr));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= iters;
+  const double fl = 2.0 * M * N * K;
+  printf("  %.4f ms  %.1f TF fp32-eq  %.0f TF bf16 issued (%.3f of 2500)\n", ms, fl / ms * 1e-9, 6 * fl / ms * 1e-9,
+         6 * fl / ms * 1e-9 / 2500.0);
+  return bad ? 2 : 0;
+}
