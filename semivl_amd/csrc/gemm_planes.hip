@@ -77,9 +77,27 @@ struct PlanesP {
   int rcnt[8], fstart[8];   // per XCD x (blocks with id % 8 == x): ragged-band tiles it takes first, first full tile of its chunk
 };
 
-__device__ __forceinline__ void glds16(const char* g, char* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// One LDS-DMA instruction: 64 lanes x 16 B from `base` (wave-uniform, SGPR pair) + `lane_off` (the constant lane * 16)
+// to LDS bytes [lds_dst, lds_dst + 1024).  Inline asm because the builtin, inside the k-loop, is selected in its 64-bit
+// VGPR-address form with a v_lshl_add_u64 per DMA: that VALU instruction has to be issued by the memory-phase wave
+// between its SIMD partner's back-to-back MFMAs, and VALU and MFMA issue do not overlap on a SIMD -- measured with
+// s_memtime: 230 cycles per DMA, the memory phase (1750 cycles) longer than the matrix phase (1580).  With the SGPR-base
+// form a DMA is SALU + one VMEM issue (67 cycles; memory phase 740).  M0 is written in the statement that reads it and
+// restored (it is compiler-reserved); the s_nop covers a base SGPR written by a VALU (v_readfirstlane) just before.
+// The compiler does not count these loads: every wait for them is an explicit vmcnt below.
+__device__ __forceinline__ void glds16(const char* base_, unsigned lane_off, unsigned lds_dst_) {
+  // (the operands ARE wave-uniform; readfirstlane makes that provable where the compiler's divergence analysis gives up --
+  // it folds away when the value already lives in SGPRs)
+  const unsigned long long bv = (unsigned long long)base_;
+  const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(bv >> 32));     // (the builtin returns int: widen as unsigned)
+  const unsigned b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bv);
+  const char* base = (const char*)(((unsigned long long)b_hi << 32) | (unsigned long long)b_lo);
+  const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(base), "v"(lane_off), "s"(lds_dst)
+               : "memory");
 }
 
 template <int N_>
@@ -88,6 +106,7 @@ __device__ __forceinline__ void wait_vm() {
   else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N_ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N_ == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else static_assert(N_ < 0, "unsupported vmcnt");
 }
 
@@ -105,16 +124,19 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], bf16x8& h0, bf16x8
 }
 
 // Block -> tile.  Blocks go to XCD (id % 8) and, inside an XCD, to CUs in id order as CUs free up.  Every XCD first takes
-// its share of the RAGGED row band's tiles (M % 256 rows: they are short, so their CUs simply start the next tile
-// early and the grid stays a whole number of rounds), then a contiguous chunk of the full tiles in n-fastest order:
+// its share of the RAGGED row band's tiles (M % 256 rows), then a contiguous chunk of the full tiles in n-fastest order:
 // concurrent tiles of an XCD share A row bands / B column bands in that XCD's L2.
+// (A ragged tile streams the whole B panel for a fraction of the MFMA work: its k-loop is bound by the memory phase, not
+// by its MFMAs, and costs ~0.4 of a full tile -- +3 % at K = 768, +7 % at K = 3072 against M = 32768.  Tried and dropped:
+// running the last full band + the leftover rows as 288-row tiles (ninth row block on the lower wave row) in a second,
+// concurrent launch on the helper stream: the fork / join and the two grids competing for CUs cost more, +2 ... +11 %.)
 // (Tried and dropped: cutting the first 32 tiles of every XCD in two row parts of s / 8 and (8 - s) / 8 so that its CUs
 // run 1/8 of a tile apart and their store bursts do not coincide -- partial tiles keep only one wave group busy and
 // cost more than the de-synchronised epilogues gain: +5...7 % on the ViT shapes.)
 struct TileRef { int m0, rows, tn; };
 __device__ __forceinline__ TileRef tile_of_block(const PlanesP& p) {
-  const int lin = (int)blockIdx.x, x = lin & 7, idx = lin >> 3;
   TileRef t;
+  const int lin = (int)blockIdx.x, x = lin & 7, idx = lin >> 3;
   const int rc = p.rcnt[x];
   if (idx < rc) {
     t.m0 = p.full_m * BM;
@@ -135,33 +157,41 @@ enum { EPI_LIGHT = 0, EPI_GELU = 1, EPI_DGELU = 2 };   // epilogue flavour compi
 template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
   extern __shared__ __attribute__((aligned(1024))) char sm[];
-  constexpr int TM = 4, TN = BN / 128;                 // 32x32 MFMA blocks per wave: wave tile 128 x (BN / 4)
+  // wave grid WM x WN over the 256 x BN tile, 32x32 MFMA blocks per wave TM x TN:
+  //   BN = 256: 2 x 4 waves of 128 x 64;  BN = 192: 4 x 2 waves of 64 x 96;  BN = 128: 2 x 4 waves of 128 x 32.
+  // The two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) are the upper / lower 128 rows in every shape.
+  constexpr int WN = BN == 192 ? 2 : 4, WM = 8 / WN;
+  constexpr int TM = BM / 32 / WM, TN = BN / 32 / WN;
   constexpr int NCHA = BM / 32 * 3, NCHB = BN / 32 * 3, NCH = NCHA + NCHB;   // chunks of one stage (A then B)
   constexpr int STAGE = NCH * CH;
   constexpr int CPW = (NCH + 7) / 8;                   // LDS-DMA instructions per wave and k-group (upper bound)
   constexpr bool EVEN = NCH % 8 == 0;                  // every wave issues CPW; else waves >= NCH % 8 issue CPW - 1
+  static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS");
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wq = wave & 3;
+  const int grp = wave >> 2, wm = wave / WN, wq = wave % WN;
 
   const TileRef tr = tile_of_block(p);
   const int m0 = tr.m0, n0 = tr.tn * BN, mvalid = tr.rows;
   const int nblk = (mvalid + 31) >> 5;                 // row blocks of A this tile needs
-  // valid 32-row blocks of this wave (wave-uniform): partial tiles skip the MFMAs of row blocks past their edge
-  const int vb = min(TM, max(0, nblk - grp * TM));
+  // valid 32-row blocks of this wave (wave-uniform): ragged tiles skip the MFMAs of row blocks past the edge
+  const int vb = min(TM, max(0, nblk - wm * TM));
 
-  const char* a_src = p.A + (long)(m0 >> 5) * (3 * CH) + lane * 16;
-  const char* b_src = p.B + (long)tr.tn * (NCHB * CH) + lane * 16;
+  // wave-uniform chunk bases (SGPRs); the per-lane part of a DMA address is the constant lane * 16 (glds16)
+  const char* a_src = p.A + (long)(m0 >> 5) * (3 * CH);
+  const char* b_src = p.B + (long)tr.tn * (NCHB * CH);
+  const unsigned lane16 = lane * 16;
+  const unsigned sm_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
   const int nk = p.K >> 4;
 
-  // chunk sources of this wave inside a k-group (wave-uniform byte offsets); A chunks of row blocks the tile does not
-  // need are redirected to row block 0 (same instruction count -- the vmcnt bookkeeping is static -- and no read past the
-  // operand's last row band)
+  // chunk sources of this wave inside a k-group (wave-uniform); A chunks of row blocks a ragged tile does not need are
+  // redirected to row block 0 (same instruction count -- the vmcnt bookkeeping is static -- and no read past the operand's
+  // last row band)
   auto issue = [&](int kg, int st) __attribute__((always_inline)) {
     const char* ak = a_src + (long)kg * p.a_ks;
     const char* bk = b_src + (long)kg * p.b_ks;
-    char* dst = sm + st * STAGE;
+    const unsigned dst = sm_base + st * STAGE;
     static_for<0, CPW>([&](auto I) {
       constexpr int i = decltype(I)::value;
       const int c = wave + 8 * i;
@@ -174,7 +204,7 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
           static_assert(8 * i >= NCHA, "A / B chunk boundary must fall on a multiple of 8");
           s = bk + (c - NCHA) * CH;
         }
-        glds16(s, dst + c * CH);
+        glds16(s, lane16, dst + c * CH);
       }
     });
   };
@@ -195,8 +225,8 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
     });
   });
 
-  // fragment addresses inside a stage: A row block (grp * 4 + i), B row block (wq * TN + j)
-  const int fa = lane * 16 + grp * (TM * 3 * CH);
+  // fragment addresses inside a stage: A row block (wm * TM + i), B row block (wq * TN + j)
+  const int fa = lane * 16 + wm * (TM * 3 * CH);
   const int fb = lane * 16 + NCHA * CH + wq * (TN * 3 * CH);
 
   issue(0, 0);
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
             });
           });
         });
-      } else {   // partial tile: row blocks past the edge are skipped (vb is wave-uniform)
+      } else {   // ragged tile: row blocks past the edge are skipped (vb is wave-uniform)
         static_for<0, TM>([&](auto I) {
           constexpr int i = decltype(I)::value;
           if (i < vb) {
@@ -286,7 +316,7 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
   else kloop(std::false_type{});
   if (grp == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two groups match: every LDS read is done
 
-  // ---- epilogue.  acc[i][j][r] = C(m, n), m = m0 + grp*128 + i*32 + l31, n = nw + j*32 + 8*(r>>2) + 4*hi + (r&3).  The
+  // ---- epilogue.  acc[i][j][r] = C(m, n), m = m0 + (wm*TM + i)*32 + l31, n = nw + j*32 + 8*(r>>2) + 4*hi + (r&3).  The
   // arithmetic runs in this layout (a lane owns 4-runs of ONE row: bias / saved pre-activation are 16 B reads, and per 16
   // columns its 8 values are exactly its lane slot of the next GEMM's A chunk: packed planes leave as 1 KiB stores).
   // fp32 outputs (C, preact) go through a per-wave LDS transpose so that every store instruction writes whole 128 /
@@ -295,15 +325,14 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
   constexpr int WC = TN * 32;                      // columns of a wave
   constexpr int RS = WC * 4 + 16;                  // LDS row stride of the transpose buffer (bytes)
   constexpr int LPR = WC / 4;                      // lanes per row in the row-major readback (16 B each)
-  constexpr int RPI = 64 / LPR;                    // rows per store instruction
+  static_assert((32 * LPR) % 64 == 0, "readback steps must be whole wave instructions");
   char* wl = sm + wave * (32 * RS);
   const int nw = n0 + wq * WC;
   const bool vec = (p.ldc % 4 == 0) && (reinterpret_cast<uintptr_t>(p.C) % 16 == 0) &&
                    (reinterpret_cast<uintptr_t>(p.preact) % 16 == 0);
   const bool rvec = p.resid && (p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.resid) % 16 == 0);
-  const int rr = lane / LPR, rc4 = (lane % LPR) * 4;   // row-major readback: row rr (+ RPI per step), columns rc4..+3
 
-  // the wave's 32 x WC block `o` (acc layout) -> dst rows, coalesced; acc_in: C += o
+  // the wave's 32 x WC block `o` (acc layout) -> dst rows, coalesced; accumulate: dst += o
   auto store_rows = [&](float* dst, const f32x16 (&o)[TN], int mloc, bool accumulate) __attribute__((always_inline)) {
     static_for<0, TN>([&](auto J) {
       constexpr int j = decltype(J)::value;
@@ -315,8 +344,8 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
     });
     // (same wave wrote and reads: DS operations of a wave execute in order, no barrier)
 #pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int row = it * RPI + rr;
+    for (int it = 0; it < 32 * LPR / 64; ++it) {
+      const int idx = it * 64 + lane, row = idx / LPR, rc4 = (idx - row * LPR) * 4;
       const f32x4 q = *reinterpret_cast<const f32x4*>(wl + row * RS + rc4 * 4);
       const int n = nw + rc4;
       if (mloc + row < mvalid && n < p.N) {
@@ -336,7 +365,7 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
 
   static_for<0, TM>([&](auto I) {
     constexpr int i = decltype(I)::value;
-    const int mloc = grp * 128 + i * 32;
+    const int mloc = (wm * TM + i) * 32;
     if (mloc < mvalid) {
       const int m = m0 + mloc + l31;
       const bool mok = mloc + l31 < mvalid;
@@ -487,23 +516,32 @@ int launch_tile(PlanesP q, hipStream_t st) {
     q.fstart[x] = (int)fs;
     fs += blocks - rag;
   }
-  const long grid = total;
-  if (q.act == SVL_ACT_GELU) return launch_kernel<BN, EPI_GELU>(q, grid, st);
-  if (q.act == SVL_ACT_MUL_DGELU) return launch_kernel<BN, EPI_DGELU>(q, grid, st);
-  return launch_kernel<BN, EPI_LIGHT>(q, grid, st);
+  if (q.act == SVL_ACT_GELU) return launch_kernel<BN, EPI_GELU>(q, total, st);
+  if (q.act == SVL_ACT_MUL_DGELU) return launch_kernel<BN, EPI_DGELU>(q, total, st);
+  return launch_kernel<BN, EPI_LIGHT>(q, total, st);
 }
 
-// Tile choice: 256 x 256 unless 256 x 128 wastes less of the last round of the grid (256 CUs x 1 block; the ragged row
-// band's tiles are short and come first, so only the full tiles count) -- N = 768 / 2304 at M = 32768.
+// Tile width: 256 unless a narrower tile wastes less of the last round of the grid (256 CUs x 1 block; the ragged row
+// band's tiles are short and come first, so only the full tiles count): N = 768 / 2304 tile as 4 / 12 x 192 into whole
+// rounds at M = 32 x 1025.
 int launch(const PlanesP& q, hipStream_t st) {
   static const int force = getenv("SVL_PLANES_TILE") ? atoi(getenv("SVL_PLANES_TILE")) : 0;
   auto cost = [&](int bn) {
     const long tiles = (long)(q.M / BM) * ((q.N + bn - 1) / bn);
     const long rounds = tiles > 0 ? (tiles + 255) / 256 : 1;
-    return (double)rounds * bn * (bn == 128 ? 1.06 : 1.0);     // time ~ rounds x tile width (x the narrow tile's overhead)
+    return (double)rounds * bn * (bn == 128 ? 1.15 : bn == 192 ? 1.04 : 1.0);   // time ~ rounds x tile width (x the narrower tiles' overhead)
   };
-  int bn = force ? force : (q.N <= 128 || cost(128) < cost(256) ? 128 : 256);
+  int bn = force;
+  if (!bn) {
+    bn = 256;
+    if (q.N <= 128) bn = 128;
+    else {
+      if (cost(192) < cost(bn)) bn = 192;
+      if (cost(128) < cost(bn)) bn = 128;
+    }
+  }
   if (bn == 128) return launch_tile<128>(q, st);
+  if (bn == 192) return launch_tile<192>(q, st);
   return launch_tile<256>(q, st);
 }
 
