@@ -135,36 +135,41 @@ def cpu_baseline(crop, nclass, warm, timed):
 
     cores = physical_cores()
     runs, total = {}, 0.0
-    for threads, (w_, t_) in ((min(32, cores), (warm, timed)), (cores, (0, 1))):   # all-cores run: one (warm-cache) step
+    full = (warm, timed) != (1, 2)      # an explicit --cpu-baseline-steps applies to the all-cores (protocol) run
+    for threads, (w_, t_) in ((min(32, cores), (1, 2) if full else (warm, timed)), (cores, (warm, timed) if full else (0, 1))):
         if threads in runs:
             continue
         med, spent = run(threads, w_, t_)
         runs[threads] = dict(threads=threads, s_per_step=round(med, 2), images_per_s=round(2.0 * bs / med, 4),
                              protocol=f"{w_} warm-up + {t_} timed, median")
         total += spent
+    prim = runs[cores]                                   # torch.set_num_threads(all physical cores)
     best = min(runs.values(), key=lambda r: r["s_per_step"])
-    return dict(value=best["images_per_s"], unit="images/s", cores=best["threads"], kind="port", cpu=cpu_model(),
-                physical_cores=cores, s_per_step=best["s_per_step"], runs=list(runs.values()),
+    return dict(value=prim["images_per_s"], unit="images/s", cores=prim["threads"], kind="port", cpu=cpu_model(),
+                physical_cores=cores, s_per_step=prim["s_per_step"], runs=list(runs.values()),
+                best_thread_count=dict(threads=best["threads"], images_per_s=best["images_per_s"], s_per_step=best["s_per_step"]),
                 sample=f"full SemiVL steps of oracle/semivl_oracle.py (PyTorch CPU fp32) at VOC N={nclass}, {crop}x{crop}, "
-                       f"bs={bs} ({2 * bs} images/step, BASELINE configs[0]) on {cpu_model()} ({cores} physical cores): "
-                       f"{best['protocol']} at {best['threads']} threads (the faster of the thread counts tried: "
-                       f"{', '.join(str(r['threads']) + ' thr -> ' + str(r['s_per_step']) + ' s/step' for r in runs.values())}); "
+                       f"bs={bs} ({2 * bs} images/step, BASELINE configs[0]) on {cpu_model()} ({cores} physical cores): `value` = "
+                       f"all {cores} physical cores, {prim['protocol']} (the SURVEY §8(d) thread setting; its 3 + 5 steps are "
+                       f"`--cpu-baseline-steps 3 5`, ~7 min on this host); PyTorch's CPU kernels scale negatively on this "
+                       f"workload, the best thread count tried is reported beside it: "
+                       f"{', '.join(str(r['threads']) + ' thr -> ' + str(r['s_per_step']) + ' s/step' for r in runs.values())}; "
                        f"{total:.0f} s of CPU work")
 
 
-def pmc_traffic_record(batch, name="pmc_gemm_traffic.json"):
-    """HBM-side bytes of the dominant launch from a committed rocprofv3 --pmc record (profiles/pmc_gemm_traffic.json for
-    the exact kernel, pmc_gemm_traffic_bf16x6.json for the split-emulation kernel; written by tools/pmc_traffic.sh):
-    used only when it was measured on the SAME kernel source (sha256 of gemm.hip)."""
+def pmc_traffic_record(batch, name="pmc_gemm_traffic.json", src="gemm.hip"):
+    """Fabric-side bytes of the dominant launch from a committed rocprofv3 --pmc record (profiles/pmc_x6p_traffic.json for
+    the packed-planes bf16x6 kernel, written by tools/pmc_x6p.sh; pmc_gemm_traffic.json for the exact fp32 kernel, written
+    by tools/pmc_traffic.sh): used only when it was measured on the SAME kernel source (sha256 of the .hip file)."""
     import hashlib
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", name)))
-        sha = hashlib.sha256(open(os.path.join(ROOT, "semivl_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
-        if rec.get("gemm_hip_sha16") == sha and rec.get("M") == 32 * 1025 * batch // 16:
+        sha = hashlib.sha256(open(os.path.join(ROOT, "semivl_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+        if rec.get("src_sha16", rec.get("gemm_hip_sha16")) == sha and rec.get("M") == 32 * 1025 * batch // 16:
             return rec["traffic_bytes"], rec.get("note", "")
     except (OSError, ValueError, KeyError):
         pass
-    return None, "no PMC record for this kernel source (profiles/pmc_gemm_traffic.json absent or from another gemm.hip)"
+    return None, f"no PMC record for this kernel source (profiles/{name} absent or from another {src})"
 
 
 def main():
@@ -269,8 +274,11 @@ def main():
         algo = sum(ALGO_GF[(a.nclass, a.crop)]) * 1e9 * a.batch if (a.nclass, a.crop) in ALGO_GF else executed
         ach = algo / t_gemm / 1e12
         step_tf = algo / (ms * 1e-3) / 1e12
-        out["roofline"] = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
-                               frac=round(ach / PEAK_F32_MFMA_TF, 4), traffic=None,
+        # (kept for continuity with rounds 1-2 under its own key: ALL MFMA kernel time of the step against the fp32-MFMA
+        # peak.  It is NOT a roofline fraction in bf16x6 mode -- most launches run on the bf16 pipe; `roofline` below
+        # prices the dominant kernel against the pipe it runs on.)
+        out["mfma_step_vs_f32_pipe"] = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
+                               frac=round(ach / PEAK_F32_MFMA_TF, 4),
                                frac_executed=round(executed / t_gemm / 1e12 / PEAK_F32_MFMA_TF, 4),
                                frac_whole_step=round(step_tf / PEAK_F32_MFMA_TF, 4), whole_step_tflops=round(step_tf, 2),
                                kernel="all MFMA launches of one step: gemm_kernel / conv kernels + attn_{fwd,bwd}_kernel "
@@ -286,14 +294,13 @@ def main():
             nprod = 6 if a.gemm_arith == "bf16x6" else 3
             t_x = sum(e0.elapsed_time(e1) for e0, e1, *_ in gx) * 1e-3
             f_x = sum(w for _, _, w, *_ in gx)
-            out["roofline"]["bf16_pipe"] = dict(
+            out["mfma_step_vs_f32_pipe"]["bf16_pipe"] = dict(
                 kernel=f"gemm_bf16x_kernel<{nprod // 2 if nprod == 6 else 2},...> (svl_gemm_f32 in emulation mode {nprod})"
                        + (" + attn_{fwd,bwd_dq,bwd_dkv}_x6_kernel" if prof.get("attention_bf16x") else ""),
                 launches=len(gx), kernel_time_ms=round(t_x * 1e3, 2), achieved=round(f_x / t_x / 1e12, 2),
                 peak=round(PEAK_BF16_MFMA_TF / nprod, 1), unit="TFLOP/s (fp32-equivalent)",
                 frac=round(f_x / t_x / 1e12 / (PEAK_BF16_MFMA_TF / nprod), 4),
-                note=f"2MNK of the launches / their summed duration vs {PEAK_BF16_MFMA_TF:.0f} TF bf16 dense / {nprod} products; "
-                     "`roofline.frac` above prices ALL MFMA kernel time of the step against the fp32-MFMA peak")
+                note=f"2MNK of the launches / their summed duration vs {PEAK_BF16_MFMA_TF:.0f} TF bf16 dense / {nprod} products")
         # the ViT encoder alone (north_star: ">= 60 % MFMA peak on the ViT encoder"): launches issued inside the encoder's
         # forward / backward regions (5 trainable + 2 frozen forwards, 4 backwards per step)
         gv = [e for e in g if e[4] == "vit"]
@@ -327,34 +334,47 @@ def main():
                 for k, v in sorted(by.items(), key=lambda kv: -kv[1][0]):
                     f.write("%-44s n=%3d  %8.2f ms  %6.1f TF\n" % (k, v[2], v[0] * 1e3, v[1] / v[0] / 1e12))
         top = sorted(by.items(), key=lambda kv: -kv[1][0])[:6]
-        out["roofline"]["top_shapes"] = [dict(mode_MNKb=list(k), ms=round(v[0] * 1e3, 2), n=v[2],
+        out["mfma_step_vs_f32_pipe"]["top_shapes"] = [dict(mode_MNKb=list(k), ms=round(v[0] * 1e3, 2), n=v[2],
                                               tflops=round(v[1] / v[0] / 1e12, 1)) for k, v in top]
-        # the single dominant launch shape (FFN-1 of the ViT blocks): per-launch roofline + its PMC traffic
-        dom = by.get((0, 0, 32 * 1025 * a.batch // 16, 3072, 768, 1))
-        if dom is not None and not g_arith_exact:
-            d_tf = dom[1] / dom[0] / 1e12
+        # ---- `roofline`: the single dominant kernel (FFN-1 of the ViT blocks, M = images x 1025, N = 3072, K = 768: the
+        # largest share of the step's kernel time), ALGORITHMIC FLOPs per launch / its average launch duration (HIP events
+        # on the launch stream), priced against the peak of the pipe it runs on: bf16 dense / 6 products per fp32 MAC in
+        # bf16x6 mode, the fp32-MFMA peak in exact mode.  Traffic: committed PMC record of the same kernel source.
+        Md = 32 * 1025 * a.batch // 16
+        if not g_arith_exact:
             nprod = 6 if a.gemm_arith == "bf16x6" else 3
-            out["roofline"]["dominant_launch"] = dict(
-                kernel="gemm_bf16x_kernel (svl_gemm_f32, split emulation), M=%d N=3072 K=768" % (32 * 1025 * a.batch // 16),
-                launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 3), achieved=round(d_tf, 1),
-                peak=round(PEAK_BF16_MFMA_TF / nprod, 1), frac=round(d_tf / (PEAK_BF16_MFMA_TF / nprod), 4),
-                algorithmic_bytes=513.0e6 * a.batch / 16)
-            if nprod == 6:
-                traffic, tnote = pmc_traffic_record(a.batch, "pmc_gemm_traffic_bf16x6.json")
-                out["roofline"]["dominant_launch"].update(traffic=traffic, traffic_note=tnote)
-                out["roofline"]["traffic"] = traffic
-            else:
-                out["roofline"]["dominant_launch"].update(traffic=None, traffic_note="no PMC record for the x3 kernel")
-        if dom is not None and g_arith_exact:
-            d_ms = dom[0] * 1e3 / dom[2]
-            d_tf = dom[1] / dom[0] / 1e12
-            traffic, tnote = pmc_traffic_record(a.batch)
-            out["roofline"]["dominant_launch"] = dict(
-                kernel="gemm_kernel<128,128,2,2,KCONTIG,KCONTIG> (svl_gemm_f32), M=%d N=3072 K=768" % (32 * 1025 * a.batch // 16),
-                launches=dom[2], avg_ms=round(d_ms, 3), achieved=round(d_tf, 1), peak=PEAK_F32_MFMA_TF,
-                frac=round(d_tf / PEAK_F32_MFMA_TF, 4), algorithmic_bytes=513.0e6 * a.batch / 16,
-                traffic=traffic, traffic_note=tnote)
-            out["roofline"]["traffic"] = traffic
+            dom = by.get(("planes", Md, 3072, 768, ops.ACT_GELU)) or by.get((0, 0, Md, 3072, 768, 1))
+            planes = ("planes", Md, 3072, 768, ops.ACT_GELU) in by
+            if dom is not None:
+                d_tf = dom[1] / dom[0] / 1e12
+                peak = PEAK_BF16_MFMA_TF / nprod
+                traffic, tnote = (pmc_traffic_record(a.batch, "pmc_x6p_traffic.json", "gemm_planes.hip") if planes and nprod == 6
+                                  else (None, "no PMC record for this kernel"))
+                out["roofline"] = dict(
+                    bound="mfma", achieved=round(d_tf, 1), peak=round(peak, 1), unit="TFLOP/s (fp32-equivalent)",
+                    frac=round(d_tf / peak, 4), traffic=traffic,
+                    kernel=("gemm_x6p_kernel<256, EPI_GELU> (svl_gemm_planes_f32: packed bf16x3 planes, 6 products on "
+                            "v_mfma_f32_32x32x16_bf16; bias + erf-GELU + saved pre-activation + result as planes)" if planes
+                            else "gemm_bf16x_kernel (svl_gemm_f32, in-register split)") + ", M=%d N=3072 K=768" % Md,
+                    launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 4),
+                    flops_per_launch=2.0 * Md * 3072 * 768, bf16_issued_tflops=round(d_tf * nprod, 1),
+                    frac_of_bf16_dense_peak=round(d_tf * nprod / PEAK_BF16_MFMA_TF, 4),
+                    algorithmic_bytes=(Md * 768 * 6 + 3072 * 768 * 6 + Md * 3072 * 10) if planes else 513.0e6 * a.batch / 16,
+                    traffic_note=tnote,
+                    note=f"achieved = 2MNK / mean launch duration; peak = {PEAK_BF16_MFMA_TF:.0f} TF bf16 dense / {nprod} "
+                         "products per fp32 MAC (MI355X_MICROARCH.md); algorithmic bytes = A and B planes (6 B/element) read "
+                         "once + pre-activation (4 B) and result planes (6 B) written once")
+        else:
+            dom = by.get((0, 0, Md, 3072, 768, 1))
+            if dom is not None:
+                d_tf = dom[1] / dom[0] / 1e12
+                traffic, tnote = pmc_traffic_record(a.batch)
+                out["roofline"] = dict(
+                    bound="mfma", achieved=round(d_tf, 1), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
+                    frac=round(d_tf / PEAK_F32_MFMA_TF, 4), traffic=traffic,
+                    kernel="gemm_kernel<128,128,2,2,KCONTIG,KCONTIG> (svl_gemm_f32, v_mfma_f32_32x32x2_f32), M=%d N=3072 K=768" % Md,
+                    launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 4), flops_per_launch=2.0 * Md * 3072 * 768,
+                    algorithmic_bytes=513.0e6 * a.batch / 16, traffic_note=tnote)
         if os.environ.get("SVL_BENCH_DUMP_SHAPES"):
             allsh = sorted(by.items(), key=lambda kv: -kv[1][0])
             with open(os.environ["SVL_BENCH_DUMP_SHAPES"], "w") as f:
@@ -364,10 +384,23 @@ def main():
         if c:
             t_ce = sum(e0.elapsed_time(e1) for e0, e1, *_ in c) * 1e-3
             by_ce = sum(w for _, _, w, *_ in c)
+            ce_traffic, ce_note = None, "no PMC record (profiles/pmc_ce_traffic.json)"
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_ce_traffic.json")))
+                if rec.get("N") == a.nclass and rec.get("B") == a.batch and rec.get("HW") == a.crop * a.crop:
+                    ce_traffic, ce_note = rec["traffic_bytes"], rec.get("note", "")
+            except (OSError, ValueError, KeyError):
+                pass
             out["roofline_hbm"] = dict(bound="hbm", kernel="ce_fused_kernel (svl_ce_fused_f32)",
                                        achieved=round(by_ce / t_ce / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                       frac=round(by_ce / t_ce / 1e9 / PEAK_HBM_GBS, 4), traffic=None, launches=len(c),
-                                       note="algorithmic bytes (12N+40) B/px per fwd+bwd branch (SURVEY §8(d))")
+                                       frac=round(by_ce / t_ce / 1e9 / PEAK_HBM_GBS, 4), traffic=ce_traffic, launches=len(c),
+                                       avg_ms=round(t_ce * 1e3 / len(c), 4), algorithmic_bytes=by_ce / len(c),
+                                       frac_real_traffic=(round(ce_traffic / (t_ce / len(c)) / 1e9 / PEAK_HBM_GBS, 4)
+                                                          if ce_traffic else None),
+                                       traffic_note=ce_note,
+                                       note="achieved = algorithmic bytes (12N+40) B/px per fwd+bwd branch (SURVEY §8(d): API-boundary "
+                                            "accounting) / mean launch duration; the fused kernel really moves (8N+28) B/px (logits read "
+                                            "once, dlogits written once): frac_real_traffic prices the PMC bytes")
     # ---- the same step in the OTHER arithmetic (exact fp32 MFMA next to a bf16x6 value, bf16x6 next to an f32 value) ----
     if not a.no_throughput_mode and a.gemm_arith in ("f32", "bf16x6"):
         other = "f32" if a.gemm_arith == "bf16x6" else "bf16x6"
@@ -385,6 +418,21 @@ def main():
                  if other == "f32" else
                  "svl_set_gemm_emulation(6): dense GEMMs with M>=256 split every fp32 operand element into 3 bf16 terms and "
                  "accumulate the 6 leading cross products in fp32 (v_mfma_f32_32x32x16_bf16)")
+    # ---- both arithmetics on the SAME weights and the SAME step (no optimizer step in between; the dropout2d masks of the
+    # feature perturbation are re-seeded): cross-mode consistency evidence next to the two throughput numbers
+    if world == 1 and not a.no_throughput_mode and a.gemm_arith in ("f32", "bf16x6"):
+        cm = {}
+        for name_, mode_ in (("bf16x6", 6), ("f32", 0)):
+            ops.set_gemm_emulation(mode_)
+            torch.manual_seed(4321)
+            l_ = semivl_train_step(model, batch, a.warmup + a.steps + 9, total_iters, cfg, optimizer=None, reducer=None)
+            cm[name_] = [round(float(v), 6) for v in l_.tolist()]
+        ops.set_gemm_emulation(EMU[a.gemm_arith])
+        out["cross_mode_same_weights"] = dict(
+            losses_bf16x6=cm["bf16x6"], losses_f32=cm["f32"],
+            max_abs_diff=round(max(abs(x - y) for x, y in zip(cm["bf16x6"], cm["f32"])), 7),
+            names=["loss", "loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "loss_mc_s2", "loss_mc_fp"],
+            note="one forward + loss evaluation of the step in each arithmetic from identical weights, inputs and dropout masks")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(512, 21, *a.cpu_baseline_steps)

@@ -277,7 +277,7 @@ def pgemm(A, B, M, N, out=None, planes_out=None, bias=None, act=ACT_NONE, preact
     d.accumulate = 1 if accumulate else 0
     e0 = _prof_begin()
     L.check(L.load().svl_gemm_planes_f32(C.byref(d), _st()), "svl_gemm_planes_f32")
-    _prof_end("gemm_bf16x", e0, 2.0 * M * N * K, ("planes", M, N, K, 1))
+    _prof_end("gemm_bf16x", e0, 2.0 * M * N * K, ("planes", M, N, K, act))
 
 
 # ------------------------------------------------------------------------------------------------ dense helpers
