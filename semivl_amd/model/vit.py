@@ -553,20 +553,32 @@ class _EncoderFn(torch.autograd.Function):
             ops.copy2d(d, 0, NP, NP * E, E, full, E, NP, T * E, E, B * NP, E)
             dvs[li] = full if dvs.get(li) is None else ops.add(dvs[li], full)
         # ---- blocks, last to first
-        dx = dxp = None
+        dx = dxp = pend = None
         grads = {}
         for i in range(L - 1, -1, -1):
             layer = m.layers[i]
             sv = s["layers"][i]
             dx, dxp, g = block_backward(dx, dvs.get(i), layer.plist(), sv, m.num_heads, B, T, dxo_p=dxp)
-            wg = attn_wgrads(layer, g, E)
+            # this block's weight gradients (two split-K GEMMs, their slab reductions, two column sums) are off the
+            # dependency chain: they go to the weight-gradient stream and run next to the chain's LayerNorm-backward /
+            # pack passes of the blocks below (ops.wgrad_side)
+            used = [t_ for pair in g["wout_parts"] for t_ in pair] + [t_ for k_ in ("in_full", "in_v") for t_ in g.get(k_, ())]
+            with ops.wgrad_side(*used):
+                wg = attn_wgrads(layer, g, E)
             a = layer.attn.attn
             grads[id(a.in_proj_weight)], grads[id(a.in_proj_bias)] = wg["win"], wg["bin"]
             grads[id(a.out_proj.weight)], grads[id(a.out_proj.bias)] = wg["wout"], wg["bout"]
             s["layers"][i] = None  # free this block's activations
-            # this block's attention gradients are complete for this graph: their all-reduce bucket may go (train.py)
-            gradsync.ready([q for q in (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias)
-                            if any(q is r_ for r_ in ctx.params)])
+            # this block's attention gradients are complete for this graph ONE BLOCK LATER (when its side-stream work has
+            # had a block's time to finish): then their all-reduce bucket may go (train.py)
+            if pend is not None:
+                ops.wgrad_join(pend[0])
+                gradsync.ready(pend[1])
+            pend = (ops.wgrad_event(), [q for q in (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias)
+                                        if any(q is r_ for r_ in ctx.params)])
+        ops.wgrad_join(produced=grads.values())     # every weight gradient of this graph is complete from here on
+        if pend is not None:
+            gradsync.ready(pend[1])
         rest = [q for q in ctx.params if q is m.pos_embed or not any(q is r_ for l_ in m.layers for r_ in l_.parameters())]
         if dx is None:
             gradsync.ready(rest)

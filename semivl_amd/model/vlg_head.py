@@ -104,9 +104,10 @@ def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True):
     gc.put_tensor(gn.weight, dg)
     gc.put_tensor(gn.bias, db)
     C2 = sv["C2"]
-    dwf = ops.conv_wgrad(dpre, Co, sv["x"], sv["ldx"], imgs, H, W, C1, Co, k, k, dil, pad, src2=sv["src2"],
-                         ld2=sv["ld2"], C2=C2, rep=sv["rep"])
-    gc.put_tensor(conv.weight, ops.unpack_conv_wgrad(dwf, Co, C1 + C2, k, k))
+    with ops.wgrad_side(dpre, sv["x"], sv["src2"]):     # off the dependency chain: weight-gradient stream (ops.wgrad_side)
+        dwf = ops.conv_wgrad(dpre, Co, sv["x"], sv["ldx"], imgs, H, W, C1, Co, k, k, dil, pad, src2=sv["src2"],
+                             ld2=sv["ld2"], C2=C2, rep=sv["rep"])
+        gc.put_tensor(conv.weight, ops.unpack_conv_wgrad(dwf, Co, C1 + C2, k, k))
     if not need_dx:
         return None
     return ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad)  # [pix, C1+C2]
@@ -362,23 +363,27 @@ def _semtr_backward(lyr, dx, dtp_acc, imgs, b, N, h, w, Ch, Ct, sv, gc):
     dt3 = ops.zeros(rows, E, device=dev)
     ops.bilinear_nhwc_bwd(dx, Ch, imgs, hp, wp, Ch, True, 1, h, w, dt3, E)
     # t3 = t2 + W2 hh + b2
-    gc.put(f[1].weight, lambda d, acc: ops.matmul_tn(dt3, sv["hh"], out=d, accumulate=acc))
-    gc.put(f[1].bias, lambda d, acc: ops.colsum(dt3, out=d, accumulate=acc))
+    with ops.wgrad_side(dt3, sv["hh"]):
+        gc.put(f[1].weight, lambda d, acc: ops.matmul_tn(dt3, sv["hh"], out=d, accumulate=acc))
+        gc.put(f[1].bias, lambda d, acc: ops.colsum(dt3, out=d, accumulate=acc))
     dh = ops.matmul_nn(dt3, p["w2"])
     dhp = ops.eltwise(1, dh, sv["h_pre"], out=dh)
-    gc.put(f[0][0].weight, lambda d, acc: ops.matmul_tn(dhp, sv["y2"], out=d, accumulate=acc))
-    gc.put(f[0][0].bias, lambda d, acc: ops.colsum(dhp, out=d, accumulate=acc))
+    with ops.wgrad_side(dhp, sv["y2"]):
+        gc.put(f[0][0].weight, lambda d, acc: ops.matmul_tn(dhp, sv["y2"], out=d, accumulate=acc))
+        gc.put(f[0][0].bias, lambda d, acc: ops.colsum(dhp, out=d, accumulate=acc))
     dy2 = ops.matmul_nn(dhp, p["w1"])
     dt2, dg2, db2 = ops.layernorm_bwd(dy2, sv["t2"], sv["st2"], p["ln2w"], dx_add=dt3, want_wgrad=True)
     gc.put_tensor(t.ln2.weight, dg2)
     gc.put_tensor(t.ln2.bias, db2)
     # t2 = tok + Wout o + bout
-    gc.put(a.out_proj.weight, lambda d, acc: ops.matmul_tn(dt2, sv["o"], out=d, accumulate=acc))
-    gc.put(a.out_proj.bias, lambda d, acc: ops.colsum(dt2, out=d, accumulate=acc))
+    with ops.wgrad_side(dt2, sv["o"]):
+        gc.put(a.out_proj.weight, lambda d, acc: ops.matmul_tn(dt2, sv["o"], out=d, accumulate=acc))
+        gc.put(a.out_proj.bias, lambda d, acc: ops.colsum(dt2, out=d, accumulate=acc))
     do = ops.matmul_nn(dt2, p["wout"])
     dqkv = ops.seqattn_bwd(do, sv["qkv"], sv["probs"], b * G, G, N, t.num_heads, N * G, 1, G)
-    gc.put(a.in_proj_weight, lambda d, acc: ops.matmul_tn(dqkv, sv["y1"], out=d, accumulate=acc))
-    gc.put(a.in_proj_bias, lambda d, acc: ops.colsum(dqkv, out=d, accumulate=acc))
+    with ops.wgrad_side(dqkv, sv["y1"]):
+        gc.put(a.in_proj_weight, lambda d, acc: ops.matmul_tn(dqkv, sv["y1"], out=d, accumulate=acc))
+        gc.put(a.in_proj_bias, lambda d, acc: ops.colsum(dqkv, out=d, accumulate=acc))
     dy1 = ops.matmul_nn(dqkv, p["win"])
     dtok, dg1, db1 = ops.layernorm_bwd(dy1, sv["tok"], sv["st1"], p["ln1w"], dx_add=dt2, want_wgrad=True)
     gc.put_tensor(t.ln1.weight, dg1)
@@ -420,9 +425,10 @@ def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
     dskip = ops.empty(b * sh * sw, Cs, device=dev)
     ops.bilinear_nhwc_bwd(dcat[:, Cu:], ld, b, sh, sw, Cs, True, N, 2 * h, 2 * w, dskip, Cs)
     # ConvTranspose half
-    gc.put(up.up.bias, lambda d, acc: ops.colsum(dcat, out=d, accumulate=acc, C_=Cu, ld=ld))
-    dwb = ops.convT2x_wgrad(sv["x"], Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
-    gc.put_tensor(up.up.weight, dwb.view(Cin, 2, 2, Cu).permute(0, 3, 1, 2).contiguous())
+    with ops.wgrad_side(dcat, sv["x"]):
+        gc.put(up.up.bias, lambda d, acc: ops.colsum(dcat, out=d, accumulate=acc, C_=Cu, ld=ld))
+        dwb = ops.convT2x_wgrad(sv["x"], Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
+        gc.put_tensor(up.up.weight, dwb.view(Cin, 2, 2, Cu).permute(0, 3, 1, 2).contiguous())
     wb = ops.cached_pack(up.up.weight, "convT_bwd", lambda w_: w_.permute(0, 2, 3, 1).reshape(Cin, 4 * Cu).contiguous())
     dx = ops.convT2x_dgrad(dcat, ld, imgs, h, w, Cu, wb, Cin)
     return dx, dskip
@@ -490,6 +496,7 @@ class _HeadFn(torch.autograd.Function):
         dv4 = undbl(dv4, mk[1], Cv, HW)
         demb = undbl(demb, mk[2], Ce, HW)
         ctx.chunks = ctx.shared = None
+        ops.wgrad_join(produced=gc.out.values())   # (the weight-gradient stream's work of this graph is ordered before what follows)
         gradsync.ready(ctx.params)     # the decoder's gradients of this graph are in the arena
         req = ctx.feat_req
         return (None, None, None, None, None, None, dv0 if req[0] else None, dv4 if req[1] else None,
@@ -509,9 +516,10 @@ def _head_backward_core(m, sv, dlogits, gc):
         # ---- head conv
         g4 = sv["g4"]
         C4 = g4.shape[1]
-        gc.put(m.head.bias, lambda d, acc: ops.colsum(dlg, out=d, accumulate=acc))
-        dwh = ops.conv_cout1_wgrad(dlg, g4, C4, imgs, 4 * h, 4 * w, C4, 1, 1)
-        gc.put_tensor(m.head.weight, ops.unpack_conv_wgrad(dwh, 1, C4, 3, 3))
+        with ops.wgrad_side(dlg, g4):
+            gc.put(m.head.bias, lambda d, acc: ops.colsum(dlg, out=d, accumulate=acc))
+            dwh = ops.conv_cout1_wgrad(dlg, g4, C4, imgs, 4 * h, 4 * w, C4, 1, 1)
+            gc.put_tensor(m.head.weight, ops.unpack_conv_wgrad(dwh, 1, C4, 3, 3))
         dg4 = ops.conv_dgrad(dlg, 1, imgs, 4 * h, 4 * w, 1, sv["whd"], C4, 3, 3, 1, 1)
         # ---- up2, up1
         dg2, dskip0 = _up_backward(m.up2, dg4, imgs, 2 * h, 2 * w, b, N, sv["up2"], gc)
@@ -524,9 +532,10 @@ def _head_backward_core(m, sv, dlogits, gc):
             Cs = ss["Cs"]
             Cf, fh, fw = ss["geo"]
             dpre = ops.eltwise(2, dsk, ss["y"], out=dsk)  # relu backward (post-activation mask)
-            gc.put(proj[0].bias, lambda d, acc, dpre=dpre: ops.colsum(dpre, out=d, accumulate=acc))
-            dwf = ops.conv_wgrad(dpre, Cs, ss["x"], Cf, b, fh, fw, Cf, Cs, 3, 3, 1, 1)
-            gc.put_tensor(proj[0].weight, ops.unpack_conv_wgrad(dwf, Cs, Cf, 3, 3))
+            with ops.wgrad_side(dpre, ss["x"]):
+                gc.put(proj[0].bias, lambda d, acc, dpre=dpre: ops.colsum(dpre, out=d, accumulate=acc))
+                dwf = ops.conv_wgrad(dpre, Cs, ss["x"], Cf, b, fh, fw, Cf, Cs, 3, 3, 1, 1)
+                gc.put_tensor(proj[0].weight, ops.unpack_conv_wgrad(dwf, Cs, Cf, 3, 3))
             dfe.append(ops.conv_dgrad(dpre, Cs, b, fh, fw, Cs, ss["wd"], Cf, 3, 3, 1, 1))
         dv4, dv0 = dfe
         # ---- semantic transformers (reverse)
@@ -554,9 +563,10 @@ def _head_backward_core(m, sv, dlogits, gc):
         sv["aspp"] = sv["cat"] = sv["proj"] = None
         # ---- conv1
         k1 = m.conv1_ksize
-        gc.put(m.conv1.bias, lambda d, acc: ops.colsum(dx1, out=d, accumulate=acc))
-        dw1 = ops.conv_wgrad(dx1, Ch, sv["sim"], 1, imgs, h, w, 1, Ch, k1, k1, 1, (k1 - 1) // 2)
-        gc.put_tensor(m.conv1.weight, ops.unpack_conv_wgrad(dw1, Ch, 1, k1, k1))
+        with ops.wgrad_side(dx1, sv["sim"]):
+            gc.put(m.conv1.bias, lambda d, acc: ops.colsum(dx1, out=d, accumulate=acc))
+            dw1 = ops.conv_wgrad(dx1, Ch, sv["sim"], 1, imgs, h, w, 1, Ch, k1, k1, 1, (k1 - 1) // 2)
+            gc.put_tensor(m.conv1.weight, ops.unpack_conv_wgrad(dw1, Ch, 1, k1, k1))
         wtap = ops.cached_pack(m.conv1.weight, "tap", lambda w_: w_.view(Ch, k1 * k1).t().contiguous())  # [tap, co]
         dsim = ops.conv_cin1_dgrad(dx1, Ch, imgs, h, w, Ch, wtap, k1, k1, 1, (k1 - 1) // 2)  # [(b n) hw, 1]
         # ---- cosine sim: demb_n[b,p,c] = sum_n dsim[b,n,p] textn[n,c]

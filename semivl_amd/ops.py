@@ -130,6 +130,83 @@ def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld
     return g
 
 
+# ------------------------------------------------------------------------------------------------ weight-gradient stream
+# Backward has one dependency chain (the input gradients) and a lot of work OFF it: the weight-gradient GEMMs / convs, their
+# split-K reductions and the bias column sums.  On one stream they queue between the chain's bandwidth-bound passes
+# (LayerNorm / GroupNorm backward, packs, resampling), which then run with the matrix pipe idle: 83 ms of a 490 ms step
+# had no MFMA kernel in flight (tools/rocpd_attrib.py).  With the off-chain work on a second stream the chip has matrix
+# work to run next to those passes.  `with wgrad_side(t1, t2, ...)`: the enclosed launches go to the per-device
+# weight-gradient stream, ordered after everything queued so far on the current stream; the listed tensors (produced on
+# the current stream, read in the block) are marked in use there (caching allocator).  wgrad_join() orders the current
+# stream after the side stream (before anything reads the gradients: all-reduce, optimizer).
+WGRAD_STREAM = not os.environ.get("SVL_NO_WGRAD_STREAM")
+_WG = {}
+
+
+def _wg_stream(dev):
+    s = _WG.get(dev.index)
+    if s is None:
+        s = _WG[dev.index] = torch.cuda.Stream(dev)
+    return s
+
+
+class wgrad_side:
+    def __init__(self, *tensors):
+        self.tensors, self.ctx = tensors, None
+
+    def __enter__(self):
+        if not WGRAD_STREAM or not torch.cuda.is_available():
+            return self
+        main = torch.cuda.current_stream()
+        wg = _wg_stream(main.device)
+        if wg.cuda_stream == main.cuda_stream:
+            return self
+        ev = torch.cuda.Event()
+        ev.record(main)
+        wg.wait_event(ev)
+        for t in self.tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(wg)
+        self.ctx = torch.cuda.stream(wg)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def wgrad_event():
+    """An event after everything queued so far on the weight-gradient stream (None when it was never used)."""
+    if not torch.cuda.is_available():
+        return None
+    wg = _WG.get(torch.cuda.current_device())
+    if wg is None:
+        return None
+    ev = torch.cuda.Event()
+    ev.record(wg)
+    return ev
+
+
+def wgrad_join(ev=None, produced=()):
+    """Order the current stream after `ev` (wgrad_event()) or after everything queued on the weight-gradient stream.
+    `produced`: tensors allocated inside wgrad_side blocks that the current stream goes on to use (gradients handed back to
+    autograd when there is no main_grad arena): marked in use here for the caching allocator."""
+    if not torch.cuda.is_available():
+        return
+    main = torch.cuda.current_stream()
+    if ev is not None:
+        main.wait_event(ev)
+        return
+    wg = _WG.get(main.device.index)
+    if wg is not None and wg.cuda_stream != main.cuda_stream:
+        main.wait_stream(wg)
+        for t in produced:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)
+
+
 # ------------------------------------------------------------------------------------------------ pre-split bf16x3 operands
 def planes_rows(rows):
     return (rows + 255) // 256 * 256

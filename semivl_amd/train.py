@@ -9,6 +9,7 @@ Mirrors (same names / argument meaning):
 """
 
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -92,6 +93,7 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         model.decode_head._bwd_ranges = None
     if reducer is not None:
         reducer.begin()
+    ops.WGRAD_STREAM = bool(cfg.get("overlap_streams", True)) and not os.environ.get("SVL_NO_WGRAD_STREAM")
     # pseudo labels + MaskCLIP guidance (model.eval(): the side encoder's BatchNorm uses its running statistics here,
     # semivl.py:228-244; nothing else on the path depends on the mode).  Both passes are gradient-free and independent of
     # the two student forwards below: they are enqueued on a second stream (event-forked from / joined back into the
