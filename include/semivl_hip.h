@@ -316,12 +316,6 @@ int svl_layernorm_bwd_parts(int64_t rows);
 int svl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int64_t rows,
                       int C, const float* dx_add, float* dx, float* dgamma_part, float* dbeta_part,
                       svl_stream_t stream);
-/* ... with dx additionally emitted as packed planes (planes may be NULL): the A operand of the input-gradient GEMM that
- * consumes it (d out_proj, d FFN-2 of the block below). */
-int svl_layernorm_bwd_planes(const float* dy, const float* x, const float* stats, const float* gamma, int64_t rows,
-                             int C, const float* dx_add, float* dx, float* dgamma_part, float* dbeta_part, void* planes,
-                             int64_t planes_rows, svl_stream_t stream);
-
 /* Row softmax in place over the first `cols` entries of rows with stride ld: p = softmax(scale * s).
  * Entries [cols, ld) are zeroed. */
 int svl_softmax_rows_fwd(float* s, int64_t rows, int cols, int64_t ld, float scale, svl_stream_t stream);

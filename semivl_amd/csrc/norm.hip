@@ -17,57 +17,115 @@ inline int grid_for(long n, int per_thread = 1) {
 // LayerNorm: one wave per row, 4 rows per block. C % 4 == 0. Two-pass (mean, then centred variance)
 // like ATen's RowwiseMoments result to fp32 rounding.
 // ---------------------------------------------------------------------------------------------
+// Packed-planes output of a 32-row block (the A operand of the following svl_gemm_planes_f32; layout: svl_common.h /
+// gemm_planes.hip).  Thread = (row r31, lane half h) of k-group kg: 2 x 16 B read from `src` rows (just written / just
+// read by this block: L1 / L2 hits), 3 x 16 B written -- the 32 rows of the block give 512 contiguous bytes per (k-group,
+// half, plane), which is what makes this 4x faster than emitting 8-byte pieces from the row-per-wave loops (measured:
+// 1.7 TB/s vs 6.6 TB/s on the plane stores).  src = x, normalised on the fly with the block's row statistics.
+__device__ __forceinline__ void ln_emit_planes(const float* __restrict__ src, long r0, long rows, int C,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               const float* st /* LDS [32][2] */, char* __restrict__ planes, long p_ks) {
+  const int t = threadIdx.x, r31 = t & 31, h = (t >> 5) & 1, kg0 = t >> 6;
+  const long r = r0 + r31;
+  const int nkg = C >> 4;
+  float mean = 0.f, rstd = 0.f;
+  mean = st[2 * r31]; rstd = st[2 * r31 + 1];
+  for (int kg = kg0; kg < nkg; kg += 4) {
+    float v[8];
+    const int k = kg * 16 + 4 * h;
+    if (r < rows) {
+      const float4 f0 = *reinterpret_cast<const float4*>(src + r * C + k), f1 = *reinterpret_cast<const float4*>(src + r * C + k + 8);
+      v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
+      {
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + k), g1 = *reinterpret_cast<const float4*>(gamma + k + 8);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + k), b1 = *reinterpret_cast<const float4*>(beta + k + 8);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (v[q] - mean) * rstd * gg[q] + bb[q];     // (the row loop's expression, bit for bit)
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    }
+    typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+    bf16x8_ h0, h1, h2;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float u = v[q];
+      h0[q] = (__bf16)u;
+      u -= (float)h0[q];
+      h1[q] = (__bf16)u;
+      u -= (float)h1[q];
+      h2[q] = (__bf16)u;
+    }
+    char* q_ = planes + (long)kg * p_ks + (r >> 5) * 3072 + (h * 32 + (int)(r & 31)) * 16;
+    *reinterpret_cast<bf16x8_*>(q_) = h0;
+    *reinterpret_cast<bf16x8_*>(q_ + 1024) = h1;
+    *reinterpret_cast<bf16x8_*>(q_ + 2048) = h2;
+  }
+}
+
+// rows_per_block = 4 (planes == null: one row per wave and pass) or 32 (planes: a whole row block, then ln_emit_planes)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, long rows, int C,
                                                             float* __restrict__ y, float* __restrict__ stats,
                                                             char* __restrict__ planes, long p_ks) {
+  __shared__ float st_s[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C4 = C >> 2;
-  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
-    const float4* xr = reinterpret_cast<const float4*>(x + r * C);
-    float s = 0.f;
-    for (int i = lane; i < C4; i += 64) {
-      const float4 v = xr[i];
-      s += (v.x + v.y) + (v.z + v.w);
+  const int rpb = planes ? 32 : 4;
+  for (long r0 = (long)blockIdx.x * rpb; r0 < rows; r0 += (long)gridDim.x * rpb) {
+    for (long r = r0 + wave; r < min(rows, r0 + rpb); r += 4) {
+      const float4* xr = reinterpret_cast<const float4*>(x + r * C);
+      float s = 0.f;
+      for (int i = lane; i < C4; i += 64) {
+        const float4 v = xr[i];
+        s += (v.x + v.y) + (v.z + v.w);
+      }
+      const float mean = wave_sum(s) / C;
+      float q = 0.f;
+      for (int i = lane; i < C4; i += 64) {
+        const float4 v = xr[i];
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+      const float var = wave_sum(q) / C;
+      const float rstd = 1.0f / sqrtf(var + eps);
+      if (y) {
+        float4* yr = reinterpret_cast<float4*>(y + r * C);
+        for (int i = lane; i < C4; i += 64) {
+          const float4 v = xr[i];
+          const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+          const float4 b = reinterpret_cast<const float4*>(beta)[i];
+          float4 o;
+          o.x = (v.x - mean) * rstd * g.x + b.x;
+          o.y = (v.y - mean) * rstd * g.y + b.y;
+          o.z = (v.z - mean) * rstd * g.z + b.z;
+          o.w = (v.w - mean) * rstd * g.w + b.w;
+          yr[i] = o;
+        }
+      }
+      if (lane == 0) {
+        stats[2 * r] = mean;
+        stats[2 * r + 1] = rstd;
+        if (planes) { st_s[2 * (r - r0)] = mean; st_s[2 * (r - r0) + 1] = rstd; }
+      }
     }
-    const float mean = wave_sum(s) / C;
-    float q = 0.f;
-    for (int i = lane; i < C4; i += 64) {
-      const float4 v = xr[i];
-      const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-      q += (a * a + b * b) + (c * c + d * d);
-    }
-    const float var = wave_sum(q) / C;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    float4* yr = reinterpret_cast<float4*>(y + r * C);
-    for (int i = lane; i < C4; i += 64) {
-      const float4 v = xr[i];
-      const float4 g = reinterpret_cast<const float4*>(gamma)[i];
-      const float4 b = reinterpret_cast<const float4*>(beta)[i];
-      float4 o;
-      o.x = (v.x - mean) * rstd * g.x + b.x;
-      o.y = (v.y - mean) * rstd * g.y + b.y;
-      o.z = (v.z - mean) * rstd * g.z + b.z;
-      o.w = (v.w - mean) * rstd * g.w + b.w;
-      if (y) yr[i] = o;
-      if (planes) svl_store_planes_f4(planes, p_ks, r, i, o.x, o.y, o.z, o.w);   // the following GEMM's A operand
-    }
-    if (lane == 0) {
-      stats[2 * r] = mean;
-      stats[2 * r + 1] = rstd;
+    if (planes) {
+      __syncthreads();
+      ln_emit_planes(x, r0, rows, C, gamma, beta, st_s, planes, p_ks);
+      __syncthreads();
     }
   }
 }
 
-// Backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma. Optional fused `+ dx_add`.
-// Optional per-block partial dgamma/dbeta: block b handles rows [b*rpb, (b+1)*rpb); C <= 1024.
 constexpr int LN_MAXV = 4;  // float4 per lane
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, long rows, int C,
                                                             const float* __restrict__ dx_add, float* __restrict__ dx,
                                                             float* __restrict__ dg_part, float* __restrict__ db_part,
-                                                            long rows_per_block, char* __restrict__ planes, long p_ks) {
+                                                            long rows_per_block) {
   __shared__ float sh[2][4][LN_MAXV * 256];  // [dg|db][wave][column]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C4 = C >> 2;
@@ -114,7 +172,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         oxr[i] = o;
-        if (planes) svl_store_planes_f4(planes, p_ks, r, i, o.x, o.y, o.z, o.w);   // dx as the next dgrad GEMM's A operand
       }
     }
   }
@@ -560,7 +617,8 @@ extern "C" int svl_layernorm_fwd_planes(const float* x, const float* gamma, cons
                 "svl_layernorm_fwd: bad args");
   SVL_CHECK_ARG(!planes || (C % 16 == 0 && planes_rows >= rows && planes_rows % 256 == 0),
                 "svl_layernorm_fwd_planes: C %% 16 == 0 and planes_rows (%% 256 == 0) >= rows");
-  const int grid = (int)((rows + 3) / 4 > 4096 * 4 ? 4096 * 4 : (rows + 3) / 4);
+  const long rpb = planes ? 32 : 4;
+  const int grid = (int)((rows + rpb - 1) / rpb > 4096 * 4 ? 4096 * 4 : (rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
                      (long)rows, C, y, stats, (char*)planes, (long)planes_rows * 96);
   SVL_LAUNCH_CHECK("svl_layernorm_fwd");
@@ -582,20 +640,17 @@ extern "C" int svl_layernorm_bwd_parts(int64_t rows) {
 extern "C" int svl_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int64_t rows,
                                  int C, const float* dx_add, float* dx, float* dgamma_part, float* dbeta_part,
                                  svl_stream_t stream) {
-  return svl_layernorm_bwd_planes(dy, x, stats, gamma, rows, C, dx_add, dx, dgamma_part, dbeta_part, nullptr, 0, stream);
-}
-extern "C" int svl_layernorm_bwd_planes(const float* dy, const float* x, const float* stats, const float* gamma,
-                                        int64_t rows, int C, const float* dx_add, float* dx, float* dgamma_part,
-                                        float* dbeta_part, void* planes, int64_t planes_rows, svl_stream_t stream) {
   SVL_CHECK_ARG(dy && x && stats && gamma && dx && rows > 0 && C > 0 && C % 4 == 0 && C <= 1024,
                 "svl_layernorm_bwd: bad args (C=%d)", C);
-  SVL_CHECK_ARG(!planes || (C % 16 == 0 && planes_rows >= rows && planes_rows % 256 == 0),
-                "svl_layernorm_bwd_planes: C %% 16 == 0 and planes_rows (%% 256 == 0) >= rows");
   SVL_CHECK_ARG((dgamma_part == nullptr) == (dbeta_part == nullptr), "svl_layernorm_bwd: dgamma/dbeta go together");
-  const int nparts = svl_layernorm_bwd_parts(rows);
+  // With weight gradients a block keeps per-column partial sums over its rows (few, long blocks: nparts slabs to reduce).
+  // Without them (the ViT's frozen LayerNorms: every call of the encoder's backward) nothing ties rows together: 8 rows per
+  // block, i.e. two per wave -- the row loop is a load -> two wave reductions -> store chain, and only many resident waves
+  // hide it (513 blocks = 2 waves per SIMD ran at 3.3 TB/s, this at 5.0).
+  const int nparts = dgamma_part ? svl_layernorm_bwd_parts(rows) : (int)((rows + 7) / 8);
   const long rpb = (rows + nparts - 1) / nparts;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma,
-                     (long)rows, C, dx_add, dx, dgamma_part, dbeta_part, rpb, (char*)planes, (long)planes_rows * 96);
+                     (long)rows, C, dx_add, dx, dgamma_part, dbeta_part, rpb);
   SVL_LAUNCH_CHECK("svl_layernorm_bwd");
   return SVL_OK;
 }

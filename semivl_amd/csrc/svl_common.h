@@ -85,28 +85,4 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
-// ---- packed bf16x3 planes (operand format of svl_gemm_planes_f32, gemm_planes.hip): producers other than the GEMM
-// epilogue own 4 consecutive k of a row (one float4) = HALF of a 16-byte lane slot: chunk (k-group k/16, row block r/32,
-// plane), slot (h*32 + r%32) with h = (k>>2)&1, first / second half by (k>>3)&1.
-typedef __bf16 svl_bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void svl_store_planes_f4(char* planes, long p_ks, long r, int k4, float v0, float v1, float v2,
-                                                    float v3) {
-  // k4 = k / 4 (index of the float4 inside the row)
-  const float v[4] = {v0, v1, v2, v3};
-  svl_bf16x4 h0, h1, h2;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float t = v[j];
-    h0[j] = (__bf16)t;
-    t -= (float)h0[j];
-    h1[j] = (__bf16)t;
-    t -= (float)h1[j];
-    h2[j] = (__bf16)t;
-  }
-  char* q = planes + (long)(k4 >> 2) * p_ks + (r >> 5) * 3072 + (((k4 & 1) * 32 + (int)(r & 31)) * 16) + ((k4 >> 1) & 1) * 8;
-  *reinterpret_cast<svl_bf16x4*>(q) = h0;
-  *reinterpret_cast<svl_bf16x4*>(q + 1024) = h1;
-  *reinterpret_cast<svl_bf16x4*>(q + 2048) = h2;
-}
-
 static inline int svl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

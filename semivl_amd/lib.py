@@ -101,7 +101,6 @@ SIGNATURES = {
     "svl_layernorm_fwd_planes": (_I, [_P, _P, _P, _F, _L, _I, _P, _P, _P, _L, _P]),
     "svl_layernorm_bwd_parts": (_I, [_L]),
     "svl_layernorm_bwd": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P]),
-    "svl_layernorm_bwd_planes": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _L, _P]),
     "svl_softmax_rows_fwd": (_I, [_P, _L, _I, _L, _F, _P]),
     "svl_softmax_rows_bwd": (_I, [_P, _P, _L, _I, _L, _F, _P]),
     "svl_l2norm_fwd": (_I, [_P, _L, _I, _F, _P, _P, _P]),

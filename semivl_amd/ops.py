@@ -146,7 +146,10 @@ _WG = {}
 def _wg_stream(dev):
     s = _WG.get(dev.index)
     if s is None:
-        s = _WG[dev.index] = torch.cuda.Stream(dev)
+        # (stream priority was tried: this runtime offers only {high, normal}; a HIGH-priority weight-gradient stream delays
+        # the dependency chain, 449 -> 494 ms, so it stays at normal priority)
+        s = torch.cuda.Stream(dev)
+        _WG[dev.index] = s
     return s
 
 
@@ -528,11 +531,15 @@ def layernorm_fwd(x, gamma, beta, eps, planes=False, want_y=True):
         L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),
                 "svl_layernorm_fwd")
         return y, stats
-    y = torch.empty_like(x) if want_y else None
+    if want_y:   # measured at [32800, 768]: row pass (39 us) + pack pass over the cache-warm result (38 us) beats the fused
+        y = torch.empty_like(x)      # kernel (102 us: its 32-row blocks leave 8 sequential rows per wave); planes-only
+        L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),
+                "svl_layernorm_fwd")                                                 # is faster fused (60 us vs 77)
+        return y, stats, split_planes(y)
     pl = Planes(rows, Cc, device=x.device)
-    L.check(L.load().svl_layernorm_fwd_planes(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats),
+    L.check(L.load().svl_layernorm_fwd_planes(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, None, _p(stats),
                                               _p(pl.buf), pl.prow, _st()), "svl_layernorm_fwd_planes")
-    return y, stats, pl
+    return None, stats, pl
 
 
 def layernorm_bwd(dy, x, stats, gamma, dx_add=None, want_wgrad=False, planes=False):
@@ -545,13 +552,11 @@ def layernorm_bwd(dy, x, stats, gamma, dx_add=None, want_wgrad=False, planes=Fal
         nparts = lib.svl_layernorm_bwd_parts(rows)
         dgp = empty(nparts, Cc, device=x.device)
         dbp = empty(nparts, Cc, device=x.device)
-    pl = Planes(rows, Cc, device=x.device) if planes else None
-    L.check(lib.svl_layernorm_bwd_planes(_p(dy), _p(x), _p(stats), _p(gamma), rows, Cc, _p(dx_add), _p(dx), _p(dgp),
-                                         _p(dbp), _p(pl.buf) if planes else None, pl.prow if planes else 0, _st()),
-            "svl_layernorm_bwd")
+    L.check(lib.svl_layernorm_bwd(_p(dy), _p(x), _p(stats), _p(gamma), rows, Cc, _p(dx_add), _p(dx), _p(dgp), _p(dbp),
+                                  _st()), "svl_layernorm_bwd")
     res = (dx, colsum(dgp), colsum(dbp)) if want_wgrad else (dx,)
-    if planes:
-        res = res + (pl,)
+    if planes:   # (measured: 81 us + a 38 us pack pass over the cache-warm dx vs 162 us for svl_layernorm_bwd_planes)
+        res = res + (split_planes(dx),)
     return res if len(res) > 1 else res[0]
 
 

@@ -202,8 +202,17 @@ def test_layernorm_emits_planes(dev):
     assert torch.equal(y, y_ref) and torch.equal(st, st_ref)
     for got, want in zip(_unpack_planes(pl), _unpack_planes(ops.split_planes(y_ref))):
         assert torch.equal(got, want)
-    y_none, _, pl2 = ops.layernorm_fwd(x, g, b, 1e-6, planes=True, want_y=False)
-    assert y_none is None and torch.equal(_unpack_planes(pl2)[1], _unpack_planes(pl)[1])
+    y_none, _, pl2 = ops.layernorm_fwd(x, g, b, 1e-6, planes=True, want_y=False)      # the fused kernel (planes only)
+    assert y_none is None
+    for got, want in zip(_unpack_planes(pl2), _unpack_planes(pl)):
+        assert torch.equal(got, want)
+    # the fused entry point with both outputs (the wrapper prefers two passes there: faster at the ViT shape)
+    from semivl_amd import lib as L
+    y3, st3, pl3 = torch.empty_like(x), torch.empty_like(st), ops.Planes(rows, Cc, device=dev)
+    L.check(L.load().svl_layernorm_fwd_planes(x.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-6, rows, Cc, y3.data_ptr(),
+                                              st3.data_ptr(), pl3.buf.data_ptr(), pl3.prow,
+                                              torch.cuda.current_stream().cuda_stream), "svl_layernorm_fwd_planes")
+    assert torch.equal(y3, y_ref) and torch.equal(st3, st_ref) and torch.equal(_unpack_planes(pl3)[2], _unpack_planes(pl)[2])
     dy, add = rnd(rows, Cc, dev=dev), rnd(rows, Cc, dev=dev)
     dx_ref = ops.layernorm_bwd(dy, x, st, g, dx_add=add)
     dx, dxp = ops.layernorm_bwd(dy, x, st, g, dx_add=add, planes=True)
