@@ -283,7 +283,7 @@ class VLGHead(nn.Module):  # vlg_head.py:140-251
             assert len(skip_feats) == len(self.skip_proj)
         text = inputs[1]
         B, Cc, H, W = img_feats.shape
-        text = text.repeat(B, 1, 1).float()
+        text = text.repeat(B, 1, 1).to(img_feats.dtype)  # (.float() in the reference, vlg_head.py; the dtype of the features so that a float64 run of this oracle is possible)
         img_feats = F.normalize(img_feats, dim=1)
         text = F.normalize(text, dim=-1)
         x = torch.einsum("bchw,bnc->bnhw", img_feats, text)

@@ -48,11 +48,20 @@ def oracle_step(orc, cfg, batch, masks, conf_thresh):
     return loss, aux
 
 
-def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, grad_tol=1e-2, noisy=()):
-    """Losses / logits within north_star's 1e-3; label maps bit-exact except at fp ties of the oracle (a flip needs the
-    oracle's top-2 logit gap to be below twice the logit error measured in this very run; MaskCLIP labels: top-2
-    probability gap or distance to the 0.9 threshold below 1e-4 -- its softmax runs at temperature 100); every parameter
-    gradient against the oracle's."""
+LOGIT_ERR_BOUND = 1.5e-5     # asserted on every logit tensor below (measured: 4.5e-6 ... 9.5e-6 over all configs and modes)
+TIE_EPS = 2 * LOGIT_ERR_BOUND   # a pseudo-label may differ only where the ORACLE's top-2 logit gap is below this constant
+GRAD_REL_L2 = 4e-3            # per-tensor ||g - g_ref|| / ||g_ref|| (measured <= 3.0e-3: skip_proj.1 / layer-0 attention / pos_embed,
+GRAD_MAX_ERR = 6e-3           # the far ends of the chains); element-wise bound in units of the tensor's largest entry (<= 4.1e-3)
+
+
+def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stack=(), after_bn=(), after_bn_tol=None):
+    """Losses / logits within north_star's 1e-3 (logits in fact within LOGIT_ERR_BOUND); label maps bit-exact except at fp
+    ties of the oracle, with a FIXED budget: a flip needs the oracle's top-2 logit gap to be below TIE_EPS (MaskCLIP
+    labels: top-2 probability gap or distance to the 0.9 threshold below 1e-4 -- its softmax runs at temperature 100);
+    every parameter gradient against the oracle's: rel-L2 <= GRAD_REL_L2 and every element within GRAD_MAX_ERR of the
+    tensor's scale.  `bn_stack`: parameter-name fragments of ReLU-on-BatchNorm stacks (3e-2: pre-activations within
+    rounding of 0 flip, test_model_gpu.py::test_conv_encoder_matches_oracle); `after_bn`: tensors fed by such a stack's
+    features, held to `after_bn_tol`."""
     from golden_util import assert_labels
     from semivl_amd import ops
     from semivl_amd.train import LOSS_NAMES, semivl_train_step
@@ -73,7 +82,7 @@ def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, grad_to
     errs = {}
     for k in ("pred_x", "pred_s1", "pred_w", "pred_w_other"):
         errs[k] = (haux[k].cpu() - aux[k].detach()).abs().max().item()
-        assert errs[k] < 1e-3, (k, errs[k])   # logits tolerance of north_star
+        assert errs[k] < LOGIT_ERR_BOUND, (k, errs[k])   # (north_star's logits tolerance is 1e-3)
     B = batch["img_w"].shape[0]
 
     def gap(logits):
@@ -81,7 +90,7 @@ def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, grad_to
         return t[:, 0] - t[:, 1]
     t2 = aux["mclip_top2"]
     mtie = ((t2[:, 0] - t2[:, 1]) < 1e-4) | ((t2[:, 0] - cfg["mcc_conf_thresh"]).abs() < 1e-4)
-    ties = dict(mask_w=gap(aux["pred_w"]) <= 2 * errs["pred_w"], mask_w_other=gap(aux["pred_w_other"]) <= 2 * errs["pred_w_other"],
+    ties = dict(mask_w=gap(aux["pred_w"]) <= TIE_EPS, mask_w_other=gap(aux["pred_w_other"]) <= TIE_EPS,
                 mclip=mtie[:B], mclip_other=mtie[B:])
     flips = {k: assert_labels(haux[k].cpu().numpy(), aux[k].numpy(), ties[k].numpy(), k)
              for k in ("mask_w", "mask_w_other", "mclip", "mclip_other")}
@@ -92,30 +101,30 @@ def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, grad_to
     hg = {n: p.grad for n, p in hip.named_parameters() if p.grad is not None}
     assert sorted(og) == sorted(hg) and len(og) > 100, sorted(set(og) ^ set(hg))
     table = sorted(((hg[n].cpu() - og[n]).abs().max().item() / max(og[n].abs().max().item(), 1e-12), n) for n in og)
+    t2_ = sorted((((hg[n].cpu() - og[n]).norm() / (og[n].norm() + 1e-20)).item(), n) for n in og)
     print(f"[gemm_mode {gemm_mode}] logit errs {errs}, label flips at ties {flips}; largest grad max-err / scale:",
-          [(f"{v:.1e}", n) for v, n in table[-6:]])
+          [(f"{v:.1e}", n) for v, n in table[-6:]], "; largest rel-L2:", [(f"{v:.1e}", n) for v, n in t2_[-10:]],
+          "; head rel-L2:", [(f"{v:.1e}", n) for v, n in t2_ if ("up2" in n or "skip_proj" in n or "up1" in n)][-8:])
     for n in og:
         ref = og[n]
         err = (hg[n].cpu() - ref).abs().max().item()
         scale = ref.abs().max().item()
-        # head.bias' gradient is sum(softmax - onehot) over all pixels: exactly 0 in exact arithmetic, pure rounding noise here
-        floor = 1e-5 if n == "decode_head.head.bias" else 1e-8   # (noise grows with the number of class planes summed)
-        # element-wise bound at 1 % of the tensor's largest entry, or (for tensors at the far end of the 12-layer chain
-        # whose entries are ~1e-6, e.g. pos_embed: a sum of cancelling terms) 2 % in the L2 sense with a 5 % element-wise cap
         rel2 = ((hg[n].cpu() - ref).norm() / (ref.norm() + 1e-20)).item()
-        tol = grad_tol
-        if any(s in n for s in noisy):   # ReLU-on-BatchNorm stacks: a pre-activation within rounding of 0 flips (see
-            tol = 3e-2                   # test_model_gpu.py::test_conv_encoder_matches_oracle)
-            assert rel2 < tol or ref.norm().item() < 1e-7, f"{n}: rel L2 {rel2}"
+        if n == "decode_head.head.bias":   # sum(softmax - onehot) over all pixels: exactly 0 in exact arithmetic, rounding noise here
+            assert err < 1e-5, (n, err)     # (the noise grows with the number of class planes summed)
             continue
-        assert err < tol * scale + floor or (rel2 < 2 * tol and err < 5 * tol * scale), \
-            f"{n}: grad max err {err} vs scale {scale} (rel L2 {rel2})"
+        if any(s_ in n for s_ in bn_stack):
+            assert rel2 < 3e-2 or ref.norm().item() < 1e-7, f"{n}: rel L2 {rel2}"
+            continue
+        tol2 = after_bn_tol if (after_bn_tol is not None and any(s_ in n for s_ in after_bn)) else GRAD_REL_L2
+        assert rel2 < tol2, f"{n}: grad rel L2 {rel2} (bound {tol2})"
+        assert err < (GRAD_MAX_ERR if tol2 == GRAD_REL_L2 else 1.5 * tol2) * scale + 1e-8, f"{n}: grad max err {err} vs scale {scale}"
     return haux
 
 
-def fp_masks_for(chans, seed=5):
+def fp_masks_for(chans, seed=5, b=2):
     g = torch.Generator().manual_seed(seed)
-    return [(torch.rand(2, c, generator=g) > 0.5).float() for c in chans]
+    return [(torch.rand(b, c, generator=g) > 0.5).float() for c in chans]
 
 
 @pytest.fixture(scope="module")
@@ -125,12 +134,12 @@ def fullsize_case():
     dev = torch.device("cuda:0")
     torch.set_num_threads(min(32, torch.get_num_threads()))
     cfg, hip, orc = build_pair(dev)
-    batch = O.synthetic_batch(1, 512, 21, seed=99)
-    masks = fp_masks_for((768, 768, 512))
+    batch = O.synthetic_batch(2, 512, 21, seed=99)      # B = 2: the memory plan's sample chunks are crossed at full size
+    masks = fp_masks_for((768, 768, 512), b=4)
     # random-init confidences are ~1/21: conf_thresh = 0 keeps the whole unsupervised CE term alive WITHOUT putting
     # thousands of pixels within rounding distance of the threshold (at 0.06 a 2e-6 logit perturbation moved pixels in
     # and out of the loss and the gradients by several per cent -- thresholding itself is covered by the fixtures)
-    cfg = dict(cfg, conf_thresh=0.0)
+    cfg = dict(cfg, conf_thresh=0.0, head_chunk_class_images=2 * 21)   # two samples per chunk: three chunks per decode
     loss, aux = oracle_step(orc, cfg, batch, masks, 0.0)
     return cfg, hip, orc, batch, masks, loss, aux
 
@@ -140,6 +149,52 @@ def test_fullsize_step_matches_oracle(dev, fullsize_case, gemm_mode):
     """gemm_mode 0: exact fp32 MFMA; 6: the ViT linears on the bf16 pipe (3-way split, 6 products) -- same tolerances."""
     cfg, hip, orc, batch, masks, loss, aux = fullsize_case
     check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode)
+
+
+def test_fullsize_gradient_error_against_fp64(dev):
+    """Where the 4e-3 of GRAD_REL_L2 comes from: the same step with the ORACLE in float64.  The fp32 oracle itself is up
+    to 1.5e-3 (rel-L2) away from it on the tensors at the far ends of the chains (the first block's attention projections,
+    the skip projection of v0); the product -- in BOTH arithmetic modes alike -- must stay within 3e-3 of the float64
+    gradients (measured <= 2.1e-3) and within 4x the fp32 oracle's own distance (measured <= 3.7x, on the ASPP weight
+    gradients: sums over 43k pixels of every class-image, a k-ordered fp32 chain per split-K slab here against the host
+    library's blocked summation)."""
+    import copy
+    from oracle import semivl_oracle as O
+    from semivl_amd import ops
+    from semivl_amd.train import semivl_train_step
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    cfg, hip, orc = build_pair(dev, seed=4243)
+    cfg = dict(cfg, conf_thresh=0.0)
+    batch = O.synthetic_batch(1, 512, 21, seed=98)
+    masks = fp_masks_for((768, 768, 512), seed=6)
+    oracle_step(orc, cfg, batch, masks, 0.0)
+    g32 = {n: p.grad.clone() for n, p in orc.named_parameters() if p.grad is not None}
+    orc64 = copy.deepcopy(orc).double()
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    oracle_step(orc64, cfg, b64, [m.double() for m in masks], 0.0)
+    g64 = {n: p.grad for n, p in orc64.named_parameters() if p.grad is not None}
+    rel = lambda a, b: ((a.double() - b).norm() / (b.norm() + 1e-30)).item()
+    own = {n: rel(g32[n], g64[n]) for n in g32}
+    rows = []
+    for mode in (0, 6):
+        for p_ in hip.parameters():
+            p_.grad = None
+        ops.set_gemm_emulation(mode)
+        try:
+            semivl_train_step(hip, {k: v.to(dev) for k, v in batch.items()}, 100, 1000, cfg, fp_masks=[m.to(dev) for m in masks])
+        finally:
+            ops.set_gemm_emulation(0)
+        for n, p_ in hip.named_parameters():
+            if p_.grad is None or n == "decode_head.head.bias":
+                continue
+            e = rel(p_.grad.cpu(), g64[n])
+            rows.append((e / (own[n] + 1e-4), mode, n, e, own[n]))
+    top = sorted(((v, n) for n, v in own.items() if n != "decode_head.head.bias"))[-4:]
+    rows.sort()
+    print("fp32 oracle vs fp64 (rel-L2), largest:", [(f"{v:.1e}", n) for v, n in top], "; product vs fp64, worst ratios to the oracle's own error:",
+          [(f"{r_:.1f}x", m_, n_, f"{e_:.1e}", f"{o_:.1e}") for r_, m_, n_, e_, o_ in rows[-14:]])
+    for r_, m_, n_, e_, o_ in rows:
+        assert e_ <= 3e-3 and e_ <= 4 * o_ + 2e-4, f"mode {m_} {n_}: {e_:.2e} vs the fp32 oracle's own {o_:.2e}"
 
 
 @pytest.mark.parametrize("nclass,dataset", [(81, "coco"), (150, "ade")])
@@ -182,7 +237,12 @@ def test_fullsize_cityscapes_recipe(dev):
     start = {k: v.clone() for k, v in hip.state_dict().items()}
     for gemm_mode in (0, 6):   # 6 = the arithmetic bench.py measures by default; T = 2602 tokens: a ragged last attention block
         hip.load_state_dict(start, strict=True)
-        check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=gemm_mode, noisy=("conv_encoder", "skip_proj.1", "up2"))
+        # the side encoder itself is a ReLU-on-BatchNorm stack (sign flips at rounding level); the decoder blocks its features
+        # feed (skip_proj.1 -> up2, and up1 through the shared upstream gradient) are held to the standard bound in exact
+        # arithmetic (measured <= 1.3e-3) and to 1.2e-2 in mode 6, where the side encoder's convolutions run as split
+        # products and flip a different set of pre-activations than the fp32 oracle (measured <= 8.0e-3)
+        check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=gemm_mode, bn_stack=("conv_encoder",),
+                   after_bn=("skip_proj.1", "up2", "up1"), after_bn_tol=1.2e-2 if gemm_mode == 6 else None)
         for (n, bo), (_, bh) in zip(sorted(orc.named_buffers()), sorted(hip.named_buffers())):
             if "conv_encoder" in n:   # SyncBN running statistics after the train-mode passes
                 assert (bh.cpu().float() - bo.float()).abs().max().item() < 1e-4 * max(1.0, bo.float().abs().max().item()), n
