@@ -59,6 +59,7 @@ def tie_masks(aux, B, mcc_thresh=0.9, eps=1e-6):
         return (t[:, 0] - t[:, 1]) < eps
     out = dict(mask_w=gap(aux["pred_w"]), mask_w_other=gap(aux["pred_w_other"]))
     t2 = aux["mclip_top2"]
+    eps = min(eps, 1e-6)     # (MaskCLIP certainties are probabilities of the frozen encoder: never scaled)
     tie = ((t2[:, 0] - t2[:, 1]) < eps) | ((t2[:, 0] - mcc_thresh).abs() < eps)
     out["mclip"], out["mclip_other"] = tie[:B], tie[B:]
     return out

@@ -155,7 +155,7 @@ def test_fullsize_gradient_error_against_fp64(dev):
     """Where the 4e-3 of GRAD_REL_L2 comes from: the same step with the ORACLE in float64.  The fp32 oracle itself is up
     to 1.5e-3 (rel-L2) away from it on the tensors at the far ends of the chains (the first block's attention projections,
     the skip projection of v0); the product -- in BOTH arithmetic modes alike -- must stay within 3e-3 of the float64
-    gradients (measured <= 2.1e-3) and within 4x the fp32 oracle's own distance (measured <= 3.7x, on the ASPP weight
+    gradients (measured <= 2.1e-3) and within 4x the fp32 oracle's own distance + 1e-4 (measured <= 3.7x, on the ASPP weight
     gradients: sums over 43k pixels of every class-image, a k-ordered fp32 chain per split-K slab here against the host
     library's blocked summation)."""
     import copy
@@ -194,7 +194,7 @@ def test_fullsize_gradient_error_against_fp64(dev):
     print("fp32 oracle vs fp64 (rel-L2), largest:", [(f"{v:.1e}", n) for v, n in top], "; product vs fp64, worst ratios to the oracle's own error:",
           [(f"{r_:.1f}x", m_, n_, f"{e_:.1e}", f"{o_:.1e}") for r_, m_, n_, e_, o_ in rows[-14:]])
     for r_, m_, n_, e_, o_ in rows:
-        assert e_ <= 3e-3 and e_ <= 4 * o_ + 2e-4, f"mode {m_} {n_}: {e_:.2e} vs the fp32 oracle's own {o_:.2e}"
+        assert e_ <= 3e-3 and e_ <= 4 * (o_ + 1e-4), f"mode {m_} {n_}: {e_:.2e} vs the fp32 oracle's own {o_:.2e}"
 
 
 @pytest.mark.parametrize("nclass,dataset", [(81, "coco"), (150, "ade")])

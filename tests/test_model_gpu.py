@@ -92,7 +92,8 @@ def test_train_step_matches_reference_fixture(dev, name):
         # between implementations and moves a whole dy term (see test_conv_encoder_matches_oracle) -> looser bound there
         # (and everything fed by its skip feature inherits part of it)
         tol = 3e-2 if "conv_encoder" in k else (2e-2 if c.get("conv_encoder") else 2e-3)
-        assert abs(g.norm().item() - ref[0]) < tol * ref[0] + 1e-7, f"grad norm of {k}: {g.norm().item()} vs {ref[0]}"
+        floor = 1e-5 if k == "decode_head.head.bias" else 1e-7   # (sum(softmax - onehot): exactly 0, rounding noise scaled by the gain)
+        assert abs(g.norm().item() - ref[0]) < tol * ref[0] + floor, f"grad norm of {k}: {g.norm().item()} vs {ref[0]}"
         if ("grad/" + k) in z.files:
             full = z["grad/" + k]
             e = np.abs(g.cpu().numpy() - full).max() / max(np.abs(full).max(), 1e-5)
@@ -318,7 +319,8 @@ def test_head_memory_plan_is_exact(dev):
     for k in g_one:
         assert torch.equal(g_chk[k], g_rec[k]), f"{k}: recompute must be bit-identical to keeping the activations"
         scale = g_one[k].abs().max().item()
-        assert (g_chk[k] - g_one[k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
+        floor = 1e-5 if k == "decode_head.head.bias" else 1e-9      # (exactly 0 in exact arithmetic: pure rounding noise)
+        assert (g_chk[k] - g_one[k]).abs().max().item() <= 2e-5 * scale + floor, (k, (g_chk[k] - g_one[k]).abs().max().item(), scale)
     hip.decode_head.chunk_class_images = 1344
 
 
