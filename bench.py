@@ -204,6 +204,7 @@ def main():
     model = build_model(cfg).to(dev)
     opt = FusedAdamW(model, cfg["optimizer"])
     red = GradAllReducer(opt)
+    red.profile = world > 1       # per-bucket all-reduce time + the un-overlapped remainder go into the JSON line
     red.broadcast_params()
     batch = synthetic_batch(a.batch, a.crop, a.nclass, seed=1234 + rank, device=dev)
     total_iters = 10000
@@ -439,6 +440,12 @@ def main():
         except Exception as e:  # the baseline leg must never take the GPU number down with it
             out["cpu_baseline"] = dict(value=None, unit="images/s", cores=physical_cores(), kind="port",
                                        sample=f"failed: {type(e).__name__}: {e}")
+    if world > 1:      # the communication side of the last timed step, so that a scaling curve explains itself
+        torch.cuda.synchronize()
+        rep = red.timing_report()
+        if rank == 0 and rep is not None:
+            out["allreduce"] = dict(rep, payload_mb=round(opt.g.numel() * 4 / 2 ** 20, 1), backend=dist.get_backend(),
+                                    world=world)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -44,9 +44,23 @@ def _sync_sums(sums):
     statistics, so each exchange depends on the previous one (same in backward) -- torch.nn.SyncBatchNorm has the same
     structure."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_syncbn_group())
         return dist.get_world_size()
     return 1
+
+
+_SYNCBN_PG = []
+
+
+def _syncbn_group():
+    """The SyncBN exchanges get a communicator of their own (created at the first exchange, the same program point on
+    every rank): on the default one they would queue behind the 25 MB gradient buckets that the reducer launches from
+    inside backward on its communication stream, and the side encoder's backward -- 13 dependent exchanges -- would wait
+    for each of them.  Every rank issues the collectives of EACH communicator in the same program order."""
+    default = dist.distributed_c10d._get_default_group()
+    if not _SYNCBN_PG or _SYNCBN_PG[0] is not default:      # (a re-initialised default group gets a new companion)
+        _SYNCBN_PG[:] = [default, dist.new_group(backend=dist.get_backend())]
+    return _SYNCBN_PG[1]
 
 
 # ------------------------------------------------------------------------------------------------ units

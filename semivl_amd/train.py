@@ -385,9 +385,15 @@ class GradAllReducer:
     With `overlap=False`, or on backends that cannot run stream-ordered collectives on GPU tensors (gloo: it stages
     through the host and stalls the launching thread), the same buckets are reduced back to back in finish()."""
 
-    def __init__(self, optimizer, bucket_mb=25, group=None, overlap=None):
+    def __init__(self, optimizer, bucket_mb=25, group=None, overlap=None, world=None, collective=None, profile=False):
+        """`world` / `collective`: test hooks -- a stand-in for the process group (world size and a callable
+        (tensor) -> work object with .wait(), run inside the communication stream's context) so that the stream-ordered
+        branch (side stream, event ordering, join in finish()) executes on a single GPU, where RCCL cannot be brought up
+        with two ranks.  `profile`: HIP events around every bucket's collective and around finish()'s join."""
         self.opt, self.group = optimizer, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._collective = collective
+        self.profile, self._ev, self.timing = bool(profile), [], None
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         optimizer.grad_scale = 1.0 / self.world
         n = optimizer.g.numel()
         per = max(1, int(bucket_mb * 1024 * 1024 // 4))
@@ -410,6 +416,8 @@ class GradAllReducer:
         for b_ in self._slot.values():
             self._members[b_] += 1
         backend = dist.get_backend(group) if (dist.is_initialized() and self.world > 1) else None
+        if collective is not None:
+            backend = "nccl"          # the injected collective is stream-ordered like RCCL's
         self.overlap = (backend == "nccl") if overlap is None else bool(overlap)
         self._async = backend == "nccl"
         self._comm = torch.cuda.Stream() if (self._async and optimizer.g.is_cuda) else None
@@ -442,12 +450,21 @@ class GradAllReducer:
         if self._comm is not None:
             self._comm.wait_stream(torch.cuda.current_stream())     # ordered after the last gradient write
             with torch.cuda.stream(self._comm):
-                self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.profile:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self._comm)
+                if self._collective is not None:
+                    self._works.append(self._collective(g))
+                else:
+                    self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.profile:
+                    e1.record(self._comm)
+                    self._ev.append((b_, (e - s) * 4, e0, e1))
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_params(self, src=0):
-        if self.world > 1:
+        if self.world > 1 and self._collective is None:
             dist.broadcast(self.opt.p, src, group=self.group)
 
     def begin(self):
@@ -466,12 +483,32 @@ class GradAllReducer:
         if self.world > 1:
             for b_ in range(len(self.buckets)):
                 self._fire(b_)
+            if self.profile and self._comm is not None:
+                j0, j1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                j0.record(torch.cuda.current_stream())
             for w in self._works:
-                w.wait()                         # stream-level wait (no host sync) for NCCL/RCCL works
+                if w is not None:
+                    w.wait()                     # stream-level wait (no host sync) for NCCL/RCCL works
             if self._comm is not None:
                 torch.cuda.current_stream().wait_stream(self._comm)
+            if self.profile and self._comm is not None:
+                j1.record(torch.cuda.current_stream())
+                self.timing = dict(events=self._ev, join=(j0, j1), early_fires=self.early_fires)
+                self._ev = []
         self._works, self._fired = [], set()
         self._complete = [0] * len(self.buckets)
         self._expected, self._done = {}, {}
 
     reduce = finish
+
+    def timing_report(self):
+        """(after a synchronize) per-bucket collective time on the communication stream and the part of the step the
+        compute stream spent waiting for them in finish() -- what backward did NOT hide."""
+        t = self.timing
+        if not t:
+            return None
+        return dict(buckets=[dict(bucket=b_, mbytes=round(nb / 2 ** 20, 1), ms=round(e0.elapsed_time(e1), 3))
+                             for b_, nb, e0, e1 in t["events"]],
+                    exposed_ms=round(t["join"][0].elapsed_time(t["join"][1]), 3), launched_inside_backward=t["early_fires"],
+                    note="ms = HIP events around each bucket's all-reduce on the communication stream; exposed_ms = time "
+                         "the compute stream waited in finish() for the collectives backward did not cover")

@@ -197,6 +197,62 @@ def test_step_with_a_lagging_side_stream(dev):
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_reducer_stream_ordered_branch_on_one_gpu(dev):
+    """The RCCL branch of GradAllReducer (communication stream ordered after the last gradient write, asynchronous works,
+    join in finish()) cannot be brought up with two ranks on one GPU, so the collective is injected: 'SUM over two ranks
+    holding identical gradients' = x2 on the communication stream, returned as a work object whose wait() is a stream
+    wait.  With grad_scale 1 / 2 the step must reproduce the single-process step BIT FOR BIT -- a bucket launched before
+    its last contribution (weight gradients arrive from the weight-gradient stream, ops.wgrad_side) would come out as
+    2 x partial + rest.  Buckets must really be launched from inside backward, and the timing report must be filled."""
+    from semivl_amd.train import FusedAdamW, GradAllReducer, semivl_train_step
+    z, c = load_fixture("tiny")
+    ocfg = dict(type="AdamW", lr=1e-3, weight_decay=0.01,
+                paramwise_cfg=dict(custom_keys=dict(backbone=dict(lr_mult=0.1), head=dict(lr_mult=10.0))))
+    cfg = dict(CFG, conf_thresh=0.05)
+
+    class Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    calls = []
+
+    def two_identical_ranks(g):
+        calls.append((torch.cuda.current_stream().cuda_stream, g.numel()))
+        torch.cuda._sleep(int(2e6))              # the collective takes a while: finish() really has to join
+        g.mul_(2.0)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return Work(ev)
+
+    res = []
+    for with_reducer in (False, True):
+        hip = build_hip(c)
+        hip.load_state_dict(fixture_state(z, c, hip), strict=True)
+        hip.to(dev)
+        opt = FusedAdamW(hip, ocfg)
+        red = GradAllReducer(opt, bucket_mb=0.25, world=2, collective=two_identical_ranks, profile=True) if with_reducer else None
+        out = []
+        for it in range(2):
+            out.append(semivl_train_step(hip, to_dev(fixture_batch(z, c), dev), it, 10, cfg, optimizer=opt, reducer=red,
+                                         fp_masks=[m.to(dev) for m in fixture_fp_masks(z, c)]).clone())
+        torch.cuda.synchronize()
+        res.append((out, opt.p.clone()))
+        if red is not None:
+            main = torch.cuda.current_stream().cuda_stream
+            assert len(red.buckets) >= 4 and len(calls) == 2 * len(red.buckets)
+            assert all(st_ != main for st_, _ in calls), "collectives must run on the communication stream"
+            assert red.early_fires >= len(red.buckets), "buckets must be launched from inside backward"
+            rep = red.timing_report()
+            assert rep and len(rep["buckets"]) == len(red.buckets) and rep["exposed_ms"] >= 0.0
+            assert opt.grad_scale == 0.5
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][1], res[1][1]), "x2 on the communication stream and x 1/2 in AdamW must cancel exactly"
+
+
 @pytest.mark.parametrize("B,S", [(2, 65), (1, 96)])
 def test_conv_encoder_matches_oracle(dev, B, S):
     """ResNetV1c stem + layer1 (the skr04 `conv_encoder`): forward, running statistics, every parameter gradient and
