@@ -158,6 +158,14 @@ class VLM(nn.Module):
     def text_feat(self, device):
         return self._on("text", self._text_feat, device)
 
+    def text_feat_f32(self, device):
+        """fp32 copy of the (fp16 on disk, vlm.py:116-117) text embedding, converted once per device instead of once per
+        forward inside the head (`text.float()`, vlg_head.py:215)."""
+        key = ("text_f32", str(device))
+        if key not in self._dev_cache:
+            self._dev_cache[key] = ops.StreamCached(self._text_feat.float().contiguous().to(device))
+        return self._dev_cache[key].get()
+
     # -- MaskCLIP guidance (vlm.py:90-110) ---------------------------------------------------------------------
     def forward_maskclip(self, img, conf_tresh, ignore_mask=None):
         """int64 [b, H, W] in {0..N-1, 255}.  `ignore_mask` (optional, fused form of semivl.py:239-240): pixels where
@@ -228,7 +236,7 @@ class VLM(nn.Module):
         # the head resizes its 4x map to (img_size, img_size) (vlg_head.py:247), forward_wrapper then resizes to the input
         # size (builder.py:93-97): one and the same interpolation when the input IS img_size (every training crop), two
         # chained ones for evaluation windows of another shape (supervised.py:104-133)
-        out = self.decode_head.forward_tokens(feats, self.text_feat(img.device), (hp, wp), masks, self.fp_rate,
+        out = self.decode_head.forward_tokens(feats, self.text_feat_f32(img.device), (hp, wp), masks, self.fp_rate,
                                               out_size=(S_, S_), fp_range=fp_range if need_fp else None,
                                               skip0_hw=skip0_hw)
         if in_size != (S_, S_):

@@ -1,17 +1,24 @@
-# End-of-round evidence run on the 1-GPU box (profiles/README.md, `r2_g_*`):  gpurun -- 'bash tools/round_end_run.sh'
+# End-of-round evidence run on the 1-GPU box (profiles/README.md):  gpurun -- 'TAG=r3_x bash tools/round_end_run.sh'
 cd $GRAFT_REPO_ROOT
-T=${TAG:-r2g}
+T=${TAG:-r3}
 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -25 > gpurun_out/${T}_pytest.log
-SVL_GEMM_EMU=0 bash tools/pmc_traffic.sh tools/one_gemm.py gemm_kernel > gpurun_out/${T}_pmc_traffic.txt 2>&1
-SVL_GEMM_EMU=6 bash tools/pmc_traffic.sh tools/one_gemm.py gemm_bf16x >> gpurun_out/${T}_pmc_traffic.txt 2>&1
-mkdir -p profiles && cp gpurun_out/pmc_gemm_traffic.json gpurun_out/pmc_gemm_traffic_bf16x6.json profiles/   # (so that the bench lines below can quote them)
+# PMC records of the dominant launches (quoted by bench.py as roofline.traffic / roofline_hbm.traffic)
+bash tools/pmc_x6p.sh 32800 3072 768 1 > gpurun_out/${T}_pmc_x6p_ffn1.txt 2>&1
+bash tools/pmc_ce.sh > gpurun_out/${T}_pmc_ce.txt 2>&1
+SVL_GEMM_EMU=0 bash tools/pmc_traffic.sh tools/one_gemm.py gemm_kernel > gpurun_out/${T}_pmc_gemm_f32.txt 2>&1
+mkdir -p profiles && cp gpurun_out/pmc_x6p_traffic.json gpurun_out/pmc_ce_traffic.json gpurun_out/pmc_gemm_traffic.json profiles/ 2>/dev/null
 python bench.py --steps 10 --warmup 3 > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
-for c in cityscapes ade coco; do python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${T}_bench_$c.json 2>/dev/null; done
+for c in cityscapes ade coco; do python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-throughput-mode > gpurun_out/${T}_bench_$c.json 2>/dev/null; done
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-throughput-mode --gemm-arith f32 > gpurun_out/${T}_bench_exact_f32.json 2>/dev/null
+# kernel-trace summaries (both arithmetics) + wall-time attribution + per-dispatch rows of the dominant kernel
 for m in bf16x6 f32; do
-  cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$m -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode --gemm-arith $m > $GRAFT_REPO_ROOT/gpurun_out/${T}_bench_under_rocprof_$m.json 2>/dev/null
-  cd $GRAFT_REPO_ROOT; python tools/rocpd_stats.py $(find gpurun_out/prof_$m -name "*.db" | head -1) > gpurun_out/${T}_kernel_stats_bs16_$m.csv; rm -rf gpurun_out/prof_$m
+  cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$m -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode --no-profile --gemm-arith $m > $GRAFT_REPO_ROOT/gpurun_out/${T}_bench_under_rocprof_$m.json 2>/dev/null
+  cd $GRAFT_REPO_ROOT; DB=$(find gpurun_out/prof_$m -name "*.db" | head -1)
+  python tools/rocpd_stats.py $DB > gpurun_out/${T}_kernel_stats_bs16_$m.csv
+  python tools/rocpd_attrib.py $DB 0.34 1.0 > gpurun_out/${T}_attrib_$m.txt
+  if [ $m = bf16x6 ]; then python tools/rocpd_dispatches.py $DB gemm_x6p_kernelILi256ELi1E 1548 > gpurun_out/${T}_dominant_dispatches.csv; fi
+  rm -rf gpurun_out/prof_$m
 done
-tail -6 gpurun_out/${T}_pytest.log; tail -3 gpurun_out/${T}_pmc_traffic.txt
+tail -4 gpurun_out/${T}_pytest.log
 for f in default cityscapes ade coco exact_f32; do python -c "
-import json; d=json.load(open('gpurun_out/${T}_bench_$f.json')); r=d.get('roofline',{}); print('$f', d['value'], d['ms_per_step'], d['config']['peak_mem_gb'], r.get('frac'), r.get('frac_whole_step'), (d.get('exact_f32') or {}).get('value'))"; done
+import json; d=json.loads(open('gpurun_out/${T}_bench_$f.json').read().strip().splitlines()[-1]); r=d.get('roofline',{}); print('$f', d['value'], d['ms_per_step'], d['config']['peak_mem_gb'], r.get('frac'), r.get('avg_ms'), (d.get('exact_f32') or {}).get('value'))"; done
