@@ -130,6 +130,10 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], bf16x8& h0, bf16x8
 // by its MFMAs, and costs ~0.4 of a full tile -- +3 % at K = 768, +7 % at K = 3072 against M = 32768.  Tried and dropped:
 // running the last full band + the leftover rows as 288-row tiles (ninth row block on the lower wave row) in a second,
 // concurrent launch on the helper stream: the fork / join and the two grids competing for CUs cost more, +2 ... +11 %.)
+// (Tried and dropped: TWO independent 256 x 128 workgroups per CU (4 waves each, 2 LDS stages, plain lockstep loop) so that one
+// workgroup's prologue / epilogue runs under the other's matrix phases: 1.5x the L2 -> LDS traffic per MFMA and two barriers
+// per k-group cost more than the overlap returns -- FFN-1 with GELU + pre-activation + planes 1.011 vs 0.922 ms, plain
+// 0.823 vs 0.764 ms, 8192^3 1424 vs 1524 TF.  The kernel is bound by the energy of its instruction mix, not by idle phases.)
 // (Tried and dropped: cutting the first 32 tiles of every XCD in two row parts of s / 8 and (8 - s) / 8 so that its CUs
 // run 1/8 of a tile apart and their store bursts do not coincide -- partial tiles keep only one wave group busy and
 // cost more than the de-synchronised epilogues gain: +5...7 % on the ViT shapes.)
@@ -153,6 +157,135 @@ __device__ __forceinline__ TileRef tile_of_block(const PlanesP& p) {
 }
 
 enum { EPI_LIGHT = 0, EPI_GELU = 1, EPI_DGELU = 2 };   // epilogue flavour compiled in (the erf code is large)
+
+// ---- epilogue, shared by both kernels.  acc[i][j][r] = C(m, n), m = m0 + (wm*TM + i)*32 + l31, n = nw + j*32 + 8*(r>>2) +
+// 4*hi + (r&3); wl = this wave's LDS transpose buffer (32 rows x (TN*128 + 16) bytes).
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void x6p_epilogue(const PlanesP& p, f32x16 (&acc)[TM][TN], int m0, int mvalid, int wm, int nw,
+                                             char* wl, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  // The
+  // arithmetic runs in this layout (a lane owns 4-runs of ONE row: bias / saved pre-activation are 16 B reads, and per 16
+  // columns its 8 values are exactly its lane slot of the next GEMM's A chunk: packed planes leave as 1 KiB stores).
+  // fp32 outputs (C, preact) go through a per-wave LDS transpose so that every store instruction writes whole 128 /
+  // 256-byte row segments (measured: 32-byte segments straight from the accumulator layout write at 2.8 TB/s, full
+  // lines at 4.6 TB/s).
+  constexpr int WC = TN * 32;                      // columns of a wave
+  constexpr int RS = WC * 4 + 16;                  // LDS row stride of the transpose buffer (bytes)
+  constexpr int LPR = WC / 4;                      // lanes per row in the row-major readback (16 B each)
+  static_assert((32 * LPR) % 64 == 0, "readback steps must be whole wave instructions");
+  const bool vec = (p.ldc % 4 == 0) && (reinterpret_cast<uintptr_t>(p.C) % 16 == 0) &&
+                   (reinterpret_cast<uintptr_t>(p.preact) % 16 == 0);
+  const bool rvec = p.resid && (p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.resid) % 16 == 0);
+
+  // the wave's 32 x WC block `o` (acc layout) -> dst rows, coalesced; accumulate: dst += o
+  auto store_rows = [&](float* dst, const f32x16 (&o)[TN], int mloc, bool accumulate) __attribute__((always_inline)) {
+    static_for<0, TN>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      static_for<0, 4>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        f32x4 q = {o[j][4 * g], o[j][4 * g + 1], o[j][4 * g + 2], o[j][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(wl + l31 * RS + (j * 32 + 8 * g + 4 * hi) * 4) = q;
+      });
+    });
+    // (same wave wrote and reads: DS operations of a wave execute in order, no barrier)
+#pragma unroll
+    for (int it = 0; it < 32 * LPR / 64; ++it) {
+      const int idx = it * 64 + lane, row = idx / LPR, rc4 = (idx - row * LPR) * 4;
+      const f32x4 q = *reinterpret_cast<const f32x4*>(wl + row * RS + rc4 * 4);
+      const int n = nw + rc4;
+      if (mloc + row < mvalid && n < p.N) {
+        float* d = dst + (long)(m0 + mloc + row) * p.ldc + n;
+        if (vec && n + 4 <= p.N) {
+          f32x4 v = q;
+          if (accumulate) v += *reinterpret_cast<const f32x4*>(d);
+          *reinterpret_cast<f32x4*>(d) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) d[e] = accumulate ? d[e] + q[e] : q[e];
+        }
+      }
+    }
+  };
+
+  static_for<0, TM>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    const int mloc = (wm * TM + i) * 32;
+    if (mloc < mvalid) {
+      const int m = m0 + mloc + l31;
+      const bool mok = mloc + l31 < mvalid;
+      // 1. bias
+      if (p.bias) {
+        static_for<0, TN>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          static_for<0, 4>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            const int n = nw + j * 32 + 8 * g + 4 * hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += n + e < p.N ? p.bias[n + e] : 0.f;
+          });
+        });
+      }
+      // 2. pre-activation copy
+      if (p.preact) store_rows(p.preact, acc[i], mloc, false);
+      // 3. activation / residual / derivative product
+      static_for<0, TN>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        static_for<0, 4>([&](auto G) {
+          constexpr int g = decltype(G)::value;
+          const int n = nw + j * 32 + 8 * g + 4 * hi;
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.resid && mok && n < p.N) {
+            const float* rp = p.resid + (long)m * p.ldr + n;
+            if (rvec && n + 4 <= p.N) {
+              const f32x4 q = *reinterpret_cast<const f32x4*>(rp);
+              rv[0] = q[0]; rv[1] = q[1]; rv[2] = q[2]; rv[3] = q[3];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) rv[e] = n + e < p.N ? rp[e] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][4 * g + e];
+            if constexpr (EPI == EPI_GELU) v = gelu_erf(v) + rv[e];
+            else if constexpr (EPI == EPI_DGELU) v *= gelu_erf_grad(rv[e]);
+            else {
+              if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
+              if (p.act == SVL_ACT_MUL_DRELU) v = rv[e] > 0.f ? v : 0.f;
+              else v += rv[e];
+            }
+            acc[i][j][4 * g + e] = v;
+          }
+        });
+      });
+      // 4. outputs
+      if (p.C) store_rows(p.C, acc[i], mloc, p.accumulate != 0);
+      if (p.P) {
+        static_for<0, TN>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          static_for<0, 2>([&](auto G2) {
+            constexpr int g2 = decltype(G2)::value;
+            const int nb = nw + j * 32 + 16 * g2;
+            if (nb < p.N) {   // (columns past N / rows past the edge land in padding nobody reads)
+              float o8[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o8[e] = acc[i][j][8 * g2 + e];
+              bf16x8 h0, h1, h2;
+              split3x8(o8, h0, h1, h2);
+              char* q = p.P + (long)(nb >> 4) * p.p_ks + (long)((m0 + mloc) >> 5) * (3 * CH) + lane * 16;
+              *reinterpret_cast<bf16x8*>(q) = h0;
+              *reinterpret_cast<bf16x8*>(q + CH) = h1;
+              *reinterpret_cast<bf16x8*>(q + 2 * CH) = h2;
+            }
+          });
+        });
+      }
+    }
+  });
+}
+
 
 template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
@@ -316,128 +449,7 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
   else kloop(std::false_type{});
   if (grp == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two groups match: every LDS read is done
 
-  // ---- epilogue.  acc[i][j][r] = C(m, n), m = m0 + (wm*TM + i)*32 + l31, n = nw + j*32 + 8*(r>>2) + 4*hi + (r&3).  The
-  // arithmetic runs in this layout (a lane owns 4-runs of ONE row: bias / saved pre-activation are 16 B reads, and per 16
-  // columns its 8 values are exactly its lane slot of the next GEMM's A chunk: packed planes leave as 1 KiB stores).
-  // fp32 outputs (C, preact) go through a per-wave LDS transpose so that every store instruction writes whole 128 /
-  // 256-byte row segments (measured: 32-byte segments straight from the accumulator layout write at 2.8 TB/s, full
-  // lines at 4.6 TB/s).
-  constexpr int WC = TN * 32;                      // columns of a wave
-  constexpr int RS = WC * 4 + 16;                  // LDS row stride of the transpose buffer (bytes)
-  constexpr int LPR = WC / 4;                      // lanes per row in the row-major readback (16 B each)
-  static_assert((32 * LPR) % 64 == 0, "readback steps must be whole wave instructions");
-  char* wl = sm + wave * (32 * RS);
-  const int nw = n0 + wq * WC;
-  const bool vec = (p.ldc % 4 == 0) && (reinterpret_cast<uintptr_t>(p.C) % 16 == 0) &&
-                   (reinterpret_cast<uintptr_t>(p.preact) % 16 == 0);
-  const bool rvec = p.resid && (p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.resid) % 16 == 0);
-
-  // the wave's 32 x WC block `o` (acc layout) -> dst rows, coalesced; accumulate: dst += o
-  auto store_rows = [&](float* dst, const f32x16 (&o)[TN], int mloc, bool accumulate) __attribute__((always_inline)) {
-    static_for<0, TN>([&](auto J) {
-      constexpr int j = decltype(J)::value;
-      static_for<0, 4>([&](auto G) {
-        constexpr int g = decltype(G)::value;
-        f32x4 q = {o[j][4 * g], o[j][4 * g + 1], o[j][4 * g + 2], o[j][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(wl + l31 * RS + (j * 32 + 8 * g + 4 * hi) * 4) = q;
-      });
-    });
-    // (same wave wrote and reads: DS operations of a wave execute in order, no barrier)
-#pragma unroll
-    for (int it = 0; it < 32 * LPR / 64; ++it) {
-      const int idx = it * 64 + lane, row = idx / LPR, rc4 = (idx - row * LPR) * 4;
-      const f32x4 q = *reinterpret_cast<const f32x4*>(wl + row * RS + rc4 * 4);
-      const int n = nw + rc4;
-      if (mloc + row < mvalid && n < p.N) {
-        float* d = dst + (long)(m0 + mloc + row) * p.ldc + n;
-        if (vec && n + 4 <= p.N) {
-          f32x4 v = q;
-          if (accumulate) v += *reinterpret_cast<const f32x4*>(d);
-          *reinterpret_cast<f32x4*>(d) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) d[e] = accumulate ? d[e] + q[e] : q[e];
-        }
-      }
-    }
-  };
-
-  static_for<0, TM>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    const int mloc = (wm * TM + i) * 32;
-    if (mloc < mvalid) {
-      const int m = m0 + mloc + l31;
-      const bool mok = mloc + l31 < mvalid;
-      // 1. bias
-      if (p.bias) {
-        static_for<0, TN>([&](auto J) {
-          constexpr int j = decltype(J)::value;
-          static_for<0, 4>([&](auto G) {
-            constexpr int g = decltype(G)::value;
-            const int n = nw + j * 32 + 8 * g + 4 * hi;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += n + e < p.N ? p.bias[n + e] : 0.f;
-          });
-        });
-      }
-      // 2. pre-activation copy
-      if (p.preact) store_rows(p.preact, acc[i], mloc, false);
-      // 3. activation / residual / derivative product
-      static_for<0, TN>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        static_for<0, 4>([&](auto G) {
-          constexpr int g = decltype(G)::value;
-          const int n = nw + j * 32 + 8 * g + 4 * hi;
-          float rv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.resid && mok && n < p.N) {
-            const float* rp = p.resid + (long)m * p.ldr + n;
-            if (rvec && n + 4 <= p.N) {
-              const f32x4 q = *reinterpret_cast<const f32x4*>(rp);
-              rv[0] = q[0]; rv[1] = q[1]; rv[2] = q[2]; rv[3] = q[3];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) rv[e] = n + e < p.N ? rp[e] : 0.f;
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[i][j][4 * g + e];
-            if constexpr (EPI == EPI_GELU) v = gelu_erf(v) + rv[e];
-            else if constexpr (EPI == EPI_DGELU) v *= gelu_erf_grad(rv[e]);
-            else {
-              if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
-              if (p.act == SVL_ACT_MUL_DRELU) v = rv[e] > 0.f ? v : 0.f;
-              else v += rv[e];
-            }
-            acc[i][j][4 * g + e] = v;
-          }
-        });
-      });
-      // 4. outputs
-      if (p.C) store_rows(p.C, acc[i], mloc, p.accumulate != 0);
-      if (p.P) {
-        static_for<0, TN>([&](auto J) {
-          constexpr int j = decltype(J)::value;
-          static_for<0, 2>([&](auto G2) {
-            constexpr int g2 = decltype(G2)::value;
-            const int nb = nw + j * 32 + 16 * g2;
-            if (nb < p.N) {   // (columns past N / rows past the edge land in padding nobody reads)
-              float o8[8];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o8[e] = acc[i][j][8 * g2 + e];
-              bf16x8 h0, h1, h2;
-              split3x8(o8, h0, h1, h2);
-              char* q = p.P + (long)(nb >> 4) * p.p_ks + (long)((m0 + mloc) >> 5) * (3 * CH) + lane * 16;
-              *reinterpret_cast<bf16x8*>(q) = h0;
-              *reinterpret_cast<bf16x8*>(q + CH) = h1;
-              *reinterpret_cast<bf16x8*>(q + 2 * CH) = h2;
-            }
-          });
-        });
-      }
-    }
-  });
+  x6p_epilogue<TM, TN, EPI>(p, acc, m0, mvalid, wm, n0 + wq * (TN * 32), sm + wave * (32 * (TN * 128 + 16)), lane);
 }
 
 // fp32 [rows, K] (element (r, k) at x[r * ld + k * ks]) -> packed planes.  Thread = (row, k-group, lane half): 2 x 16 B read,

@@ -204,10 +204,10 @@ class VLM(nn.Module):
         `fp_masks` (list of three {0,1} tensors [b, C_i]) injects the F.dropout2d channel masks for parity tests;
         `split_fp=False` returns the un-chunked [2b, ...] tensor; `fp_range=(s0, s1)` (with split_fp=False) perturbs
         and decodes only samples [s0, s1): output [b + s1 - s0, ...]."""
+        if forward_mode == "maskclip_trust":    # builder.py:57-58 calls a method the reference never defines
+            raise AttributeError("'VLM' object has no attribute 'train_maskclip_trust'")
         if forward_mode != "default":
             raise ValueError(forward_mode)
-        if only_fp:
-            raise NotImplementedError("only_fp is not used by semivl.py (SURVEY §8(a) V4)")
         S_ = self.decode_head.image_size
         in_size = tuple(img.shape[2:])
         feats, _ = self.backbone.forward_tokens(self.renormalize_img_for_clip(img), need_global=False)
@@ -219,14 +219,21 @@ class VLM(nn.Module):
         ps = self.backbone.patch_size
         hp, wp = (img.shape[2] + ps - 1) // ps, (img.shape[3] + ps - 1) // ps
         masks = None
-        if need_fp:
+        if only_fp or need_fp:
             masks = fp_masks
             drop_order = list(feats) + ([ctok] if self.conv_encoder is not None else [])  # builder.py:80-85
             if masks is None:  # F.dropout2d: one Bernoulli(1-p) draw per (sample, channel); always stochastic (App. E.7)
                 masks = [torch.bernoulli(torch.full((f.shape[0], f.shape[2]), 1.0 - self.fp_rate, device=img.device))
                          for f in drop_order]
             assert len(masks) == len(drop_order)
-            if fp_range is not None:
+            if only_fp:     # builder.py:65-77: every feature REPLACED by its channel-dropout copy (no doubling), then decoded
+                sc = 1.0 / (1.0 - self.fp_rate)
+                drop_order = [_ChanMaskFn.apply(f, mk.contiguous(), sc) for f, mk in zip(drop_order, masks)]
+                feats = drop_order[:len(feats)]
+                if self.conv_encoder is not None:
+                    ctok = drop_order[-1]
+                masks = None
+            elif fp_range is not None:
                 assert not split_fp, "fp_range returns the un-chunked tensor"
                 masks = [mk[fp_range[0]:fp_range[1]] for mk in masks]
         if self.conv_encoder is not None:   # head slots [second-Up skip, first-Up skip, embedding]
@@ -244,6 +251,24 @@ class VLM(nn.Module):
         if need_fp and split_fp:
             return out.chunk(2)
         return out
+
+
+class _ChanMaskFn(torch.autograd.Function):
+    """F.dropout2d with a given {0,1} channel mask [b, C] on a token tensor [b, P, C]: y = x * mask / (1 - p); the same
+    product backward (builder.py:68-72)."""
+
+    @staticmethod
+    def forward(ctx, f, mask, scale):
+        ctx.save_for_backward(mask)
+        ctx.scale = scale
+        b, P, Cc = f.shape
+        return ops.chanmask(f.contiguous().view(b * P, Cc), mask, scale, P).view(b, P, Cc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        b, P, Cc = dy.shape
+        return ops.chanmask(dy.contiguous().view(b * P, Cc), mask, ctx.scale, P).view(b, P, Cc), None, None
 
 
 class _PlanesResizeFn(torch.autograd.Function):

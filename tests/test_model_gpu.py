@@ -197,6 +197,39 @@ def test_step_with_a_lagging_side_stream(dev):
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_only_fp_and_maskclip_trust_modes(dev):
+    """forward_wrapper's remaining modes (builder.py:56-77): `only_fp` replaces every feature by its channel-dropout copy
+    and decodes that alone == the perturbed half of a `need_fp` forward with the same masks, values and gradients;
+    `forward_mode='maskclip_trust'` calls a method the reference never defines (AttributeError there and here)."""
+    z, c = load_fixture("tiny")
+    hip = build_hip(c)
+    hip.load_state_dict(fixture_state(z, c, hip), strict=True)
+    hip.to(dev).train()
+    img = to_dev(fixture_batch(z, c), dev)["img_w"]
+    b = img.shape[0]
+    masks = [m[:b].to(dev) for m in fixture_fp_masks(z, c)]
+    w = torch.randn(b, 21, c["S"], c["S"], device=dev, generator=torch.Generator(dev).manual_seed(3))
+
+    def grads(out):
+        for p_ in hip.parameters():
+            p_.grad = None
+        (out * w).sum().backward()
+        return {k: p_.grad.clone() for k, p_ in hip.named_parameters() if p_.grad is not None}
+
+    o_fp = hip(img, only_fp=True, fp_masks=masks)
+    g_fp = grads(o_fp)
+    _, o_second = hip(img, need_fp=True, fp_masks=masks)
+    g_second = grads(o_second)
+    assert torch.equal(o_fp.detach(), o_second.detach())
+    assert sorted(g_fp) == sorted(g_second) and len(g_fp) > 50
+    for k in g_fp:
+        assert (g_fp[k] - g_second[k]).abs().max().item() <= 1e-5 * g_second[k].abs().max().item() + 1e-9, k
+    with pytest.raises(AttributeError):
+        hip(img, forward_mode="maskclip_trust")
+    with pytest.raises(ValueError):
+        hip(img, forward_mode="nope")
+
+
 def test_reducer_stream_ordered_branch_on_one_gpu(dev):
     """The RCCL branch of GradAllReducer (communication stream ordered after the last gradient write, asynchronous works,
     join in finish()) cannot be brought up with two ranks on one GPU, so the collective is injected: 'SUM over two ranks
