@@ -62,6 +62,7 @@ struct PlanesP {
   const char* A;            // first chunk of row block 0, k-group 0
   const char* B;
   long a_ks, b_ks;          // bytes between k-groups (rows_padded * 96)
+  int b_rb;                 // 32-row blocks the B operand's buffer holds
   int M, N, K;              // M valid rows from A's row block 0
   float* C;
   long ldc;
@@ -134,6 +135,13 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], bf16x8& h0, bf16x8
 // workgroup's prologue / epilogue runs under the other's matrix phases: 1.5x the L2 -> LDS traffic per MFMA and two barriers
 // per k-group cost more than the overlap returns -- FFN-1 with GELU + pre-activation + planes 1.011 vs 0.922 ms, plain
 // 0.823 vs 0.764 ms, 8192^3 1424 vs 1524 TF.  The kernel is bound by the energy of its instruction mix, not by idle phases.)
+// (Tried and dropped: TWO independent 256 x 128 workgroups per CU (4 waves each, 2 LDS stages, plain lockstep loop) so that one
+// workgroup's prologue / epilogue runs under the other's matrix phases: 1.5x the L2 -> LDS traffic per MFMA and two barriers
+// per k-group cost more than the overlap returns -- FFN-1 with GELU + pre-activation + planes 1.011 vs 0.922 ms, plain
+// 0.823 vs 0.764 ms, 8192^3 1424 vs 1524 TF.  And a PERSISTENT grid (one block per CU walking its tiles, the next tile's first
+// two k-groups requested before the current epilogue, transposes through the third stage): 0.5 ... 1.3 % on the kernel, nothing
+// on the step, register spills in the erf epilogues.  The kernel is bound by the energy of its instruction mix -- the clock it
+// is given -- not by idle phases.)
 // (Tried and dropped: cutting the first 32 tiles of every XCD in two row parts of s / 8 and (8 - s) / 8 so that its CUs
 // run 1/8 of a tile apart and their store bursts do not coincide -- partial tiles keep only one wave group busy and
 // cost more than the de-synchronised epilogues gain: +5...7 % on the ViT shapes.)
@@ -335,7 +343,10 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
           s = ak + (rb < nblk ? c : c - 3 * rb) * CH;
         } else {
           static_assert(8 * i >= NCHA, "A / B chunk boundary must fall on a multiple of 8");
-          s = bk + (c - NCHA) * CH;
+          // (the last column tile may reach past the B operand's padded rows -- N = 512 cut in 192-wide tiles: those
+          // row blocks are redirected to the tile's first one; their columns are masked in the epilogue)
+          const int cb = c - NCHA, rb = cb / 3;
+          s = bk + (tr.tn * (BN / 32) + rb < p.b_rb ? cb : cb - 3 * rb) * CH;
         }
         glds16(s, lane16, dst + c * CH);
       }
@@ -601,6 +612,7 @@ extern "C" int svl_gemm_planes_f32(const svl_pgemm_desc* d, svl_stream_t stream)
   p.A = (const char*)d->A + (mo >> 5) * (3 * CH);
   p.B = (const char*)d->B;
   p.a_ks = d->a_rows * 96; p.b_ks = d->b_rows * 96;
+  p.b_rb = (int)(d->b_rows / 32);
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.C = d->C ? d->C + mo * d->ldc : nullptr; p.ldc = d->ldc;
   p.P = d->planes_out ? (char*)d->planes_out + (mo >> 5) * (3 * CH) : nullptr; p.p_ks = d->p_rows * 96;

@@ -222,7 +222,8 @@ def test_layernorm_emits_planes(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(8 * 1025, 768, 768), (1300, 3072, 768), (2050, 768, 3072), (260, 96, 64),
-                                   (4 * 1025, 2304, 768), (16 * 1025, 3072, 768)])
+                                   (4 * 1025, 2304, 768), (16 * 1025, 3072, 768),
+                                   (8 * 2601, 512, 768)])      # 81 row bands: 192-wide tiles, the third one past N = 512
 def test_gemm_planes_path(dev, emu_mode, M, N, K):
     """The pre-split form of mode 6 (csrc/gemm_planes.hip): error vs fp64 at or below the fp32 MFMA chain's for the
     forward and input-gradient layouts, ragged token counts (M = 8 x 1025: a short row band whose tiles are scheduled
