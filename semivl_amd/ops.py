@@ -3,6 +3,7 @@
 torch is used here for device memory (torch.empty), views and the current HIP stream only; every FLOP of the hot
 path is issued through libsemivl_hip.so.  All tensors are fp32 CUDA(HIP) tensors unless stated.
 """
+import collections
 import ctypes as C
 import os
 import math
@@ -137,10 +138,19 @@ def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld
 # had no MFMA kernel in flight (tools/rocpd_attrib.py).  With the off-chain work on a second stream the chip has matrix
 # work to run next to those passes.  `with wgrad_side(t1, t2, ...)`: the enclosed launches go to the per-device
 # weight-gradient stream, ordered after everything queued so far on the current stream; the listed tensors (produced on
-# the current stream, read in the block) are marked in use there (caching allocator).  wgrad_join() orders the current
+# the current stream, read in the block) are kept alive until the block has run (below).  wgrad_join() orders the current
 # stream after the side stream (before anything reads the gradients: all-reduce, optimizer).
+# Lifetime of the operands: the block's tensors are NOT handed to the allocator with record_stream (a block released on the
+# current stream would then stay unusable until the side stream has caught up -- with the multi-GB decoder tensors of the
+# N = 81 / 150 configs the side stream's lag piled up tens of GB of such blocks, the allocator ran into the device limit and
+# fell into its free-everything-and-retry path: 1.6 s -> 6.9 s per ADE step).  Instead every block leaves (event, tensors)
+# in a short queue; once more than WGRAD_DEPTH blocks are outstanding the current stream WAITS for the oldest one's event
+# and only then drops the references: the side stream is never more than WGRAD_DEPTH blocks behind, and a released block
+# is reusable at once (the current stream is ordered after its last reader).
 WGRAD_STREAM = not os.environ.get("SVL_NO_WGRAD_STREAM")
+WGRAD_DEPTH = int(os.environ.get("SVL_WGRAD_DEPTH", "2"))
 _WG = {}
+_WG_KEEP = {}   # device index -> deque of (event on the side stream, tensors read before it)
 
 
 def _wg_stream(dev):
@@ -150,12 +160,20 @@ def _wg_stream(dev):
         # the dependency chain, 449 -> 494 ms, so it stays at normal priority)
         s = torch.cuda.Stream(dev)
         _WG[dev.index] = s
+        _WG_KEEP[dev.index] = collections.deque()
     return s
+
+
+def _wg_retire(main, keep_at_most):
+    q = _WG_KEEP.get(main.device.index)
+    while q and len(q) > keep_at_most:
+        ev, _ = q.popleft()
+        main.wait_event(ev)
 
 
 class wgrad_side:
     def __init__(self, *tensors):
-        self.tensors, self.ctx = tensors, None
+        self.tensors, self.ctx, self.main, self.wg = tensors, None, None, None
 
     def __enter__(self):
         if not WGRAD_STREAM or not torch.cuda.is_available():
@@ -167,9 +185,7 @@ class wgrad_side:
         ev = torch.cuda.Event()
         ev.record(main)
         wg.wait_event(ev)
-        for t in self.tensors:
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                t.record_stream(wg)
+        self.main, self.wg = main, wg
         self.ctx = torch.cuda.stream(wg)
         self.ctx.__enter__()
         return self
@@ -177,6 +193,12 @@ class wgrad_side:
     def __exit__(self, *exc):
         if self.ctx is not None:
             self.ctx.__exit__(*exc)
+            ev = torch.cuda.Event()
+            ev.record(self.wg)
+            _WG_KEEP[self.main.device.index].append(
+                (ev, [t for t in self.tensors if isinstance(t, torch.Tensor) and t.is_cuda]))
+            _wg_retire(self.main, WGRAD_DEPTH)
+            self.tensors = ()
         return False
 
 
@@ -205,6 +227,7 @@ def wgrad_join(ev=None, produced=()):
     wg = _WG.get(main.device.index)
     if wg is not None and wg.cuda_stream != main.cuda_stream:
         main.wait_stream(wg)
+        _WG_KEEP[main.device.index].clear()
         for t in produced:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(main)
