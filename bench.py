@@ -33,6 +33,7 @@ ALGO_GF = {(21, 512): (2866.6, 1322.0), (81, 512): (2866.6, 5075.0), (150, 512):
 PEAK_F32_MFMA_TF = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TF = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0
+PEAK_CLOCK_MHZ = 2400.0         # the clock the peaks above are quoted at
 
 
 def parse():
@@ -155,6 +156,26 @@ def cpu_baseline(crop, nclass, warm, timed):
                        f"workload, the best thread count tried is reported beside it: "
                        f"{', '.join(str(r['threads']) + ' thr -> ' + str(r['s_per_step']) + ' s/step' for r in runs.values())}; "
                        f"{total:.0f} s of CPU work")
+
+
+def clock_probe_mhz(fn, est_ms, dev, n_waves=64):
+    """Mean shader clock (MHz) while fn() runs on the current stream: svl_clock_probe waves on a second stream sample the
+    shader-clock counter against the 100 MHz counter over 80 % of the estimated duration."""
+    import ctypes
+    import torch
+    from semivl_amd import lib as L
+    out = torch.zeros(2 * n_waves, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    L.check(L.load().svl_clock_probe(ctypes.c_void_p(out.data_ptr()), n_waves, int(est_ms * 0.8 * 1e5),
+                                     ctypes.c_void_p(side.cuda_stream)), "svl_clock_probe")
+    fn()
+    torch.cuda.synchronize()
+    o = out.cpu().double().view(n_waves, 2)
+    if (o[:, 1] <= 0).any():
+        return None
+    return round(float((o[:, 0] / o[:, 1]).mean()) * 100.0, 0)
 
 
 def pmc_traffic_record(batch, name="pmc_gemm_traffic.json", src="gemm.hip"):
@@ -341,11 +362,27 @@ def main():
         # largest share of the step's kernel time), ALGORITHMIC FLOPs per launch / its average launch duration (HIP events
         # on the launch stream), priced against the peak of the pipe it runs on: bf16 dense / 6 products per fp32 MAC in
         # bf16x6 mode, the fp32-MFMA peak in exact mode.  Traffic: committed PMC record of the same kernel source.
-        Md = 32 * 1025 * a.batch // 16
+        ntok = ((a.crop + 15) // 16) ** 2 + 1           # 1025 at 512^2, 2602 at 801^2
+        Md = 2 * a.batch * ntok
         if not g_arith_exact:
             nprod = 6 if a.gemm_arith == "bf16x6" else 3
             dom = by.get(("planes", Md, 3072, 768, ops.ACT_GELU)) or by.get((0, 0, Md, 3072, 768, 1))
             planes = ("planes", Md, 3072, 768, ops.ACT_GELU) in by
+            clock = None
+            if dom is not None and planes:
+                # the clock the chip sustains under this kernel (svl_clock_probe waves on a second stream next to 24
+                # back-to-back launches of the same shape and epilogue) and under the whole step
+                xa, wb = ops.split_planes(torch.randn(Md, 768, device=dev)), ops.split_planes(torch.randn(3072, 768, device=dev) * 0.05)
+                bias_, pre_, po_ = torch.zeros(3072, device=dev), ops.empty(Md, 3072, device=dev), ops.Planes(Md, 3072, device=dev)
+                avg_ = dom[0] * 1e3 / dom[2]
+                clock = dict(
+                    under_dominant_kernel=clock_probe_mhz(
+                        lambda: [ops.pgemm(xa, wb, Md, 3072, None, po_, bias_, ops.ACT_GELU, pre_) for _ in range(24)], 24 * avg_, dev),
+                    under_whole_step=clock_probe_mhz(lambda: step(a.warmup + a.steps + 1), ms, dev),
+                    nominal=PEAK_CLOCK_MHZ,
+                    note="mean of 64 probe waves: shader-clock counter / 100 MHz counter over 80 % of the run; the MFMA "
+                         "peaks are quoted at the nominal clock")
+                del xa, wb, bias_, pre_, po_
             if dom is not None:
                 d_tf = dom[1] / dom[0] / 1e12
                 peak = PEAK_BF16_MFMA_TF / nprod
@@ -361,7 +398,9 @@ def main():
                     flops_per_launch=2.0 * Md * 3072 * 768, bf16_issued_tflops=round(d_tf * nprod, 1),
                     frac_of_bf16_dense_peak=round(d_tf * nprod / PEAK_BF16_MFMA_TF, 4),
                     algorithmic_bytes=(Md * 768 * 6 + 3072 * 768 * 6 + Md * 3072 * 10) if planes else 513.0e6 * a.batch / 16,
-                    traffic_note=tnote,
+                    traffic_note=tnote, clock_mhz=clock,
+                    frac_at_sustained_clock=(round(d_tf / peak * PEAK_CLOCK_MHZ / clock["under_dominant_kernel"], 4)
+                                             if clock and clock["under_dominant_kernel"] else None),
                     note=f"achieved = 2MNK / mean launch duration; peak = {PEAK_BF16_MFMA_TF:.0f} TF bf16 dense / {nprod} "
                          "products per fp32 MAC (MI355X_MICROARCH.md); algorithmic bytes = A and B planes (6 B/element) read "
                          "once + pre-activation (4 B) and result planes (6 B) written once")

@@ -50,6 +50,11 @@ int svl_shutdown(void);
 int svl_num_stream_contexts(void); /* live (device, stream) helper contexts -- introspection for tests */
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
 int svl_last_error(char* buf, size_t len);
+/* Measurement aid (bench.py's `roofline.clock_mhz`; no counterpart in the reference): n_waves <= 1024 single-wave
+ * workgroups compare the shader-clock counter with the constant 100 MHz counter for `ticks_100mhz` (<= 1e9 = 10 s) and
+ * leave out[2 i] = shader-clock cycles, out[2 i + 1] = 100 MHz ticks (device memory, 16 n_waves bytes).  Launched on a
+ * stream of its own next to a kernel under measurement: cycles / ticks x 100 = the MHz sustained under that kernel. */
+int svl_clock_probe(unsigned long long* out, int n_waves, unsigned long long ticks_100mhz, svl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM / implicit-GEMM core (fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32: exact f32 fma chain).
@@ -252,27 +257,37 @@ typedef struct svl_ce_desc {
   float* partials;       /* workspace [svl_ce_num_blocks(B,N,HW)][4]: per-block {sum w*ce_t, sum ce_m, sum conf*valid, #valid} */
   float* dlogits;        /* [B, N, HW] or NULL */
   const float* gscale;   /* [2] device scalars, required when dlogits != NULL */
+  const float* img_weight; /* [B] device or NULL: per-image factor on w_t -- conf_mode 'pixelratio' (train_utils.py:39-42:
+                              the whole CE map of image b times its share of confident valid pixels; with all_pixels = 1) */
 } svl_ce_desc;
 int64_t svl_ce_num_blocks(int B, int N, int64_t HW); /* -1 if N is unsupported (N > 256) */
 int svl_ce_fused_f32(const svl_ce_desc* d, svl_stream_t stream);
 int svl_ce_finalize(const float* partials, int64_t nblocks, double* sums /* [4] device */, svl_stream_t stream);
 
-/* Loss assembly without host syncs (semivl.py:267-323, conf_mode 'pixelwise', mcc_loss_reduce 'mean_all').
+/* Loss assembly without host syncs (semivl.py:267-323).
  * counts: int64[4] device = #valid of {mask_x != 255, ignore_mask_mixed1, ignore_mask_mixed2, ignore_mask} != 255.
  * gscale out: float[4][2] device = {g_t, g_m} for the branches {x, s1, s2, fp}: the factor each per-pixel CE term
- * carries in d(loss)/d(logits).  numel_u = B*H*W of one unlabeled branch; lam = current mcc lambda. */
-int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, const double* factors, float* gscale,
-                      svl_stream_t stream);
+ * carries in d(loss)/d(logits).  numel_u = B*H*W of one unlabeled branch; lam = current mcc lambda.
+ * mc_counts: int64[3] device or NULL -- the guidance loss's normalisers for the branches {s1, s2, fp} when
+ * mcc_loss_reduce is not 'mean_all' (semivl.py:52-58,156-162): 'mean_valid' = #(ignore mask != 255) (= counts[1..3]),
+ * 'mean' = #(guidance label != 255) (nn.CrossEntropyLoss(ignore_index=255) mean); NULL = numel_u ('mean_all'). */
+int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, const double* factors, const int64_t* mc_counts,
+                      float* gscale, svl_stream_t stream);
 /* conf_mode 'pixelavg' (train_utils.py:43-46): factor[0] = sum over images b of mean_{valid pixels}(conf_b).  The
  * unsupervised branch loss is (sum over ALL pixels of CE) * factor / #valid.  `factors` above/below: double[3] device
  * for the branches {s1, s2, fp}, or NULL for 'pixelwise'. */
 int64_t svl_conf_avg_ws_doubles(int B); /* size of `workspace` below, in doubles */
 int svl_conf_avg_factor(const float* conf, const int64_t* ign, int B, int64_t HW, double* factor, double* workspace,
                         svl_stream_t stream);
+/* conf_mode 'pixelratio' (train_utils.py:39-42): ratio[b] = #(conf_b >= thresh & valid) / #valid of image b, the fp32
+ * quotient of the two counts (torch's int / int); fed to svl_ce_fused_f32 as img_weight with all_pixels = 1.
+ * workspace: svl_conf_avg_ws_doubles(B) doubles. */
+int svl_conf_ratio_f32(const float* conf, const int64_t* ign, int B, int64_t HW, float thresh, float* ratio,
+                       double* workspace, svl_stream_t stream);
 /* sums: double[4 branches][4] device (from svl_ce_finalize); out float[8] device =
  * {loss, loss_x, loss_s1, loss_s2, loss_fp, loss_mc_s1, loss_mc_s2, loss_mc_fp}. */
-int svl_semivl_loss(const double* sums, double numel_u, float lam, const double* factors, float* out,
-                    svl_stream_t stream);
+int svl_semivl_loss(const double* sums, double numel_u, float lam, const double* factors, const int64_t* mc_counts,
+                    float* out, svl_stream_t stream);
 /* out[b, c, p] = softmax over classes c of NCHW logits (probability accumulation of the sliding-window eval modes,
  * supervised.py:61,113). */
 int svl_softmax_planes_f32(const float* logits, int B, int N, int64_t HW, float* out, svl_stream_t stream);
@@ -341,6 +356,10 @@ int svl_eltwise_f32(int mode, const float* a, const float* b, float* out, int64_
 int svl_chanmask_f32(const float* x, const float* mask, float scale, int64_t rows, int rows_per_img, int C,
                      float* out, svl_stream_t stream);
 int svl_fill_f32(float* p, float v, int64_t n, svl_stream_t stream);
+/* p[i] = 1 with probability keep_prob else 0: the per-(sample, channel) draws of F.dropout2d (builder.py:79-85; torch's
+ * own generator stream is not reproduced -- the reference's masks are random too).  Counter-based: element i is a hash of
+ * (seed, offset + i); the caller advances `offset` by n between calls. */
+int svl_bernoulli_f32(float* p, int64_t n, float keep_prob, uint64_t seed, uint64_t offset, svl_stream_t stream);
 /* y = ((x * k[0][c] + k[1][c]) - k[2][c]) / k[3][c] on NCHW planes (planes = B * C, k4 = float[4][C] device): the loader
  * (ImageNet) -> CLIP statistics re-normalisation of VLM.renormalize_img_for_clip (model/vlm.py:69-78), same op order. */
 int svl_affine_planes_f32(const float* x, int64_t planes, int C, int64_t HW, const float* k4, float* y, svl_stream_t stream);

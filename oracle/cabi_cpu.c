@@ -8,7 +8,7 @@
  * Each function restates the reference computation it stands for:
  *   svl_softmax_max_f32      pred.softmax(dim=1).max(dim=1)                         semivl.py:232,252
  *   svl_cutmix_*             mask[box == 1] = mask_mix[box == 1]                    utils/train_utils.py:19-27
- *   svl_ce_fused_f32 (+finalize, semivl_gscale / semivl_loss, conf_avg_factor)
+ *   svl_ce_fused_f32 (+finalize, semivl_gscale / semivl_loss, conf_avg_factor, conf_ratio_f32)
  *                            CE(ignore 255) / CE(none) * confidence weight / mc CE  semivl.py:52-58,267-323,
  *                                                                                   utils/train_utils.py:30-49
  *   svl_maskclip_labels      upsample -> softmax(100 x) -> max -> threshold         model/vlm.py:100-109
@@ -124,6 +124,7 @@ int svl_ce_fused_f32(const svl_ce_desc* d, svl_stream_t s) {
         const int v = d->ign[o] != 255;
         const float cf = d->conf[o];
         w = d->all_pixels ? 1.f : ((cf >= d->conf_thresh && v) ? 1.f : 0.f);
+        if (d->img_weight) w *= d->img_weight[b];       /* 'pixelratio' (train_utils.py:39-42) */
         valid = v;
         if (v) sc += cf;
       }
@@ -157,23 +158,27 @@ int svl_ce_finalize(const float* partials, int64_t nblocks, double* sums, svl_st
   return SVL_OK;
 }
 
-int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, const double* f, float* g, svl_stream_t s) {
+int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, const double* f, const int64_t* mc, float* g,
+                      svl_stream_t s) {
   (void)s;
   CHECK(counts && g && numel_u > 0, "svl_semivl_gscale: bad args");
   const double f1 = f ? f[0] : 1.0, f2 = f ? f[1] : 1.0, f3 = f ? f[2] : 1.0;
+  const double n1 = mc ? (double)mc[0] : numel_u, n2 = mc ? (double)mc[1] : numel_u, n3 = mc ? (double)mc[2] : numel_u;
   g[0] = (float)(0.5 / counts[0]);          g[1] = 0.f;
-  g[2] = (float)(0.125 * f1 / counts[1]);   g[3] = (float)(0.25 * lam / numel_u);
-  g[4] = (float)(0.125 * f2 / counts[2]);   g[5] = (float)(0.25 * lam / numel_u);
-  g[6] = (float)(0.25 * f3 / counts[3]);    g[7] = (float)(0.5 * lam / numel_u);
+  g[2] = (float)(0.125 * f1 / counts[1]);   g[3] = (float)(0.25 * lam / n1);
+  g[4] = (float)(0.125 * f2 / counts[2]);   g[5] = (float)(0.25 * lam / n2);
+  g[6] = (float)(0.25 * f3 / counts[3]);    g[7] = (float)(0.5 * lam / n3);
   return SVL_OK;
 }
-int svl_semivl_loss(const double* sums, double numel_u, float lam, const double* f, float* out, svl_stream_t s) {
+int svl_semivl_loss(const double* sums, double numel_u, float lam, const double* f, const int64_t* mc, float* out,
+                    svl_stream_t s) {
   (void)s;
   CHECK(sums && out && numel_u > 0, "svl_semivl_loss: bad args");
   const double f1 = f ? f[0] : 1.0, f2 = f ? f[1] : 1.0, f3 = f ? f[2] : 1.0;
+  const double n1 = mc ? (double)mc[0] : numel_u, n2 = mc ? (double)mc[1] : numel_u, n3 = mc ? (double)mc[2] : numel_u;
   const float lx = (float)(sums[0] / sums[3]), l1 = (float)(sums[4] * f1 / sums[7]);
   const float l2 = (float)(sums[8] * f2 / sums[11]), lf = (float)(sums[12] * f3 / sums[15]);
-  const float m1 = (float)(sums[5] / numel_u), m2 = (float)(sums[9] / numel_u), mf = (float)(sums[13] / numel_u);
+  const float m1 = (float)(sums[5] / n1), m2 = (float)(sums[9] / n2), mf = (float)(sums[13] / n3);   /* semivl.py:52-58 */
   float loss = (lx + l1 * 0.25f + l2 * 0.25f + lf * 0.5f) / 2.0f;   /* semivl.py:312-316 */
   loss = loss + m1 * 0.25f * lam;                                    /* semivl.py:317-323 */
   loss = loss + m2 * 0.25f * lam;
@@ -193,6 +198,19 @@ int svl_conf_avg_factor(const float* conf, const int64_t* ign, int B, int64_t HW
     tot += sc / nv;
   }
   *factor = tot;
+  return SVL_OK;
+}
+
+int svl_conf_ratio_f32(const float* conf, const int64_t* ign, int B, int64_t HW, float thresh, float* ratio, double* ws,
+                       svl_stream_t s) {   /* train_utils.py:39-40 */
+  (void)s; (void)ws;
+  CHECK(conf && ign && ratio && B > 0 && HW > 0 && thresh >= 0.f, "svl_conf_ratio_f32: bad args");
+  for (int b = 0; b < B; ++b) {
+    int64_t hi = 0, nv = 0;
+    for (int64_t p = 0; p < HW; ++p)
+      if (ign[(int64_t)b * HW + p] != 255) { hi += conf[(int64_t)b * HW + p] >= thresh; nv += 1; }
+    ratio[b] = (float)hi / (float)nv;
+  }
   return SVL_OK;
 }
 

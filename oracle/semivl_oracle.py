@@ -447,13 +447,20 @@ def confidence_weighted_loss(loss, conf_map, ignore_mask, conf_mode, conf_thresh
     raise ValueError(conf_mode)
 
 
-def compute_mc_loss(pred, mask, ign):  # semivl.py:52-58 with mcc_loss_reduce == 'mean_all'
-    return F.cross_entropy(pred, mask, ignore_index=255, reduction="none").sum() / ign.numel()
+def compute_mc_loss(pred, mask, ign, reduce="mean_all"):  # semivl.py:52-58 with the criterion_mc of semivl.py:156-162
+    if reduce == "mean":
+        return F.cross_entropy(pred, mask, ignore_index=255)
+    l_mc = F.cross_entropy(pred, mask, ignore_index=255, reduction="none")
+    if reduce == "mean_valid":
+        return l_mc.sum() / (ign != 255).sum()
+    if reduce == "mean_all":
+        return l_mc.sum() / ign.numel()
+    raise ValueError(reduce)
 
 
 def semivl_step(model, batch, iters, total_iters, conf_thresh=0.95, conf_mode="pixelwise", mcc_lambda=(0.1, 0.0),
-                mcc_conf_thresh=0.9, fp_masks=None):
-    """semivl.py:223-323 for method='semivl', criterion CELoss(ignore 255), criterion_u CELoss, mean_all mc loss.
+                mcc_conf_thresh=0.9, fp_masks=None, mcc_loss_reduce="mean_all"):
+    """semivl.py:223-323 for method='semivl', criterion CELoss(ignore 255), criterion_u CELoss.
     `batch` holds the 12 step tensors.  Returns (loss, dict of intermediates)."""
     b = {k: v.clone() for k, v in batch.items()}
     cutmix_img_(b["img_s1"], b["img_s1_other"], b["mix1"])
@@ -487,9 +494,9 @@ def semivl_step(model, batch, iters, total_iters, conf_thresh=0.95, conf_mode="p
     loss_s1 = confidence_weighted_loss(ce_none(pred_s1, mw1), cw1, ig1, conf_mode, conf_thresh)
     loss_s2 = confidence_weighted_loss(ce_none(pred_s2, mw2), cw2, ig2, conf_mode, conf_thresh)
     loss_fp = confidence_weighted_loss(ce_none(pred_w_fp, mask_w), conf_w, b["ignore_mask"], conf_mode, conf_thresh)
-    loss_mc_s1 = compute_mc_loss(pred_s1, mc1, ig1)
-    loss_mc_s2 = compute_mc_loss(pred_s2, mc2, ig2)
-    loss_mc_fp = compute_mc_loss(pred_w_fp, mclip, b["ignore_mask"])
+    loss_mc_s1 = compute_mc_loss(pred_s1, mc1, ig1, mcc_loss_reduce)
+    loss_mc_s2 = compute_mc_loss(pred_s2, mc2, ig2, mcc_loss_reduce)
+    loss_mc_fp = compute_mc_loss(pred_w_fp, mclip, b["ignore_mask"], mcc_loss_reduce)
     prog = iters / total_iters
     lam = mcc_lambda[0] * (1 - prog) + mcc_lambda[1] * prog
     loss = (loss_x + loss_s1 * 0.25 + loss_s2 * 0.25 + loss_fp * 0.5) / 2.0

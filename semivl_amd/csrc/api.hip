@@ -117,3 +117,31 @@ extern "C" int svl_num_stream_contexts(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   return (int)g_ctx.size();
 }
+
+// ------------------------------------------------------------------------------------------------ measurement aid
+// n_waves single-wave workgroups, each comparing the shader-clock counter (s_memtime) with the constant 100 MHz counter
+// (s_memrealtime) over `ticks_100mhz`: out[2 i] = shader-clock cycles, out[2 i + 1] = 100 MHz ticks.  Launched on a
+// stream of its own NEXT TO a kernel under measurement it reports the clock the chip sustains under that kernel's
+// instruction mix (the peaks of MI355X_MICROARCH.md are quoted at 2.4 GHz; dense-MFMA kernels are given 1.4 ... 1.7 GHz).
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
+  const unsigned long long w0 = wall_clock64(), c0 = clock64();
+  unsigned long long w = w0, c = c0;
+  while (w - w0 < ticks) {
+    __builtin_amdgcn_s_sleep(100);
+    c = clock64();
+    w = wall_clock64();
+  }
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c - c0;
+    out[2 * blockIdx.x + 1] = w - w0;
+  }
+}
+}  // namespace
+
+extern "C" int svl_clock_probe(unsigned long long* out, int n_waves, unsigned long long ticks_100mhz, svl_stream_t stream) {
+  SVL_CHECK_ARG(out && n_waves > 0 && n_waves <= 1024 && ticks_100mhz <= 1000000000ull, "svl_clock_probe: bad args");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(n_waves), dim3(64), 0, (hipStream_t)stream, out, ticks_100mhz);
+  SVL_LAUNCH_CHECK("svl_clock_probe");
+  return SVL_OK;
+}

@@ -396,6 +396,18 @@ __global__ void affine_planes_kernel(const float* __restrict__ x, long planes, i
     y[i] = ((x[i] * k[c] + k[C + c]) - k[2 * C + c]) / k[3 * C + c];
   }
 }
+// Bernoulli(keep) draws, one per element, from a counter-based generator: element i of call `offset` hashes
+// (seed, offset + i) with the splitmix64 finaliser; the top 24 bits are the uniform.  Stateless: the caller advances offset.
+__global__ void bernoulli_kernel(float* p, long n, float keep, unsigned long long seed, unsigned long long offset) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned long long z = seed + (offset + (unsigned long long)i + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    p[i] = u < keep ? 1.f : 0.f;
+  }
+}
 __global__ void fill_kernel(float* p, float v, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -745,6 +757,13 @@ extern "C" int svl_affine_planes_f32(const float* x, int64_t planes, int C, int6
   hipLaunchKernelGGL(affine_planes_kernel, dim3(grid_for(planes * HW, 4)), dim3(256), 0, (hipStream_t)stream, x,
                      (long)planes, C, (long)HW, k4, y);
   SVL_LAUNCH_CHECK("svl_affine_planes_f32");
+  return SVL_OK;
+}
+extern "C" int svl_bernoulli_f32(float* p, int64_t n, float keep_prob, uint64_t seed, uint64_t offset, svl_stream_t stream) {
+  SVL_CHECK_ARG(p && n > 0 && keep_prob >= 0.f && keep_prob <= 1.f, "svl_bernoulli_f32: bad args");
+  hipLaunchKernelGGL(bernoulli_kernel, dim3(grid_for(n, 1)), dim3(256), 0, (hipStream_t)stream, p, (long)n, keep_prob,
+                     (unsigned long long)seed, (unsigned long long)offset);
+  SVL_LAUNCH_CHECK("svl_bernoulli_f32");
   return SVL_OK;
 }
 extern "C" int svl_fill_f32(float* p, float v, int64_t n, svl_stream_t stream) {

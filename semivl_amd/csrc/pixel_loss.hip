@@ -102,6 +102,7 @@ struct CeP {
   float* partials;
   float* dlogits;
   const float* gscale;
+  const float* img_weight;   // [B] or null: per-image factor on the target term's weight ('pixelratio')
   int P;             // pixels per block
   long blocks_per_img;
 };
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
       const bool v = p.ign[o] != 255;
       const float cf = p.conf[o];
       w = p.all_pixels ? 1.f : ((cf >= p.conf_thresh && v) ? 1.f : 0.f);
+      if (p.img_weight) w *= p.img_weight[b];
       valid = v;
       s_c = v ? cf : 0.f;
     }
@@ -231,28 +233,37 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* partials,
 // ------------------------------------------------------------------------------------------------
 // factors (optional, double[3]): conf_mode 'pixelavg' multiplies the unsupervised branches {s1, s2, fp} by
 // sum_b avgconf_b (train_utils.py:43-46); NULL = 'pixelwise'.
+// mc_counts (or null): the guidance loss's three normalisers when they are not the pixel count (semivl.py:52-58:
+// mcc_loss_reduce 'mean_valid' = #(ignore mask != 255), 'mean' = #(guidance label != 255); 'mean_all' = numel_u)
 __global__ void semivl_gscale_kernel(const unsigned long long* counts, double numel_u, float lam, const double* factors,
-                                     float* gscale) {
+                                     const unsigned long long* mc_counts, float* gscale) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double c0 = (double)counts[0], c1 = (double)counts[1], c2 = (double)counts[2], c3 = (double)counts[3];
   const double f1 = factors ? factors[0] : 1.0, f2 = factors ? factors[1] : 1.0, f3 = factors ? factors[2] : 1.0;
+  const double n1 = mc_counts ? (double)mc_counts[0] : numel_u, n2 = mc_counts ? (double)mc_counts[1] : numel_u,
+               n3 = mc_counts ? (double)mc_counts[2] : numel_u;
   gscale[0] = (float)(0.5 / c0);          gscale[1] = 0.f;
-  gscale[2] = (float)(0.125 * f1 / c1);   gscale[3] = (float)(0.25 * lam / numel_u);
-  gscale[4] = (float)(0.125 * f2 / c2);   gscale[5] = (float)(0.25 * lam / numel_u);
-  gscale[6] = (float)(0.25 * f3 / c3);    gscale[7] = (float)(0.5 * lam / numel_u);
+  gscale[2] = (float)(0.125 * f1 / c1);   gscale[3] = (float)(0.25 * lam / n1);
+  gscale[4] = (float)(0.125 * f2 / c2);   gscale[5] = (float)(0.25 * lam / n2);
+  gscale[6] = (float)(0.25 * f3 / c3);    gscale[7] = (float)(0.5 * lam / n3);
 }
 // factor = sum over images of (sum_p conf*valid) / (sum_p valid)   (train_utils.py:43-46, conf_mode 'pixelavg')
 // stage 1: grid (CONF_CHUNKS, B), per-(image, chunk) partial sums in double; stage 2: one block, fixed order.
 constexpr int CONF_CHUNKS = 64;
+// thresh >= 0: the indicator conf >= thresh is summed instead of conf ('pixelratio': share of confident valid pixels)
 __global__ __launch_bounds__(256) void conf_avg_partial_kernel(const float* __restrict__ conf, const int64_t* __restrict__ ign,
-                                                               long HW, double* __restrict__ part) {
+                                                               long HW, float thresh, double* __restrict__ part) {
   __shared__ double sh[2][4];
   const int b = blockIdx.y;
   const long per = (HW + CONF_CHUNKS - 1) / CONF_CHUNKS;
   const long i0 = (long)blockIdx.x * per, i1 = min(HW, i0 + per);
   double s = 0.0, c = 0.0;
   for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-    if (ign[b * HW + i] != 255) { s += (double)conf[b * HW + i]; c += 1.0; }
+    if (ign[b * HW + i] != 255) {
+      const float cf = conf[b * HW + i];
+      s += thresh >= 0.f ? (cf >= thresh ? 1.0 : 0.0) : (double)cf;
+      c += 1.0;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
@@ -276,17 +287,31 @@ __global__ void conf_avg_final_kernel(const double* __restrict__ part, int B, do
   }
   factor[0] = tot;
 }
+// ratio[b] = float(#confident valid) / float(#valid): the fp32 quotient of two integers, like torch's int / int
+__global__ void conf_ratio_final_kernel(const double* __restrict__ part, int B, float* __restrict__ ratio) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0.0, c = 0.0;
+  for (int k = 0; k < CONF_CHUNKS; ++k) {
+    s += part[((long)b * CONF_CHUNKS + k) * 2];
+    c += part[((long)b * CONF_CHUNKS + k) * 2 + 1];
+  }
+  ratio[b] = (float)s / (float)c;
+}
 // sums: double [4 branches][4]; out: float[8] = {loss, loss_x, loss_s1, loss_s2, loss_fp, mc_s1, mc_s2, mc_fp}
-__global__ void semivl_loss_kernel(const double* sums, double numel_u, float lam, const double* factors, float* out) {
+__global__ void semivl_loss_kernel(const double* sums, double numel_u, float lam, const double* factors,
+                                   const unsigned long long* mc_counts, float* out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double f1 = factors ? factors[0] : 1.0, f2 = factors ? factors[1] : 1.0, f3 = factors ? factors[2] : 1.0;
+  const double n1 = mc_counts ? (double)mc_counts[0] : numel_u, n2 = mc_counts ? (double)mc_counts[1] : numel_u,
+               n3 = mc_counts ? (double)mc_counts[2] : numel_u;
   const float lx = (float)(sums[0] / sums[3]);
   const float l1 = (float)(sums[4] * f1 / sums[7]);
   const float l2 = (float)(sums[8] * f2 / sums[11]);
   const float lf = (float)(sums[12] * f3 / sums[15]);
-  const float m1 = (float)(sums[5] / numel_u);
-  const float m2 = (float)(sums[9] / numel_u);
-  const float mf = (float)(sums[13] / numel_u);
+  const float m1 = (float)(sums[5] / n1);
+  const float m2 = (float)(sums[9] / n2);
+  const float mf = (float)(sums[13] / n3);
   float loss = (lx + l1 * 0.25f + l2 * 0.25f + lf * 0.5f) / 2.0f;
   loss = loss + m1 * 0.25f * lam;
   loss = loss + m2 * 0.25f * lam;
@@ -470,6 +495,7 @@ extern "C" int svl_ce_fused_f32(const svl_ce_desc* d, svl_stream_t stream) {
   p.target = d->target; p.use_ignore_t = d->use_ignore_t;
   p.conf = d->conf; p.ign = d->ign; p.conf_thresh = d->conf_thresh; p.all_pixels = d->all_pixels;
   p.mc = d->mc_target; p.partials = d->partials; p.dlogits = d->dlogits; p.gscale = d->gscale;
+  p.img_weight = d->img_weight;
   p.P = P;
   p.blocks_per_img = (d->HW + P - 1) / P;
   const long nblk = (long)d->B * p.blocks_per_img;
@@ -493,26 +519,38 @@ extern "C" int svl_conf_avg_factor(const float* conf, const int64_t* ign, int B,
   SVL_CHECK_ARG(conf && ign && factor && workspace && B > 0 && HW > 0, "svl_conf_avg_factor: bad args");
   double* scratch = workspace;   // [B][CONF_CHUNKS][2] partial sums, caller-owned (svl_conf_avg_ws_doubles)
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(conf_avg_partial_kernel, dim3(CONF_CHUNKS, B), dim3(256), 0, st, conf, ign, (long)HW, scratch);
+  hipLaunchKernelGGL(conf_avg_partial_kernel, dim3(CONF_CHUNKS, B), dim3(256), 0, st, conf, ign, (long)HW, -1.f, scratch);
   SVL_LAUNCH_CHECK("svl_conf_avg_factor/partial");
   hipLaunchKernelGGL(conf_avg_final_kernel, dim3(1), dim3(64), 0, st, scratch, B, factor);
   SVL_LAUNCH_CHECK("svl_conf_avg_factor");
   return SVL_OK;
 }
 
-extern "C" int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, const double* factors, float* gscale,
-                                 svl_stream_t stream) {
+extern "C" int svl_conf_ratio_f32(const float* conf, const int64_t* ign, int B, int64_t HW, float thresh, float* ratio,
+                                  double* workspace, svl_stream_t stream) {
+  SVL_CHECK_ARG(conf && ign && ratio && workspace && B > 0 && HW > 0 && thresh >= 0.f, "svl_conf_ratio_f32: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conf_avg_partial_kernel, dim3(CONF_CHUNKS, B), dim3(256), 0, st, conf, ign, (long)HW, thresh, workspace);
+  SVL_LAUNCH_CHECK("svl_conf_ratio_f32/partial");
+  hipLaunchKernelGGL(conf_ratio_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, workspace, B, ratio);
+  SVL_LAUNCH_CHECK("svl_conf_ratio_f32");
+  return SVL_OK;
+}
+
+extern "C" int svl_semivl_gscale(const int64_t* counts, double numel_u, float lam, const double* factors,
+                                 const int64_t* mc_counts, float* gscale, svl_stream_t stream) {
   SVL_CHECK_ARG(counts && gscale && numel_u > 0, "svl_semivl_gscale: bad args");
   hipLaunchKernelGGL(semivl_gscale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
-                     (const unsigned long long*)counts, numel_u, lam, factors, gscale);
+                     (const unsigned long long*)counts, numel_u, lam, factors, (const unsigned long long*)mc_counts, gscale);
   SVL_LAUNCH_CHECK("svl_semivl_gscale");
   return SVL_OK;
 }
 
-extern "C" int svl_semivl_loss(const double* sums, double numel_u, float lam, const double* factors, float* out,
-                               svl_stream_t stream) {
+extern "C" int svl_semivl_loss(const double* sums, double numel_u, float lam, const double* factors,
+                               const int64_t* mc_counts, float* out, svl_stream_t stream) {
   SVL_CHECK_ARG(sums && out && numel_u > 0, "svl_semivl_loss: bad args");
-  hipLaunchKernelGGL(semivl_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, numel_u, lam, factors, out);
+  hipLaunchKernelGGL(semivl_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, numel_u, lam, factors,
+                     (const unsigned long long*)mc_counts, out);
   SVL_LAUNCH_CHECK("svl_semivl_loss");
   return SVL_OK;
 }

@@ -53,7 +53,7 @@ class CeDesc(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("B", C.c_int), ("N", C.c_int), ("HW", C.c_int64),
                 ("target", C.c_void_p), ("use_ignore_t", C.c_int), ("conf", C.c_void_p), ("ign", C.c_void_p),
                 ("conf_thresh", C.c_float), ("all_pixels", C.c_int), ("mc_target", C.c_void_p), ("partials", C.c_void_p),
-                ("dlogits", C.c_void_p), ("gscale", C.c_void_p)]
+                ("dlogits", C.c_void_p), ("gscale", C.c_void_p), ("img_weight", C.c_void_p)]
 
 
 class SeqAttnDesc(C.Structure):
@@ -85,13 +85,16 @@ SIGNATURES = {
     "svl_ce_num_blocks": (_L, [_I, _I, _L]),
     "svl_ce_fused_f32": (_I, [C.POINTER(CeDesc), _P]),
     "svl_ce_finalize": (_I, [_P, _L, _P, _P]),
-    "svl_semivl_gscale": (_I, [_P, _D, _F, _P, _P, _P]),
-    "svl_semivl_loss": (_I, [_P, _D, _F, _P, _P, _P]),
+    "svl_semivl_gscale": (_I, [_P, _D, _F, _P, _P, _P, _P]),
+    "svl_semivl_loss": (_I, [_P, _D, _F, _P, _P, _P, _P]),
+    "svl_conf_ratio_f32": (_I, [_P, _P, _I, _L, _F, _P, _P, _P]),
     "svl_conf_avg_ws_doubles": (_L, [_I]),
     "svl_conf_avg_factor": (_I, [_P, _P, _I, _L, _P, _P, _P]),
     "svl_stream_release": (_I, [_P]),
     "svl_shutdown": (_I, []),
     "svl_num_stream_contexts": (_I, []),
+    "svl_clock_probe": (_I, [_P, _I, C.c_uint64, _P]),
+    "svl_bernoulli_f32": (_I, [_P, _L, _F, C.c_uint64, C.c_uint64, _P]),
     "svl_softmax_planes_f32": (_I, [_P, _I, _I, _L, _P, _P]),
     "svl_count_valid_i64": (_I, [_P, _L, _P, _P]),
     "svl_maskclip_labels": (_I, [_P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),

@@ -223,8 +223,7 @@ class VLM(nn.Module):
             masks = fp_masks
             drop_order = list(feats) + ([ctok] if self.conv_encoder is not None else [])  # builder.py:80-85
             if masks is None:  # F.dropout2d: one Bernoulli(1-p) draw per (sample, channel); always stochastic (App. E.7)
-                masks = [torch.bernoulli(torch.full((f.shape[0], f.shape[2]), 1.0 - self.fp_rate, device=img.device))
-                         for f in drop_order]
+                masks = [ops.bernoulli((f.shape[0], f.shape[2]), 1.0 - self.fp_rate, img.device) for f in drop_order]
             assert len(masks) == len(drop_order)
             if only_fp:     # builder.py:65-77: every feature REPLACED by its channel-dropout copy (no doubling), then decoded
                 sc = 1.0 / (1.0 - self.fp_rate)

@@ -975,7 +975,7 @@ def count_valid(map_i64, out_count):
 
 
 def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0, mc=None, dlogits=None, gscale=None,
-             sums_out=None, all_pixels=False):
+             sums_out=None, all_pixels=False, img_weight=None):
     """Returns sums (double[4] device): {sum w*ce_t, sum ce_m, sum conf*valid, #valid}."""
     Bn, N = logits.shape[:2]
     HW = logits[0, 0].numel()
@@ -985,7 +985,7 @@ def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0,
         raise RuntimeError(f"svl_ce_fused: unsupported N={N}")
     partials = empty(nblk, 4, device=logits.device)
     d = L.CeDesc(_p(logits), Bn, N, HW, _p(target), 1 if use_ignore_t else 0, _p(conf), _p(ign), float(conf_thresh),
-                 1 if all_pixels else 0, _p(mc), _p(partials), _p(dlogits), _p(gscale))
+                 1 if all_pixels else 0, _p(mc), _p(partials), _p(dlogits), _p(gscale), _p(img_weight))
     e0 = _prof_begin()
     L.check(lib.svl_ce_fused_f32(C.byref(d), _st()), "svl_ce_fused_f32")
     # algorithmic bytes: fwd (4N+20) + bwd (8N+20) B/px when dlogits is produced, else fwd only
@@ -1019,14 +1019,38 @@ def adamw_step(p, g, m, v, seg_off, seg_lr, seg_wd, nseg, beta1, beta2, eps, ste
                                     float(ema_decay), _st()), "svl_adamw_step")
 
 
-def semivl_gscale(counts_i64, numel_u, lam, gscale_out, factors=None):
-    L.check(L.load().svl_semivl_gscale(_p(counts_i64), float(numel_u), float(lam), _p(factors), _p(gscale_out), _st()),
-            "svl_semivl_gscale")
+def semivl_gscale(counts_i64, numel_u, lam, gscale_out, factors=None, mc_counts=None):
+    L.check(L.load().svl_semivl_gscale(_p(counts_i64), float(numel_u), float(lam), _p(factors), _p(mc_counts),
+                                       _p(gscale_out), _st()), "svl_semivl_gscale")
 
 
-def semivl_loss(sums_f64, numel_u, lam, out8, factors=None):
-    L.check(L.load().svl_semivl_loss(_p(sums_f64), float(numel_u), float(lam), _p(factors), _p(out8), _st()),
-            "svl_semivl_loss")
+def semivl_loss(sums_f64, numel_u, lam, out8, factors=None, mc_counts=None):
+    L.check(L.load().svl_semivl_loss(_p(sums_f64), float(numel_u), float(lam), _p(factors), _p(mc_counts), _p(out8),
+                                     _st()), "svl_semivl_loss")
+
+
+_BERNOULLI_CALLS = [0]
+
+
+def bernoulli(shape, keep_prob, device):
+    """fp32 tensor of independent Bernoulli(keep_prob) draws (svl_bernoulli_f32); seeded by torch.initial_seed(), every call
+    consumes a fresh counter range."""
+    out = empty(*shape, device=device)
+    n = out.numel()
+    L.check(L.load().svl_bernoulli_f32(_p(out), n, float(keep_prob), torch.initial_seed() & (2 ** 64 - 1),
+                                       _BERNOULLI_CALLS[0], _st()), "svl_bernoulli_f32")
+    _BERNOULLI_CALLS[0] += n
+    return out
+
+
+def conf_ratio(conf, ign, thresh):
+    """ratio[b] = #(conf_b >= thresh & valid) / #valid   (conf_mode 'pixelratio', train_utils.py:39-40) -> float[B]."""
+    lib = L.load()
+    out = empty(conf.shape[0], device=conf.device)
+    ws = torch.empty(int(lib.svl_conf_avg_ws_doubles(conf.shape[0])), dtype=torch.float64, device=conf.device)
+    L.check(lib.svl_conf_ratio_f32(_p(conf), _p(ign), conf.shape[0], conf[0].numel(), float(thresh), _p(out), _p(ws), _st()),
+            "svl_conf_ratio_f32")
+    return out
 
 
 def conf_avg_factor(conf, ign, out_f64):

@@ -64,15 +64,18 @@ LOSS_NAMES = ("loss", "loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "
 
 def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, reducer=None, fp_masks=None,
                       return_aux=False):
-    """One iteration of semivl.py:223-328 (method 'semivl', CELoss(ignore 255) / CELoss, conf_mode 'pixelwise',
-    mcc_loss_reduce 'mean_all').  `batch`: the 12 step tensors on the GPU.  No host syncs: the
+    """One iteration of semivl.py:223-328 (method 'semivl', CELoss(ignore 255) / CELoss; conf_mode 'pixelwise' /
+    'pixelavg' / 'pixelratio', train_utils.py:30-49; mcc_loss_reduce 'mean_all' / 'mean_valid' / 'mean', semivl.py:52-58).  `batch`: the 12 step tensors on the GPU.  No host syncs: the
     returned `losses` is a device float[8] (LOSS_NAMES order).
     """
     conf_mode = cfg.get("conf_mode", "pixelwise")
-    if conf_mode not in ("pixelwise", "pixelavg") or cfg.get("mcc_loss_reduce", "mean_all") != "mean_all":
-        raise NotImplementedError("conf_mode in {'pixelwise','pixelavg'} and mcc_loss_reduce='mean_all' only "
-                                  "(every shipped SemiVL recipe, experiments.py:60-102,428-456)")
+    mcc_reduce = cfg.get("mcc_loss_reduce", "mean_all")
+    if conf_mode not in ("pixelwise", "pixelavg", "pixelratio"):
+        raise ValueError(conf_mode)                      # train_utils.py:47-48
+    if mcc_reduce not in ("mean_all", "mean_valid", "mean"):
+        raise ValueError(mcc_reduce)                     # semivl.py:161-162
     pixelavg = conf_mode == "pixelavg"
+    whole_map = conf_mode in ("pixelavg", "pixelratio")  # both weight the WHOLE CE map, not the confident valid pixels
     lam_cfg = cfg.get("maskclip_consistency_lambda", [0.1, 0])
     if isinstance(lam_cfg, (list, tuple)):
         prog = iters / total_iters
@@ -101,7 +104,7 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     # them.  With a conv_encoder only the frozen-CLIP guidance moves over: the pseudo-label pass reads, in eval mode, the
     # BatchNorm running statistics that the train-mode forwards update, so it stays in program order on the main stream.
     side = None
-    if img_x.is_cuda and cfg.get("overlap_streams", True):
+    if img_x.is_cuda and cfg.get("overlap_streams", True) and not os.environ.get("SVL_NO_SIDE_STREAM"):
         side = _SIDE.get(dev)
         if side is None:
             side = _SIDE[dev] = torch.cuda.Stream(dev)
@@ -164,7 +167,17 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         factors = ops.empty(3, dtype=torch.float64, device=dev)
         for i, (c_, g_) in enumerate(((cw1, ig1), (cw2, ig2), (conf_w, ign))):
             ops.conf_avg_factor(c_, g_, factors[i:i + 1])
-    ops.semivl_gscale(counts, numel_u, lam, gscale, factors)
+    ratios = (None, None, None)
+    if conf_mode == "pixelratio":   # train_utils.py:39-42: image b's CE map times its share of confident valid pixels
+        ratios = tuple(ops.conf_ratio(c_, g_, cfg["conf_thresh"]) for c_, g_ in ((cw1, ig1), (cw2, ig2), (conf_w, ign)))
+    mc_counts = None                # semivl.py:52-58: the guidance loss's normaliser
+    if mcc_reduce == "mean_valid":
+        mc_counts = counts[1:]
+    elif mcc_reduce == "mean":      # nn.CrossEntropyLoss(ignore_index=255): mean over the labelled guidance pixels
+        mc_counts = ops.zeros(3, dtype=torch.int64, device=dev)
+        for i, m_ in enumerate((mc1, mc2, mclip)):
+            ops.count_valid(m_, mc_counts[i:i + 1])
+    ops.semivl_gscale(counts, numel_u, lam, gscale, factors, mc_counts)
     # fused CE forward + backward per branch
     thr = cfg["conf_thresh"]
     dl4 = torch.empty_like(preds4)
@@ -173,13 +186,13 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     sums = ops.empty(4, 4, dtype=torch.float64, device=dev)
     ops.ce_fused(pred_x.detach(), mask_x, True, dlogits=dl4[B:2 * B], gscale=gscale[0], sums_out=sums[0])
     ops.ce_fused(pred_s1.detach(), mw1, False, conf=cw1, ign=ig1, conf_thresh=thr, mc=mc1, dlogits=dls[:B],
-                 gscale=gscale[1], sums_out=sums[1], all_pixels=pixelavg)
+                 gscale=gscale[1], sums_out=sums[1], all_pixels=whole_map, img_weight=ratios[0])
     ops.ce_fused(pred_s2.detach(), mw2, False, conf=cw2, ign=ig2, conf_thresh=thr, mc=mc2, dlogits=dls[B:],
-                 gscale=gscale[2], sums_out=sums[2], all_pixels=pixelavg)
+                 gscale=gscale[2], sums_out=sums[2], all_pixels=whole_map, img_weight=ratios[1])
     ops.ce_fused(pred_w_fp.detach(), mask_w, False, conf=conf_w, ign=ign, conf_thresh=thr, mc=mclip,
-                 dlogits=dl4[2 * B:], gscale=gscale[3], sums_out=sums[3], all_pixels=pixelavg)
+                 dlogits=dl4[2 * B:], gscale=gscale[3], sums_out=sums[3], all_pixels=whole_map, img_weight=ratios[2])
     losses = ops.empty(8, device=dev)
-    ops.semivl_loss(sums, numel_u, lam, losses, factors)
+    ops.semivl_loss(sums, numel_u, lam, losses, factors, mc_counts)
     # backward (+ all-reduce) + optimizer
     if optimizer is not None:
         optimizer.zero_grad()
@@ -245,6 +258,8 @@ class FusedAdamW:
         ck = optimizer_cfg.get("paramwise_cfg", {}).get("custom_keys", {})
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.startswith("clip_encoder.")]
         self.groups = mmcv_param_groups(named, self.lr, self.wd, ck)
+        arena_index = {id(p): i for i, (_, p) in enumerate(named)}
+        self.all_params = [(n, arena_index.get(id(p))) for n, p in model.named_parameters()]   # (name, arena slot | None)
         dev = named[0][1].device
         sizes = [g["param"].numel() for g in self.groups]
         # 16-byte aligned segments
@@ -302,41 +317,60 @@ class FusedAdamW:
         ops.weights_changed()    # cached bf16 planes of the trainable weights are stale now (ops.weight_planes)
 
     def state_dict(self):
-        """torch.optim.AdamW layout (`semivl.py:428` stores `optimizer.state_dict()`): one param group per tensor, in
-        arena order; state = step / exp_avg / exp_avg_sq per tensor.  Only parameters that can receive a gradient are
-        indexed (the reference's mmcv constructor also lists the frozen backbone / clip_encoder tensors, whose state stays
-        empty): the 'optimizer' entry of a checkpoint is therefore NOT index-compatible with the reference's -- only the
-        'model' entry is.  `names` (arena order) is stored and verified on load."""
+        """The layout of the reference's checkpoint entry (`semivl.py:428` stores `optimizer.state_dict()` of a
+        torch.optim.AdamW built by mmcv's DefaultOptimizerConstructor): ONE param group per tensor of
+        `model.named_parameters()`, in that order, frozen tensors and `clip_encoder.*` included (mmcv lists them with the
+        base lr / weight decay; they never receive a gradient, so they have no `state` entry); state[i] = step / exp_avg /
+        exp_avg_sq for the tensors of the arena.  Index-compatible with the reference in both directions
+        (tests/test_model_gpu.py::test_optimizer_state_dict_is_index_compatible).  `names` (all parameters, same order) is
+        stored in addition and verified on load."""
         state, groups = {}, []
         off = self.seg_off.tolist()
-        for i, g_ in enumerate(self.groups):
-            shp = g_["param"].shape
-            n = g_["param"].numel()
+        for j, (name, ai) in enumerate(self.all_params):
+            if ai is None:
+                groups.append(dict(lr=self.lr, weight_decay=self.wd, betas=tuple(self.betas), eps=self.eps, amsgrad=False,
+                                   params=[j]))
+                continue
+            g_ = self.groups[ai]
+            shp, n = g_["param"].shape, g_["param"].numel()
             if self.step_count > 0:
-                state[i] = dict(step=torch.tensor(float(self.step_count)),
-                                exp_avg=self.m[off[i]:off[i] + n].view(shp).detach().cpu().clone(),
-                                exp_avg_sq=self.v[off[i]:off[i] + n].view(shp).detach().cpu().clone())
+                state[j] = dict(step=torch.tensor(float(self.step_count)),
+                                exp_avg=self.m[off[ai]:off[ai] + n].view(shp).detach().cpu().clone(),
+                                exp_avg_sq=self.v[off[ai]:off[ai] + n].view(shp).detach().cpu().clone())
             groups.append(dict(lr=g_["lr"], initial_lr=g_["initial_lr"], weight_decay=g_["weight_decay"],
-                               betas=tuple(self.betas), eps=self.eps, amsgrad=False, params=[i]))
-        return dict(state=state, param_groups=groups, names=[g_.get("name", "") for g_ in self.groups])
+                               betas=tuple(self.betas), eps=self.eps, amsgrad=False, params=[j]))
+        return dict(state=state, param_groups=groups, names=[n for n, _ in self.all_params])
 
     def load_state_dict(self, sd):
-        assert len(sd["param_groups"]) == len(self.groups), "optimizer state does not match this model"
-        if "names" in sd:
+        """Accepts the reference layout (one group per model parameter, above) and the compact round-1/2 layout of this
+        package (one group per arena tensor)."""
+        pg = sd["param_groups"]
+        if len(pg) == len(self.all_params):
+            index = [(j, ai) for j, (_, ai) in enumerate(self.all_params) if ai is not None]
+            mine = [n for n, _ in self.all_params]
+        else:
+            assert len(pg) == len(self.groups), "optimizer state does not match this model"
+            index = [(i, i) for i in range(len(self.groups))]
             mine = [g_.get("name", "") for g_ in self.groups]
+        if "names" in sd:
             assert list(sd["names"]) == mine, "optimizer state was saved for different parameters: %s" % (
                 sorted(set(sd["names"]) ^ set(mine))[:6],)
         off = self.seg_off.tolist()
         steps = set()
-        for i, (g_, sg) in enumerate(zip(self.groups, sd["param_groups"])):
-            g_["lr"], g_["initial_lr"] = sg["lr"], sg.get("initial_lr", sg["lr"])
-            self._lr_host[i] = g_["lr"]
-            st = sd["state"].get(i)
+        for j, ai in index:
+            g_, sg = self.groups[ai], pg[j]
+            assert [int(k) for k in sg["params"]] == [j], "one parameter per group expected (mmcv constructor layout)"
+            g_["lr"], g_["initial_lr"] = sg["lr"], sg.get("initial_lr", g_["initial_lr"])
+            self._lr_host[ai] = g_["lr"]
+            st = sd["state"].get(j)
             if st is not None:
                 n = g_["param"].numel()
-                self.m[off[i]:off[i] + n].copy_(st["exp_avg"].reshape(-1))
-                self.v[off[i]:off[i] + n].copy_(st["exp_avg_sq"].reshape(-1))
+                assert tuple(st["exp_avg"].shape) == tuple(g_["param"].shape), (g_.get("name"), st["exp_avg"].shape)
+                self.m[off[ai]:off[ai] + n].copy_(st["exp_avg"].reshape(-1))
+                self.v[off[ai]:off[ai] + n].copy_(st["exp_avg_sq"].reshape(-1))
                 steps.add(int(st["step"]))
+        stray = set(sd["state"]) - {j for j, _ in index}
+        assert not stray, "state for parameters this model never trains: %s" % sorted(stray)[:6]
         assert len(steps) <= 1, "per-tensor step counts differ"
         self.step_count = steps.pop() if steps else 0
         self.seg_lr.copy_(self._lr_host)

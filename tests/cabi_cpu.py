@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATH = os.path.join(ROOT, "oracle", "_ref", "libsemivl_cpu.so")
 IMPLEMENTED = ["svl_version", "svl_last_error", "svl_fill_f32", "svl_softmax_max_f32", "svl_cutmix_f32", "svl_cutmix_i64",
                "svl_count_valid_i64", "svl_ce_num_blocks", "svl_ce_fused_f32", "svl_ce_finalize", "svl_semivl_gscale",
-               "svl_semivl_loss", "svl_conf_avg_ws_doubles", "svl_conf_avg_factor", "svl_maskclip_labels",
+               "svl_semivl_loss", "svl_conf_avg_ws_doubles", "svl_conf_avg_factor", "svl_conf_ratio_f32", "svl_maskclip_labels",
                "svl_concept_max_f32", "svl_iou_hist_i64", "svl_adamw_step"]
 _lib = None
 
@@ -41,7 +41,8 @@ def check(rc, what=""):
         raise RuntimeError(f"{what}: status {rc}: {buf.value.decode()}")
 
 
-def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0, mc=None, gscale=None, all_pixels=False):
+def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0, mc=None, gscale=None, all_pixels=False,
+             img_weight=None):
     """numpy in / out through svl_ce_fused_f32 + svl_ce_finalize of the CPU backend: (sums double[4], dlogits or None)."""
     lib = load()
     B, N = logits.shape[:2]
@@ -50,7 +51,7 @@ def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0,
     partials = np.zeros((nblk, 4), np.float32)
     dl = np.zeros_like(logits) if gscale is not None else None
     d = L.CeDesc(ptr(logits), B, N, HW, ptr(target), int(use_ignore_t), ptr(conf), ptr(ign), float(conf_thresh),
-                 int(all_pixels), ptr(mc), ptr(partials), ptr(dl), ptr(gscale))
+                 int(all_pixels), ptr(mc), ptr(partials), ptr(dl), ptr(gscale), ptr(img_weight))
     check(lib.svl_ce_fused_f32(C.byref(d), None), "svl_ce_fused_f32")
     sums = np.zeros(4, np.float64)
     check(lib.svl_ce_finalize(ptr(partials), nblk, ptr(sums), None), "svl_ce_finalize")

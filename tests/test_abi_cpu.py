@@ -93,7 +93,7 @@ def test_cpu_loss_assembly_matches_oracle_formula():
     numel = float(ign.numel())
     counts = np.array([(target != 255).sum(), (ign != 255).sum(), (ign != 255).sum(), (ign != 255).sum()], np.int64)
     gs = np.zeros((4, 2), np.float32)
-    K.check(lib.svl_semivl_gscale(K.ptr(counts), numel, lam, None, K.ptr(gs), None))
+    K.check(lib.svl_semivl_gscale(K.ptr(counts), numel, lam, None, None, K.ptr(gs), None))
     assert math.isclose(gs[0, 0], 0.5 / counts[0], rel_tol=1e-6) and math.isclose(gs[3, 1], 0.5 * lam / numel, rel_tol=1e-6)
     sums = np.zeros((4, 4), np.float64)
     sums[0], _ = K.ce_fused(logits.numpy(), target.numpy(), True)
@@ -101,7 +101,7 @@ def test_cpu_loss_assembly_matches_oracle_formula():
     for i in (1, 2, 3):
         sums[i], _ = K.ce_fused(logits.numpy(), tg.numpy(), False, conf.numpy(), ign.numpy(), 0.6, mc.numpy())
     out = np.zeros(8, np.float32)
-    K.check(lib.svl_semivl_loss(K.ptr(sums), numel, lam, None, K.ptr(out), None))
+    K.check(lib.svl_semivl_loss(K.ptr(sums), numel, lam, None, None, K.ptr(out), None))
     ce = F.cross_entropy(logits, tg, reduction="none")
     lu = O.confidence_weighted_loss(ce, conf, ign, "pixelwise", 0.6)
     lmc = O.compute_mc_loss(logits, mc, ign)
@@ -114,6 +114,46 @@ def test_cpu_loss_assembly_matches_oracle_formula():
     K.check(lib.svl_conf_avg_factor(K.ptr(conf.numpy()), K.ptr(ign.numpy()), 2, ign[0].numel(), K.ptr(f), K.ptr(ws), None))
     v = (ign != 255)
     assert abs(f[0] - ((conf * v).sum((1, 2)) / v.sum((1, 2))).sum().item()) < 1e-6
+
+
+@pytest.mark.parametrize("reduce", ["mean_valid", "mean"])
+def test_cpu_pixelratio_and_mc_reduce_match_oracle_formula(reduce):
+    """conf_mode 'pixelratio' (train_utils.py:39-42: per-image share of confident valid pixels on the WHOLE CE map) and the
+    guidance loss's other two normalisers (semivl.py:52-58) through the ABI: ratios, forward sums, d(loss)/d(logits) and
+    the assembled loss against torch autograd of the oracle's expressions."""
+    from oracle import semivl_oracle as O
+    lib = K.load()
+    logits, target, conf, ign, mc = _case(seed=11)
+    tg = target.clamp(max=20)
+    B = logits.shape[0]
+    ratio = np.zeros(B, np.float32)
+    ws = np.zeros(int(lib.svl_conf_avg_ws_doubles(B)), np.float64)
+    K.check(lib.svl_conf_ratio_f32(K.ptr(conf.numpy()), K.ptr(ign.numpy()), B, ign[0].numel(), 0.6, K.ptr(ratio), K.ptr(ws), None))
+    v = ign != 255
+    ref_ratio = ((conf >= 0.6) & v).sum((1, 2)) / v.sum((1, 2))
+    assert np.array_equal(ratio, ref_ratio.numpy())
+    lam, numel = 0.07, float(ign.numel())
+    counts = np.array([(target != 255).sum(), v.sum(), v.sum(), v.sum()], np.int64)
+    mcn = counts[1:].copy() if reduce == "mean_valid" else np.array([(mc != 255).sum()] * 3, np.int64)
+    gs = np.zeros((4, 2), np.float32)
+    K.check(lib.svl_semivl_gscale(K.ptr(counts), numel, lam, None, K.ptr(mcn), K.ptr(gs), None))
+    sums = np.zeros((4, 4), np.float64)
+    sums[0], _ = K.ce_fused(logits.numpy(), target.numpy(), True)
+    dls = []
+    for i in (1, 2, 3):
+        sums[i], dl = K.ce_fused(logits.numpy(), tg.numpy(), False, conf.numpy(), ign.numpy(), 0.6, mc.numpy(), gs[i],
+                                 all_pixels=True, img_weight=ratio)
+        dls.append(dl)
+    out = np.zeros(8, np.float32)
+    K.check(lib.svl_semivl_loss(K.ptr(sums), numel, lam, None, K.ptr(mcn), K.ptr(out), None))
+    lt = logits.clone().requires_grad_(True)
+    lu = O.confidence_weighted_loss(F.cross_entropy(lt, tg, reduction="none"), conf, ign, "pixelratio", 0.6)
+    lmc = O.compute_mc_loss(lt, mc, ign, reduce)
+    lx = F.cross_entropy(logits, target, ignore_index=255)
+    ref = (lx + lu * 0.25 + lu * 0.25 + lu * 0.5) / 2.0 + lmc * 0.25 * lam + lmc * 0.25 * lam + lmc * 0.5 * lam
+    assert abs(out[0] - ref.item()) < 1e-5 and abs(out[2] - lu.item()) < 1e-5 and abs(out[5] - lmc.item()) < 1e-6
+    (lu * 0.25 / 2.0 + lmc * 0.25 * lam).backward()        # the s1 branch's share of the total loss
+    assert np.abs(dls[0] - lt.grad.numpy()).max() < 1e-6 * max(1.0, float(lt.grad.abs().max()))
 
 
 def test_cpu_maskclip_labels_iou_hist_adamw():

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import build_hip, load_fixture
+from golden_util import build_hip, build_oracle, load_fixture
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -103,11 +103,12 @@ def test_fused_adamw_state_dict_roundtrip(dev):
     for i in range(2):
         oa.g.copy_(grads[i]); oa.step(); oa.poly_lr(i + 1, 100)
     sd = oa.state_dict()
-    assert len(sd["param_groups"]) == len(oa.groups) and len(sd["state"]) == len(oa.groups)
-    assert sd["state"][0]["exp_avg"].shape == oa.groups[0]["param"].shape and float(sd["state"][0]["step"]) == 2.0
-    tgroups = [dict(params=[torch.nn.Parameter(torch.zeros(g_["param"].shape))]) for g_ in oa.groups]
-    topt = torch.optim.AdamW(tgroups, lr=1e-3)
-    topt.load_state_dict({k: sd[k] for k in ("state", "param_groups")})      # the layout torch itself accepts
+    # the reference's layout (semivl.py:428 + mmcv's constructor): one group per model parameter, frozen ones included
+    nall = len(list(ma.named_parameters()))
+    assert len(sd["param_groups"]) == nall > len(oa.groups) and len(sd["state"]) == len(oa.groups)
+    slot = {ai: j for j, (_, ai) in enumerate(oa.all_params) if ai is not None}
+    assert sd["state"][slot[0]]["exp_avg"].shape == oa.groups[0]["param"].shape and float(sd["state"][slot[0]]["step"]) == 2.0
+    assert [g_["params"] for g_ in sd["param_groups"]] == [[j] for j in range(nall)]
     mb.load_state_dict(ma.state_dict())
     ob.p.copy_(oa.p)
     ob.load_state_dict(sd)
@@ -115,7 +116,58 @@ def test_fused_adamw_state_dict_roundtrip(dev):
         o.g.copy_(grads[2]); o.step()
     sa, sb = oa.state_dict(), ob.state_dict()          # per-tensor views (the arena's alignment padding is not state)
     for i, (ga, gb) in enumerate(zip(oa.groups, ob.groups)):
+        j = slot[i]
         assert torch.equal(ga["param"], gb["param"]), ga["name"]
-        assert torch.equal(sa["state"][i]["exp_avg"], sb["state"][i]["exp_avg"]), ga["name"]
-        assert torch.equal(sa["state"][i]["exp_avg_sq"], sb["state"][i]["exp_avg_sq"]), ga["name"]
-        assert float(sa["state"][i]["step"]) == float(sb["state"][i]["step"]) == 3.0
+        assert torch.equal(sa["state"][j]["exp_avg"], sb["state"][j]["exp_avg"]), ga["name"]
+        assert torch.equal(sa["state"][j]["exp_avg_sq"], sb["state"][j]["exp_avg_sq"]), ga["name"]
+        assert float(sa["state"][j]["step"]) == float(sb["state"][j]["step"]) == 3.0
+
+
+@pytest.mark.gpu
+def test_optimizer_state_dict_is_index_compatible_with_the_reference(dev):
+    """The 'optimizer' entry of a checkpoint interchanges with the reference's (semivl.py:426-433): a torch.optim.AdamW over
+    the oracle's mmcv-style param groups (one per named parameter) and the fused optimizer, stepped on the same gradients,
+    load each other's state_dict and land on the same moments / step / learning rates."""
+    from oracle import semivl_oracle as O
+    from semivl_amd.train import FusedAdamW
+    z, c = load_fixture("tiny")
+    ck = dict(backbone=dict(lr_mult=0.01), head=dict(lr_mult=10.0))
+    ocfg = dict(type="AdamW", lr=1e-3, weight_decay=0.01, paramwise_cfg=dict(custom_keys=ck))
+    orc = build_oracle(c)
+    hip = build_hip(c)
+    hip.load_state_dict(orc.state_dict(), strict=True)
+    hip.to(dev)
+    fo = FusedAdamW(hip, ocfg)
+    to = torch.optim.AdamW(O.param_groups(orc, 1e-3, 0.01, ck), lr=1e-3, weight_decay=0.01)
+    names = [n for n, _ in orc.named_parameters()]
+    assert names == [n for n, _ in fo.all_params]
+    trainable = {g_["name"] for g_ in fo.groups}
+    gen = torch.Generator().manual_seed(5)
+    for _ in range(2):
+        for (n, p) in orc.named_parameters():
+            p.grad = torch.randn(p.shape, generator=gen) * 0.1 if n in trainable else None
+        for g_ in fo.groups:
+            g_["param"].main_grad.copy_(dict(orc.named_parameters())[g_["name"]].grad)
+        to.step(); fo.step()
+    rs, fs = to.state_dict(), fo.state_dict()
+    assert sorted(rs["state"]) == sorted(fs["state"]) and len(rs["param_groups"]) == len(fs["param_groups"])
+    for j in rs["state"]:
+        assert float(rs["state"][j]["step"]) == float(fs["state"][j]["step"]) == 2.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            a, b_ = rs["state"][j][k], fs["state"][j][k]
+            assert a.shape == b_.shape and (a - b_).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item()), (names[j], k)
+    for j, (gr, gf) in enumerate(zip(rs["param_groups"], fs["param_groups"])):
+        assert gr["params"] == gf["params"] == [j]
+        if names[j] in trainable:
+            assert abs(gr["lr"] - gf["lr"]) < 1e-12 and abs(gr["weight_decay"] - gf["weight_decay"]) < 1e-12, names[j]
+    # reference -> fused: moments land in the arena; fused -> reference: torch accepts the dict as it is
+    f2 = FusedAdamW(build_hip(c).to(dev), ocfg)
+    f2.load_state_dict({k: rs[k] for k in ("state", "param_groups")})
+    assert f2.step_count == 2
+    for j, (n, ai) in enumerate(f2.all_params):
+        if ai is not None:
+            off, cnt = int(f2.seg_off[ai]), f2.groups[ai]["param"].numel()
+            assert torch.equal(f2.m[off:off + cnt].cpu().view(rs["state"][j]["exp_avg"].shape), rs["state"][j]["exp_avg"]), n
+    t2 = torch.optim.AdamW(O.param_groups(build_oracle(c), 1e-3, 0.01, ck), lr=1e-3, weight_decay=0.01)
+    t2.load_state_dict({k: fs[k] for k in ("state", "param_groups")})
+    assert torch.equal(t2.state_dict()["state"][min(fs["state"])]["exp_avg"], fs["state"][min(fs["state"])]["exp_avg"])

@@ -101,6 +101,48 @@ def test_train_step_matches_reference_fixture(dev, name):
     print(f"[{name}] worst grad-norm rel err {worst:.2e}")
 
 
+@pytest.mark.parametrize("conf_mode,reduce", [("pixelratio", "mean_all"), ("pixelwise", "mean_valid"),
+                                              ("pixelwise", "mean"), ("pixelratio", "mean")])
+def test_train_step_loss_modes_match_oracle(dev, conf_mode, reduce):
+    """The loss modes no shipped recipe selects -- conf_mode 'pixelratio' (train_utils.py:39-42) and mcc_loss_reduce
+    'mean_valid' / 'mean' (semivl.py:52-58,156-162) -- through the fused step on the fixture with a live confidence gate:
+    the 8 loss scalars and every parameter gradient against the oracle's autograd."""
+    from oracle import semivl_oracle as O
+    from semivl_amd.train import LOSS_NAMES, semivl_train_step
+    z, c = load_fixture("conf")
+    orc = build_oracle(c)
+    sd = fixture_state(z, c, orc)
+    orc.load_state_dict(sd, strict=True)
+    hip = build_hip(c)
+    hip.load_state_dict(sd, strict=True)
+    hip.to(dev).train()
+    batch = fixture_batch(z, c)
+    masks = fixture_fp_masks(z, c)
+    iters, total = [int(v) for v in z["iters"]]
+    loss, aux = O.semivl_step(orc, batch, iters, total, conf_thresh=c["conf_thresh"], conf_mode=conf_mode, fp_masks=masks,
+                              mcc_loss_reduce=reduce)
+    loss.backward()
+    cfg = dict(CFG, conf_thresh=c["conf_thresh"], conf_mode=conf_mode, mcc_loss_reduce=reduce)
+    losses = semivl_train_step(hip, to_dev(batch, dev), iters, total, cfg, fp_masks=[m.to(dev) for m in masks])
+    got = dict(zip(LOSS_NAMES, losses.cpu().tolist()))
+    assert abs(got["loss"] - loss.item()) < 1e-3 * max(1.0, abs(loss.item())), (got["loss"], loss.item())
+    for k in LOSS_NAMES[1:]:
+        assert abs(got[k] - aux[k].item()) < 1e-3 * max(1.0, abs(aux[k].item())), (k, got[k], aux[k].item())
+    if reduce != "mean_all":   # the normaliser really differs from the pixel count on this fixture
+        assert abs(aux["loss_mc_fp"].item() - O.compute_mc_loss(aux["pred_w"], aux["mclip"], batch["ignore_mask"]).item()) >= 0
+        assert (aux["mclip"] != 255).sum() < batch["ignore_mask"].numel()
+    og = {n: p.grad for n, p in orc.named_parameters() if p.grad is not None}
+    hg = {n: p.grad for n, p in hip.named_parameters() if p.grad is not None}
+    assert sorted(og) == sorted(hg)
+    for n in og:
+        rel = ((hg[n].cpu() - og[n]).norm() / (og[n].norm() + 1e-12)).item()
+        assert rel < 5e-3 or og[n].norm().item() < 1e-5, (n, rel, og[n].norm().item())
+    with pytest.raises(ValueError):
+        semivl_train_step(hip, to_dev(batch, dev), iters, total, dict(cfg, conf_mode="nope"))
+    with pytest.raises(ValueError):
+        semivl_train_step(hip, to_dev(batch, dev), iters, total, dict(cfg, mcc_loss_reduce="nope"))
+
+
 def test_train_step_matches_oracle_with_fused_optimizer(dev):
     """Same inputs through the oracle (torch autograd + torch AdamW on CPU) and the product (HIP kernels, flat-arena
     FusedAdamW): post-step parameters agree."""

@@ -1062,3 +1062,41 @@ def test_two_host_threads_two_streams(dev):
         t.join()
     assert not errs, errs
     assert torch.equal(res[0], refs[0]) and torch.equal(res[1], refs[1])
+
+
+@pytest.mark.gpu
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """svl_clock_probe (bench.py's roofline.clock_mhz): cycles / 100 MHz ticks of every probe wave is a clock between the
+    idle floor and the 2.4 GHz nominal, and the probe stops after the requested ticks."""
+    import ctypes
+    from semivl_amd import lib as L
+    n = 8
+    out = torch.zeros(2 * n, dtype=torch.int64, device="cuda")
+    L.check(L.load().svl_clock_probe(ctypes.c_void_p(out.data_ptr()), n, 200000,      # 2 ms
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "svl_clock_probe")
+    torch.cuda.synchronize()
+    o = out.cpu().view(n, 2)
+    assert (o[:, 1] >= 200000).all() and (o[:, 1] < 400000).all()
+    mhz = o[:, 0].double() / o[:, 1].double() * 100.0
+    assert (mhz > 90).all() and (mhz < 2600).all(), mhz
+    assert L.load().svl_clock_probe(None, n, 1000, None) != 0
+
+
+@pytest.mark.gpu
+def test_bernoulli_masks():
+    """svl_bernoulli_f32 (the dropout2d draws of the feature perturbation, builder.py:79-85): values in {0, 1}, the keep
+    rate within 5 sigma, successive calls independent, the same seed + offset reproducible."""
+    torch.manual_seed(123)
+    a = ops.bernoulli((64, 768), 0.5, "cuda")
+    b = ops.bernoulli((64, 768), 0.5, "cuda")
+    n = a.numel()
+    assert set(a.unique().tolist()) == {0.0, 1.0}
+    for t in (a, b):
+        assert abs(t.mean().item() - 0.5) < 5 * 0.5 / n ** 0.5
+    assert abs(((a == b).float().mean().item()) - 0.5) < 5 * 0.5 / n ** 0.5
+    k = ops.bernoulli((1000, 100), 0.9, "cuda")
+    assert abs(k.mean().item() - 0.9) < 5 * (0.09 / 1e5) ** 0.5
+    ops._BERNOULLI_CALLS[0] = 0
+    c1 = ops.bernoulli((8, 8), 0.5, "cuda")
+    ops._BERNOULLI_CALLS[0] = 0
+    assert torch.equal(c1, ops.bernoulli((8, 8), 0.5, "cuda"))

@@ -17,6 +17,21 @@ static inline float bf16_to_f(unsigned short h) { unsigned int u = (unsigned int
 static unsigned long long rng = 88172645463325252ull;
 static inline float urand() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (float)((rng >> 40) * (1.0 / 16777216.0)) * 2.f - 1.f; }
 
+// One wave per workgroup that samples the shader-clock counter (s_memtime) against the constant 100 MHz counter
+// (s_memrealtime) for `wall_ticks`: launched on its own stream BEFORE the timed GEMMs (X6P_CLOCK=1), it reports the clock
+// the chip actually sustains under the kernel's instruction mix (the 2500 TF bf16 peak is quoted at 2.4 GHz).
+__global__ void clock_probe(unsigned long long* out, unsigned long long wall_ticks) {
+  const unsigned long long w0 = wall_clock64(), c0 = clock64();
+  unsigned long long w = w0, c = c0;
+  while (w - w0 < wall_ticks) { __builtin_amdgcn_s_sleep(100); c = clock64(); w = wall_clock64(); }
+  out[2 * blockIdx.x] = c - c0; out[2 * blockIdx.x + 1] = w - w0;
+}
+static void probe_report(const char* what, unsigned long long* h, int n) {
+  double lo = 1e30, hi = 0, sum = 0;
+  for (int i = 0; i < n; ++i) { const double mhz = (double)h[2 * i] / (double)h[2 * i + 1] * 100.0; lo = mhz < lo ? mhz : lo; hi = mhz > hi ? mhz : hi; sum += mhz; }
+  printf("  shader clock %s: mean %.0f MHz (min %.0f, max %.0f over %d probe waves)\n", what, sum / n, lo, hi, n);
+}
+
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 32800, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
   const int iters = argc > 4 ? atoi(argv[4]) : 20, mode = argc > 5 ? atoi(argv[5]) : 0;
@@ -103,6 +118,20 @@ int main(int argc, char** argv) {
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= iters;
+  if (getenv("X6P_CLOCK")) {
+    const int NP = 64;
+    unsigned long long *dpr, hpr[2 * NP];
+    hipStream_t ps;
+    CK(hipMalloc(&dpr, sizeof hpr)); CK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    const unsigned long long ticks = (unsigned long long)(ms * iters * 0.8 * 1e5);   // 100 MHz ticks over 80 % of the timed loop
+    hipLaunchKernelGGL(clock_probe, dim3(NP), dim3(64), 0, ps, dpr, ticks);            // idle chip
+    CK(hipStreamSynchronize(ps)); CK(hipMemcpy(hpr, dpr, sizeof hpr, hipMemcpyDeviceToHost));
+    probe_report("with the chip otherwise idle", hpr, NP);
+    hipLaunchKernelGGL(clock_probe, dim3(NP), dim3(64), 0, ps, dpr, ticks);
+    for (int i = 0; i < iters; ++i) SV(svl_gemm_planes_f32(&d, nullptr));
+    CK(hipDeviceSynchronize()); CK(hipMemcpy(hpr, dpr, sizeof hpr, hipMemcpyDeviceToHost));
+    probe_report("under the back-to-back GEMM launches", hpr, NP);
+  }
   const double fl = 2.0 * M * N * K;
   printf("  %.4f ms  %.1f TF fp32-eq  %.0f TF bf16 issued (%.3f of 2500)\n", ms, fl / ms * 1e-9, 6 * fl / ms * 1e-9,
          6 * fl / ms * 1e-9 / 2500.0);
