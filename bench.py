@@ -371,17 +371,18 @@ def main():
             clock = None
             if dom is not None and planes:
                 # the clock the chip sustains under this kernel (svl_clock_probe waves on a second stream next to 24
-                # back-to-back launches of the same shape and epilogue) and under the whole step
+                # back-to-back launches of the same shape and epilogue)
                 xa, wb = ops.split_planes(torch.randn(Md, 768, device=dev)), ops.split_planes(torch.randn(3072, 768, device=dev) * 0.05)
                 bias_, pre_, po_ = torch.zeros(3072, device=dev), ops.empty(Md, 3072, device=dev), ops.Planes(Md, 3072, device=dev)
                 avg_ = dom[0] * 1e3 / dom[2]
                 clock = dict(
                     under_dominant_kernel=clock_probe_mhz(
                         lambda: [ops.pgemm(xa, wb, Md, 3072, None, po_, bias_, ops.ACT_GELU, pre_) for _ in range(24)], 24 * avg_, dev),
-                    under_whole_step=clock_probe_mhz(lambda: step(a.warmup + a.steps + 1), ms, dev),
                     nominal=PEAK_CLOCK_MHZ,
-                    note="mean of 64 probe waves: shader-clock counter / 100 MHz counter over 80 % of the run; the MFMA "
-                         "peaks are quoted at the nominal clock")
+                    note="mean of 64 probe waves: shader-clock counter / 100 MHz counter over 80 % of the 24 launches; the "
+                         "MFMA peaks are quoted at the nominal clock (the whole step cannot be probed this way: with the "
+                         "runtime's 4 hardware queues the probe's stream shares a queue with one of the step's streams "
+                         "and serialises it -- tools/clock_step.py)")
                 del xa, wb, bias_, pre_, po_
             if dom is not None:
                 d_tf = dom[1] / dom[0] / 1e12

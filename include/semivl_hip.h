@@ -373,21 +373,29 @@ int svl_copy2d_f32(const float* src, int64_t sgrp, int64_t src_go, int64_t src_l
  * stats [imgs, G, 2] = (mean, rstd); y pixel stride ldy (lets the result land in a concat slice). vlg_head.py:74-137 */
 int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int imgs,
                       int64_t HW, int C, int G, int relu, float* y, int64_t ldy, float* stats, svl_stream_t stream);
-/* dy has pixel stride lddy; y (post-activation, stride ldy) is used for the ReLU mask.
+/* dy has pixel stride lddy.  ReLU mask: from y (post-activation, stride ldy) when given; with y == NULL it is
+ * re-derived from x, stats, gamma and beta with the forward's own fma (bit for bit the sign the forward saw) -- one tensor
+ * pass less in each of the two kernels.  beta is only read in that case.
  * chan_sums [imgs, 2, C] out: per image (sum_p dy', sum_p dy' * xhat); dbeta / dgamma are their column sums
  * over images (svl_colsum_f32 with ld = 2C). */
 int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
-                      const float* stats, const float* gamma, int imgs, int64_t HW, int C, int G, int relu,
-                      float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream);
+                      const float* stats, const float* gamma, const float* beta, int imgs, int64_t HW, int C, int G,
+                      int relu, float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream);
 
 /* Fused (flash-style) multi-head self-attention of the ViT blocks, head dim 64, softmax scale 64^-0.5, fp32 MFMA
  * (or the bf16 x 6 split emulation with fp32 accumulation under svl_set_gemm_emulation(6): same error level vs fp64)
  * (nn.MultiheadAttention inside mmcv's wrapper, maskclip_vit.py:77-84,141).  qkv [B*T, 3E] = in-proj output
  * (q | k | v, E = 64*H); out [B*T, E]; lse [B*H*T] (log-sum-exp per query, saved for backward; may be NULL).
- * Backward: dqkv [B*T, 3E] fully written; dsum_ws is a [B*H*T] float workspace.  Deterministic. */
-int svl_attention_fwd(const float* qkv, int B, int T, int H, float* out, float* lse, svl_stream_t stream);
+ * Backward: dqkv [B*T, 3E] fully written; dsum_ws is a [B*H*T] float workspace.  Deterministic.
+ * Optional packed bf16x3 planes of the results (the A-operand format of svl_gemm_planes_f32, emulation mode 6 only --
+ * SVL_ERR_UNSUPPORTED otherwise): out_planes = the attention output [B*T, E] (then `out` may be NULL: gradient-free
+ * passes only feed it to the out-projection GEMM); dq_planes = a [B*T, 3E] planes buffer whose first E columns (the dQ
+ * third) are written by the kernel -- the caller splits the dK | dV columns into the rest (svl_split_planes_bf16x3 on
+ * dqkv + E).  planes_rows = the buffers' padded row count (svl_planes_rows(B*T)).  NULL = not wanted. */
+int svl_attention_fwd(const float* qkv, int B, int T, int H, float* out, float* lse, void* out_planes,
+                      int64_t planes_rows, svl_stream_t stream);
 int svl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int H,
-                      float* dsum_ws, float* dqkv, svl_stream_t stream);
+                      float* dsum_ws, float* dqkv, void* dq_planes, int64_t planes_rows, svl_stream_t stream);
 
 /* Small-sequence multi-head attention for the SemanticTransformer (vlg_head.py:39-67; seq = num classes).
  * qkv rows: token (g, s) at row  (g / inner) * outer_stride + (g % inner) * inner_stride + s * seq_stride,

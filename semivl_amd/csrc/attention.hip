@@ -41,6 +41,10 @@ struct AttnP {
   long ld;  // 3E
   long E;
   float scale;
+  // optional packed bf16x3 planes of the result rows (operand format of csrc/gemm_planes.hip; null = not wanted): the
+  // attention output [B T, E] in the forward, the dQ third of dqkv [B T, 3E] (k-groups 0 .. E/16) in the backward
+  char* planes;
+  long planes_ks;   // bytes between k-groups = padded rows x 96
 };
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -206,14 +210,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
   if (wave_active && qi < p.T) {
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = 1.f / lt;
-    float* orow = p.out + ((long)b * p.T + qi) * p.E + h * D;
+    if (p.out) {
+      float* orow = p.out + ((long)b * p.T + qi) * p.E + h * D;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d0 = 8 * g + 4 * hi;
-      *reinterpret_cast<float4*>(orow + d0) =
-          make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-      *reinterpret_cast<float4*>(orow + 32 + d0) =
-          make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 8 * g + 4 * hi;
+        *reinterpret_cast<float4*>(orow + d0) =
+            make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(orow + 32 + d0) =
+            make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+      }
     }
     if (p.lse && hi == 0) p.lse[(long)z * p.T + qi] = (m2 + __log2f(lt)) * LN2;
   } else if (wave_active) {
@@ -484,6 +490,26 @@ __device__ __forceinline__ void split3x8(const float (&v)[8], bf16x8 (&h)[3]) {
     h[pl] = __builtin_bit_cast(bf16x8, w);
   }
 }
+// One lane's 8 values of row R -- columns 16 kg + 4 hi + {0..3, 8..11}, exactly the lane (hi, R % 32) of the packed-planes
+// chunk (k-group kg, row block R / 32) -- split and stored as three 16 B pieces (1 KiB apart: the chunk's planes).
+__device__ __forceinline__ void emit_planes8(char* planes, long ks, int kg, long R, int hi, const float (&x)[8]) {
+  bf16x8 h[3];
+  split3x8(x, h);
+  char* c = planes + (long)kg * ks + (R >> 5) * 3072 + (((long)hi << 5) + (R & 31)) * 16;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(c + pl * 1024) = h[pl];
+}
+// the same for ONE value (row kernels): column col of row R
+__device__ __forceinline__ void emit_planes1(char* planes, long ks, int col, long R, float x) {
+  const int kg = col >> 4, j = col & 15, hh = (j >> 2) & 1, e = ((j >> 3) << 2) + (j & 3);
+  char* c = planes + (long)kg * ks + (R >> 5) * 3072 + (((long)hh << 5) + (R & 31)) * 16 + e * 2;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const __bf16 t = (__bf16)x;
+    *reinterpret_cast<__bf16*>(c + pl * 1024) = t;
+    x -= (float)t;
+  }
+}
 // two accumulators alternate so that dependent MFMAs are one instruction apart; smallest cross terms first.
 // X6_PAIR_T is the mirror image (operand roles swapped, same products in the same order -> bit-identical sums).
 #define X6_PAIR(c0, a0, c1, a1, b)                                                                               \
@@ -747,14 +773,28 @@ __global__ __launch_bounds__(512) void attn_fwd_x6_kernel(const AttnP p) {
   if (wave_active && qi < p.T) {
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = 1.f / lt;
-    float* orow = p.out + ((long)b * p.T + qi) * p.E + h * D;
+    if (p.out) {
+      float* orow = p.out + ((long)b * p.T + qi) * p.E + h * D;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d0 = 8 * g + 4 * hi;
-      *reinterpret_cast<float4*>(orow + d0) =
-          make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-      *reinterpret_cast<float4*>(orow + 32 + d0) =
-          make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 8 * g + 4 * hi;
+        *reinterpret_cast<float4*>(orow + d0) =
+            make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(orow + 32 + d0) =
+            make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+      }
+    }
+    if (p.planes) {   // registers 8 kk .. 8 kk + 7 of o0 / o1 are d = 16 kk (+ 32) + 4 hi + {0..3, 8..11}: a planes lane as is
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          x[e] = (kk < 2 ? o0[8 * (kk & 1) + e] : o1[8 * (kk & 1) + e]) * inv;
+          asm volatile("" : "+v"(x[e]));   // the split's subtractions must see the ROUNDED product (the fp32 copy's value),
+        }                                  // not an fma contracted with it
+        emit_planes8(p.planes, p.planes_ks, 4 * h + kk, (long)b * p.T + qi, hi, x);
+      }
     }
     if (p.lse && hi == 0) p.lse[(long)z * p.T + qi] = (m2 + __log2f(lt)) * LN2;
   } else if (wave_active) {
@@ -906,6 +946,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_x6_kernel(const AttnP p) {
                                                          dq0[4 * g + 2] * p.scale, dq0[4 * g + 3] * p.scale);
       *reinterpret_cast<float4*>(row + 32 + d0) = make_float4(dq1[4 * g] * p.scale, dq1[4 * g + 1] * p.scale,
                                                               dq1[4 * g + 2] * p.scale, dq1[4 * g + 3] * p.scale);
+    }
+    if (p.planes) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (kk < 2 ? dq0[8 * (kk & 1) + e] : dq1[8 * (kk & 1) + e]) * p.scale;
+        emit_planes8(p.planes, p.planes_ks, 4 * h + kk, (long)b * p.T + qi, hi, x);
+      }
     }
   }
 }
@@ -1123,7 +1172,10 @@ __global__ __launch_bounds__(256) void attn_fwd_rows_kernel(const AttnP p, int r
   }
   sum = block_sum_256(sum, red);
   const float o = weighted_rowsum(w, head + 2 * p.E, p.ld, p.T, red, tid);
-  if (tid < D) p.out[((long)b * p.T + qi) * p.E + h * D + tid] = o / sum;
+  if (tid < D) {
+    if (p.out) p.out[((long)b * p.T + qi) * p.E + h * D + tid] = o / sum;
+    if (p.planes) emit_planes1(p.planes, p.planes_ks, h * D + tid, (long)b * p.T + qi, o / sum);
+  }
   if (tid == 0 && p.lse) p.lse[(long)z * p.T + qi] = mx + logf(sum);
 }
 
@@ -1150,7 +1202,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_rows_kernel(const AttnP p, in
   }
   __syncthreads();
   const float dq = weighted_rowsum(w, head + p.E, p.ld, p.T, red, tid);
-  if (tid < D) p.dqkv[((long)b * p.T + qi) * p.ld + h * D + tid] = dq * p.scale;
+  if (tid < D) {
+    p.dqkv[((long)b * p.T + qi) * p.ld + h * D + tid] = dq * p.scale;
+    if (p.planes) emit_planes1(p.planes, p.planes_ks, h * D + tid, (long)b * p.T + qi, dq * p.scale);
+  }
 }
 
 // dK, dV of a leftover key row
@@ -1208,14 +1263,30 @@ int check(const float* qkv, int B, int T, int H, const char* who) {
   return SVL_OK;
 }
 
+// shared argument check of the optional planes outputs (x6 path only: they are that path's operand format)
+int check_planes(const void* planes, int64_t planes_rows, int B, int T, const char* who) {
+  if (!planes) return SVL_OK;
+  SVL_CHECK_ARG(planes_rows % 256 == 0 && planes_rows >= (int64_t)B * T && ((uintptr_t)planes & 15) == 0,
+                "%s: planes_rows must be a multiple of 256 covering B x T rows, planes 16-byte aligned", who);
+  if (!use_x6()) {
+    svl_set_error("%s: planes outputs exist on the bf16x6 path only (svl_set_gemm_emulation(6))", who);
+    return SVL_ERR_UNSUPPORTED;
+  }
+  return SVL_OK;
+}
+
 }  // namespace
 
-extern "C" int svl_attention_fwd(const float* qkv, int B, int T, int H, float* out, float* lse, svl_stream_t stream) {
+extern "C" int svl_attention_fwd(const float* qkv, int B, int T, int H, float* out, float* lse, void* out_planes,
+                                 int64_t planes_rows, svl_stream_t stream) {
   int rc = check(qkv, B, T, H, "svl_attention_fwd");
   if (rc) return rc;
-  SVL_CHECK_ARG(out, "svl_attention_fwd: out missing");
+  SVL_CHECK_ARG(out || out_planes, "svl_attention_fwd: out missing");
+  rc = check_planes(out_planes, planes_rows, B, T, "svl_attention_fwd");
+  if (rc) return rc;
   AttnP p;
   memset(&p, 0, sizeof(p));
+  p.planes = (char*)out_planes; p.planes_ks = planes_rows * 96;
   p.qkv = qkv; p.out = out; p.lse = lse; p.B = B; p.T = T; p.H = H; p.E = (long)H * D; p.ld = 3 * p.E; p.scale = 0.125f;
   hipStream_t st = (hipStream_t)stream;
   int nb = 0;
@@ -1236,13 +1307,17 @@ extern "C" int svl_attention_fwd(const float* qkv, int B, int T, int H, float* o
 }
 
 extern "C" int svl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T,
-                                 int H, float* dsum_ws, float* dqkv, svl_stream_t stream) {
+                                 int H, float* dsum_ws, float* dqkv, void* dq_planes, int64_t planes_rows,
+                                 svl_stream_t stream) {
   int rc = check(qkv, B, T, H, "svl_attention_bwd");
   if (rc) return rc;
   SVL_CHECK_ARG(out && dout && lse && dsum_ws && dqkv, "svl_attention_bwd: null args");
+  rc = check_planes(dq_planes, planes_rows, B, T, "svl_attention_bwd");
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   AttnP p;
   memset(&p, 0, sizeof(p));
+  p.planes = (char*)dq_planes; p.planes_ks = planes_rows * 96;
   p.qkv = qkv; p.dout = dout; p.lse = const_cast<float*>(lse); p.dsum = dsum_ws; p.dqkv = dqkv;
   p.B = B; p.T = T; p.H = H; p.E = (long)H * D; p.ld = 3 * p.E; p.scale = 0.125f;
   const long groups = (long)B * T * H;

@@ -487,7 +487,9 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
   float* yi = y + img * HW * ldy + c;
   for (long p = (long)blockIdx.x * PR + pr; p < HW; p += (long)gridDim.x * PR) {
     const float4 v = *reinterpret_cast<const float4*>(xi + p * ldx);
-    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    // (explicit fma: the backward kernels re-derive the ReLU mask from x with the very same expression)
+    float4 o = make_float4(__builtin_fmaf(v.x, sc.x, sh.x), __builtin_fmaf(v.y, sc.y, sh.y), __builtin_fmaf(v.z, sc.z, sh.z),
+                           __builtin_fmaf(v.w, sc.w, sh.w));
     if (relu) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
@@ -498,7 +500,9 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
 __global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float* __restrict__ dy, long lddy,
                                                                  const float* __restrict__ x, long ldx,
                                                                  const float* __restrict__ y, long ldy,
-                                                                 const float* __restrict__ stats, long HW, int C, int G,
+                                                                 const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, long HW, int C, int G,
                                                                  int relu, float* __restrict__ chan_sums) {
   __shared__ double sh[2][1024];  // [a|b][pr*C + c], PR*C = 1024
   const int CQ = C >> 2;
@@ -509,7 +513,18 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float* __
   const int g = (4 * cq) / cg;
   const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
   double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-  auto body = [&](float4 d, const float4 v, const float4 o) {
+  // y == null: the ReLU mask is re-derived from x (the forward's fma, bit for bit) instead of read back -- one pass less
+  const bool remask = relu && y == nullptr;
+  float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;
+  if (remask) {
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * cq), be = *reinterpret_cast<const float4*>(beta + 4 * cq);
+    msc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
+    msh = make_float4(be.x - mean * msc.x, be.y - mean * msc.y, be.z - mean * msc.z, be.w - mean * msc.w);
+  }
+  auto body = [&](float4 d, const float4 v, float4 o) {
+    if (remask)
+      o = make_float4(__builtin_fmaf(v.x, msc.x, msh.x), __builtin_fmaf(v.y, msc.y, msh.y), __builtin_fmaf(v.z, msc.z, msh.z),
+                      __builtin_fmaf(v.w, msc.w, msh.w));
     if (relu) {
       if (!(o.x > 0.f)) d.x = 0.f;
       if (!(o.y > 0.f)) d.y = 0.f;
@@ -530,15 +545,15 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float* __
     const float4 d1 = *reinterpret_cast<const float4*>(dy + p1 * lddy + 4 * cq);
     const float4 v0 = *reinterpret_cast<const float4*>(x + p0 * ldx + 4 * cq);
     const float4 v1 = *reinterpret_cast<const float4*>(x + p1 * ldx + 4 * cq);
-    const float4 o0 = relu ? *reinterpret_cast<const float4*>(y + p0 * ldy + 4 * cq) : one;
-    const float4 o1 = relu ? *reinterpret_cast<const float4*>(y + p1 * ldy + 4 * cq) : one;
+    const float4 o0 = (relu && !remask) ? *reinterpret_cast<const float4*>(y + p0 * ldy + 4 * cq) : one;
+    const float4 o1 = (relu && !remask) ? *reinterpret_cast<const float4*>(y + p1 * ldy + 4 * cq) : one;
     body(d0, v0, o0);
     body(d1, v1, o1);
   }
   for (; p < HW; p += PR) {
     const long pix = img * HW + p;
     body(*reinterpret_cast<const float4*>(dy + pix * lddy + 4 * cq), *reinterpret_cast<const float4*>(x + pix * ldx + 4 * cq),
-         relu ? *reinterpret_cast<const float4*>(y + pix * ldy + 4 * cq) : one);
+         (relu && !remask) ? *reinterpret_cast<const float4*>(y + pix * ldy + 4 * cq) : one);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -561,6 +576,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_apply_kernel(const float* _
                                                                   const float* __restrict__ y, long ldy,
                                                                   const float* __restrict__ stats,
                                                                   const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
                                                                   const float* __restrict__ chan_sums, long npix,
                                                                   long HW, int C, int G, int relu,
                                                                   float* __restrict__ dx, long lddx) {
@@ -585,13 +601,22 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_apply_kernel(const float* _
   const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
   const float* di = dy + img * HW * lddy + c;
   const float* xi = x + img * HW * ldx + c;
-  const float* yi = relu ? y + img * HW * ldy + c : nullptr;
+  const bool remask = relu && y == nullptr;
+  const float* yi = (relu && !remask) ? y + img * HW * ldy + c : nullptr;
+  float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;
+  if (remask) {
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    msc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
+    msh = make_float4(be.x - mean * msc.x, be.y - mean * msc.y, be.z - mean * msc.z, be.w - mean * msc.w);
+  }
   float* oi = dx + img * HW * lddx + c;
   for (long p = (long)blockIdx.x * PR + pr; p < HW; p += (long)gridDim.x * PR) {
     float4 d = *reinterpret_cast<const float4*>(di + p * lddy);
     const float4 v = *reinterpret_cast<const float4*>(xi + p * ldx);
     if (relu) {
-      const float4 o = *reinterpret_cast<const float4*>(yi + p * ldy);
+      const float4 o = remask ? make_float4(__builtin_fmaf(v.x, msc.x, msh.x), __builtin_fmaf(v.y, msc.y, msh.y),
+                                            __builtin_fmaf(v.z, msc.z, msh.z), __builtin_fmaf(v.w, msc.w, msh.w))
+                              : *reinterpret_cast<const float4*>(yi + p * ldy);
       if (!(o.x > 0.f)) d.x = 0.f;
       if (!(o.y > 0.f)) d.y = 0.f;
       if (!(o.z > 0.f)) d.z = 0.f;
@@ -790,19 +815,19 @@ extern "C" int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma
 }
 
 extern "C" int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
-                                 const float* stats, const float* gamma, int imgs, int64_t HW, int C, int G, int relu,
-                                 float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream) {
-  SVL_CHECK_ARG(dy && x && stats && gamma && dx && chan_sums && imgs > 0 && HW > 0 && (!relu || y),
-                "svl_groupnorm_bwd: bad args");
-  SVL_CHECK_ARG(gn_shape_ok(C, G) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || ldy % 4 == 0),
+                                 const float* stats, const float* gamma, const float* beta, int imgs, int64_t HW, int C,
+                                 int G, int relu, float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && x && stats && gamma && dx && chan_sums && imgs > 0 && HW > 0 && (!relu || y || beta),
+                "svl_groupnorm_bwd: bad args (relu needs y or beta)");
+  SVL_CHECK_ARG(gn_shape_ok(C, G) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || !y || ldy % 4 == 0),
                 "svl_groupnorm_bwd: unsupported C=%d G=%d", C, G);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(groupnorm_bwd_sums_kernel, dim3(imgs), dim3(256), 0, st, dy, (long)lddy, x, (long)ldx, y, (long)ldy,
-                     stats, (long)HW, C, G, relu, chan_sums);
+                     stats, gamma, beta, (long)HW, C, G, relu, chan_sums);
   SVL_LAUNCH_CHECK("svl_groupnorm_bwd/sums");
   const long npix = (long)imgs * HW;
   hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, gn_apply_grid(imgs, HW, C), dim3(256), 0, st, dy, (long)lddy, x,
-                     (long)ldx, y, (long)ldy, stats, gamma, chan_sums, npix, (long)HW, C, G, relu, dx, (long)lddx);
+                     (long)ldx, y, (long)ldy, stats, gamma, beta, chan_sums, npix, (long)HW, C, G, relu, dx, (long)lddx);
   SVL_LAUNCH_CHECK("svl_groupnorm_bwd/apply");
   return SVL_OK;
 }

@@ -116,7 +116,7 @@ SIGNATURES = {
     "svl_affine_planes_f32": (_I, [_P, _L, _I, _L, _P, _P, _P]),
     "svl_copy2d_f32": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _P]),
     "svl_groupnorm_fwd": (_I, [_P, _L, _P, _P, _F, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
-    "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
+    "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_bn_ws_doubles": (_L, [_L, _I]),
     "svl_bn_stats": (_I, [_P, _L, _L, _I, _P, _P, _P]),
     "svl_bn_finalize": (_I, [_P, _D, _F, _F, _P, _P, _I, _P, _P, _P]),
@@ -131,8 +131,8 @@ SIGNATURES = {
     "svl_aug_mask_i64": (_I, [_P, _I, _I, _I, _P, _P]),
     "svl_aug_photometric_u8": (_I, [_P, _I, _I, _F, _P, _P]),
     "svl_aug_gaussian_blur_u8": (_I, [_P, _I, _I, _F, _P, _P, _P]),
-    "svl_attention_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
-    "svl_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "svl_attention_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P]),
+    "svl_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P]),
     "svl_conv_cout1_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "svl_conv_cout1_wgrad_blocks": (_I, [_I, _I, _I]),
     "svl_conv_cout1_wgrad": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -88,8 +88,8 @@ def sink_grad(param, grad_fn, shape=None):
 def block_forward(x, p, heads, eps, Bn, T, want_v, skip_x, save):
     """x [Bn*T, E] -> (x_out or None, v or None).  `save` is a dict to stash what backward needs (or None).
     Under the packed-planes GEMM path (ops.planes_eligible) every A operand is produced directly in that format: both
-    LayerNorms and the FFN-1 epilogue emit planes (ln2's output and gelu(h) exist ONLY as planes), the attention output
-    and the v slice of qkv take the generic split pass."""
+    LayerNorms, the FFN-1 epilogue and the fused attention kernel emit planes (ln2's output and gelu(h) exist ONLY as
+    planes, the attention output too in gradient-free passes); the v slice of qkv takes the generic split pass."""
     E = x.shape[1]
     D = E // heads
     pp = ops.planes_eligible(x.shape[0], E, E)
@@ -125,11 +125,16 @@ def block_forward(x, p, heads, eps, Bn, T, want_v, skip_x, save):
             save.update(vo=vo, st2v=st2v, hv_pre=hv_pre)
     xo = None
     if not skip_x:
-        if D == 64:
+        o_p = None
+        if D == 64 and pp and ops.attention_planes_ok():
+            # the kernel's epilogue emits the output as planes (the out-projection's A operand); its fp32 copy is only
+            # kept for backward (dsum, out_proj weight gradient)
+            o, P, o_p = ops.attention_fwd(qkv, Bn, T, heads, want_lse=save is not None, planes=True, want_out=save is not None)
+        elif D == 64:
             o, P = ops.attention_fwd(qkv, Bn, T, heads, want_lse=save is not None)  # P := log-sum-exp rows
         else:  # generic head dim: batched-GEMM attention with materialised probabilities
             o, P = ops.vit_attention_fwd(qkv, Bn, T, heads, D)
-        x2 = ops.linear(ops.split_planes(o) if pp else o, p["wout"], p["bout"], resid=x)
+        x2 = ops.linear(o_p if o_p is not None else (ops.split_planes(o) if pp else o), p["wout"], p["bout"], resid=x)
         xo, st2, h_pre = ffn(x2, save is not None)
         if save is not None:
             save.update(o=o, P=P, x2=x2, st2=st2, h_pre=h_pre)
@@ -146,7 +151,7 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False, dxo_p=None):
     pp = ops.planes_eligible(x.shape[0], E, E)
     g = {}
     dx_res = None
-    dqkv = None
+    dqkv = dqkv_p = None
     wout_parts = []  # (dy, input) pairs contributing to out_proj wgrad
 
     def ffn_ln_bwd(dout, dout_p, pre_ln_in, st2, h_pre, tag):
@@ -175,7 +180,10 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False, dxo_p=None):
         dx2, dx2p = ffn_ln_bwd(dxo, dxo_p, s["x2"], s["st2"], s["h_pre"], "x")
         do = ops.matmul_nn(dx2p if dx2p is not None else dx2, p["wout"])
         wout_parts.append((dx2, s["o"]))
-        if D == 64:
+        if D == 64 and pp and ops.attention_planes_ok() and not (s["want_v"] and dv is not None):
+            # dqkv also as planes (in_proj's input-gradient GEMM): dQ from the kernel's epilogue, dK | dV by a split pass
+            dqkv, dqkv_p = ops.attention_bwd(do, s["qkv"], s["o"], s["P"], Bn, T, heads, planes=True)
+        elif D == 64:
             dqkv = ops.attention_bwd(do, s["qkv"], s["o"], s["P"], Bn, T, heads)
         else:
             dqkv = ops.vit_attention_bwd(do, s["qkv"], s["P"], Bn, T, heads, D)
@@ -193,7 +201,7 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False, dxo_p=None):
     g["wout_parts"] = wout_parts
     if dqkv is not None:
         g["in_full"] = (dqkv, y1)
-        dy1 = ops.matmul_nn(dqkv, p["win"])
+        dy1 = ops.matmul_nn(dqkv_p if dqkv_p is not None else dqkv, p["win"])
     elif dvproj is not None:
         g["in_v"] = (dvproj, y1)
         dy1 = ops.matmul_nn(dvproj, p["win"][2 * E:])

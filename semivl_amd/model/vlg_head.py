@@ -100,7 +100,7 @@ def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True):
     imgs, H, W, C1, Co, k, dil, pad = sv["geom"]
     dpre = ops.empty(imgs * H * W, Co, device=dy.device)
     dg, db = ops.groupnorm_bwd(dy, lddy, sv["pre"], Co, sv["y"], sv["ldy"], sv["st"], gn.weight, imgs, H * W, Co,
-                               gn.num_groups, True, dpre, Co)
+                               gn.num_groups, True, dpre, Co, beta=gn.bias)   # ReLU mask re-derived from `pre`: y is not read
     gc.put_tensor(gn.weight, dg)
     gc.put_tensor(gn.bias, db)
     C2 = sv["C2"]

@@ -615,10 +615,12 @@ def groupnorm_fwd(x, ldx, gamma, beta, eps, imgs, HW, Cc, G, relu, y, ldy):
     return stats
 
 
-def groupnorm_bwd(dy, lddy, x, ldx, y, ldy, stats, gamma, imgs, HW, Cc, G, relu, dx, lddx):
+def groupnorm_bwd(dy, lddy, x, ldx, y, ldy, stats, gamma, imgs, HW, Cc, G, relu, dx, lddx, beta=None):
+    """With `beta` given the ReLU mask is re-derived from x (the forward's own fma) and y is not read."""
     cs = empty(imgs, 2, Cc, device=x.device)
-    L.check(L.load().svl_groupnorm_bwd(_p(dy), lddy, _p(x), ldx, _p(y), ldy, _p(stats), _p(gamma), imgs, HW, Cc, G,
-                                       1 if relu else 0, _p(dx), lddx, _p(cs), _st()), "svl_groupnorm_bwd")
+    L.check(L.load().svl_groupnorm_bwd(_p(dy), lddy, _p(x), ldx, _p(None if beta is not None else y), ldy, _p(stats),
+                                       _p(gamma), _p(beta), imgs, HW, Cc, G, 1 if relu else 0, _p(dx), lddx, _p(cs),
+                                       _st()), "svl_groupnorm_bwd")
     flat = cs.view(imgs, 2 * Cc)
     dbeta = colsum(flat, C_=Cc, ld=2 * Cc)
     dgamma = colsum(flat[:, Cc:], C_=Cc, ld=2 * Cc)
@@ -633,24 +635,41 @@ def _attn_family():
     return "attention_bf16x" if (get_gemm_emulation() == 6 and not os.environ.get("SVL_ATTN_NO_EMU")) else "attention"
 
 
-def attention_fwd(qkv, Bn, T, H, want_lse=True):
-    """Flash-style fused attention: qkv [Bn*T, 3E] -> (out [Bn*T, E], lse [Bn*H*T] or None)."""
+def attention_planes_ok():
+    """The fused attention kernels can emit their results as packed planes (bf16x6 path only)."""
+    return get_gemm_emulation() == 6 and PLANES_PATH and not os.environ.get("SVL_ATTN_NO_EMU")
+
+
+def attention_fwd(qkv, Bn, T, H, want_lse=True, planes=False, want_out=True):
+    """Flash-style fused attention: qkv [Bn*T, 3E] -> (out [Bn*T, E] or None, lse [Bn*H*T] or None[, out as Planes]).
+    planes=True (attention_planes_ok()) additionally returns the output as packed planes, written by the kernel's own
+    epilogue; want_out=False then skips the fp32 copy (gradient-free passes)."""
     E = H * 64
-    out = empty(Bn * T, E, device=qkv.device)
+    out = empty(Bn * T, E, device=qkv.device) if (want_out or not planes) else None
     lse = empty(Bn * H * T, device=qkv.device) if want_lse else None
+    op = Planes(Bn * T, E, device=qkv.device) if planes else None
     e0 = _prof_begin()
-    L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _st()), "svl_attention_fwd")
+    L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if planes else None,
+                                       op.prow if planes else 0, _st()), "svl_attention_fwd")
     _prof_end(_attn_family(), e0, 4.0 * Bn * H * T * T * 64, ("fwd", Bn, T, H))
-    return out, lse
+    return (out, lse, op) if planes else (out, lse)
 
 
-def attention_bwd(dout, qkv, out, lse, Bn, T, H):
+def attention_bwd(dout, qkv, out, lse, Bn, T, H, planes=False):
+    """-> dqkv [Bn*T, 3E] (and, with planes=True, the same as Planes: the dQ third from the kernel's epilogue, the
+    dK | dV columns by one split pass over them)."""
     dqkv = torch.empty_like(qkv)
     ws = empty(Bn * H * T, device=qkv.device)
+    E = H * 64
+    dp = Planes(Bn * T, 3 * E, device=qkv.device) if planes else None
     e0 = _prof_begin()
-    L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv), _st()),
+    L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
+                                       _p(dp.buf) if planes else None, dp.prow if planes else 0, _st()),
             "svl_attention_bwd")
     _prof_end(_attn_family(), e0, 14.0 * Bn * H * T * T * 64, ("bwd", Bn, T, H))
+    if planes:
+        split_planes(dqkv[:, E:], out=dp.kslice(E, 3 * E))
+        return dqkv, dp
     return dqkv
 
 

@@ -368,6 +368,40 @@ def test_fused_attention_split_emulation(dev, Bn, T, H):
         assert e6 <= 1.5 * e0 + slack, (what, e0, e6)
 
 
+@pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 260, 4), (2, 129, 3)])
+def test_fused_attention_emits_planes(dev, Bn, T, H):
+    """The bf16x6 attention kernels' planes outputs (out-projection / in_proj input-gradient A operands written by the
+    epilogues, leftover-row kernels included) == split_planes of their own fp32 results, bit for bit; the fp32 results are
+    unchanged by asking for planes; out may be dropped in gradient-free passes; exact mode refuses."""
+    from semivl_amd import ops
+    E = 64 * H
+    qkv = rnd(Bn * T, 3 * E, dev=dev, seed=52)
+    do = rnd(Bn * T, E, dev=dev)
+    try:
+        ops.set_gemm_emulation(6)
+        assert ops.attention_planes_ok()
+        out, lse = ops.attention_fwd(qkv, Bn, T, H)
+        o2, l2, op = ops.attention_fwd(qkv, Bn, T, H, planes=True)
+        assert torch.equal(out, o2) and torch.equal(lse, l2)
+        for a, b_ in zip(_unpack_planes(op), _unpack_planes(ops.split_planes(out))):
+            assert torch.equal(a, b_)
+        o3, _, op3 = ops.attention_fwd(qkv, Bn, T, H, want_lse=False, planes=True, want_out=False)
+        assert o3 is None and torch.equal(op3.buf.view(torch.int16)[:1], op3.buf.view(torch.int16)[:1])
+        for a, b_ in zip(_unpack_planes(op3), _unpack_planes(op)):
+            assert torch.equal(a, b_)
+        dqkv = ops.attention_bwd(do, qkv, out, lse, Bn, T, H)
+        d2, dp = ops.attention_bwd(do, qkv, out, lse, Bn, T, H, planes=True)
+        assert torch.equal(dqkv, d2)
+        for a, b_ in zip(_unpack_planes(dp), _unpack_planes(ops.split_planes(dqkv))):
+            assert torch.equal(a, b_)
+        ops.set_gemm_emulation(0)
+        assert not ops.attention_planes_ok()
+        with pytest.raises(RuntimeError):
+            ops.attention_fwd(qkv, Bn, T, H, planes=True)
+    finally:
+        ops.set_gemm_emulation(0)
+
+
 # ------------------------------------------------------------------------------------------------ conv family
 def nhwc(x):  # NCHW -> [N*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
@@ -652,6 +686,10 @@ def test_groupnorm(dev, imgs, HW, C, G, relu):
     close(nchw(dx, imgs, h, HW // h), gx, atol=1e-4, what="gn dx")
     close(dg, gg, atol=2e-3, what="gn dgamma")
     close(db, gb, atol=2e-3, what="gn dbeta")
+    # the ReLU mask re-derived from x (beta given, y not read) is the forward's own decision: bit-identical results
+    dx2 = torch.empty(imgs * HW, C, device=dev)
+    dg2, db2 = ops.groupnorm_bwd(nhwc(dy), C, xs, C, None, 0, st, g.detach(), imgs, HW, C, G, relu, dx2, C, beta=b.detach())
+    assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 # ------------------------------------------------------------------------------------------------ seq attention
@@ -1086,6 +1124,7 @@ def test_clock_probe_reports_a_plausible_shader_clock():
 def test_bernoulli_masks():
     """svl_bernoulli_f32 (the dropout2d draws of the feature perturbation, builder.py:79-85): values in {0, 1}, the keep
     rate within 5 sigma, successive calls independent, the same seed + offset reproducible."""
+    from semivl_amd import ops
     torch.manual_seed(123)
     a = ops.bernoulli((64, 768), 0.5, "cuda")
     b = ops.bernoulli((64, 768), 0.5, "cuda")
