@@ -389,13 +389,12 @@ int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx
  * Backward: dqkv [B*T, 3E] fully written; dsum_ws is a [B*H*T] float workspace.  Deterministic.
  * Optional packed bf16x3 planes of the results (the A-operand format of svl_gemm_planes_f32, emulation mode 6 only --
  * SVL_ERR_UNSUPPORTED otherwise): out_planes = the attention output [B*T, E] (then `out` may be NULL: gradient-free
- * passes only feed it to the out-projection GEMM); dq_planes = a [B*T, 3E] planes buffer whose first E columns (the dQ
- * third) are written by the kernel -- the caller splits the dK | dV columns into the rest (svl_split_planes_bf16x3 on
- * dqkv + E).  planes_rows = the buffers' padded row count (svl_planes_rows(B*T)).  NULL = not wanted. */
+ * passes only feed it to the out-projection GEMM); dq_planes = dqkv [B*T, 3E] (in_proj's input-gradient operand).
+ * planes_rows = the buffers' padded row count (svl_planes_rows(B*T)).  NULL = not wanted. */
 int svl_attention_fwd(const float* qkv, int B, int T, int H, float* out, float* lse, void* out_planes,
                       int64_t planes_rows, svl_stream_t stream);
 int svl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int H,
-                      float* dsum_ws, float* dqkv, void* dq_planes, int64_t planes_rows, svl_stream_t stream);
+                      float* dsum_ws, float* dqkv, void* dqkv_planes, int64_t planes_rows, svl_stream_t stream);
 
 /* Small-sequence multi-head attention for the SemanticTransformer (vlg_head.py:39-67; seq = num classes).
  * qkv rows: token (g, s) at row  (g / inner) * outer_stride + (g % inner) * inner_stride + s * seq_stride,

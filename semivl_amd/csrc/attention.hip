@@ -42,7 +42,7 @@ struct AttnP {
   long E;
   float scale;
   // optional packed bf16x3 planes of the result rows (operand format of csrc/gemm_planes.hip; null = not wanted): the
-  // attention output [B T, E] in the forward, the dQ third of dqkv [B T, 3E] (k-groups 0 .. E/16) in the backward
+  // attention output [B T, E] in the forward, dqkv [B T, 3E] in the backward (dQ by the dq kernel, dK | dV by the dkv kernel)
   char* planes;
   long planes_ks;   // bytes between k-groups = padded rows x 96
 };
@@ -1115,6 +1115,33 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_x6_kernel(const AttnP p) {
         row[2 * p.E + 32 + l31] = dv1[r];
       }
     }
+    if (p.planes) {
+      // the dK | dV columns of the planes: a planes lane is (key, 8 d) where a C register is (d, key) -- the wave's
+      // [32 keys][64 d] tile goes through its own 9 KB of the (now idle) staging LDS; row stride 72 floats keeps the two
+      // half-waves' scalar writes (keys 4 apart) on disjoint banks.  LDS traffic of one wave is in order: no barrier.
+      float* tr = reinterpret_cast<float*>(sm) + wave * (32 * 72);
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          tr[crow(r, hi) * 72 + l31] = which ? dv0[r] : dk0[r];
+          tr[crow(r, hi) * 72 + 32 + l31] = which ? dv1[r] : dk1[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (k0 + l31 < p.T) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const float4 u = *reinterpret_cast<const float4*>(tr + l31 * 72 + 16 * kk + 4 * hi);
+            const float4 w = *reinterpret_cast<const float4*>(tr + l31 * 72 + 16 * kk + 4 * hi + 8);
+            const float x[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+            emit_planes8(p.planes, p.planes_ks, (int)((which + 1) * (p.E >> 4)) + 4 * h + kk, (long)b * p.T + k0 + l31, hi, x);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
   }
 }
 
@@ -1240,6 +1267,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_rows_kernel(const AttnP p, i
     float* row = p.dqkv + ((long)b * p.T + kj) * p.ld + h * D;
     row[p.E + tid] = dk * p.scale;
     row[2 * p.E + tid] = dv;
+    if (p.planes) {
+      emit_planes1(p.planes, p.planes_ks, (int)p.E + h * D + tid, (long)b * p.T + kj, dk * p.scale);
+      emit_planes1(p.planes, p.planes_ks, 2 * (int)p.E + h * D + tid, (long)b * p.T + kj, dv);
+    }
   }
 }
 

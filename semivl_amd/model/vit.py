@@ -181,7 +181,7 @@ def block_backward(dxo, dv, p, s, heads, Bn, T, train_ffn_ln=False, dxo_p=None):
         do = ops.matmul_nn(dx2p if dx2p is not None else dx2, p["wout"])
         wout_parts.append((dx2, s["o"]))
         if D == 64 and pp and ops.attention_planes_ok() and not (s["want_v"] and dv is not None):
-            # dqkv also as planes (in_proj's input-gradient GEMM): dQ from the kernel's epilogue, dK | dV by a split pass
+            # dqkv also as planes (in_proj's input-gradient GEMM), from the two kernels' epilogues
             dqkv, dqkv_p = ops.attention_bwd(do, s["qkv"], s["o"], s["P"], Bn, T, heads, planes=True)
         elif D == 64:
             dqkv = ops.attention_bwd(do, s["qkv"], s["o"], s["P"], Bn, T, heads)

@@ -637,7 +637,8 @@ def _attn_family():
 
 def attention_planes_ok():
     """The fused attention kernels can emit their results as packed planes (bf16x6 path only)."""
-    return get_gemm_emulation() == 6 and PLANES_PATH and not os.environ.get("SVL_ATTN_NO_EMU")
+    return (get_gemm_emulation() == 6 and PLANES_PATH and not os.environ.get("SVL_ATTN_NO_EMU")
+            and not os.environ.get("SVL_ATTN_NO_PLANES"))
 
 
 def attention_fwd(qkv, Bn, T, H, want_lse=True, planes=False, want_out=True):
@@ -656,8 +657,7 @@ def attention_fwd(qkv, Bn, T, H, want_lse=True, planes=False, want_out=True):
 
 
 def attention_bwd(dout, qkv, out, lse, Bn, T, H, planes=False):
-    """-> dqkv [Bn*T, 3E] (and, with planes=True, the same as Planes: the dQ third from the kernel's epilogue, the
-    dK | dV columns by one split pass over them)."""
+    """-> dqkv [Bn*T, 3E] (and, with planes=True, the same as Planes, written by the kernels' epilogues)."""
     dqkv = torch.empty_like(qkv)
     ws = empty(Bn * H * T, device=qkv.device)
     E = H * 64
@@ -667,10 +667,7 @@ def attention_bwd(dout, qkv, out, lse, Bn, T, H, planes=False):
                                        _p(dp.buf) if planes else None, dp.prow if planes else 0, _st()),
             "svl_attention_bwd")
     _prof_end(_attn_family(), e0, 14.0 * Bn * H * T * T * 64, ("bwd", Bn, T, H))
-    if planes:
-        split_planes(dqkv[:, E:], out=dp.kslice(E, 3 * E))
-        return dqkv, dp
-    return dqkv
+    return (dqkv, dp) if planes else dqkv
 
 
 # ------------------------------------------------------------------------------------------------ ViT attention (materialised probabilities; head dims != 64)
