@@ -1045,17 +1045,14 @@ def semivl_loss(sums_f64, numel_u, lam, out8, factors=None, mc_counts=None):
                                      _st()), "svl_semivl_loss")
 
 
-_BERNOULLI_CALLS = [0]
-
-
 def bernoulli(shape, keep_prob, device):
-    """fp32 tensor of independent Bernoulli(keep_prob) draws (svl_bernoulli_f32); seeded by torch.initial_seed(), every call
-    consumes a fresh counter range."""
+    """fp32 tensor of independent Bernoulli(keep_prob) draws (svl_bernoulli_f32).  The counter range of a call is drawn from
+    torch's CPU generator (one host-side randint, no device sync): the masks follow torch.manual_seed like the reference's
+    F.dropout2d does, without reproducing its exact stream."""
     out = empty(*shape, device=device)
-    n = out.numel()
-    L.check(L.load().svl_bernoulli_f32(_p(out), n, float(keep_prob), torch.initial_seed() & (2 ** 64 - 1),
-                                       _BERNOULLI_CALLS[0], _st()), "svl_bernoulli_f32")
-    _BERNOULLI_CALLS[0] += n
+    off = int(torch.randint(0, 2 ** 62, (1,)).item())
+    L.check(L.load().svl_bernoulli_f32(_p(out), out.numel(), float(keep_prob), torch.initial_seed() & (2 ** 64 - 1), off,
+                                       _st()), "svl_bernoulli_f32")
     return out
 
 

@@ -1123,7 +1123,7 @@ def test_clock_probe_reports_a_plausible_shader_clock():
 @pytest.mark.gpu
 def test_bernoulli_masks():
     """svl_bernoulli_f32 (the dropout2d draws of the feature perturbation, builder.py:79-85): values in {0, 1}, the keep
-    rate within 5 sigma, successive calls independent, the same seed + offset reproducible."""
+    rate within 5 sigma, successive calls independent, reproducible under torch.manual_seed."""
     from semivl_amd import ops
     torch.manual_seed(123)
     a = ops.bernoulli((64, 768), 0.5, "cuda")
@@ -1135,7 +1135,7 @@ def test_bernoulli_masks():
     assert abs(((a == b).float().mean().item()) - 0.5) < 5 * 0.5 / n ** 0.5
     k = ops.bernoulli((1000, 100), 0.9, "cuda")
     assert abs(k.mean().item() - 0.9) < 5 * (0.09 / 1e5) ** 0.5
-    ops._BERNOULLI_CALLS[0] = 0
+    torch.manual_seed(7)
     c1 = ops.bernoulli((8, 8), 0.5, "cuda")
-    ops._BERNOULLI_CALLS[0] = 0
-    assert torch.equal(c1, ops.bernoulli((8, 8), 0.5, "cuda"))
+    torch.manual_seed(7)
+    assert torch.equal(c1, ops.bernoulli((8, 8), 0.5, "cuda"))      # follows torch.manual_seed
