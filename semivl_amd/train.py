@@ -10,6 +10,7 @@ Mirrors (same names / argument meaning):
 
 import contextlib
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -495,7 +496,10 @@ class GradAllReducer:
                     e1.record(self._comm)
                     self._ev.append((b_, (e - s) * 4, e0, e1))
         else:
+            t0 = time.perf_counter() if self.profile else 0.0
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            if self.profile:       # blocking collective on the compute thread (gloo dry runs): host wall time, all of it exposed
+                self._ev.append((b_, (e - s) * 4, None, time.perf_counter() - t0))
 
     def broadcast_params(self, src=0):
         if self.world > 1 and self._collective is None:
@@ -529,6 +533,9 @@ class GradAllReducer:
                 j1.record(torch.cuda.current_stream())
                 self.timing = dict(events=self._ev, join=(j0, j1), early_fires=self.early_fires)
                 self._ev = []
+            elif self.profile:
+                self.timing = dict(events=self._ev, join=None, early_fires=self.early_fires)
+                self._ev = []
         self._works, self._fired = [], set()
         self._complete = [0] * len(self.buckets)
         self._expected, self._done = {}, {}
@@ -541,6 +548,11 @@ class GradAllReducer:
         t = self.timing
         if not t:
             return None
+        if t["join"] is None:      # synchronous backend: every bucket blocks the compute thread for its whole duration
+            bk = [dict(bucket=b_, mbytes=round(nb / 2 ** 20, 1), ms=round(dt * 1e3, 3)) for b_, nb, _, dt in t["events"]]
+            return dict(buckets=bk, exposed_ms=round(sum(b_["ms"] for b_ in bk), 3), launched_inside_backward=t["early_fires"],
+                        note="blocking all-reduce on the compute thread (backend without stream-ordered collectives): host "
+                             "wall time per bucket, all of it exposed")
         return dict(buckets=[dict(bucket=b_, mbytes=round(nb / 2 ** 20, 1), ms=round(e0.elapsed_time(e1), 3))
                              for b_, nb, e0, e1 in t["events"]],
                     exposed_ms=round(t["join"][0].elapsed_time(t["join"][1]), 3), launched_inside_backward=t["early_fires"],

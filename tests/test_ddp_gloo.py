@@ -25,10 +25,13 @@ def _worker(rank, world, port, n, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from semivl_amd.train import GradAllReducer
     arena = _Arena(n, rank)
-    red = GradAllReducer(arena, bucket_mb=0.01)
+    red = GradAllReducer(arena, bucket_mb=0.01, profile=True)
     assert len(red.buckets) > 3 and red.buckets[0][0] == 0 and red.buckets[-1][1] == n
     red.broadcast_params()
     red.reduce()
+    rep = red.timing_report()          # bench.py's "allreduce" object: one entry per bucket, blocking backend = all exposed
+    assert rep is not None and len(rep["buckets"]) == len(red.buckets) and rep["exposed_ms"] > 0
+    assert abs(sum(b["mbytes"] for b in rep["buckets"]) - n * 4 / 2 ** 20) < 0.1 * len(red.buckets)
     q.put((rank, arena.g.numpy().copy(), arena.p.numpy().copy(), arena.grad_scale))  # by value, not shm handles
     dist.destroy_process_group()
 
