@@ -42,7 +42,8 @@ typedef enum svl_status {
   SVL_ERR_UNSUPPORTED = -3
 } svl_status;
 
-int svl_version(void); /* 200: round-2 ABI (helper-stream contexts, caller-owned scratch everywhere) */
+int svl_version(void); /* 300: round-3 ABI (packed-planes operands; planes outputs of LayerNorm / attention; loss-mode arguments of
+                           the pixel-loss entries; 200 = round 2: helper-stream contexts, caller-owned scratch everywhere) */
 /* Destroys the helper stream/events this library created for `stream` on the current device (no-op if none), or for
  * every stream.  Call after the stream has been synchronised; not required before process exit. */
 int svl_stream_release(svl_stream_t stream);

@@ -33,7 +33,7 @@ static int fail(const char* fmt, ...) {
 }
 #define CHECK(c, ...) do { if (!(c)) return fail(__VA_ARGS__); } while (0)
 
-int svl_version(void) { return 200; }
+int svl_version(void) { return 300; }
 int svl_last_error(char* buf, size_t len) {
   const size_t n = strlen(g_err);
   if (buf && len > 0) {

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in semivl_hip.h but not exported"
         assert n in L.SIGNATURES, f"{n} has no ctypes signature in semivl_amd/lib.py"
     assert sorted(L.SIGNATURES) == names, set(L.SIGNATURES) ^ set(names)
-    assert lib.svl_version() >= 200
+    assert lib.svl_version() >= 300
     # error convention: bad arguments -> negative status + message, never an exception across the ABI
     rc = lib.svl_fill_f32(None, 0.0, 0, None)
     assert rc == -1 and "svl_fill_f32" in L.last_error()

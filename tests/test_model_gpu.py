@@ -23,7 +23,7 @@ def test_native_library_is_loaded():
     """The product must run on the in-tree .so — there is no eager fallback to hide behind."""
     import semivl_amd.lib as L
     lib = L.load()
-    assert lib.svl_version() >= 200
+    assert lib.svl_version() >= 300
     maps = open("/proc/self/maps").read()
     assert "libsemivl_hip.so" in maps
 
