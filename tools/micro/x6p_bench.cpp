@@ -1,7 +1,8 @@
 // Stand-alone check + timing of svl_gemm_planes_f32 through the C-ABI (no Python): packs random fp32 operands, runs the
 // GEMM, compares sampled outputs against fp64 on the host, times it with HIP events.
 //   hipcc --offload-arch=gfx950 -O2 tools/micro/x6p_bench.cpp -Iinclude -Lsemivl_amd -lsemivl_hip -Wl,-rpath,$PWD/semivl_amd -o tools/micro/x6p_bench
-//   tools/micro/x6p_bench M N K [iters] [mode]     mode: 0 plain C, 1 bias+GELU+preact+planes_out, 2 resid add, 3 planes_out only
+//   tools/micro/x6p_bench M N K [iters] [mode]     mode: 0 plain C, 1 bias+GELU+preact+planes_out+C, 2 resid add, 3 planes_out only,
+//                                                  4 bias+GELU+preact+planes_out without C (FFN-1 as the training step launches it)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -51,8 +52,8 @@ int main(int argc, char** argv) {
   CK(hipMemset(pA, 0, svl_planes_bytes(M, K))); CK(hipMemset(pB, 0, svl_planes_bytes(N, K)));
   SV(svl_split_planes_bf16x3(dA, K, 1, M, K, pA, Mp, 0, nullptr));
   SV(svl_split_planes_bf16x3(dB, K, 1, N, K, pB, Np, 0, nullptr));
-  if (mode == 1) CK(hipMalloc(&dpre, (size_t)M * N * 4));
-  if (mode == 1 || mode == 3) { CK(hipMalloc(&pO, svl_planes_bytes(M, N))); CK(hipMemset(pO, 0, svl_planes_bytes(M, N))); }
+  if (mode == 1 || mode == 4) CK(hipMalloc(&dpre, (size_t)M * N * 4));
+  if (mode == 1 || mode == 3 || mode == 4) { CK(hipMalloc(&pO, svl_planes_bytes(M, N))); CK(hipMemset(pO, 0, svl_planes_bytes(M, N))); }
   if (mode == 2) {
     hres.resize((size_t)M * N);
     for (auto& v : hres) v = urand();
@@ -63,9 +64,9 @@ int main(int argc, char** argv) {
   svl_pgemm_desc d;
   memset(&d, 0, sizeof d);
   d.A = pA; d.B = pB; d.a_rows = Mp; d.b_rows = Np; d.m_off = 0; d.M = M; d.N = N; d.K = K;
-  d.C = mode == 3 ? nullptr : dC; d.ldc = N;
-  if (mode == 1) { d.bias = dbias; d.act = SVL_ACT_GELU; d.preact = dpre; }
-  if (mode == 1 || mode == 3) { d.planes_out = pO; d.p_rows = Mp; }
+  d.C = (mode == 3 || mode == 4) ? nullptr : dC; d.ldc = N;
+  if (mode == 1 || mode == 4) { d.bias = dbias; d.act = SVL_ACT_GELU; d.preact = dpre; }
+  if (mode == 1 || mode == 3 || mode == 4) { d.planes_out = pO; d.p_rows = Mp; }
   if (mode == 2) { d.resid = dres; d.ldr = N; d.bias = dbias; }
   SV(svl_gemm_planes_f32(&d, nullptr));
   CK(hipDeviceSynchronize());
@@ -87,10 +88,10 @@ int main(int argc, char** argv) {
     double acc = 0;
     for (int k = 0; k < K; ++k) acc += (double)hA[m * K + k] * (double)hB[n * K + k];
     double pre = acc, ref = acc;
-    if (mode == 1) { pre = acc + hbias[n]; ref = 0.5 * pre * (1.0 + erf(pre * 0.70710678118654752440)); }
+    if (mode == 1 || mode == 4) { pre = acc + hbias[n]; ref = 0.5 * pre * (1.0 + erf(pre * 0.70710678118654752440)); }
     if (mode == 2) ref = acc + hbias[n] + hres[m * N + n];
     scale = fmax(scale, fabs(ref));
-    if (mode != 3) {
+    if (mode != 3 && mode != 4) {
       const double e = fabs((double)hC[m * N + n] - ref);
       if (!(e <= 1e-3)) ++bad;
       worst = fmax(worst, e);

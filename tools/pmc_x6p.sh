@@ -38,7 +38,7 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     rec=dict(src_sha16=sha, M=int(a[0]), N=int(a[1]), K=int(a[2]), mode=int(a[4]), fetch_bytes=fb, write_bytes=wb, traffic_bytes=fb+wb,
              counters=vals,
              note="FETCH_SIZE (KB, doubled: gfx950 under-reads 16 B/lane loads by 2x, MI355X_MICROARCH.md) + WRITE_SIZE of the last "
-                  "gemm_x6p_kernel launch of tools/micro/x6p_bench (mode 1 = bias + GELU + pre-activation + planes out), separate "
+                  "gemm_x6p_kernel launch of tools/micro/x6p_bench (mode %s: 1 = bias + GELU + pre-activation + planes out + fp32 C, 4 = the same without C -- FFN-1 as the training step launches it)" % a[4] + ", separate "
                   "rocprofv3 --pmc passes (tools/pmc_x6p.sh).  FETCH_SIZE counts L2 -> fabric requests, Infinity-Cache hits included: "
                   "the B panels (14 MB) are re-read by every XCD once per round of its tiles and are served from the Infinity Cache")
     json.dump(rec, open(R+"/gpurun_out/pmc_x6p_traffic.json","w"), indent=1)

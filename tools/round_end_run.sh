@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 T=${TAG:-r3}
 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -25 > gpurun_out/${T}_pytest.log
 # PMC records of the dominant launches (quoted by bench.py as roofline.traffic / roofline_hbm.traffic)
-bash tools/pmc_x6p.sh 32800 3072 768 1 > gpurun_out/${T}_pmc_x6p_ffn1.txt 2>&1
+bash tools/pmc_x6p.sh 32800 3072 768 4 > gpurun_out/${T}_pmc_x6p_ffn1.txt 2>&1   # mode 4 = FFN-1 as the step launches it (no fp32 C)
 bash tools/pmc_ce.sh > gpurun_out/${T}_pmc_ce.txt 2>&1
 SVL_GEMM_EMU=0 bash tools/pmc_traffic.sh tools/one_gemm.py gemm_kernel > gpurun_out/${T}_pmc_gemm_f32.txt 2>&1
 mkdir -p profiles && cp gpurun_out/pmc_x6p_traffic.json gpurun_out/pmc_ce_traffic.json gpurun_out/pmc_gemm_traffic.json profiles/ 2>/dev/null
