@@ -76,6 +76,7 @@ struct PlanesP {
   int accumulate;
   int tiles_n, full_m, tail_rows;   // full_m = M / 256 row bands; tail_rows = M % 256
   int rcnt[8], fstart[8];   // per XCD x (blocks with id % 8 == x): ragged-band tiles it takes first, first full tile of its chunk
+  int panel;                // column tiles per panel of the full-tile order (tile_of_block)
 };
 
 // One LDS-DMA instruction: 64 lanes x 16 B from `base` (wave-uniform, SGPR pair) + `lane_off` (the constant lane * 16)
@@ -156,8 +157,14 @@ __device__ __forceinline__ TileRef tile_of_block(const PlanesP& p) {
     t.tn = idx * 8 + x;
   } else {
     const int f = p.fstart[x] + idx - rc;
-    const int tm = f / p.tiles_n;
-    t.tn = f - tm * p.tiles_n;
+    // full tiles in PANEL order: column groups of p.panel tiles, row bands inside a group, columns inside a band -- an
+    // XCD's 32 concurrent tiles are (32 / panel) bands x panel columns, and the group's B panels (panel x 1.2 MB) stay in
+    // its 4 MB L2 while it walks down the bands (row-major order = panel of tiles_n columns: every round re-reads all of B)
+    const int gsz = p.full_m * p.panel;
+    const int cg = f / gsz, r = f - cg * gsz;
+    const int w = min(p.panel, p.tiles_n - cg * p.panel);
+    const int tm = r / w;
+    t.tn = cg * p.panel + (r - tm * w);
     t.m0 = tm * BM;
     t.rows = BM;
   }
@@ -532,6 +539,11 @@ int launch_tile(PlanesP q, hipStream_t st) {
     svl_set_error("svl_gemm_planes_f32: bad tile count %ld", total);
     return SVL_ERR_INVALID_ARG;
   }
+  static const int panel_env = getenv("SVL_PLANES_PANEL") ? atoi(getenv("SVL_PLANES_PANEL")) : 0;
+  // 6 columns per panel: FETCH x 2 of FFN-1 (12 column tiles) 1.035 -> 0.82 GB at unchanged time; 2 / 3 are worse than
+  // row-major (A bands re-read per panel), shapes with <= 6 column tiles are row-major anyway (tools/micro/run12.sh)
+  const int pw = panel_env > 0 ? panel_env : 6;
+  q.panel = pw < q.tiles_n ? pw : q.tiles_n;
   long fs = 0;
   for (int x = 0; x < 8; ++x) {   // XCD x runs the blocks with id % 8 == x
     const long blocks = (total - x + 7) / 8, rag = nr > x ? (nr - x + 7) / 8 : 0;
