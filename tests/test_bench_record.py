@@ -1,0 +1,61 @@
+"""The committed end-of-round bench line (profiles/r3_f_bench_default.json) is self-consistent and follows the bench.py
+contract: every number a reader would recompute from the line (and from the per-dispatch rocprof rows next to it) agrees."""
+import csv
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def _line(name):
+    with open(os.path.join(P, name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_default_line_contract_and_arithmetic():
+    d = _line("r3_f_bench_default.json")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["unit"] == "images/s" and d["metric"].startswith("train images/sec") and base["metric"].startswith("train images/sec")
+    assert "ViT-B/16" in d["metric"] and "BASELINE configs[1]" in d["config"]["workload"]
+    # value = images of one step / step time (16 labeled + 16 unlabeled per GPU)
+    assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_ms"] * 1e-3) / 1e12) < 0.5          # TF = FLOP / s
+    assert abs(r["flops_per_launch"] - 2.0 * 32800 * 3072 * 768) < 1 and abs(r["peak"] - 2500.0 / 6) < 0.1
+    assert r["traffic"] is not None and r["traffic"] > r["algorithmic_bytes"] > 1.0e9
+    assert 1000 < r["clock_mhz"]["under_dominant_kernel"] < 2400
+    assert abs(r["frac_at_sustained_clock"] - r["frac"] * 2400.0 / r["clock_mhz"]["under_dominant_kernel"]) < 2e-3
+    h = d["roofline_hbm"]
+    assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 2e-3 and h["traffic"] is not None
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    x = d["cross_mode_same_weights"]
+    assert x["max_abs_diff"] < 1e-3 and len(x["losses_bf16x6"]) == 8
+    # 40 dominant launches of 0.77 ms are a small part of the step, and the step holds them
+    assert r["launches"] * r["avg_ms"] < 0.2 * d["ms_per_step"]
+
+
+def test_dominant_kernel_duration_agrees_with_rocprof_rows():
+    """roofline.avg_ms (HIP events inside bench.py, streams back to back) against the per-dispatch rows of the same kernel
+    and grid size in the rocprofv3 kernel trace of the same command (streams overlapped: the fastest dispatches are the
+    solo ones)."""
+    r = _line("r3_f_bench_default.json")["roofline"]
+    rows = [row for row in csv.reader(open(os.path.join(P, "r3_f_dominant_dispatches.csv"))) if row and row[0][0].isdigit()]
+    dur = sorted(float(row[1]) for row in rows)
+    assert len(dur) >= 100 and all(int(row[2]) == 1548 for row in rows)
+    solo = dur[len(dur) // 4]                      # lower quartile: launches that did not share the chip
+    assert abs(solo - r["avg_ms"] * 1e3) < 0.08 * r["avg_ms"] * 1e3, (solo, r["avg_ms"])
+
+
+def test_other_config_lines():
+    for name, lo in (("cityscapes", 20.0), ("ade", 18.0), ("coco", 30.0), ("exact_f32", 45.0)):
+        d = _line(f"r3_f_bench_{name}.json")
+        assert d["value"] > lo and d["n_gpus"] == 1
+        assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
