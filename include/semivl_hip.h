@@ -493,15 +493,18 @@ int svl_bn_eval_invstd(const float* running_var, float eps, int C, float* invstd
 int svl_bn_apply(const float* x, int64_t ldx, int64_t rows, int C, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, const float* resid, int64_t ldr, int relu, float* y, int64_t ldy,
                  svl_stream_t stream);
-/* sums[0][c] = sum dy', sums[1][c] = sum dy' * xhat, dy' = dy masked by the fused ReLU (y > 0; y may be NULL) */
+/* sums[0][c] = sum dy', sums[1][c] = sum dy' * xhat, dy' = dy masked by the fused ReLU: y > 0 when y is given; with
+ * y == NULL and remask_gamma / remask_beta given, the forward's own output expression re-evaluated from x (bit-identical
+ * sign; BatchNorm + ReLU WITHOUT a residual input only) -- one tensor pass less; all three NULL = no ReLU. */
 int svl_bn_bwd_reduce(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
-                      const float* mean, const float* invstd, int64_t rows, int C, double* sums, double* ws,
-                      svl_stream_t stream);
+                      const float* mean, const float* invstd, const float* remask_gamma, const float* remask_beta,
+                      int64_t rows, int C, double* sums, double* ws, svl_stream_t stream);
 /* dx = gamma * invstd * (dy' - sums0/count - xhat * sums1/count); dres (optional) = dy' for the residual branch;
  * dgamma = sums1, dbeta = sums0 (of this rank's rows, i.e. BEFORE the all-reduce) */
 int svl_bn_bwd_apply(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
-                     const float* mean, const float* invstd, const float* gamma, const double* sums, double count,
-                     int64_t rows, int C, float* dx, int64_t lddx, float* dres, int64_t lddr, svl_stream_t stream);
+                     const float* mean, const float* invstd, const float* gamma, const float* remask_beta,
+                     const double* sums, double count, int64_t rows, int C, float* dx, int64_t lddx, float* dres,
+                     int64_t lddr, svl_stream_t stream);
 /* NHWC max pooling, kernel 3, stride 2, padding 1 (Ho = (H-1)/2+1); idx = winning tap 0..8 per output element */
 int svl_maxpool3x3s2_fwd(const float* x, int imgs, int H, int W, int C, float* y, unsigned char* idx,
                          svl_stream_t stream);

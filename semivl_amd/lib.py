@@ -122,8 +122,8 @@ SIGNATURES = {
     "svl_bn_finalize": (_I, [_P, _D, _F, _F, _P, _P, _I, _P, _P, _P]),
     "svl_bn_eval_invstd": (_I, [_P, _F, _I, _P, _P]),
     "svl_bn_apply": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _I, _P, _L, _P]),
-    "svl_bn_bwd_reduce": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _P, _P, _P]),
-    "svl_bn_bwd_apply": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _D, _L, _I, _P, _L, _P, _L, _P]),
+    "svl_bn_bwd_reduce": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "svl_bn_bwd_apply": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _D, _L, _I, _P, _L, _P, _L, _P]),
     "svl_maxpool3x3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "svl_maxpool3x3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "svl_aug_resample_u8": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -106,18 +106,23 @@ def _bn(z, bn, training, relu, resid=None, sv=None):
         mean, invstd, count = bn.running_mean, ops.bn_eval_invstd(bn.running_var, bn.eps), z.shape[0]
     y = ops.bn_apply(z, C, mean, invstd, bn.weight, bn.bias, relu=relu, resid=resid)
     if sv is not None:
-        sv.update(z=z, y=y if relu else None, mean=mean, invstd=invstd, count=count)
+        # BatchNorm + ReLU without a residual input: backward re-derives the ReLU mask from z (the forward's own expression,
+        # bit-identical sign) and does not read y back; with a residual the post-activation y is the mask
+        sv.update(z=z, y=y if (relu and resid is not None) else None, remask=relu and resid is None, mean=mean,
+                  invstd=invstd, count=count)
     return y
 
 
 def _bn_bwd(dy, bn, sv, gc, want_dres=False):
     z, y = sv["z"], sv["y"]
     C = z.shape[1]
-    sums = ops.bn_bwd_reduce(dy, z, y, C, sv["mean"], sv["invstd"])
+    rm = sv.get("remask", False)
+    sums = ops.bn_bwd_reduce(dy, z, y, C, sv["mean"], sv["invstd"], remask=(bn.weight, bn.bias) if rm else None)
     gc.put_tensor(bn.bias, sums[0].float())      # this rank's sums: the data-parallel mean is the reducer's job
     gc.put_tensor(bn.weight, sums[1].float())
     _sync_sums(sums)
-    return ops.bn_bwd_apply(dy, z, y, C, sv["mean"], sv["invstd"], bn.weight, sums, sv["count"], want_dres=want_dres)
+    return ops.bn_bwd_apply(dy, z, y, C, sv["mean"], sv["invstd"], bn.weight, sums, sv["count"], want_dres=want_dres,
+                            remask_beta=bn.bias if rm else None)
 
 
 def _encoder_forward(m, img, sv):

@@ -1133,23 +1133,29 @@ def bn_apply(x, C, mean, invstd, gamma, beta, relu=False, resid=None, out=None):
     return out
 
 
-def bn_bwd_reduce(dy, x, y, C, mean, invstd):
-    """[2, C] float64: (sum dy', sum dy' * xhat); y (the ReLU output) masks dy when given."""
+def bn_bwd_reduce(dy, x, y, C, mean, invstd, remask=None):
+    """[2, C] float64: (sum dy', sum dy' * xhat); y (the ReLU output) masks dy when given; remask = (gamma, beta): the mask is
+    re-derived from x with the forward's own expression instead (BatchNorm + ReLU without a residual input)."""
     rows = x.shape[0]
     lib = L.load()
     sums = torch.empty(2, C, dtype=torch.float64, device=x.device)
     ws = torch.empty(int(lib.svl_bn_ws_doubles(rows, C)), dtype=torch.float64, device=x.device)
+    if remask is not None:
+        y = None
     L.check(lib.svl_bn_bwd_reduce(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(y), y.stride(0) if y is not None else 0,
-                                  _p(mean), _p(invstd), rows, C, _p(sums), _p(ws), _st()), "svl_bn_bwd_reduce")
+                                  _p(mean), _p(invstd), _p(remask[0] if remask else None), _p(remask[1] if remask else None),
+                                  rows, C, _p(sums), _p(ws), _st()), "svl_bn_bwd_reduce")
     return sums
 
 
-def bn_bwd_apply(dy, x, y, C, mean, invstd, gamma, sums, count, want_dres=False):
+def bn_bwd_apply(dy, x, y, C, mean, invstd, gamma, sums, count, want_dres=False, remask_beta=None):
     rows = x.shape[0]
     dx = empty(rows, C, device=x.device)
     dres = empty(rows, C, device=x.device) if want_dres else None
+    if remask_beta is not None:
+        y = None
     L.check(L.load().svl_bn_bwd_apply(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(y), y.stride(0) if y is not None else 0,
-                                      _p(mean), _p(invstd), _p(gamma), _p(sums), float(count), rows, C, _p(dx),
+                                      _p(mean), _p(invstd), _p(gamma), _p(remask_beta), _p(sums), float(count), rows, C, _p(dx),
                                       dx.stride(0), _p(dres), dres.stride(0) if dres is not None else 0, _st()),
             "svl_bn_bwd_apply")
     return (dx, dres) if want_dres else dx

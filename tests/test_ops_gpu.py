@@ -936,6 +936,10 @@ def test_batchnorm_train_fwd_bwd(dev, rows, C, relu, res):
     close(bs[0].float(), grads[2], atol=1e-3 * max(1.0, float(grads[2].abs().max())), what="dbeta")
     if res:
         close(out[1], grads[3], atol=1e-6, what="dres")
+    if relu and not res:   # the ReLU mask re-derived from x (no y read) is the forward's own decision: bit-identical results
+        bs2 = ops.bn_bwd_reduce(dy, x.detach(), None, C, mean, invstd, remask=(gamma.detach(), beta.detach()))
+        dx2 = ops.bn_bwd_apply(dy, x.detach(), None, C, mean, invstd, gamma.detach(), bs2, rows, remask_beta=beta.detach())
+        assert torch.equal(bs2, bs) and torch.equal(dx2, dx)
     # eval mode: running statistics
     ye = ops.bn_apply(x.detach(), C, rm, ops.bn_eval_invstd(rv, 1e-5), gamma.detach(), beta.detach())
     close(ye, F.batch_norm(x.detach(), rm_t, rv_t, gamma.detach(), beta.detach(), training=False, eps=1e-5), atol=2e-5)
