@@ -416,12 +416,15 @@ __global__ void fill_kernel(float* p, float v, long n) {
 // GroupNorm on NHWC class-images. One block per image; thread = (pixel lane, channel quad).
 // Statistics are accumulated in double (one image group is up to 16384 x 16 values).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __restrict__ x, long ldx, float eps, long HW,
-                                                              int C, int G, float* __restrict__ stats) {
-  __shared__ double sh_s[256], sh_q[256];
+// NT threads per block: 256, or 1024 when there are too few class-images to fill the chip with 4 waves each (one block
+// per image: 456 images at 801^2 left the reduction at the pace of 4 waves per CU)
+template <int NT>
+__global__ __launch_bounds__(NT) void groupnorm_stats_kernel(const float* __restrict__ x, long ldx, float eps, long HW,
+                                                             int C, int G, float* __restrict__ stats) {
+  __shared__ double sh_s[NT], sh_q[NT];
   __shared__ double g_s[64], g_q[64];
   const int CQ = C >> 2;             // channel quads
-  const int PR = 256 / CQ;           // pixel rows per iteration
+  const int PR = NT / CQ;            // pixel rows per iteration
   const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
   const long img = blockIdx.x;
   const float* xi = x + img * HW * ldx;
@@ -497,16 +500,17 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
   }
 }
 // chan_sums[img][0][c] = sum_p dy', chan_sums[img][1][c] = sum_p dy' * xhat   (dy' = dy masked by relu)
-__global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float* __restrict__ dy, long lddy,
+template <int NT>
+__global__ __launch_bounds__(NT) void groupnorm_bwd_sums_kernel(const float* __restrict__ dy, long lddy,
                                                                  const float* __restrict__ x, long ldx,
                                                                  const float* __restrict__ y, long ldy,
                                                                  const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, long HW, int C, int G,
                                                                  int relu, float* __restrict__ chan_sums) {
-  __shared__ double sh[2][1024];  // [a|b][pr*C + c], PR*C = 1024
+  __shared__ double sh[2][4 * NT];  // [a|b][pr*C + c], PR*C = 4 NT
   const int CQ = C >> 2;
-  const int PR = 256 / CQ;
+  const int PR = NT / CQ;
   const int cq = threadIdx.x % CQ, pr = threadIdx.x / CQ;
   const int cg = C / G;
   const long img = blockIdx.x;
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float* __
     sh[1][pr * C + 4 * cq + j] = b[j];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += NT) {
     double ta = 0.0, tb = 0.0;
     for (int rr = 0; rr < PR; ++rr) {
       ta += sh[0][rr * C + c];
@@ -639,6 +643,9 @@ inline dim3 gn_apply_grid(int imgs, long HW, int C) {
   return dim3((unsigned)gx, (unsigned)imgs);
 }
 
+// one block per class-image: 16 waves per block when the image is large (a function of the image's shape ONLY: the
+// summation order of a statistic must not depend on how many images share the launch -- sample-chunked decode is bit-identical)
+inline bool gn_wide(int /*imgs*/, long HW, int C) { return HW * C >= 262144; }
 inline bool gn_shape_ok(int C, int G) {
   if (C % 4 != 0 || G <= 0 || C % G != 0 || (C / G) % 4 != 0) return false;
   const int CQ = C / 4;
@@ -805,7 +812,10 @@ extern "C" int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma
   SVL_CHECK_ARG(gn_shape_ok(C, G) && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
                 "svl_groupnorm_fwd: unsupported C=%d G=%d ldx=%ld ldy=%ld", C, G, (long)ldx, (long)ldy);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(imgs), dim3(256), 0, st, x, (long)ldx, eps, (long)HW, C, G, stats);
+  if (gn_wide(imgs, HW, C))
+    hipLaunchKernelGGL(groupnorm_stats_kernel<1024>, dim3(imgs), dim3(1024), 0, st, x, (long)ldx, eps, (long)HW, C, G, stats);
+  else
+    hipLaunchKernelGGL(groupnorm_stats_kernel<256>, dim3(imgs), dim3(256), 0, st, x, (long)ldx, eps, (long)HW, C, G, stats);
   SVL_LAUNCH_CHECK("svl_groupnorm_fwd/stats");
   const long npix = (long)imgs * HW;
   hipLaunchKernelGGL(groupnorm_apply_kernel, gn_apply_grid(imgs, HW, C), dim3(256), 0, st, x, (long)ldx, gamma, beta,
@@ -822,7 +832,11 @@ extern "C" int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, 
   SVL_CHECK_ARG(gn_shape_ok(C, G) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || !y || ldy % 4 == 0),
                 "svl_groupnorm_bwd: unsupported C=%d G=%d", C, G);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(groupnorm_bwd_sums_kernel, dim3(imgs), dim3(256), 0, st, dy, (long)lddy, x, (long)ldx, y, (long)ldy,
+  if (gn_wide(imgs, HW, C))
+    hipLaunchKernelGGL(groupnorm_bwd_sums_kernel<1024>, dim3(imgs), dim3(1024), 0, st, dy, (long)lddy, x, (long)ldx, y, (long)ldy,
+                     stats, gamma, beta, (long)HW, C, G, relu, chan_sums);
+  else
+    hipLaunchKernelGGL(groupnorm_bwd_sums_kernel<256>, dim3(imgs), dim3(256), 0, st, dy, (long)lddy, x, (long)ldx, y, (long)ldy,
                      stats, gamma, beta, (long)HW, C, G, relu, chan_sums);
   SVL_LAUNCH_CHECK("svl_groupnorm_bwd/sums");
   const long npix = (long)imgs * HW;
