@@ -45,9 +45,31 @@ struct AttnP {
   // attention output [B T, E] in the forward, dqkv [B T, 3E] in the backward (dQ by the dq kernel, dK | dV by the dkv kernel)
   char* planes;
   long planes_ks;   // bytes between k-groups = padded rows x 96
+  int interleaved;  // 1: row blocks of a z interleaved with its partial one (SVL_ATTN_INTERLEAVED, A/B aid); 0: partials last
 };
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// Block -> (row block of BQ rows, (image, head) z) for the x6 kernels' 1-D grids: the FULL row blocks first, row-block-major
+// inside a z (consecutive blocks share K / V in L2), the partial last row blocks of all z at the END of the grid -- they are
+// the cheap ones (2 of 8 waves active at T = 2602) and so fill the last round instead of standing in every 11th slot:
+// 2112 blocks on 256 CUs = 8.25 rounds of which the last quarter round used to cost a full one.
+__device__ __forceinline__ void attn_block(const AttnP& p, int BQ, int& rb, int& z) {
+  const int nfull = p.T / BQ, BH = p.B * p.H, lin = (int)blockIdx.x;
+  if (p.interleaved) {
+    const int nb = (p.T + BQ - 1) / BQ;
+    z = lin / nb;
+    rb = lin - z * nb;
+    return;
+  }
+  if (lin < nfull * BH) {
+    z = lin / nfull;
+    rb = lin - z * nfull;
+  } else {
+    z = lin - nfull * BH;
+    rb = nfull;
+  }
+}
 
 // Cooperative load of a [64 rows x 64 floats] tile (rows row0.. of one head slice) into registers: 4 float4 per thread.
 __device__ __forceinline__ void tile_gload(float4 (&rg)[4], const float* base, long ld, int row0, int T, int tid) {
@@ -644,8 +666,10 @@ __global__ __launch_bounds__(512) void attn_fwd_x6_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) __bf16 sm[2 * 2 * XIMG];   // [buffer][K | Vt][plane][64 x 64]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int z = blockIdx.y, b = z / p.H, h = z - b * p.H;
-  const int q0 = blockIdx.x * FQ + wave * 32;
+  int rb_, z;
+  attn_block(p, FQ, rb_, z);
+  const int b = z / p.H, h = z - b * p.H;
+  const int q0 = rb_ * FQ + wave * 32;
   const int qi = q0 + l31;
   const bool wave_active = q0 < p.T;
   const bool late = wave >= 4;
@@ -840,8 +864,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_x6_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) __bf16 sm[2 * 3 * XIMG];   // [buffer][K | V | Kt][plane][64 x 64]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int z = blockIdx.y, b = z / p.H, h = z - b * p.H;
-  const int q0 = blockIdx.x * FQ + wave * 32;
+  int rb_, z;
+  attn_block(p, FQ, rb_, z);
+  const int b = z / p.H, h = z - b * p.H;
+  const int q0 = rb_ * FQ + wave * 32;
   const int qi = q0 + l31, qc = min(qi, p.T - 1);
   const bool wave_active = q0 < p.T;
   const float* image = p.qkv + (long)b * p.T * p.ld;
@@ -978,8 +1004,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_x6_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) float Ls[2][32], Ds[2][32];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int z = blockIdx.y, b = z / p.H, h = z - b * p.H;
-  const int k0 = blockIdx.x * FQ + wave * 32;
+  int rb_, z;
+  attn_block(p, FQ, rb_, z);
+  const int b = z / p.H, h = z - b * p.H;
+  const int k0 = rb_ * FQ + wave * 32;
   const int kj = k0 + l31, kc = min(kj, p.T - 1);
   const bool wave_active = k0 < p.T;
   const float* image = p.qkv + (long)b * p.T * p.ld;
@@ -1318,6 +1346,8 @@ extern "C" int svl_attention_fwd(const float* qkv, int B, int T, int H, float* o
   AttnP p;
   memset(&p, 0, sizeof(p));
   p.planes = (char*)out_planes; p.planes_ks = planes_rows * 96;
+  static const int interleaved_f = getenv("SVL_ATTN_INTERLEAVED") ? 1 : 0;
+  p.interleaved = interleaved_f;
   p.qkv = qkv; p.out = out; p.lse = lse; p.B = B; p.T = T; p.H = H; p.E = (long)H * D; p.ld = 3 * p.E; p.scale = 0.125f;
   hipStream_t st = (hipStream_t)stream;
   int nb = 0;
@@ -1331,7 +1361,7 @@ extern "C" int svl_attention_fwd(const float* qkv, int B, int T, int H, float* o
     hipLaunchKernelGGL(attn_fwd_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * BQ);
     SVL_LAUNCH_CHECK("svl_attention_fwd/rows");
   }
-  if (x6) hipLaunchKernelGGL(attn_fwd_x6_kernel, dim3(nb, B * H), dim3(512), 0, st, p);
+  if (x6) hipLaunchKernelGGL(attn_fwd_x6_kernel, dim3(nb * B * H), dim3(512), 0, st, p);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(nb, B * H), dim3(256), 0, st, p);
   SVL_LAUNCH_CHECK("svl_attention_fwd");
   return r > 0 ? svl_join(st) : SVL_OK;
@@ -1349,6 +1379,8 @@ extern "C" int svl_attention_bwd(const float* qkv, const float* out, const float
   AttnP p;
   memset(&p, 0, sizeof(p));
   p.planes = (char*)dq_planes; p.planes_ks = planes_rows * 96;
+  static const int interleaved_b = getenv("SVL_ATTN_INTERLEAVED") ? 1 : 0;
+  p.interleaved = interleaved_b;
   p.qkv = qkv; p.dout = dout; p.lse = const_cast<float*>(lse); p.dsum = dsum_ws; p.dqkv = dqkv;
   p.B = B; p.T = T; p.H = H; p.E = (long)H * D; p.ld = 3 * p.E; p.scale = 0.125f;
   const long groups = (long)B * T * H;
@@ -1368,10 +1400,10 @@ extern "C" int svl_attention_bwd(const float* qkv, const float* out, const float
     hipLaunchKernelGGL(attn_bwd_dq_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * BQ);
     SVL_LAUNCH_CHECK("svl_attention_bwd/dq_rows");
   }
-  if (x6) hipLaunchKernelGGL(attn_bwd_dkv_x6_kernel, dim3(nb, B * H), dim3(512), 0, st, p);
+  if (x6) hipLaunchKernelGGL(attn_bwd_dkv_x6_kernel, dim3(nb * B * H), dim3(512), 0, st, p);
   else hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nb, B * H), dim3(256), 0, st, p);
   SVL_LAUNCH_CHECK("svl_attention_bwd/dkv");
-  if (x6) hipLaunchKernelGGL(attn_bwd_dq_x6_kernel, dim3(nb, B * H), dim3(512), 0, st, p);
+  if (x6) hipLaunchKernelGGL(attn_bwd_dq_x6_kernel, dim3(nb * B * H), dim3(512), 0, st, p);
   else hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nb, B * H), dim3(256), 0, st, p);
   SVL_LAUNCH_CHECK("svl_attention_bwd/dq");
   return r > 0 ? svl_join(st) : SVL_OK;
