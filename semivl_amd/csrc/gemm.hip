@@ -787,14 +787,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   (void)total;
+  // loads run TWO work items ahead (three register sets): the epilogue's store burst of all resident waves saturates the
+  // memory pipe, and a load issued one item ahead queued behind it -- the matrix phase then waited for its operand
+  float an2[32];
+  auto next_item = [&](long rbi, int kci, long& rbo, int& kco) {
+    rbo = rbi;
+    kco = kci + 1;
+    if (kco == nkc) { kco = 0; rbo = rbi + wstride; }
+  };
+  long rbn;
+  int kcn;
+  next_item(rb, 0, rbn, kcn);
   if (rb < nrb) a_load(a, rb, 0);
+  if (rbn < nrb) a_load(an, rbn, kcn);
   f32x16 acc[1][TN];
   while (rb < nrb) {
-    // next work item of this wave
-    long rbn = rb;
-    int kcn = kc + 1;
-    if (kcn == nkc) { kcn = 0; rbn = rb + wstride; }
-    if (rbn < nrb) a_load(an, rbn, kcn);
+    long rbn2;
+    int kcn2;
+    next_item(rbn, kcn, rbn2, kcn2);
+    if (rbn2 < nrb) a_load(an2, rbn2, kcn2);
     if (kc == 0) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
@@ -873,9 +884,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
 #pragma unroll
-    for (int s = 0; s < 32; ++s) a[s] = an[s];
+    for (int s = 0; s < 32; ++s) { a[s] = an[s]; an[s] = an2[s]; }
     rb = rbn;
     kc = kcn;
+    rbn = rbn2;
+    kcn = kcn2;
   }
 }
 
