@@ -1,4 +1,4 @@
-"""The committed end-of-round bench line (profiles/r3_h_bench_default.json) is self-consistent and follows the bench.py
+"""The committed end-of-round bench line (profiles/r3_i_bench_default.json) is self-consistent and follows the bench.py
 contract: every number a reader would recompute from the line (and from the per-dispatch rocprof rows next to it) agrees."""
 import csv
 import json
@@ -14,7 +14,7 @@ def _line(name):
 
 
 def test_default_line_contract_and_arithmetic():
-    d = _line("r3_h_bench_default.json")
+    d = _line("r3_i_bench_default.json")
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -46,8 +46,8 @@ def test_dominant_kernel_duration_agrees_with_rocprof_rows():
     """roofline.avg_ms (HIP events inside bench.py, streams back to back) against the per-dispatch rows of the same kernel
     and grid size in the rocprofv3 kernel trace of the same command (streams overlapped: the fastest dispatches are the
     solo ones)."""
-    r = _line("r3_h_bench_default.json")["roofline"]
-    rows = [row for row in csv.reader(open(os.path.join(P, "r3_h_dominant_dispatches.csv"))) if row and row[0][0].isdigit()]
+    r = _line("r3_i_bench_default.json")["roofline"]
+    rows = [row for row in csv.reader(open(os.path.join(P, "r3_i_dominant_dispatches.csv"))) if row and row[0][0].isdigit()]
     dur = sorted(float(row[1]) for row in rows)
     assert len(dur) >= 100 and all(int(row[2]) == 1548 for row in rows)
     solo = dur[len(dur) // 4]                      # lower quartile: launches that did not share the chip
@@ -56,6 +56,6 @@ def test_dominant_kernel_duration_agrees_with_rocprof_rows():
 
 def test_other_config_lines():
     for name, lo in (("cityscapes", 20.0), ("ade", 18.0), ("coco", 30.0), ("exact_f32", 45.0)):
-        d = _line(f"r3_h_bench_{name}.json")
+        d = _line(f"r3_i_bench_{name}.json")
         assert d["value"] > lo and d["n_gpus"] == 1
         assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
