@@ -17,6 +17,14 @@ import time
 
 # the host driver only supports dmabuf IPC: must be in the environment before the HIP/HSA runtime initialises
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # The runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues in creation order, and two
+    # streams on one queue are serialised (tools/queue_map.py).  A rank of a multi-GPU job owns main + second +
+    # helper + weight-gradient + communication streams (+ the communicator's own): with 4 queues the bucketed all-reduce can
+    # end up BEHIND the backward kernels it is meant to overlap.  Eight queues give every stream its own; the weight-gradient
+    # stream is switched off there, because truly concurrent with the chain's GEMMs it costs 20 ms (measured on one GPU).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("SVL_NO_WGRAD_STREAM", "1")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
