@@ -96,7 +96,9 @@ def _conv_gn_fwd(x, ldx, imgs, H, W, C1, conv, gn, k, dil, sv, src2=None, ld2=0,
     return y
 
 
-def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True):
+def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None):
+    """`dx_acc`: an existing input-gradient buffer the convolution's dgrad is ADDED to in the GEMM epilogue (the branches of a
+    residual / multi-branch node) instead of returned as a new tensor and added by a separate pass."""
     imgs, H, W, C1, Co, k, dil, pad = sv["geom"]
     dpre = ops.empty(imgs * H * W, Co, device=dy.device)
     dg, db = ops.groupnorm_bwd(dy, lddy, sv["pre"], Co, sv["y"], sv["ldy"], sv["st"], gn.weight, imgs, H * W, Co,
@@ -110,6 +112,9 @@ def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True):
         gc.put_tensor(conv.weight, ops.unpack_conv_wgrad(dwf, Co, C1 + C2, k, k))
     if not need_dx:
         return None
+    if dx_acc is not None:
+        return ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad, out=dx_acc, ldo=dx_acc.stride(0),
+                              accumulate=True)
     return ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad)  # [pix, C1+C2]
 
 
@@ -551,8 +556,7 @@ def _head_backward_core(m, sv, dlogits, gc):
         dx1 = dx  # residual branch (dx is not used afterwards; accumulate into it)
         for j, d in enumerate(m.aspp.rates):
             seq = m.aspp.aspp_convs[j]
-            dbr = _conv_gn_bwd(dcat[:, j * Ch:], 5 * Ch, seq[0], seq[1], sv["aspp"][j], gc)
-            ops.add(dx1, dbr, out=dx1)
+            _conv_gn_bwd(dcat[:, j * Ch:], 5 * Ch, seq[0], seq[1], sv["aspp"][j], gc, dx_acc=dx1)   # dx1 += branch dgrad
         gap = m.aspp.aspp_convs[4].gap
         dgy = ops.empty(imgs, Ch, device=dev)
         ops.bilinear_nhwc_bwd(dcat[:, 4 * Ch:], 5 * Ch, imgs, 1, 1, Ch, True, 1, h, w, dgy, Ch)
