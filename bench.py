@@ -17,7 +17,8 @@ import time
 
 # the host driver only supports dmabuf IPC: must be in the environment before the HIP/HSA runtime initialises
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+AS_MULTI = "--as-multi" in sys.argv     # one GPU, but with the stream / queue settings every rank of an N > 1 run gets
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or AS_MULTI:
     # The runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues in creation order, and two
     # streams on one queue are serialised (tools/queue_map.py).  A rank of a multi-GPU job owns main + second +
     # helper + weight-gradient + communication streams (+ the communicator's own): with 4 queues the bucketed all-reduce can
@@ -38,6 +39,10 @@ DEC_GF_PER_UNIT_B = 1322.0      # 7 decoder fwd + 6 x 2 fwd-equivalents bwd, 69.
 # (nclass, crop) -> (ViT, decoder) algorithmic GFLOP per step per unit batch
 ALGO_GF = {(21, 512): (2866.6, 1322.0), (81, 512): (2866.6, 5075.0), (150, 512): (2866.6, 9412.0),
            (19, 801): (5 * 725.0 + 2 * 669.8 + 4 * 1098.1, 3027.0)}
+# Of SURVEY's 19 decoder forward-equivalents per image pair (7 forwards + 6 backwards x 2) the step EXECUTES 14: the
+# feature-perturbed copy of the labeled half is never decoded (semivl.py:247 discards it) and the detached pred_w is not
+# back-propagated (semivl.py:251): 6 forwards + 4 backwards x 2.  The ViT figure is what is executed.
+DEC_EXECUTED_SHARE = 14.0 / 19.0
 PEAK_F32_MFMA_TF = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TF = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0
@@ -60,11 +65,17 @@ def parse():
                     help="oracle steps on the host cores (SURVEY §8(d) asks for 3 5; the default 1 2 keeps the default "
                          "run within a few minutes)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--as-multi", action="store_true",
+                    help="single GPU with the settings of a multi-GPU rank (GPU_MAX_HW_QUEUES=8, no weight-gradient stream): "
+                         "the N=1 anchor a scaling curve should be divided by")
+    ap.add_argument("--no-multi-anchor", action="store_true",
+                    help="skip the `n1_same_settings` leg of the default N=1 run (a child process re-measuring the step "
+                         "with --as-multi)")
     ap.add_argument("--gemm-arith", choices=["f32", "bf16x6", "bf16x3"], default="bf16x6",
                     help="arithmetic of the large dense GEMMs in the timed region (include/semivl_hip.h, "
                          "svl_set_gemm_emulation); 'value' is always measured in this mode.  bf16x6 (default): fp32 "
                          "in / out / accumulate, every operand split into 3 bf16 terms, 6 cross products -- error vs fp64 "
-                         "at or below the plain fp32 MFMA chain's on every operand layout (tests/test_ops_gpu.py); f32: "
+                         "at the level of the plain fp32 MFMA chain's on every operand layout (tests/test_ops_gpu.py: <= 1.2x, measured 0.85-1.15x); f32: "
                          "v_mfma_f32_32x32x2_f32 everywhere (reported next to `value` as `exact_f32`); bf16x3 is a "
                          "16-bit-product mode for experiments and is never the default")
     ap.add_argument("--no-throughput-mode", "--no-second-mode", dest="no_throughput_mode", action="store_true",
@@ -145,7 +156,9 @@ def cpu_baseline(crop, nclass, warm, timed):
     cores = physical_cores()
     runs, total = {}, 0.0
     full = (warm, timed) != (1, 2)      # an explicit --cpu-baseline-steps applies to the all-cores (protocol) run
-    for threads, (w_, t_) in ((min(32, cores), (1, 2) if full else (warm, timed)), (cores, (warm, timed) if full else (0, 1))):
+    # default: all cores 1 warm-up + 1 timed step (a step is ~50 s there), 32 threads 1 + 2; the protocol actually run is the
+    # first thing `sample` says
+    for threads, (w_, t_) in ((min(32, cores), (1, 2) if full else (warm, timed)), (cores, (warm, timed) if full else (1, 1))):
         if threads in runs:
             continue
         med, spent = run(threads, w_, t_)
@@ -157,7 +170,8 @@ def cpu_baseline(crop, nclass, warm, timed):
     return dict(value=prim["images_per_s"], unit="images/s", cores=prim["threads"], kind="port", cpu=cpu_model(),
                 physical_cores=cores, s_per_step=prim["s_per_step"], runs=list(runs.values()),
                 best_thread_count=dict(threads=best["threads"], images_per_s=best["images_per_s"], s_per_step=best["s_per_step"]),
-                sample=f"full SemiVL steps of oracle/semivl_oracle.py (PyTorch CPU fp32) at VOC N={nclass}, {crop}x{crop}, "
+                sample=f"protocol: {prim['protocol']} at {prim['threads']} threads (= `value`); "
+                       f"full SemiVL steps of oracle/semivl_oracle.py (PyTorch CPU fp32) at VOC N={nclass}, {crop}x{crop}, "
                        f"bs={bs} ({2 * bs} images/step, BASELINE configs[0]) on {cpu_model()} ({cores} physical cores): `value` = "
                        f"all {cores} physical cores, {prim['protocol']} (the SURVEY §8(d) thread setting; its 3 + 5 steps are "
                        f"`--cpu-baseline-steps 3 5`, ~7 min on this host); PyTorch's CPU kernels scale negatively on this "
@@ -275,7 +289,7 @@ def main():
                vs_baseline=None,
                dtype="f32" if a.gemm_arith == "f32" else
                f"f32 (fp32 in/out/accumulate everywhere; large dense GEMMs as {a.gemm_arith} split products on the bf16 MFMA pipe, "
-               f"error vs fp64 <= the plain fp32 MFMA chain's: the dense GEMMs, the fused ViT attention and the >= 32-channel "
+               f"error vs fp64 at the level of the plain fp32 MFMA chain's (tests: <= 1.2x, measured 0.85-1.15x): the dense GEMMs, the fused ViT attention, the >= 32-channel "
                f"convolutions' forward / input gradient and the tiled 3x3 weight gradient; the remaining MFMA kernels on the fp32 pipe)",
                data="synthetic",
                config=dict(workload=f"SemiVL step, {dataset} N={a.nclass}, {cfg['model'].replace('mmseg.', '')}, {a.crop}x{a.crop}, "
@@ -294,14 +308,33 @@ def main():
         # for `value` a kernel's interval includes the time it shares the chip with the other stream's kernels
         step(a.warmup + a.steps, overlap_streams=False)
         torch.cuda.synchronize()
+        # ... and once more in the configuration `value` is measured in (streams overlapped): the same HIP-event brackets
+        # then give every launch's duration INSIDE the real step (it shares the chip with the other streams' kernels)
+        prof_solo = ops.PROFILE if rank == 0 else None
+        if rank == 0:
+            ops.PROFILE = {}
+        step(a.warmup + a.steps + 1)
+        torch.cuda.synchronize()
     if rank == 0 and not a.no_profile:
         g_arith_exact = a.gemm_arith == "f32"
-        prof, ops.PROFILE = ops.PROFILE, None
+        prof_in, prof, ops.PROFILE = ops.PROFILE, prof_solo, None
+        in_step = {}        # launch shape -> [summed ms, launches] with the streams overlapped
+        for fam_ in ("gemm", "gemm_bf16x", "attention", "attention_bf16x"):
+            for e0, e1, w, tag, _sc in prof_in.get(fam_, []):
+                r_ = in_step.setdefault(tag, [0.0, 0])
+                r_[0] += e0.elapsed_time(e1)
+                r_[1] += 1
         gx = prof.get("gemm_bf16x", []) + prof.get("attention_bf16x", [])   # launches served by the bf16 pipe (split emulation)
         g = prof.get("gemm", []) + gx + prof.get("attention", [])   # every MFMA kernel family
         t_gemm = sum(e0.elapsed_time(e1) for e0, e1, *_ in g) * 1e-3
         executed = sum(w for _, _, w, *_ in g)
-        algo = sum(ALGO_GF[(a.nclass, a.crop)]) * 1e9 * a.batch if (a.nclass, a.crop) in ALGO_GF else executed
+        issued = executed       # sum of 2MNK over the launches
+        if (a.nclass, a.crop) in ALGO_GF:
+            vit_gf, dec_gf = ALGO_GF[(a.nclass, a.crop)]
+            algo_contract = (vit_gf + dec_gf) * 1e9 * a.batch                         # 19 decoder fwd-equivalents
+            algo = (vit_gf + dec_gf * DEC_EXECUTED_SHARE) * 1e9 * a.batch            # what the step executes: 14
+        else:
+            algo_contract = algo = issued
         ach = algo / t_gemm / 1e12
         step_tf = algo / (ms * 1e-3) / 1e12
         # (kept for continuity with rounds 1-2 under its own key: ALL MFMA kernel time of the step against the fp32-MFMA
@@ -309,17 +342,25 @@ def main():
         # prices the dominant kernel against the pipe it runs on.)
         out["mfma_step_vs_f32_pipe"] = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
                                frac=round(ach / PEAK_F32_MFMA_TF, 4),
-                               frac_executed=round(executed / t_gemm / 1e12 / PEAK_F32_MFMA_TF, 4),
+                               frac_executed=round(issued / t_gemm / 1e12 / PEAK_F32_MFMA_TF, 4),
                                frac_whole_step=round(step_tf / PEAK_F32_MFMA_TF, 4), whole_step_tflops=round(step_tf, 2),
+                               algorithmic_gflop_per_step=round(algo / 1e9, 1),
+                               contract=dict(algorithmic_gflop_per_step=round(algo_contract / 1e9, 1),
+                                             achieved=round(algo_contract / t_gemm / 1e12, 2),
+                                             whole_step_tflops=round(algo_contract / (ms * 1e-3) / 1e12, 2),
+                                             note="SURVEY §8(d)'s per-step figure: 19 decoder forward-equivalents per image "
+                                                  "pair, of which the step (like the reference's useful work) executes 14"),
                                kernel="all MFMA launches of one step: gemm_kernel / conv kernels + attn_{fwd,bwd}_kernel "
                                       "(v_mfma_f32_32x32x2_f32)" + (" + gemm_bf16x_kernel / attn_*_x6_kernel (v_mfma_f32_32x32x16_bf16, 6 products)"
                                                                        if gx else ""), launches=len(g),
                                kernel_time_ms=round(t_gemm * 1e3, 2),
-                               executed_tflops=round(executed / t_gemm / 1e12, 2),
-                               note="achieved = algorithmic FLOPs of one step (SURVEY §8(d): (2866.6+1322.0) GF x B) / "
+                               executed_tflops=round(issued / t_gemm / 1e12, 2),
+                               note="achieved = EXECUTED algorithmic FLOPs of one step (ViT 2866.6 GF x B + decoder 1322.0 GF x "
+                                    "14/19 x B: the unused pred_x_fp decode and the backward of the detached pred_w are not run) / "
                                     "summed duration of all svl_gemm_f32 + svl_attention_* launches of one step (HIP events on the launch stream); "
-                                    "frac_executed = FLOPs actually issued by those launches / the same time; frac_whole_step = "
-                                    "algorithmic FLOPs / the WHOLE step time (every non-MFMA pass counted against the MFMA peak)")
+                                    "frac_executed = 2MNK actually issued by those launches / the same time; frac_whole_step = "
+                                    "executed algorithmic FLOPs / the WHOLE step time (every non-MFMA pass counted against the MFMA "
+                                    "peak); `contract` = the same ratios with SURVEY §8(d)'s 19-forward-equivalent figure")
         if gx:   # the split-emulation GEMM family against ITS pipe: bf16 dense peak / products per fp32 MAC
             nprod = 6 if a.gemm_arith == "bf16x6" else 3
             t_x = sum(e0.elapsed_time(e1) for e0, e1, *_ in gx) * 1e-3
@@ -362,12 +403,14 @@ def main():
                                note="HIP-event durations of the timed kernel families in one step; the rest of the step is "
                                     "normalisation / elementwise / resampling / optimizer passes (profiles/)")
         # largest single launch shapes
-        by = {}
-        for e0, e1, w, tag, _scope in g:
-            r = by.setdefault(tag, [0.0, 0.0, 0])
-            r[0] += e0.elapsed_time(e1) * 1e-3
-            r[1] += w
-            r[2] += 1
+        by, fam_of = {}, {}
+        for fam_ in ("gemm", "gemm_bf16x", "attention", "attention_bf16x"):
+            for e0, e1, w, tag, _scope in prof.get(fam_, []):
+                r = by.setdefault(tag, [0.0, 0.0, 0])
+                r[0] += e0.elapsed_time(e1) * 1e-3
+                r[1] += w
+                r[2] += 1
+                fam_of[tag] = fam_
         if os.environ.get("SVL_BENCH_SHAPES"):  # every launch shape of the step, for tuning (tools/README.md)
             with open(os.environ["SVL_BENCH_SHAPES"], "w") as f:
                 for k, v in sorted(by.items(), key=lambda kv: -kv[1][0]):
@@ -381,10 +424,49 @@ def main():
         # bf16x6 mode, the fp32-MFMA peak in exact mode.  Traffic: committed PMC record of the same kernel source.
         ntok = ((a.crop + 15) // 16) ** 2 + 1           # 1025 at 512^2, 2602 at 801^2
         Md = 2 * a.batch * ntok
-        if not g_arith_exact:
+
+        def in_step_fields(tag, flops, peak_):
+            """The same launches inside the real (stream-overlapped) step: mean duration and the fraction it gives."""
+            r_ = in_step.get(tag)
+            if not r_ or not r_[1]:
+                return {}
+            avg = r_[0] / r_[1]
+            return dict(avg_ms_in_step=round(avg, 4), frac_in_step=round(flops / (avg * 1e-3) / 1e12 / peak_, 4),
+                        in_step_note="avg_ms = HIP events with the step's streams run back to back (a solo duration); "
+                                     "avg_ms_in_step = the same brackets in the step as `value` measures it (streams "
+                                     "overlapped: a launch shares the chip with the other streams' kernels)")
+
+        voc_cfg = (a.nclass, a.crop) == (21, 512)
+        if not voc_cfg and by:
+            # Other configs: the launch SHAPE with the largest summed duration of THIS run (at N = 81 / 150 the decoder's
+            # convolutions, at 801^2 the attention), priced against the pipe its kernel family runs on.
+            tag, v = max(by.items(), key=lambda kv: kv[1][0])
+            fam = fam_of[tag]
+            on_bf16 = fam.endswith("bf16x")
+            nprod = {"bf16x6": 6, "bf16x3": 3}.get(a.gemm_arith, 6)
+            peak = PEAK_BF16_MFMA_TF / nprod if on_bf16 else PEAK_F32_MFMA_TF
+            d_tf = v[1] / v[0] / 1e12
+            fl = v[1] / v[2]
+            kern = {"gemm": "svl_gemm_f32 on v_mfma_f32_32x32x2_f32 (gemm_kernel / tiled 3x3 / short-K stream)",
+                    "gemm_bf16x": "svl_gemm_f32 / svl_gemm_planes_f32 / tiled 3x3 in the split arithmetic (gemm_bf16x_kernel, "
+                                  "gemm_x6p_kernel, conv3x3_*_bf16x_kernel: v_mfma_f32_32x32x16_bf16)",
+                    "attention": "svl_attention_* (attn_*_kernel, fp32 MFMA)",
+                    "attention_bf16x": "svl_attention_* (attn_*_x6_kernel, v_mfma_f32_32x32x16_bf16)"}[fam]
+            out["roofline"] = dict(
+                bound="mfma", achieved=round(d_tf, 1), peak=round(peak, 1),
+                unit="TFLOP/s (fp32-equivalent)" if on_bf16 else "TFLOP/s", frac=round(d_tf / peak, 4), traffic=None,
+                kernel=f"{kern}, launch shape (a_mode, b_mode, M, N, K, batch | name, ...) = {tag}",
+                launches=v[2], avg_ms=round(v[0] * 1e3 / v[2], 4), **in_step_fields(tag, fl, peak), flops_per_launch=fl,
+                share_of_mfma_time=round(v[0] / t_gemm, 4),
+                traffic_note="no PMC record for this launch shape (profiles/ holds the records of the VOC line's kernels)",
+                note="the launch shape with the largest summed duration of this run; achieved = its 2MNK / mean launch "
+                     "duration (HIP events, streams back to back); peak = the pipe its kernel family runs on (2500 TF bf16 "
+                     f"dense / {nprod} products per fp32 MAC, or the 157.3 TF fp32 MFMA peak)")
+        elif not g_arith_exact:
             nprod = 6 if a.gemm_arith == "bf16x6" else 3
-            dom = by.get(("planes", Md, 3072, 768, ops.ACT_GELU)) or by.get((0, 0, Md, 3072, 768, 1))
             planes = ("planes", Md, 3072, 768, ops.ACT_GELU) in by
+            dom_tag = ("planes", Md, 3072, 768, ops.ACT_GELU) if planes else (0, 0, Md, 3072, 768, 1)
+            dom = by.get(dom_tag)
             clock = None
             if dom is not None and planes:
                 # the clock the chip sustains under this kernel (svl_clock_probe waves on a second stream next to 24
@@ -413,6 +495,7 @@ def main():
                             "v_mfma_f32_32x32x16_bf16; bias + erf-GELU + saved pre-activation + result as planes)" if planes
                             else "gemm_bf16x_kernel (svl_gemm_f32, in-register split)") + ", M=%d N=3072 K=768" % Md,
                     launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 4),
+                    **in_step_fields(dom_tag, 2.0 * Md * 3072 * 768, peak),
                     flops_per_launch=2.0 * Md * 3072 * 768, bf16_issued_tflops=round(d_tf * nprod, 1),
                     frac_of_bf16_dense_peak=round(d_tf * nprod / PEAK_BF16_MFMA_TF, 4),
                     algorithmic_bytes=(Md * 768 * 6 + 3072 * 768 * 6 + Md * 3072 * 10) if planes else 513.0e6 * a.batch / 16,
@@ -423,7 +506,8 @@ def main():
                          "products per fp32 MAC (MI355X_MICROARCH.md); algorithmic bytes = A and B planes (6 B/element) read "
                          "once + pre-activation (4 B) and result planes (6 B) written once")
         else:
-            dom = by.get((0, 0, Md, 3072, 768, 1))
+            dom_tag = (0, 0, Md, 3072, 768, 1)
+            dom = by.get(dom_tag)
             if dom is not None:
                 d_tf = dom[1] / dom[0] / 1e12
                 traffic, tnote = pmc_traffic_record(a.batch)
@@ -431,7 +515,8 @@ def main():
                     bound="mfma", achieved=round(d_tf, 1), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
                     frac=round(d_tf / PEAK_F32_MFMA_TF, 4), traffic=traffic,
                     kernel="gemm_kernel<128,128,2,2,KCONTIG,KCONTIG> (svl_gemm_f32, v_mfma_f32_32x32x2_f32), M=%d N=3072 K=768" % Md,
-                    launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 4), flops_per_launch=2.0 * Md * 3072 * 768,
+                    launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 4),
+                    **in_step_fields(dom_tag, 2.0 * Md * 3072 * 768, PEAK_F32_MFMA_TF), flops_per_launch=2.0 * Md * 3072 * 768,
                     algorithmic_bytes=513.0e6 * a.batch / 16, traffic_note=tnote)
         if os.environ.get("SVL_BENCH_DUMP_SHAPES"):
             allsh = sorted(by.items(), key=lambda kv: -kv[1][0])
@@ -497,6 +582,29 @@ def main():
         except Exception as e:  # the baseline leg must never take the GPU number down with it
             out["cpu_baseline"] = dict(value=None, unit="images/s", cores=physical_cores(), kind="port",
                                        sample=f"failed: {type(e).__name__}: {e}")
+    if AS_MULTI:
+        out["settings"] = dict(as_multi=True, gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
+                               weight_gradient_stream=bool(ops.WGRAD_STREAM),
+                               note="one GPU with the stream / hardware-queue settings of a multi-GPU rank")
+    if rank == 0 and world == 1 and not AS_MULTI and not a.no_multi_anchor:
+        # The ranks of an N > 1 run use 8 hardware queues and no weight-gradient stream (top of this file): re-measure
+        # N = 1 in a child process with exactly those settings, so that a scaling curve has an apples-to-apples anchor.
+        import subprocess
+        torch.cuda.empty_cache()
+        n3 = min(a.steps, 5)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--as-multi", "--steps", str(n3), "--warmup", "2",
+               "--batch", str(a.batch), "--crop", str(a.crop), "--nclass", str(a.nclass), "--gemm-arith", a.gemm_arith,
+               "--no-profile", "--no-cpu-baseline", "--no-throughput-mode"]
+        try:
+            r_ = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            child = json.loads(r_.stdout.strip().splitlines()[-1])
+            out["n1_same_settings"] = dict(value=child["value"], unit="images/s", ms_per_step=child["ms_per_step"], steps=n3,
+                                           settings=child.get("settings"),
+                                           note="python bench.py --gpus 1 --as-multi: what every rank of `--gpus N` runs with; "
+                                                "divide a multi-GPU `value` by N x THIS for scaling efficiency of the "
+                                                "communication alone")
+        except Exception as e:
+            out["n1_same_settings"] = dict(value=None, note=f"child run failed: {type(e).__name__}: {e}")
     if world > 1:      # the communication side of the last timed step, so that a scaling curve explains itself
         torch.cuda.synchronize()
         rep = red.timing_report()

@@ -47,6 +47,10 @@ int svl_version(void); /* 300: round-3 ABI (packed-planes operands; planes outpu
 /* Destroys the helper stream/events this library created for `stream` on the current device (no-op if none), or for
  * every stream.  Call after the stream has been synchronised; not required before process exit. */
 int svl_stream_release(svl_stream_t stream);
+/* Creates the helper stream/events of `stream` NOW instead of on first use (no-op if they exist).  The HIP runtime maps a
+ * process's streams onto its hardware queues in creation order: a caller that wants a reproducible map (the data-parallel
+ * reducer creates the step's streams before its communication stream) creates them up front.  No reference counterpart. */
+int svl_stream_prepare(svl_stream_t stream);
 int svl_shutdown(void);
 int svl_num_stream_contexts(void); /* live (device, stream) helper contexts -- introspection for tests */
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
@@ -155,6 +159,11 @@ int svl_get_gemm_emulation(void);
 /* 1 (default): narrow (N = 32 / 64) 3x3 stride-1 convolutions run on the spatially tiled kernel; 0: implicit GEMM only.
  * Initial value: 0 if the environment variable SVL_CONV_NO_TILED is set. */
 int svl_set_conv_tiled(int on);
+/* Measurement aid (bench.py prices a launch against the pipe that served it; no reference counterpart): which kernel family
+ * the calling thread's LAST svl_gemm_f32 call dispatched to -- 0 exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 bf16 split
+ * products (v_mfma_f32_32x32x16_bf16; emulation mode 3 / 6: dense, implicit-GEMM forward / input gradient / weight gradient,
+ * tiled 3x3), 2 the short-K row stream (fp32 MFMA, HBM-bound), 3 an elementwise kernel (no MFMA). */
+int svl_last_gemm_path(void);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32-accurate GEMM with PRE-SPLIT, fragment-packed operands (the fast form of emulation mode 6; csrc/gemm_planes.hip).
@@ -374,6 +383,22 @@ int svl_copy2d_f32(const float* src, int64_t sgrp, int64_t src_go, int64_t src_l
  * stats [imgs, G, 2] = (mean, rstd); y pixel stride ldy (lets the result land in a concat slice). vlg_head.py:74-137 */
 int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int imgs,
                       int64_t HW, int C, int G, int relu, float* y, int64_t ldy, float* stats, svl_stream_t stream);
+/* Conv2d(3x3, stride 1, pad 1, no bias; NHWC, optional second concat source read at image img / rep) of the Up blocks
+ * FUSED with the statistics of the GroupNorm that follows it (vlg_head.py:120-127, groups of 16 channels): out [imgs H W, N]
+ * (pixel stride ldo) and stats [imgs, N / 16, 2] = (mean, rstd), the latter from per-tile partial sums left by the
+ * convolution's epilogue (ws: svl_conv3x3_gn_ws_doubles(...) doubles of device scratch) -- the separate statistics pass
+ * over the result (4 B per element of HBM reads) disappears.  w = the forward pack [N, 9 (C1 + C2)].  Returns
+ * SVL_ERR_UNSUPPORTED without launching anything when the spatially tiled kernel does not take the shape (N not 32 / 64,
+ * channels not a multiple of 16, fewer than 16384 pixels): run svl_gemm_f32 + svl_groupnorm_fwd instead. */
+int64_t svl_conv3x3_gn_ws_doubles(int imgs, int H, int W, int N);
+int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const float* src2, int64_t ld2, int C2, int rep,
+                       const float* w, int imgs, int H, int W, int N, float* out, int64_t ldo, float eps, double* ws,
+                       float* stats, svl_stream_t stream);
+/* The apply pass of svl_groupnorm_fwd alone, on given statistics: bit-identical y.  Backward uses it to re-materialise a
+ * normalised activation from the kept pre-normalisation tensor instead of keeping both (no reference counterpart: autograd
+ * keeps every intermediate, vlg_head.py:84-137). */
+int svl_groupnorm_apply(const float* x, int64_t ldx, const float* gamma, const float* beta, int imgs, int64_t HW, int C, int G,
+                        int relu, const float* stats, float* y, int64_t ldy, svl_stream_t stream);
 /* dy has pixel stride lddy.  ReLU mask: from y (post-activation, stride ldy) when given; with y == NULL it is
  * re-derived from x, stats, gamma and beta with the forward's own fma (bit for bit the sign the forward saw) -- one tensor
  * pass less in each of the two kernels.  beta is only read in that case.

@@ -459,9 +459,16 @@ def compute_mc_loss(pred, mask, ign, reduce="mean_all"):  # semivl.py:52-58 with
 
 
 def semivl_step(model, batch, iters, total_iters, conf_thresh=0.95, conf_mode="pixelwise", mcc_lambda=(0.1, 0.0),
-                mcc_conf_thresh=0.9, fp_masks=None, mcc_loss_reduce="mean_all"):
+                mcc_conf_thresh=0.9, fp_masks=None, mcc_loss_reduce="mean_all", helpers=None):
     """semivl.py:223-323 for method='semivl', criterion CELoss(ignore 255), criterion_u CELoss.
-    `batch` holds the 12 step tensors.  Returns (loss, dict of intermediates)."""
+    `batch` holds the 12 step tensors.  Returns (loss, dict of intermediates).
+    `helpers`: the loss helpers to drive the loop with -- the golden generator (tests/golden/gen_golden.py) passes the
+    REFERENCE's own utils/train_utils.py functions and its semivl.py::compute_mc_loss here, so the fixtures pin this
+    file's restatements of them (above) by execution; signature (cutmix_img_, cutmix_mask, confidence_weighted_loss(loss,
+    conf, ign, conf_mode, conf_thresh), compute_mc_loss(pred, mask, ign, reduce))."""
+    cutmix_img_, cutmix_mask, confidence_weighted_loss, compute_mc_loss = helpers or (
+        globals()["cutmix_img_"], globals()["cutmix_mask"], globals()["confidence_weighted_loss"],
+        globals()["compute_mc_loss"])
     b = {k: v.clone() for k, v in batch.items()}
     cutmix_img_(b["img_s1"], b["img_s1_other"], b["mix1"])
     cutmix_img_(b["img_s2"], b["img_s2_other"], b["mix2"])

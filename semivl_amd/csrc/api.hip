@@ -93,6 +93,11 @@ int svl_join(hipStream_t st) {
   return SVL_OK;
 }
 
+extern "C" int svl_stream_prepare(svl_stream_t stream) {
+  StreamCtx c;
+  return ctx_for((hipStream_t)stream, &c);
+}
+
 extern "C" int svl_stream_release(svl_stream_t stream) {
   int dev = 0;
   int rc = stream_device((hipStream_t)stream, &dev);

@@ -10,7 +10,9 @@ struct ConvTiledP {
   const float* bias; int act; int accumulate;
   int imgs, H, W, N;
   int sign;                                         // +1: correlation taps, -1: mirrored taps (input-gradient form)
+  double* gn_part;                                  // null, or [blocks][N / 16][2]: per-tile (sum, sum of squares) of the
+                                                    // result per 16-channel GroupNorm group (svl_conv3x3_gn_f32)
 };
 
 bool svl_conv3x3_tiled_eligible(const ConvTiledP& p);
-int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st);
+int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st, int* tiles_per_img = nullptr);

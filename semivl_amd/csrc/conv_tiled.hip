@@ -13,12 +13,72 @@ namespace {
 constexpr int PH = 8, PW = 16, IH = PH + 2, IW = PW + 2, SLAB = 16, XS = SLAB + 1;
 constexpr int NPIX = IH * IW;  // 180
 
+// GroupNorm statistics in the convolution's epilogue (vlg_head.py:116-137: every narrow 3x3 convolution feeds a
+// GroupNorm over groups of 16 channels).  A wave's accumulator columns are channels (lane & 31: two groups per 32-column
+// tile), its rows pixels: every lane adds up its own valid pixels in fp32 (<= 32 values), the 32 lanes of a group (16
+// channels x 2 row halves) and then the four waves are combined in DOUBLE in a fixed order, and the block leaves one (sum,
+// sum of squares) pair per group in p.gn_part[blockIdx.x] -- a statistics pass over the tensor (4 B per element of HBM
+// reads) becomes ~60 instructions per wave.  gn_finalize_kernel adds an image's tiles up (fixed order: deterministic,
+// independent of how many images share the launch).
+template <int TN>
+__device__ __forceinline__ void gn_tile_partials(const ConvTiledP& p, const float (&s)[TN], const float (&q)[TN], double* red,
+                                                 int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    double ds = (double)s[j], dq = (double)q[j];
+#pragma unroll
+    for (int m = 1; m <= 8; m <<= 1) {
+      ds += __shfl_xor(ds, m, 64);
+      dq += __shfl_xor(dq, m, 64);
+    }
+    ds += __shfl_xor(ds, 32, 64);
+    dq += __shfl_xor(dq, 32, 64);
+    if ((lane & 47) == 0) {                       // lanes 0 and 16: the two groups of this 32-column tile
+      double* d = red + ((wave * TN + j) * 2 + (lane >> 4)) * 2;
+      d[0] = ds;
+      d[1] = dq;
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * TN) {                             // group tid = 2 j + half
+    double ts = 0.0, tq = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      ts += red[(w * 2 * TN + tid) * 2];
+      tq += red[(w * 2 * TN + tid) * 2 + 1];
+    }
+    double* o = p.gn_part + ((long)blockIdx.x * (2 * TN) + tid) * 2;
+    o[0] = ts;
+    o[1] = tq;
+  }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ part, int tiles, int G, double n, float eps, long count,
+                                   float* __restrict__ stats) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;    // (img, group)
+  if (i >= count) return;
+  const long img = i / G;
+  const int g = (int)(i - img * G);
+  const double* q = part + ((img * tiles) * G + g) * 2;
+  double ts = 0.0, tq = 0.0;
+  for (int t = 0; t < tiles; ++t) {
+    ts += q[(long)t * G * 2];
+    tq += q[(long)t * G * 2 + 1];
+  }
+  const double mean = ts / n;
+  double var = tq / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[i * 2] = (float)mean;
+  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 template <int TN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv3x3_tiled_kernel(const ConvTiledP p, int tiles_x, int tiles_y) {
   constexpr int N = 32 * TN;
   constexpr int XP = (NPIX * 4 + 255) / 256;       // input float4 pieces per thread (3)
   __shared__ float xs[NPIX * XS];
-  __shared__ float ws[9 * SLAB * N];
+  __shared__ __attribute__((aligned(16))) float ws[9 * SLAB * N];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   int t = blockIdx.x;
   const int txi = t % tiles_x;
@@ -108,6 +168,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   // C layout: column = output channel (l31 + 32 j), row i = (r & 3) + 8 (r >> 2) + 4 hi = pixel (i >> 4, i & 15) of the wave
   // Straight-line epilogue (see gemm_epilogue): uniform decisions once per 32-channel block, previous values (accumulate)
   // read before the first store, one pointer per block plus per-register pixel offsets.
+  float gs[TN], gq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = l31 + 32 * j;
@@ -123,6 +186,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       ok[r] = y < p.H && x < p.W;
       off[r] = ((long)y * p.W + x) * p.ldo;
       v[r] = acc[j][r] + bv;
+    }
+    if (p.gn_part) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = ok[r] ? v[r] : 0.f;
+        gs[j] += t;
+        gq[j] += t * t;
+      }
     }
     if (p.act == SVL_ACT_GELU) {
 #pragma unroll
@@ -142,6 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     for (int r = 0; r < 16; ++r)
       if (ok[r]) ob[off[r]] = v[r];
   }
+  if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, reinterpret_cast<double*>(ws), tid);   // (the K loop ended with a barrier)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -297,6 +369,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   // epilogue: identical to the fp32 kernel's (column = output channel, row = pixel of the wave)
+  float gs[TN], gq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
 #pragma unroll
   for (int u = 0; u < PT; ++u)
 #pragma unroll
@@ -314,6 +389,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ok[r] = y < p.H && x < p.W;
       off[r] = ((long)y * p.W + x) * p.ldo;
       v[r] = acc[u][j][r] + bv;
+    }
+    if (p.gn_part) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = ok[r] ? v[r] : 0.f;
+        gs[j] += t;
+        gq[j] += t * t;
+      }
     }
     if (p.act == SVL_ACT_GELU) {
 #pragma unroll
@@ -333,6 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int r = 0; r < 16; ++r)
       if (ok[r]) ob[off[r]] = v[r];
   }
+  if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, reinterpret_cast<double*>(ws), tid);   // (the K loop ended with a barrier)
 }
 
 }  // namespace
@@ -347,8 +431,9 @@ bool svl_conv3x3_tiled_eligible(const ConvTiledP& p) {
   return (long)p.imgs * p.H * p.W >= 16384 && p.H >= PH && p.W >= PW;
 }
 
-int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st) {
+int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st, int* tiles_per_img) {
   const int tx = (p.W + PW - 1) / PW, ty = (p.H + PH - 1) / PH;
+  if (tiles_per_img) *tiles_per_img = tx * ty;
   const long blocks = (long)p.imgs * tx * ty;
   SVL_CHECK_ARG(blocks < (1L << 31), "svl_conv3x3_tiled: grid too large");
   static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
@@ -356,12 +441,43 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st) {
   if (emu_ok && svl_get_gemm_emulation() == 6) {   // the split emulation covers the narrow convolutions too
     if (p.N == 32 && pt2 && p.H >= 2 * PH) {        // 16 x 16 patches: two pixel tiles per wave
       const int ty2 = (p.H + 2 * PH - 1) / (2 * PH);
+      if (tiles_per_img) *tiles_per_img = tx * ty2;
       hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 2>), dim3((unsigned)((long)p.imgs * tx * ty2)), dim3(256), 0, st, p, tx, ty2);
     } else if (p.N == 32) hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
     else hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   } else if (p.N == 32) hipLaunchKernelGGL(conv3x3_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   else hipLaunchKernelGGL(conv3x3_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   SVL_LAUNCH_CHECK("svl_gemm_f32 (tiled 3x3 conv)");
+  return SVL_OK;
+}
+
+// Conv2d(3x3, pad 1, no bias) of the Up blocks WITH the statistics of the GroupNorm that follows it (vlg_head.py:120-127):
+// the tiled kernel's epilogue leaves per-tile partial sums, gn_finalize_kernel turns them into (mean, rstd) per
+// (class-image, group of 16 channels).  SVL_ERR_UNSUPPORTED (and no launch) when the tiled kernel does not take the shape:
+// the caller then runs the convolution and svl_groupnorm_fwd's statistics pass separately.
+extern "C" int64_t svl_conv3x3_gn_ws_doubles(int imgs, int H, int W, int N) {
+  const long tiles = (long)imgs * ((W + PW - 1) / PW) * ((H + PH - 1) / PH);   // (an upper bound for the 16 x 16 patch variant)
+  return tiles * (N / 16) * 2;
+}
+
+extern "C" int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const float* src2, int64_t ld2, int C2, int rep,
+                                  const float* w, int imgs, int H, int W, int N, float* out, int64_t ldo, float eps,
+                                  double* ws, float* stats, svl_stream_t stream) {
+  SVL_CHECK_ARG(src1 && w && out && ws && stats && imgs > 0 && N % 16 == 0, "svl_conv3x3_gn_f32: bad args");
+  ConvTiledP t;
+  t.src1 = src1; t.ld1 = ld1; t.C1 = C1; t.src2 = src2; t.ld2 = ld2; t.C2 = C2; t.rep = rep < 1 ? 1 : rep;
+  t.w = w; t.K = 9 * (C1 + C2); t.out = out; t.ldo = ldo; t.bias = nullptr; t.act = SVL_ACT_NONE; t.accumulate = 0;
+  t.imgs = imgs; t.H = H; t.W = W; t.N = N; t.sign = 1; t.gn_part = ws;
+  if (!svl_conv3x3_tiled_eligible(t)) return SVL_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  int tiles = 0;
+  const int rc = svl_conv3x3_tiled_launch(t, st, &tiles);
+  if (rc != SVL_OK) return rc;
+  const int G = N / 16;
+  const long count = (long)imgs * G;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, tiles, G,
+                     (double)H * W * 16.0, eps, count, stats);
+  SVL_LAUNCH_CHECK("svl_conv3x3_gn_f32/finalize");
   return SVL_OK;
 }
 

@@ -977,6 +977,52 @@ __device__ __forceinline__ void emu_split_store(__bf16* dst, int plane_stride, i
   }
 }
 
+// B operand = im2col(x)^T (SVL_B_CONVW, the weight gradient of an implicit-GEMM convolution): row n = (tap, ci) is FIXED
+// per thread for the whole K loop, k = output pixel advances.  A thread's 8 consecutive k are 8 consecutive pixels of one
+// image row (the launcher requires Wo % 8 == 0 and 16-aligned K slabs), so one row test and eight column tests decide the
+// zero padding; the loads themselves go to clamped addresses and are selected afterwards (a load under a per-lane
+// condition becomes an exec-masked branch with its own s_waitcnt).
+struct ConvBT {
+  const float* src;   // channel ci of pixel (0, 0) of image 0 of this row's concat source
+  long ld;            // floats per pixel of that source
+  int div;            // class-images per source image (rep for the second source)
+  int dih, diw;       // tap offset in input pixels
+  int img, oh, ow;    // output pixel of the thread's first k of the NEXT step
+};
+__device__ __forceinline__ void convbt_init(const GemmP& p, int n, int k, ConvBT& s) {
+  const svl_conv_geom& cv = p.cv;
+  const int Ct = cv.C1 + cv.C2;
+  const int tap = n / Ct, ci = n - tap * Ct;
+  const int ti = tap / cv.KW, tj = tap - ti * cv.KW;
+  const bool first = ci < cv.C1;
+  s.src = first ? p.B.p + ci : cv.src2 + (ci - cv.C1);
+  s.ld = first ? p.B.ld : cv.ld2;
+  s.div = first ? 1 : cv.rep;
+  s.dih = cv.sign * (ti * cv.dil - cv.pad);
+  s.diw = cv.sign * (tj * cv.dil - cv.pad);
+  s.ow = k % cv.Wo;
+  const int t = k / cv.Wo;
+  s.oh = t % cv.Ho;
+  s.img = t / cv.Ho;
+}
+template <int BK>
+__device__ __forceinline__ void convbt_load(const GemmP& p, ConvBT& s, EmuRaw& r) {
+  const svl_conv_geom& cv = p.cv;
+  const int ih = s.oh * cv.stride + s.dih, iw0 = s.ow * cv.stride + s.diw;
+  const bool rowok = (unsigned)ih < (unsigned)cv.H;
+  const float* rp = s.src + ((long)(s.img / s.div) * cv.H + min(max(ih, 0), cv.H - 1)) * cv.W * s.ld;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = rp[(long)min(max(iw0 + j * cv.stride, 0), cv.W - 1) * s.ld];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r.v[j] = (rowok && (unsigned)(iw0 + j * cv.stride) < (unsigned)cv.W) ? v[j] : 0.f;
+  s.ow += BK;
+  while (s.ow >= cv.Wo) {
+    s.ow -= cv.Wo;
+    if (++s.oh == cv.Ho) { s.oh = 0; ++s.img; }
+  }
+}
+
 template <int NS, int A_RM, int B_RM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x_kernel(const GemmP p) {
   constexpr int BM = 128, BN = 128, BKE = 16, LDR = 24;  // LDR: bf16 elements per LDS row (48 B)
@@ -1040,7 +1086,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     conv_advance_k<BKE>(p.cv, cs0);
     cs1.ti = cs0.ti; cs1.tj = cs0.tj; cs1.ci = cs0.ci;
   };
-  const float* pb = B + (B_RM ? b_r : b_r * p.B.ld) + (long)(kbeg + b_ko) * b_ks;
+  constexpr bool B_CV = B_RM == 2;   // B operand = im2col^T of an NHWC tensor (row-contiguous store shape, conv addressing)
+  const float* pb = B_CV ? B : B + (B_RM ? b_r : b_r * p.B.ld) + (long)(kbeg + b_ko) * b_ks;
+  ConvBT cbt;
+  if constexpr (B_CV) convbt_init(p, (int)b_r, kbeg + b_ko, cbt);   // (like the conv A operand: loads are requested in step order)
   const long a_d2 = A_RM ? 0 : (a_r2 - a_r) * p.A.ld, b_d2 = B_RM ? 0 : (b_r2 - b_r) * p.B.ld;  // second-row offsets
   const bool a_vec = p.A.vec, b_vec = p.B.vec;
   const int klen = kend - kbeg;
@@ -1062,13 +1111,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float* qb = pb + (long)t * BKE * b_ks;
       if constexpr (A_CV) aload_conv(xa);            // (K % 16 == 0 for this mode: every step is a full one)
       else emu_gload<A_RM>(xa, qa, qa + a_d2, a_ks, a_vec);
-      emu_gload<B_RM>(xb, qb, qb + b_d2, b_ks, b_vec);
+      if constexpr (B_CV) convbt_load<BKE>(p, cbt, xb);   // (16-aligned K slabs for this mode: every step is a full one)
+      else emu_gload<B_RM>(xb, qb, qb + b_d2, b_ks, b_vec);
     } else if (t < nk) {
       const int rem = klen - t * BKE;
       const float* qa = pa + (long)t * BKE * a_ks;
       const float* qb = pb + (long)t * BKE * b_ks;
       emu_gload_tail<A_ST>(xa, qa, qa + a_d2, a_ks, rem - a_ko);
-      emu_gload_tail<B_RM>(xb, qb, qb + b_d2, b_ks, rem - b_ko);
+      if constexpr (!B_CV) emu_gload_tail<B_RM>(xb, qb, qb + b_d2, b_ks, rem - b_ko);
     }
   };
   auto sstore = [&](const EmuRaw& xa, const EmuRaw& xb, int buf) {
@@ -1121,7 +1171,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto fast_step = [&](EmuRaw& la, EmuRaw& lb, EmuRaw& ca, EmuRaw& cb, int buf) {
       if constexpr (A_CV) aload_conv(la);
       else emu_gload<A_RM>(la, qa, qa + a_d2, a_ks, true);
-      emu_gload<B_RM>(lb, qb, qb + b_d2, b_ks, true);
+      if constexpr (B_CV) convbt_load<BKE>(p, cbt, lb);
+      else emu_gload<B_RM>(lb, qb, qb + b_d2, b_ks, true);
       qa += a_step;
       qb += b_step;
       // opaque re-definition: keeps this step's split after the previous barrier (it is pure register arithmetic on
@@ -1226,6 +1277,9 @@ static int svl_band_n(int tiles_n) {
 static std::atomic<int> g_conv_tiled{-1};  // -1: read SVL_CONV_NO_TILED once
 static std::atomic<int> g_emu_mode{-1};    // -1: read SVL_GEMM_EMU once; 0 exact fp32 MFMA; 3 / 6: bf16 split emulation
 static std::atomic<int> g_ragged_fork{-1};
+// which kernel family served the calling thread's last svl_gemm_f32 (svl_last_gemm_path: measurement aid of bench.py)
+enum { SVL_PATH_F32 = 0, SVL_PATH_BF16X = 1, SVL_PATH_SHORTK = 2, SVL_PATH_ELTWISE = 3 };
+static thread_local int g_last_path = 0;
 // hipFuncSetAttribute is per device: one bit per device ordinal and kernel instantiation
 static bool attr_needed(std::atomic<uint64_t>& mask) {
   int dev = 0;
@@ -1242,7 +1296,8 @@ int launch_emu(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
   q.band_n = svl_band_n(q.tiles_n);
   const long tiles = (long)((p.M + 127) / 128) * q.tiles_n;
   dim3 grid((unsigned)tiles, 1, (unsigned)batch);
-  if (a_rm == 2) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 2, 0>), grid, dim3(256), 0, st, q);
+  if (b_rm == 2) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 2>), grid, dim3(256), 0, st, q);
+  else if (a_rm == 2) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 2, 0>), grid, dim3(256), 0, st, q);
   else if (a_rm == 0 && b_rm == 0) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 0>), grid, dim3(256), 0, st, q);
   else if (a_rm == 0 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 1>), grid, dim3(256), 0, st, q);
   else if (a_rm == 1 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 1>), grid, dim3(256), 0, st, q);
@@ -1409,17 +1464,30 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     g_emu_mode.store(emu_mode, std::memory_order_relaxed);
   }
   static const int emu_conv = getenv("SVL_GEMM_EMU_NO_CONV") ? 0 : 1;
+  g_last_path = SVL_PATH_F32;
   auto launch = [&](const GemmP& q) -> int {
     // implicit-GEMM convolutions (NHWC im2col on the fly, forward and mirrored-tap input gradient) join the split
     // emulation when every 4-k piece stays inside one tap (channels % 4) and K is a whole number of 16-deep steps
     if ((emu_mode == 3 || emu_mode == 6) && am == SVL_A_CONV && bm == SVL_B_KCONTIG && d->out_mode == SVL_OUT_STRIDED &&
         d->batch == 1 && d->ksplit == 0 && q.M >= 256 && q.N >= 96 && q.K >= 64 && (q.K % 16) == 0 && q.A.vec && q.B.vec &&
         emu_conv) {
+      g_last_path = SVL_PATH_BF16X;
       return emu_mode == 6 ? launch_emu<3>(q, 2, 0, 1, st) : launch_emu<2>(q, 2, 0, 1, st);
+    }
+    // weight gradients of the implicit-GEMM convolutions (A = dy^T, B = im2col(x)^T, split-K over the pixels): the
+    // dilated / 1x1 / transposed-conv layers of the decoder.  One 128-row tile holds all of Cout = 128 (64 wastes half a
+    // tile and still beats the fp32 pipe); a thread's 8 consecutive k must be pixels of one image row.
+    static const int emu_convw = getenv("SVL_GEMM_EMU_NO_CONVW") ? 0 : 1;
+    if ((emu_mode == 3 || emu_mode == 6) && am == SVL_A_MCONTIG && bm == SVL_B_CONVW && d->out_mode == SVL_OUT_STRIDED &&
+        q.M >= 64 && q.N >= 96 && q.K >= 1024 && (q.K % 16) == 0 && (d->ksplit % 16) == 0 && (q.cv.Wo % 8) == 0 &&
+        q.A.vec && q.B.vec && emu_convw) {
+      g_last_path = SVL_PATH_BF16X;
+      return emu_mode == 6 ? launch_emu<3>(q, 1, 2, d->batch, st) : launch_emu<2>(q, 1, 2, d->batch, st);
     }
     if ((emu_mode == 3 || emu_mode == 6) && (am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) &&
         (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && q.M >= 256 && q.N >= 96 &&
         q.K >= 64) {
+      g_last_path = SVL_PATH_BF16X;
       return emu_mode == 6 ? launch_emu<3>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
                              : launch_emu<2>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
     }
@@ -1448,6 +1516,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         (d->out_mode == SVL_OUT_STRIDED || d->out_mode == SVL_OUT_CONVT2X)) {
       const bool fast = (d->ldc_n == 1 || d->out_mode == SVL_OUT_CONVT2X) && !d->resid && !d->preact && !d->accumulate &&
                         (d->act == SVL_ACT_NONE || d->act == SVL_ACT_RELU || d->act == SVL_ACT_GELU);
+      g_last_path = SVL_PATH_SHORTK;
       return launch_shortk(p, fast, st);
     }
   }
@@ -1461,6 +1530,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     long blocks = ((long)d->M + ppb - 1) / ppb;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(conv_cin1_fwd_kernel<9>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    g_last_path = SVL_PATH_ELTWISE;
     SVL_LAUNCH_CHECK("svl_gemm_f32/conv_cin1");
     return SVL_OK;
   }
@@ -1483,7 +1553,12 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     t.bias = d->bias_mod > 0 ? nullptr : d->bias; t.act = d->act; t.accumulate = d->accumulate;
     t.imgs = (int)((long)d->M / ((long)cv.H * cv.W)); t.H = cv.H; t.W = cv.W; t.N = d->N;
     t.sign = cv.sign;
-    if ((d->bias == nullptr || d->bias_mod == 0) && svl_conv3x3_tiled_eligible(t)) return svl_conv3x3_tiled_launch(t, st);
+    t.gn_part = nullptr;
+    if ((d->bias == nullptr || d->bias_mod == 0) && svl_conv3x3_tiled_eligible(t)) {
+      static const int temu = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
+      g_last_path = (temu && emu_mode == 6) ? SVL_PATH_BF16X : SVL_PATH_F32;
+      return svl_conv3x3_tiled_launch(t, st);
+    }
   }
 
   // Ragged token count (M = images x 1025 tokens = 128 k + r): the r leftover rows would cost one more full-length
@@ -1526,6 +1601,7 @@ extern "C" int svl_set_gemm_emulation(int mode) {
   g_emu_mode.store(mode, std::memory_order_relaxed);
   return SVL_OK;
 }
+extern "C" int svl_last_gemm_path(void) { return g_last_path; }
 extern "C" int svl_set_conv_tiled(int on) {
   g_conv_tiled.store(on ? 1 : 0, std::memory_order_relaxed);
   return SVL_OK;

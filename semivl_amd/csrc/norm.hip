@@ -824,6 +824,21 @@ extern "C" int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma
   return SVL_OK;
 }
 
+// The apply pass alone, on statistics computed earlier (by svl_groupnorm_fwd, or -- round 4 -- by the epilogue of the
+// convolution that produced x): bit-identical to the y svl_groupnorm_fwd wrote from the same statistics, which is what lets
+// backward RE-MATERIALISE y instead of keeping it (model/vlg_head.py, memory plan).
+extern "C" int svl_groupnorm_apply(const float* x, int64_t ldx, const float* gamma, const float* beta, int imgs, int64_t HW,
+                                   int C, int G, int relu, const float* stats, float* y, int64_t ldy, svl_stream_t stream) {
+  SVL_CHECK_ARG(x && gamma && beta && y && stats && imgs > 0 && HW > 0, "svl_groupnorm_apply: bad args");
+  SVL_CHECK_ARG(gn_shape_ok(C, G) && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
+                "svl_groupnorm_apply: unsupported C=%d G=%d ldx=%ld ldy=%ld", C, G, (long)ldx, (long)ldy);
+  const long npix = (long)imgs * HW;
+  hipLaunchKernelGGL(groupnorm_apply_kernel, gn_apply_grid(imgs, HW, C), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                     gamma, beta, npix, (long)HW, C, G, relu, stats, y, (long)ldy);
+  SVL_LAUNCH_CHECK("svl_groupnorm_apply");
+  return SVL_OK;
+}
+
 extern "C" int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
                                  const float* stats, const float* gamma, const float* beta, int imgs, int64_t HW, int C,
                                  int G, int relu, float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream) {

@@ -91,6 +91,8 @@ SIGNATURES = {
     "svl_conf_avg_ws_doubles": (_L, [_I]),
     "svl_conf_avg_factor": (_I, [_P, _P, _I, _L, _P, _P, _P]),
     "svl_stream_release": (_I, [_P]),
+    "svl_stream_prepare": (_I, [_P]),
+    "svl_last_gemm_path": (_I, []),
     "svl_shutdown": (_I, []),
     "svl_num_stream_contexts": (_I, []),
     "svl_clock_probe": (_I, [_P, _I, C.c_uint64, _P]),
@@ -116,6 +118,9 @@ SIGNATURES = {
     "svl_affine_planes_f32": (_I, [_P, _L, _I, _L, _P, _P, _P]),
     "svl_copy2d_f32": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _P]),
     "svl_groupnorm_fwd": (_I, [_P, _L, _P, _P, _F, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
+    "svl_conv3x3_gn_ws_doubles": (_L, [_I, _I, _I, _I]),
+    "svl_conv3x3_gn_f32": (_I, [_P, _L, _I, _P, _L, _I, _I, _P, _I, _I, _I, _I, _P, _L, _F, _P, _P, _P]),
+    "svl_groupnorm_apply": (_I, [_P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _P, _L, _P]),
     "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_bn_ws_doubles": (_L, [_L, _I]),
     "svl_bn_stats": (_I, [_P, _L, _L, _I, _P, _P, _P]),

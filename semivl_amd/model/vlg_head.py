@@ -80,25 +80,93 @@ class _GradCollector:
                                           else ops.eltwise(4, t.reshape(-1), None, out=dst.view(-1))))
 
 
+# ------------------------------------------------------------------------------------------------ re-materialised activations
+# Memory plan, second level (round 4).  Of the ~25 MB a class-image keeps for backward at 512^2, ~8 MB are GroupNorm+ReLU
+# outputs y = relu(gn(pre)) whose `pre` is kept anyway (GroupNorm backward needs it) and ~4.5 MB are ConvTranspose2d outputs
+# whose input is kept anyway.  With `remat` on they are NOT kept: backward re-creates them right before their one use (the
+# consumer's weight gradient) by the forward's own apply pass (`svl_groupnorm_apply`: same kernel, same statistics) or
+# ConvTranspose launch -- bit-identical tensors, 8-12 B per element of extra traffic instead of a re-run of the whole
+# chunk's forward.  ADE N = 150 at B = 16: every live chunk then fits and none is recomputed (`_head_forward`).
+class _LazyGN:
+    """relu(groupnorm(pre)) of one conv + GN unit, described by what backward keeps anyway."""
+
+    def __init__(self, sv, gn):
+        self.sv, self.gn = sv, gn
+
+    def get(self, out=None, ldo=None):
+        imgs, H, W, _C1, Co, _k, _dil, _pad = self.sv["geom"]
+        pre = self.sv["pre"]
+        if out is None:
+            out, ldo = ops.empty(imgs * H * W, Co, device=pre.device), Co
+        return ops.groupnorm_apply(pre, Co, self.gn.weight, self.gn.bias, imgs, H * W, Co, self.gn.num_groups, True,
+                                   self.sv["st"], out, ldo)
+
+
+class _LazyCat:
+    """The ASPP concat buffer [pix, 5 Ch]: four GroupNorm outputs and the upsampled pooling branch."""
+
+    def __init__(self, branches, gy, imgs, h, w, Ch):
+        self.branches, self.gy, self.dims = branches, gy, (imgs, h, w, Ch)
+
+    def get(self):
+        imgs, h, w, Ch = self.dims
+        cat = ops.empty(imgs * h * w, 5 * Ch, device=self.gy.device)
+        for j, lz in enumerate(self.branches):
+            lz.get(cat[:, j * Ch:], 5 * Ch)
+        ops.bilinear_nhwc_fwd(self.gy, Ch, imgs, 1, 1, Ch, True, 1, h, w, cat[:, 4 * Ch:], 5 * Ch)
+        return cat
+
+
+class _LazyConvT:
+    """ConvTranspose2d(k 2, s 2) output of an Up block, from the block's (kept or itself lazy) input."""
+
+    def __init__(self, x, Cin, imgs, h, w, wp, Cu, bias):
+        self.x, self.args = x, (Cin, imgs, h, w, wp, Cu, bias)
+
+    def get(self, xin=None):
+        Cin, imgs, h, w, wp, Cu, bias = self.args
+        xin = _mat(self.x) if xin is None else xin
+        u = ops.empty(imgs * 4 * h * w, Cu, device=xin.device)
+        ops.convT2x_fwd(xin, Cin, imgs, h, w, Cin, wp, Cu, bias, u, Cu)
+        return u
+
+
+def _mat(x):
+    return x if (x is None or isinstance(x, torch.Tensor)) else x.get()
+
+
 # ------------------------------------------------------------------------------------------------ conv + GN (+ReLU) unit
-def _conv_gn_fwd(x, ldx, imgs, H, W, C1, conv, gn, k, dil, sv, src2=None, ld2=0, C2=0, rep=1, y=None, ldy=None):
+def _conv_gn_fwd(x, ldx, imgs, H, W, C1, conv, gn, k, dil, sv, src2=None, ld2=0, C2=0, rep=1, y=None, ldy=None,
+                 remat=False, x_keep=None):
+    """`remat`: y is not kept in `sv` (callers keep `sv["lazy"]`, a _LazyGN, instead of the tensor); `x_keep`: what to
+    remember as this unit's input in place of the tensor x (a lazy handle of the producer)."""
     Co = conv.weight.shape[0]
     wf, wd = ops.pack_conv_w(conv.weight)
     pad = dil * (k - 1) // 2
-    pre = ops.conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, k, k, dil, pad, src2=src2, ld2=ld2, C2=C2, rep=rep)
     if y is None:
         y = ops.empty(imgs * H * W, Co, device=x.device)
         ldy = Co
-    st = ops.groupnorm_fwd(pre, Co, gn.weight, gn.bias, gn.eps, imgs, H * W, Co, gn.num_groups, True, y, ldy)
+    # the narrow 3x3 layers: GroupNorm statistics come out of the convolution's epilogue (one tensor pass less)
+    fused = (ops.conv3x3_gn(x, ldx, imgs, H, W, C1, wf, Co, gn.eps, src2=src2, ld2=ld2, C2=C2, rep=rep)
+             if (k == 3 and dil == 1 and gn.num_groups * 16 == Co) else None)
+    if fused is not None:
+        pre, st = fused
+        ops.groupnorm_apply(pre, Co, gn.weight, gn.bias, imgs, H * W, Co, gn.num_groups, True, st, y, ldy)
+    else:
+        pre = ops.conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, k, k, dil, pad, src2=src2, ld2=ld2, C2=C2, rep=rep)
+        st = ops.groupnorm_fwd(pre, Co, gn.weight, gn.bias, gn.eps, imgs, H * W, Co, gn.num_groups, True, y, ldy)
     if sv is not None:
-        sv.update(x=x, ldx=ldx, pre=pre, y=y, ldy=ldy, st=st, wd=wd, geom=(imgs, H, W, C1, Co, k, dil, pad),
-                  src2=src2, ld2=ld2, C2=C2, rep=rep)
+        sv.update(x=x if x_keep is None else x_keep, ldx=ldx, pre=pre, y=None if remat else y, ldy=ldy, st=st, wd=wd,
+                  geom=(imgs, H, W, C1, Co, k, dil, pad), src2=src2, ld2=ld2, C2=C2, rep=rep)
+        if remat:
+            sv["lazy"] = _LazyGN(sv, gn)
     return y
 
 
-def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None):
+def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None, x=None):
     """`dx_acc`: an existing input-gradient buffer the convolution's dgrad is ADDED to in the GEMM epilogue (the branches of a
-    residual / multi-branch node) instead of returned as a new tensor and added by a separate pass."""
+    residual / multi-branch node) instead of returned as a new tensor and added by a separate pass.  `x`: the unit's input
+    when the caller has already re-materialised it (else `sv["x"]`, tensor or lazy handle)."""
     imgs, H, W, C1, Co, k, dil, pad = sv["geom"]
     dpre = ops.empty(imgs * H * W, Co, device=dy.device)
     dg, db = ops.groupnorm_bwd(dy, lddy, sv["pre"], Co, sv["y"], sv["ldy"], sv["st"], gn.weight, imgs, H * W, Co,
@@ -106,8 +174,9 @@ def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None):
     gc.put_tensor(gn.weight, dg)
     gc.put_tensor(gn.bias, db)
     C2 = sv["C2"]
-    with ops.wgrad_side(dpre, sv["x"], sv["src2"]):     # off the dependency chain: weight-gradient stream (ops.wgrad_side)
-        dwf = ops.conv_wgrad(dpre, Co, sv["x"], sv["ldx"], imgs, H, W, C1, Co, k, k, dil, pad, src2=sv["src2"],
+    x = _mat(sv["x"]) if x is None else x
+    with ops.wgrad_side(dpre, x, sv["src2"]):     # off the dependency chain: weight-gradient stream (ops.wgrad_side)
+        dwf = ops.conv_wgrad(dpre, Co, x, sv["ldx"], imgs, H, W, C1, Co, k, k, dil, pad, src2=sv["src2"],
                              ld2=sv["ld2"], C2=C2, rep=sv["rep"])
         gc.put_tensor(conv.weight, ops.unpack_conv_wgrad(dwf, Co, C1 + C2, k, k))
     if not need_dx:
@@ -145,6 +214,7 @@ class VLGHead(nn.Module):
         # chunk's activations are not kept but recomputed in backward (None: keep everything), live sample ranges
         self.chunk_class_images = 1344
         self.act_limit_bytes = None
+        self.remat = None              # None: decide per step from the activation budget (_remat_decision)
         self._bwd_ranges = None
         if (channels + text_channels) % num_heads or (channels + text_channels) // num_heads != 64:
             raise NotImplementedError("SemanticTransformer head dim must be 64")
@@ -211,6 +281,38 @@ def _chunk_plan(m, b, N):
     return out
 
 
+def _kept_bytes_per_class_image(m, HW):
+    """What backward keeps per class-image WITHOUT re-materialisation (fp32): conv1 out, 4 ASPP pre + the concat, project
+    pre / out, the residual sum (13 Ch maps at h x w), ~1.8 MB of SemanticTransformer tokens per 1024 pixels, and per Up
+    block at 4x / 16x the pixels: ConvTranspose out + 2 x (pre, out)."""
+    Ch = m.channels
+    c_up1, c_up2 = m.up1.conv[0].weight.shape[0], m.up2.conv[0].weight.shape[0]
+    cu1, cu2 = m.up1.up.weight.shape[1], m.up2.up.weight.shape[1]
+    return 4 * HW * (13 * Ch + 450 + 4 * (cu1 + 4 * c_up1) + 16 * (cu2 + 4 * c_up2))
+
+
+def _remat_decision(m, plan, N, HW, dev):
+    """Re-materialise (see _LazyGN) instead of keeping?  `m.remat`: True / False, or None = decide: on when everything the
+    step's grad-carrying decodes would keep does not fit under the activation budget (then no chunk has to be re-run as a
+    whole).  The training step announces the class-image count of ALL its live decodes (`m._live_class_images`) and the
+    decision of the step's first decode holds for the others (`m._remat_step`)."""
+    mode = getattr(m, "remat", None)
+    if mode is not None:
+        return bool(mode)
+    step = getattr(m, "_remat_step", None)
+    if isinstance(step, dict) and "on" in step:
+        return step["on"]
+    limit = getattr(m, "act_limit_bytes", None)
+    on = False
+    if limit is not None and dev.type == "cuda":
+        live = getattr(m, "_live_class_images", None) or sum(s1 - s0 for s0, s1, lv in plan if lv) * N
+        need = live * _kept_bytes_per_class_image(m, HW)
+        on = need > 0.9 * (limit - torch.cuda.memory_allocated(dev))
+    if isinstance(step, dict):
+        step["on"] = on
+    return on
+
+
 def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, chunks_out):
     """Whole-batch forward, executed chunk by chunk.  chunks_out: None (inference) or a list that receives
     (s0, s1, live, saved-or-None) per chunk; `saved` is None for dead chunks and for chunks whose activations did not
@@ -246,10 +348,22 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, chunks_out):
     tp = ops.linear(textn, m.text_proj[0].weight, m.text_proj[0].bias, act=ops.ACT_RELU)
     shared = dict(textn=textn, tp=tp, b0=b0, b=b, N=N, hw=hw, out_size=out_size, fp=(fp_masks, fp_rate, fp_range),
                   feats=(v0, v4, emb))
+    # ---- skip projections (order [v4, v0], vlg_head.py:207): per SAMPLE, not per class-image -> once for the whole decoded
+    # batch (per chunk of 8 samples they were 15 launches of an M = 8192, N = 16 / 32, K = 6912 GEMM at 4-9 TF each)
+    skips, skip_sv = [], []
+    for proj, f, (Cf, fh, fw) in zip(m.skip_proj, (v4, v0), ((Cv, h, w), (C0, h0, w0))):
+        wf, wd = ops.pack_conv_w(proj[0].weight)
+        Cs = proj[0].weight.shape[0]
+        sk = ops.conv_fwd(f, Cf, b, fh, fw, Cf, wf, Cs, 3, 3, 1, 1, bias=proj[0].bias, act=ops.ACT_RELU)
+        skips.append(sk)
+        skip_sv.append(dict(x=f, wd=wd, y=sk, Cs=Cs, geo=(Cf, fh, fw)))
+    shared.update(skips=skips, skip_sv=skip_sv)
     logits = ops.empty(b, N, out_size[0], out_size[1], device=dev)
     limit = getattr(m, "act_limit_bytes", None)
+    plan = _chunk_plan(m, b, N)
+    shared["remat"] = chunks_out is not None and _remat_decision(m, plan, N, HW, dev)
     over = False
-    for s0, s1, live in _chunk_plan(m, b, N):
+    for s0, s1, live in plan:
         sv = {} if (chunks_out is not None and live and not over) else None
         _head_core_forward(m, shared, s0, s1, sv, logits[s0:s1])
         if sv is not None and limit is not None and torch.cuda.memory_allocated(dev) > limit:
@@ -282,12 +396,14 @@ def _head_core_forward(m, shared, s0, s1, sv, logits_out):
     w1f, w1d = ops.pack_conv_w(m.conv1.weight)
     x1 = ops.conv_fwd(sim, 1, imgs, h, w, 1, w1f, Ch, k1, k1, 1, (k1 - 1) // 2, bias=m.conv1.bias)
     # ---- ASPP ----------------------------------------------------------------------------------------------
+    remat = bool(shared.get("remat")) and sv is not None
     cat = ops.empty(imgs * HW, 5 * Ch, device=dev)
     aspp_sv = []
     for j, d in enumerate(m.aspp.rates):
         seq = m.aspp.aspp_convs[j]
         s_ = {} if sv is not None else None
-        _conv_gn_fwd(x1, Ch, imgs, h, w, Ch, seq[0], seq[1], 1 if d == 1 else 3, d, s_, y=cat[:, j * Ch:], ldy=5 * Ch)
+        _conv_gn_fwd(x1, Ch, imgs, h, w, Ch, seq[0], seq[1], 1 if d == 1 else 3, d, s_, y=cat[:, j * Ch:], ldy=5 * Ch,
+                     remat=remat)
         aspp_sv.append(s_)
     gap = m.aspp.aspp_convs[4].gap
     pooled = ops.avgpool_cat_fwd(x1, imgs, h, w, Ch, (h, w), None, 1)      # AdaptiveAvgPool2d(1) on any map shape
@@ -295,27 +411,26 @@ def _head_core_forward(m, shared, s0, s1, sv, logits_out):
     gy = _conv_gn_fwd(pooled, Ch, imgs, 1, 1, Ch, gap[1], gap[2], 1, 1, s_gap)
     ops.bilinear_nhwc_fwd(gy, Ch, imgs, 1, 1, Ch, True, 1, h, w, cat[:, 4 * Ch:], 5 * Ch)
     s_proj = {} if sv is not None else None
-    x2 = _conv_gn_fwd(cat, 5 * Ch, imgs, h, w, 5 * Ch, m.aspp.project[0], m.aspp.project[1], 1, 1, s_proj)
-    x = ops.add(x2, x1)  # y = x + project(cat); new buffer: x2 stays intact as the ReLU mask of the project GN
+    x2 = _conv_gn_fwd(cat, 5 * Ch, imgs, h, w, 5 * Ch, m.aspp.project[0], m.aspp.project[1], 1, 1, s_proj, remat=remat,
+                      x_keep=_LazyCat([a_["lazy"] for a_ in aspp_sv], gy, imgs, h, w, Ch) if remat else None)
+    # y = x + project(cat).  (x2 is not needed again: the project GN's ReLU mask is re-derived from its `pre`; without
+    # remat a new buffer is used all the same so that the unit's kept `y` stays what it was.)
+    x = ops.add(x2, x1, out=x2) if remat else ops.add(x2, x1)
+    del cat
     # ---- semantic reasoning ----------------------------------------------------------------------------------
     tr_sv = []
     for lyr in m.layers:
         s_ = {} if sv is not None else None
         x = _semtr_forward(lyr, x, tp, imgs, b, N, h, w, Ch, Ct, s_)
         tr_sv.append(s_)
-    # ---- skip projections (order [v4, v0], vlg_head.py:207) ----------------------------------------------------
-    skips, skip_sv = [], []
-    for proj, f, (Cf, fh, fw) in zip(m.skip_proj, (v4, v0), ((Cv, h, w), (C0, h0, w0))):
-        wf, wd = ops.pack_conv_w(proj[0].weight)
-        Cs = proj[0].weight.shape[0]
-        sk = ops.conv_fwd(f, Cf, b, fh, fw, Cf, wf, Cs, 3, 3, 1, 1, bias=proj[0].bias, act=ops.ACT_RELU)
-        skips.append(sk)
-        skip_sv.append(dict(x=f, wd=wd, y=sk, Cs=Cs, geo=(Cf, fh, fw)))
+    # ---- skip projections: computed once per decoded batch (_head_forward); this chunk's samples ---------------------
+    skips = [shared["skips"][0][s0 * HW:s1 * HW], shared["skips"][1][s0 * HW0:s1 * HW0]]
     # ---- upsampling ------------------------------------------------------------------------------------------
     s_up1 = {} if sv is not None else None
-    g2 = _up_forward(m.up1, x, imgs, h, w, skips[0], h, w, b, N, s_up1)
+    g2 = _up_forward(m.up1, x, imgs, h, w, skips[0], h, w, b, N, s_up1, remat)
     s_up2 = {} if sv is not None else None
-    g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], h0, w0, b, N, s_up2)
+    g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], h0, w0, b, N, s_up2, remat,
+                     x_keep=s_up1["b"]["lazy"] if remat else None)
     C4 = g4.shape[1]
     whf, whd = ops.pack_conv_w(m.head.weight)
     if logits_out is not None:
@@ -328,7 +443,7 @@ def _head_core_forward(m, shared, s0, s1, sv, logits_out):
     if sv is not None:
         sv.update(dims=(b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0), embn=embn,
                   inv_e=inv_e, textn=textn, sim=sim, w1d=w1d, x1=x1, aspp=aspp_sv, gap=s_gap, pooled=pooled, proj=s_proj,
-                  cat=cat, tp=tp, tr=tr_sv, skip=skip_sv, up1=s_up1, up2=s_up2, g4=g4, whd=whd,
+                  tp=tp, tr=tr_sv, up1=s_up1, up2=s_up2, g4=s_up2["b"]["lazy"] if remat else g4, whd=whd,
                   out_size=out_size)
 
 
@@ -398,8 +513,9 @@ def _semtr_backward(lyr, dx, dtp_acc, imgs, b, N, h, w, Ch, Ct, sv, gc):
     return ops.add(dx, dxin_pool, out=dxin_pool)
 
 
-def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv):
-    """vlg_head.py:129-137.  x [(b n) h w, Cin]; skip [b sh sw, Cs] -> [(b n) 2h 2w, Cout]."""
+def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv, remat=False, x_keep=None):
+    """vlg_head.py:129-137.  x [(b n) h w, Cin]; skip [b sh sw, Cs] -> [(b n) 2h 2w, Cout].  `remat` (memory plan): the
+    ConvTranspose output and the two GroupNorm outputs are not kept; `x_keep`: lazy handle of x when x itself is one."""
     Cin = up.up.weight.shape[0]
     Cu = up.up.weight.shape[1]
     Cs = skip.shape[1]
@@ -410,12 +526,17 @@ def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv):
     ops.convT2x_fwd(x, Cin, imgs, h, w, Cin, wp_, Cu, up.up.bias, u, Cu)
     sup = ops.empty(b * 4 * h * w, Cs, device=dev)
     ops.bilinear_nhwc_fwd(skip, Cs, b, sh, sw, Cs, True, 1, 2 * h, 2 * w, sup, Cs)
+    remat = remat and sv is not None
+    xk = x if x_keep is None else x_keep
     sa = {} if sv is not None else None
-    g1 = _conv_gn_fwd(u, Cu, imgs, 2 * h, 2 * w, Cu, up.conv[0], up.conv[1], 3, 1, sa, src2=sup, ld2=Cs, C2=Cs, rep=N)
+    g1 = _conv_gn_fwd(u, Cu, imgs, 2 * h, 2 * w, Cu, up.conv[0], up.conv[1], 3, 1, sa, src2=sup, ld2=Cs, C2=Cs, rep=N,
+                      remat=remat, x_keep=_LazyConvT(xk, Cin, imgs, h, w, wp_, Cu, up.up.bias) if remat else None)
+    del u
     sb = {} if sv is not None else None
-    g2 = _conv_gn_fwd(g1, g1.shape[1], imgs, 2 * h, 2 * w, g1.shape[1], up.conv[3], up.conv[4], 3, 1, sb)
+    g2 = _conv_gn_fwd(g1, g1.shape[1], imgs, 2 * h, 2 * w, g1.shape[1], up.conv[3], up.conv[4], 3, 1, sb, remat=remat,
+                      x_keep=sa["lazy"] if remat else None)
     if sv is not None:
-        sv.update(x=x, wp=wp_, a=sa, b=sb, dims=(Cin, Cu, Cs, sh, sw))
+        sv.update(x=xk, wp=wp_, a=sa, b=sb, dims=(Cin, Cu, Cs, sh, sw))
     return g2
 
 
@@ -424,15 +545,18 @@ def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
     Cin, Cu, Cs, sh, sw = sv["dims"]
     dev = dg2.device
     dg1 = _conv_gn_bwd(dg2, dg2.shape[1], up.conv[3], up.conv[4], sv["b"], gc)
-    dcat = _conv_gn_bwd(dg1, dg1.shape[1], up.conv[0], up.conv[1], sv["a"], gc)  # [pix, Cu + Cs]
+    xin = _mat(sv["x"])                 # the block's input (re-materialised once when it is a lazy GroupNorm output) ...
+    xa = sv["a"]["x"]                   # ... feeds the re-created ConvTranspose output and the ConvTranspose weight gradient
+    dcat = _conv_gn_bwd(dg1, dg1.shape[1], up.conv[0], up.conv[1], sv["a"], gc,
+                        x=xa.get(xin) if isinstance(xa, _LazyConvT) else None)  # [pix, Cu + Cs]
     ld = Cu + Cs
     # skip half: sum over the N repeats, then bilinear backward
     dskip = ops.empty(b * sh * sw, Cs, device=dev)
     ops.bilinear_nhwc_bwd(dcat[:, Cu:], ld, b, sh, sw, Cs, True, N, 2 * h, 2 * w, dskip, Cs)
     # ConvTranspose half
-    with ops.wgrad_side(dcat, sv["x"]):
+    with ops.wgrad_side(dcat, xin):
         gc.put(up.up.bias, lambda d, acc: ops.colsum(dcat, out=d, accumulate=acc, C_=Cu, ld=ld))
-        dwb = ops.convT2x_wgrad(sv["x"], Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
+        dwb = ops.convT2x_wgrad(xin, Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
         gc.put_tensor(up.up.weight, dwb.view(Cin, 2, 2, Cu).permute(0, 3, 1, 2).contiguous())
     wb = ops.cached_pack(up.up.weight, "convT_bwd", lambda w_: w_.permute(0, 2, 3, 1).reshape(Cin, 4 * Cu).contiguous())
     dx = ops.convT2x_dgrad(dcat, ld, imgs, h, w, Cu, wb, Cin)
@@ -471,18 +595,35 @@ class _HeadFn(torch.autograd.Function):
         # ranges before the forward (`_bwd_ranges`); dead chunks were decoded without saving anything and are skipped here.
         all_live = all(c[2] for c in ctx.chunks)
         mk_ = ops.empty if (all_live and len(ctx.chunks) == 1) else ops.zeros
-        dv0, dv4, demb = mk_(b * HW0, C0, device=dev), mk_(b * HW, Cv, device=dev), mk_(b * HW, Ce, device=dev)
+        sk4, sk0 = sh["skip_sv"]
+        dv0, dv4, demb = ops.zeros(b * HW0, C0, device=dev), ops.zeros(b * HW, Cv, device=dev), mk_(b * HW, Ce, device=dev)
+        dsk0, dsk4 = mk_(b * HW0, sk0["Cs"], device=dev), mk_(b * HW, sk4["Cs"], device=dev)
+        lo, hi = b, 0          # sample span of the live chunks
         for i, (s0, s1, live, sv) in enumerate(ctx.chunks):
             if not live:
                 continue
+            lo, hi = min(lo, s0), max(hi, s1)
             if sv is None:     # activations were not kept (memory plan): recompute this chunk's forward, no logits
                 sv = {}
                 _head_core_forward(m, sh, s0, s1, sv, None)
             a0, a4, ae = _head_backward_core(m, sv, dlogits[s0:s1], gc)
             ctx.chunks[i] = None
             del sv
-            for full, part, hw_ in ((dv0, a0, HW0), (dv4, a4, HW), (demb, ae, HW)):
+            for full, part, hw_ in ((dsk0, a0, HW0), (dsk4, a4, HW), (demb, ae, HW)):
                 ops.eltwise(4, part.view(-1), None, out=full[s0 * hw_:s1 * hw_].view(-1))
+        # ---- skip projections -> grads for v4 / v0, once over the live sample span (dead samples: exactly zero)
+        if hi > lo:
+            nb = hi - lo
+            for proj, ss, dsk, dvf, hw_ in ((m.skip_proj[0], sk4, dsk4, dv4, HW), (m.skip_proj[1], sk0, dsk0, dv0, HW0)):
+                Cs = ss["Cs"]
+                Cf, fh, fw = ss["geo"]
+                dsl, ysl, xsl = dsk[lo * hw_:hi * hw_], ss["y"][lo * hw_:hi * hw_], ss["x"][lo * hw_:hi * hw_]
+                dpre = ops.eltwise(2, dsl, ysl, out=dsl)  # relu backward (post-activation mask)
+                with ops.wgrad_side(dpre, xsl):
+                    gc.put(proj[0].bias, lambda d, acc, dpre=dpre: ops.colsum(dpre, out=d, accumulate=acc))
+                    dwf = ops.conv_wgrad(dpre, Cs, xsl, Cf, nb, fh, fw, Cf, Cs, 3, 3, 1, 1)
+                    gc.put_tensor(proj[0].weight, ops.unpack_conv_wgrad(dwf, Cs, Cf, 3, 3))
+                ops.conv_dgrad(dpre, Cs, nb, fh, fw, Cs, ss["wd"], Cf, 3, 3, 1, 1, out=dvf[lo * hw_:hi * hw_], ldo=Cf)
         # ---- undo the feature-perturbation doubling
         fp_masks, fp_rate, fp_range = sh["fp"]
         r0, r1 = fp_range if fp_range is not None else (0, b0)
@@ -509,7 +650,8 @@ class _HeadFn(torch.autograd.Function):
 
 
 def _head_backward_core(m, sv, dlogits, gc):
-    """Backward of the head for the (sub-)batch described by `sv`; returns grads wrt the (doubled) v0, v4, emb tokens."""
+    """Backward of the head for the (sub-)batch described by `sv`; returns grads wrt the chunk's two projected skip features
+    ([b h0 w0, Cs0], [b h w, Cs4]) and wrt its (doubled) emb tokens."""
     if True:
         b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0 = sv["dims"]
         dev = dlogits.device
@@ -519,7 +661,7 @@ def _head_backward_core(m, sv, dlogits, gc):
             dlg = dlogits
         dlg = dlg.view(imgs * 16 * HW, 1)
         # ---- head conv
-        g4 = sv["g4"]
+        g4 = _mat(sv["g4"])
         C4 = g4.shape[1]
         with ops.wgrad_side(dlg, g4):
             gc.put(m.head.bias, lambda d, acc: ops.colsum(dlg, out=d, accumulate=acc))
@@ -531,18 +673,7 @@ def _head_backward_core(m, sv, dlogits, gc):
         sv["up2"] = sv["g4"] = None
         dx, dskip4 = _up_backward(m.up1, dg2, imgs, h, w, b, N, sv["up1"], gc)
         sv["up1"] = None
-        # ---- skip projections -> grads for v4 / v0
-        dfe = []
-        for proj, ss, dsk in zip(m.skip_proj, sv["skip"], (dskip4, dskip0)):
-            Cs = ss["Cs"]
-            Cf, fh, fw = ss["geo"]
-            dpre = ops.eltwise(2, dsk, ss["y"], out=dsk)  # relu backward (post-activation mask)
-            with ops.wgrad_side(dpre, ss["x"]):
-                gc.put(proj[0].bias, lambda d, acc, dpre=dpre: ops.colsum(dpre, out=d, accumulate=acc))
-                dwf = ops.conv_wgrad(dpre, Cs, ss["x"], Cf, b, fh, fw, Cf, Cs, 3, 3, 1, 1)
-                gc.put_tensor(proj[0].weight, ops.unpack_conv_wgrad(dwf, Cs, Cf, 3, 3))
-            dfe.append(ops.conv_dgrad(dpre, Cs, b, fh, fw, Cs, ss["wd"], Cf, 3, 3, 1, 1))
-        dv4, dv0 = dfe
+        # (the skip projections' backward runs once for all chunks: _HeadFn._backward)
         # ---- semantic transformers (reverse)
         dtp = ops.zeros(N, Ct, device=dev)
         for lyr, s_ in zip(reversed(list(m.layers)), reversed(sv["tr"])):
@@ -564,7 +695,7 @@ def _head_backward_core(m, sv, dlogits, gc):
         # avgpool over the whole map: every pixel gets dpooled / HW
         dgap, _ = ops.avgpool_cat_bwd(dpooled, imgs, h, w, Ch, (h, w), 0, 1)
         ops.add(dx1, dgap, out=dx1)
-        sv["aspp"] = sv["cat"] = sv["proj"] = None
+        sv["aspp"] = sv["proj"] = None
         # ---- conv1
         k1 = m.conv1_ksize
         with ops.wgrad_side(dx1, sv["sim"]):
@@ -578,4 +709,4 @@ def _head_backward_core(m, sv, dlogits, gc):
         ops.gemm(ops.A_MC, ops.B_NC, HW, Ce, N, ops.Op(dsim, HW, 0, N * HW, 0), ops.Op(sv["textn"], Ce), dembn,
                  ldc_m=Ce, batch=b, c_bso=HW * Ce)
         demb = ops.l2norm_bwd(dembn, sv["embn"], sv["inv_e"])
-        return dv0, dv4, demb
+        return dskip0, dskip4, demb

@@ -114,9 +114,9 @@ def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batc
     e0 = _prof_begin()
     L.check(L.load().svl_gemm_f32(C.byref(d), _st()), "svl_gemm_f32")
     if e0 is not None:
-        # which matrix pipe served this launch (the dispatch rule of svl_gemm_f32 for the split-emulation modes)
-        emu = (get_gemm_emulation() in (3, 6) and a_mode in (A_KC, A_MC) and b_mode in (B_KC, B_NC) and
-               out_mode == OUT_STRIDED and M >= 256 and N >= 96 and K >= 64)
+        # which matrix pipe served this launch: the library reports the kernel family its dispatch chose
+        # (svl_last_gemm_path: 1 = bf16 split products; 0 / 2 / 3 = exact fp32 MFMA, short-K stream, elementwise)
+        emu = L.load().svl_last_gemm_path() == 1
         _prof_end("gemm_bf16x" if emu else "gemm", e0, 2.0 * M * N * K * (1 if ksplit > 0 else batch),
                   (a_mode, b_mode, M, N, K, batch))
 
@@ -147,10 +147,16 @@ def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld
 # in a short queue; once more than WGRAD_DEPTH blocks are outstanding the current stream WAITS for the oldest one's event
 # and only then drops the references: the side stream is never more than WGRAD_DEPTH blocks behind, and a released block
 # is reusable at once (the current stream is ordered after its last reader).
-WGRAD_STREAM = not os.environ.get("SVL_NO_WGRAD_STREAM")
+# Default: on for a single-GPU process; OFF for the ranks of a multi-GPU job (WORLD_SIZE > 1), where every stream owns a
+# hardware queue (semivl_amd/__init__.py raises GPU_MAX_HW_QUEUES to 8 so that the communication stream does not share a
+# queue with the compute it overlaps) and weight-gradient GEMMs truly concurrent with the chain's GEMMs cost 20 ms per step
+# (DESIGN §9).  SVL_WGRAD_STREAM=1 / SVL_NO_WGRAD_STREAM=1 force either setting; cfg["wgrad_stream"] overrides per step.
+WGRAD_STREAM = (bool(os.environ.get("SVL_WGRAD_STREAM")) or int(os.environ.get("WORLD_SIZE", "1")) <= 1) \
+    and not os.environ.get("SVL_NO_WGRAD_STREAM")
 WGRAD_DEPTH = int(os.environ.get("SVL_WGRAD_DEPTH", "2"))
 _WG = {}
-_WG_KEEP = {}   # device index -> deque of (event on the side stream, tensors read before it)
+_WG_KEEP = {}   # device index -> deque of (event on the side stream, tensors read before it, block number)
+_WG_SEQ = 0     # blocks closed so far
 
 
 def _wg_stream(dev):
@@ -167,7 +173,7 @@ def _wg_stream(dev):
 def _wg_retire(main, keep_at_most):
     q = _WG_KEEP.get(main.device.index)
     while q and len(q) > keep_at_most:
-        ev, _ = q.popleft()
+        ev = q.popleft()[0]
         main.wait_event(ev)
 
 
@@ -195,8 +201,10 @@ class wgrad_side:
             self.ctx.__exit__(*exc)
             ev = torch.cuda.Event()
             ev.record(self.wg)
+            global _WG_SEQ
+            _WG_SEQ += 1
             _WG_KEEP[self.main.device.index].append(
-                (ev, [t for t in self.tensors if isinstance(t, torch.Tensor) and t.is_cuda]))
+                (ev, [t for t in self.tensors if isinstance(t, torch.Tensor) and t.is_cuda], _WG_SEQ))
             _wg_retire(self.main, WGRAD_DEPTH)
             self.tensors = ()
         return False
@@ -211,7 +219,27 @@ def wgrad_event():
         return None
     ev = torch.cuda.Event()
     ev.record(wg)
+    ev._svl_seq = _WG_SEQ      # every block closed so far is ordered before this event
     return ev
+
+
+def streams_share_queue(x, y, busy_ms=3.0):
+    """Do streams x and y sit on the same hardware queue?  The runtime multiplexes a process's streams onto
+    GPU_MAX_HW_QUEUES queues and serialises streams that share one: a `busy_ms` single-wave kernel goes to x,
+    a tiny one to y ordered only after an event recorded BEFORE the long one -- if y's kernel finishes after x's they
+    share a queue.  Costs `busy_ms` of device time and a synchronize: construction-time probe, never in the step."""
+    lib = L.load()
+    dev = x.device
+    buf = torch.zeros(4, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(x)
+    L.check(lib.svl_clock_probe(C.c_void_p(buf.data_ptr()), 1, int(busy_ms * 1e5), C.c_void_p(x.cuda_stream)), "svl_clock_probe")
+    y.wait_event(e0)
+    L.check(lib.svl_clock_probe(C.c_void_p(buf[2:].data_ptr()), 1, 100, C.c_void_p(y.cuda_stream)), "svl_clock_probe")
+    e1.record(y)
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) > 0.66 * busy_ms
 
 
 def wgrad_join(ev=None, produced=()):
@@ -223,6 +251,9 @@ def wgrad_join(ev=None, produced=()):
     main = torch.cuda.current_stream()
     if ev is not None:
         main.wait_event(ev)
+        q, seq = _WG_KEEP.get(main.device.index), getattr(ev, "_svl_seq", -1)
+        while q and q[0][2] <= seq:      # blocks the waited event retires: their operands need not be held any longer
+            q.popleft()
         return
     wg = _WG.get(main.device.index)
     if wg is not None and wg.cuda_stream != main.cuda_stream:
@@ -451,12 +482,12 @@ def matmul_nn(a, b, out=None, accumulate=False, dact=ACT_NONE, z=None, planes_on
     return out
 
 
-def _ksplit_plan(M, N, K, dense=False):
+def _ksplit_plan(M, N, K, dense=False, emu_tiles=False):
     bm = 32 if M <= 32 else (64 if M <= 64 else 128)
     bn = 128 if (M <= 64 and N > 64) else (32 if N <= 32 else (64 if N <= 64 else 128))
     tiles = math.ceil(M / bm) * math.ceil(N / bn)
     slots = 768
-    if dense and M >= 256 and N >= 96 and get_gemm_emulation():
+    if emu_tiles or (dense and M >= 256 and N >= 96 and get_gemm_emulation()):
         tiles, slots = math.ceil(M / 128) * math.ceil(N / 128), 512   # the emulated kernel keeps 2 blocks per CU
     # slices so that tiles x slices fills, but does not exceed, ONE round of resident blocks (256 CUs x 3): 36 tiles x 29
     # slices = 1044 blocks was 1.36 rounds, i.e. a second, mostly idle round
@@ -613,6 +644,39 @@ def groupnorm_fwd(x, ldx, gamma, beta, eps, imgs, HW, Cc, G, relu, y, ldy):
     L.check(L.load().svl_groupnorm_fwd(_p(x), ldx, _p(gamma), _p(beta), float(eps), imgs, HW, Cc, G, 1 if relu else 0,
                                        _p(y), ldy, _p(stats), _st()), "svl_groupnorm_fwd")
     return stats
+
+
+CONV_GN_FUSED = not os.environ.get("SVL_NO_CONV_GN_FUSED")
+
+
+def conv3x3_gn(x, ldx, imgs, H, W, C1, wf, Co, eps, src2=None, ld2=0, C2=0, rep=1):
+    """3x3 / pad 1 convolution fused with the statistics of the following GroupNorm (groups of 16 channels): returns
+    (pre [imgs*H*W, Co], stats [imgs, Co/16, 2]), or None when the tiled kernel does not take the shape (the caller then
+    runs conv_fwd + groupnorm_fwd)."""
+    if not (CONV_GN_FUSED and CONV_TILED and Co % 16 == 0):
+        return None
+    lib = L.load()
+    ws = torch.empty(max(1, lib.svl_conv3x3_gn_ws_doubles(imgs, H, W, Co)), dtype=torch.float64, device=x.device)
+    pre = empty(imgs * H * W, Co, device=x.device)
+    stats = empty(imgs, Co // 16, 2, device=x.device)
+    e0 = _prof_begin()
+    rc = lib.svl_conv3x3_gn_f32(_p(x), ldx, C1, _p(src2), ld2, C2, rep, _p(wf), imgs, H, W, Co, _p(pre), Co, float(eps),
+                                _p(ws), _p(stats), _st())
+    if rc == -3:            # SVL_ERR_UNSUPPORTED: nothing was launched
+        return None
+    L.check(rc, "svl_conv3x3_gn_f32")
+    if e0 is not None:
+        x6 = get_gemm_emulation() == 6 and not os.environ.get("SVL_CONV_TILED_NO_EMU")
+        K = 9 * (C1 + C2)
+        _prof_end("gemm_bf16x" if x6 else "gemm", e0, 2.0 * imgs * H * W * Co * K, (A_CONV, B_KC, imgs * H * W, Co, K, 1))
+    return pre, stats
+
+
+def groupnorm_apply(x, ldx, gamma, beta, imgs, HW, Cc, G, relu, stats, y, ldy):
+    """y = relu?(groupnorm(x)) from existing statistics: the forward's apply pass alone (bit-identical result)."""
+    L.check(L.load().svl_groupnorm_apply(_p(x), ldx, _p(gamma), _p(beta), imgs, HW, Cc, G, 1 if relu else 0, _p(stats),
+                                         _p(y), ldy, _st()), "svl_groupnorm_apply")
+    return y
 
 
 def groupnorm_bwd(dy, lddy, x, ldx, y, ldy, stats, gamma, imgs, HW, Cc, G, relu, dx, lddx, beta=None):
@@ -818,12 +882,18 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
         e0 = _prof_begin()
         L.check(lib.svl_conv3x3_wgrad_tiled(_p(dy), lddy, Co, _p(x), ldx, C1, _p(src2), ld2, C2, rep, imgs, H, W,
                                             _p(slabs), groups, _st()), "svl_conv3x3_wgrad_tiled")
-        _prof_end("gemm", e0, 2.0 * Co * N * Kpix, ("wgrad3x3_tiled", Co, N, Kpix, 1))
+        x6 = (get_gemm_emulation() == 6 and not os.environ.get("SVL_CONV_TILED_NO_EMU") and
+              (Co >= 64 or (C1 + C2) % 64 == 0))       # the dispatch rule of svl_conv3x3_wgrad_tiled
+        _prof_end("gemm_bf16x" if x6 else "gemm", e0, 2.0 * Co * N * Kpix, ("wgrad3x3_tiled", Co, N, Kpix, 1))
         out = empty(Co, N, device=dy.device)
         reduce_slabs(out, slabs)
         return out
     g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
-    s, ks = _ksplit_plan(Co, N, Kpix)
+    # (the split-emulation kernel serves this launch when Cout >= 64, N >= 96 and the output rows are whole 8-pixel groups:
+    # 128-row tiles, two resident blocks per CU)
+    x6 = (get_gemm_emulation() in (3, 6) and Co >= 64 and N >= 96 and Wo % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0 and
+          not os.environ.get("SVL_GEMM_EMU_NO_CONVW"))
+    s, ks = _ksplit_plan(Co, N, Kpix, emu_tiles=x6)
     out = empty(Co, N, device=dy.device)
     if s == 1:
         gemm(A_MC, B_CONVW, Co, N, Kpix, Op(dy, lddy), Op(x, ldx), out, conv=g)
@@ -888,7 +958,9 @@ def convT2x_wgrad(x, ldx, du, lddu, imgs, H, W, Ci, Co):
     Kpix = imgs * H * W
     N = 4 * Co
     g = conv_geom(2 * H, 2 * W, Co, 2, 2, 1, 0, 1, stride=2, Ho=H, Wo=W)
-    s, ks = _ksplit_plan(Ci, N, Kpix)
+    x6 = (get_gemm_emulation() in (3, 6) and Ci >= 64 and N >= 96 and W % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0 and
+          not os.environ.get("SVL_GEMM_EMU_NO_CONVW"))
+    s, ks = _ksplit_plan(Ci, N, Kpix, emu_tiles=x6)
     out = empty(Ci, N, device=x.device)
     if s == 1:
         gemm(A_MC, B_CONVW, Ci, N, Kpix, Op(x, ldx), Op(du, lddu), out, conv=g)

@@ -60,6 +60,28 @@ def _cat2(a, b):
 
 _SIDE = {}     # device -> second stream for the gradient-free passes of the step
 
+
+def create_step_streams(dev):
+    """Create every stream a training step uses on `dev` NOW (the gradient-free passes' second stream, the weight-gradient
+    stream when it is enabled, and the library's helper streams of both and of the current stream) instead of lazily inside
+    the first step.  The HIP runtime assigns streams to its GPU_MAX_HW_QUEUES hardware queues in creation order and
+    serialises streams that share a queue: creating the step's streams first, and only then a communicator's,
+    makes that map the same in every process -- GradAllReducer calls this before it creates its communication stream."""
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        return []
+    from . import lib as L
+    out = [torch.cuda.current_stream(dev)]
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(dev)
+    out.append(_SIDE[dev])
+    if ops.WGRAD_STREAM:
+        out.append(ops._wg_stream(dev))
+    with torch.cuda.device(dev):
+        for s_ in out:
+            L.check(L.load().svl_stream_prepare(s_.cuda_stream), "svl_stream_prepare")
+    return out
+
 LOSS_NAMES = ("loss", "loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "loss_mc_s2", "loss_mc_fp")
 
 
@@ -97,7 +119,12 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         model.decode_head._bwd_ranges = None
     if reducer is not None:
         reducer.begin()
-    ops.WGRAD_STREAM = bool(cfg.get("overlap_streams", True)) and not os.environ.get("SVL_NO_WGRAD_STREAM")
+    # the weight-gradient stream is a process-wide switch (ops.WGRAD_STREAM: environment, multi_rank_defaults() or the
+    # caller); the step only overrides it when its cfg says so explicitly
+    if "wgrad_stream" in cfg:
+        ops.WGRAD_STREAM = bool(cfg["wgrad_stream"])
+    elif not cfg.get("overlap_streams", True):
+        ops.WGRAD_STREAM = False
     # pseudo labels + MaskCLIP guidance (model.eval(): the side encoder's BatchNorm uses its running statistics here,
     # semivl.py:228-244; nothing else on the path depends on the mode).  Both passes are gradient-free and independent of
     # the two student forwards below: they are enqueued on a second stream (event-forked from / joined back into the
@@ -138,6 +165,12 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     head = getattr(model, "decode_head", None)
     if head is not None:
         head._bwd_ranges = {3 * B: [(B, 3 * B)]}
+        # both grad-carrying decodes of the step ([x, w_fp] here, [s1, s2] below) keep activations until backward: the
+        # head decides ONCE per step whether they fit or are re-materialised (model/vlg_head.py::_remat_decision)
+        head._live_class_images = 4 * B * head.num_classes
+        head._remat_step = {}
+        if "head_remat" in cfg:
+            head.remat = cfg["head_remat"]
         if cfg.get("head_chunk_class_images"):
             head.chunk_class_images = int(cfg["head_chunk_class_images"])
         frac = cfg.get("act_mem_fraction", 0.70)
@@ -195,6 +228,11 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
     losses = ops.empty(8, device=dev)
     ops.semivl_loss(sums, numel_u, lam, losses, factors, mc_counts)
     # backward (+ all-reduce) + optimizer
+    if cfg.get("step_barrier", False) and dist.is_initialized() and dist.get_world_size() > 1:
+        # semivl.py:325: the reference synchronises all ranks before every backward.  It orders nothing the gradient
+        # all-reduce does not order already, so it is off by default; the flag restores the reference's
+        # lock-step pacing (useful when per-rank logging / timing is compared against the reference's).
+        dist.barrier()
     if optimizer is not None:
         optimizer.zero_grad()
     try:
@@ -292,6 +330,7 @@ class FusedAdamW:
         self._lr_evt = None
         self.step_count = 0
         self.grad_scale = 1.0
+        self._lr_factor = 1.0     # the schedule's current factor (poly_lr): lr of the groups outside the arena
 
     @property
     def param_groups(self):
@@ -328,9 +367,10 @@ class FusedAdamW:
         state, groups = {}, []
         off = self.seg_off.tolist()
         for j, (name, ai) in enumerate(self.all_params):
-            if ai is None:
-                groups.append(dict(lr=self.lr, weight_decay=self.wd, betas=tuple(self.betas), eps=self.eps, amsgrad=False,
-                                   params=[j]))
+            if ai is None:      # mmcv lists them with the base lr; semivl.py:124-125 gives EVERY group an initial_lr and
+                # :341-345 re-schedules every group from it, so a reference-style loop can load this dict as it is
+                groups.append(dict(lr=self.lr * self._lr_factor, initial_lr=self.lr, weight_decay=self.wd,
+                                   betas=tuple(self.betas), eps=self.eps, amsgrad=False, params=[j]))
                 continue
             g_ = self.groups[ai]
             shp, n = g_["param"].shape, g_["param"].numel()
@@ -370,6 +410,11 @@ class FusedAdamW:
                 self.m[off[ai]:off[ai] + n].copy_(st["exp_avg"].reshape(-1))
                 self.v[off[ai]:off[ai] + n].copy_(st["exp_avg_sq"].reshape(-1))
                 steps.add(int(st["step"]))
+        if len(pg) == len(self.all_params):
+            for j, (_, ai) in enumerate(self.all_params):
+                if ai is None and pg[j].get("initial_lr"):
+                    self._lr_factor = pg[j]["lr"] / pg[j]["initial_lr"]
+                    break
         stray = set(sd["state"]) - {j for j, _ in index}
         assert not stray, "state for parameters this model never trains: %s" % sorted(stray)[:6]
         assert len(steps) <= 1, "per-tensor step counts differ"
@@ -387,6 +432,7 @@ class FusedAdamW:
         # (issued a whole step ago, so this never stalls in the training loop) before overwriting it
         if self._lr_evt is not None:
             self._lr_evt.synchronize()
+        self._lr_factor = f
         for i, g_ in enumerate(self.groups):
             g_["lr"] = g_["initial_lr"] * f
             self._lr_host[i] = g_["lr"]
@@ -455,7 +501,22 @@ class GradAllReducer:
             backend = "nccl"          # the injected collective is stream-ordered like RCCL's
         self.overlap = (backend == "nccl") if overlap is None else bool(overlap)
         self._async = backend == "nccl"
-        self._comm = torch.cuda.Stream() if (self._async and optimizer.g.is_cuda) else None
+        # stream -> hardware-queue map: the step's own streams are created FIRST (deterministic map, see
+        # create_step_streams), then the communication stream, and the result is probed once and kept for the bench line
+        self.queue_info = None
+        on_gpu = optimizer.g.is_cuda
+        if on_gpu and self.world > 1:
+            step_streams = create_step_streams(optimizer.g.device)
+        self._comm = torch.cuda.Stream() if (self._async and on_gpu) else None
+        if on_gpu and self.world > 1 and not os.environ.get("SVL_NO_QUEUE_PROBE"):
+            # (blocking backends have no communication stream: probe what one created at this point WOULD share)
+            probe = self._comm if self._comm is not None else torch.cuda.Stream()
+            names = ["main", "second"] + (["weight_gradient"] if len(step_streams) > 2 else [])
+            shared = [n_ for n_, s_ in zip(names, step_streams) if ops.streams_share_queue(s_, probe)]
+            self.queue_info = dict(gpu_max_hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                                   comm_stream_shares_queue=bool(shared), shares_queue_with=shared,
+                                   weight_gradient_stream=bool(ops.WGRAD_STREAM),
+                                   comm_stream="dedicated" if self._comm is not None else "none (blocking backend; probed a stand-in)")
         self._works, self._fired, self._complete = [], set(), [0] * len(self.buckets)
         self.early_fires = 0
         if self.world > 1 and groups:
@@ -489,9 +550,15 @@ class GradAllReducer:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self._comm)
                 if self._collective is not None:
-                    self._works.append(self._collective(g))
+                    w = self._collective(g)
                 else:
-                    self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                # ProcessGroupNCCL runs an async collective on its OWN stream, which only waits for the caller's; the
+                # stream-level wait below orders the communication stream after the collective itself, so the events
+                # around it bracket its duration (not its enqueue) and joining `_comm` joins every collective
+                if w is not None:
+                    w.wait()
+                self._works.append(w)
                 if self.profile:
                     e1.record(self._comm)
                     self._ev.append((b_, (e - s) * 4, e0, e1))
@@ -510,6 +577,10 @@ class GradAllReducer:
         backward that raised, or a grad-enabled forward that never ran its backward, would otherwise carry `expected` /
         `done` counts into this step and fire a bucket before its last contribution (or never fire it early).
         semivl_train_step calls it before the first grad-enabled forward (the forwards register their `expect`s)."""
+        if self._works and self._comm is not None:
+            # collectives of an aborted step may still be in flight on arena slices: the next zero_grad / gradient
+            # writes on the compute stream must not overtake them
+            torch.cuda.current_stream().wait_stream(self._comm)
         self._works, self._fired = [], set()
         self._complete = [0] * len(self.buckets)
         self._expected, self._done = {}, {}
@@ -551,10 +622,12 @@ class GradAllReducer:
         if t["join"] is None:      # synchronous backend: every bucket blocks the compute thread for its whole duration
             bk = [dict(bucket=b_, mbytes=round(nb / 2 ** 20, 1), ms=round(dt * 1e3, 3)) for b_, nb, _, dt in t["events"]]
             return dict(buckets=bk, exposed_ms=round(sum(b_["ms"] for b_ in bk), 3), launched_inside_backward=t["early_fires"],
+                        queues=self.queue_info,
                         note="blocking all-reduce on the compute thread (backend without stream-ordered collectives): host "
                              "wall time per bucket, all of it exposed")
         return dict(buckets=[dict(bucket=b_, mbytes=round(nb / 2 ** 20, 1), ms=round(e0.elapsed_time(e1), 3))
                              for b_, nb, e0, e1 in t["events"]],
                     exposed_ms=round(t["join"][0].elapsed_time(t["join"][1]), 3), launched_inside_backward=t["early_fires"],
+                    queues=self.queue_info,
                     note="ms = HIP events around each bucket's all-reduce on the communication stream; exposed_ms = time "
                          "the compute stream waited in finish() for the collectives backward did not cover")

@@ -51,7 +51,7 @@ CONFIGS = {
                 conv_encoder=True),
     # peaked predictions (decoder's last conv x150, low-passed inputs): with conf_mode 'pixelwise' at the shipped threshold
     # 0.95 a large share of the pixels passes the confidence gate, so loss_s1 / loss_s2 / loss_fp are non-zero against
-    # the reference's own confidence_weighted_loss (train_utils.py:30-49)
+    # the reference's own confidence_weighted_loss (train_utils.py:30-49), which the reference run below really calls
     "conf": dict(S=128, B=2, embed=64, layers=3, heads=1, out_indices=[0, 1, 3], channels=32, text_channels=32,
                  dec_heads=1, up=(32, 16), skip=(16, 16), seed=15, conf_thresh=0.95, logit_gain=150.0,
                  smooth_inputs=True),
@@ -112,6 +112,22 @@ def main():
     from oracle import semivl_oracle as O
     from model.text_embeddings import get_class_to_concept_idxs
     cls2con = get_class_to_concept_idxs(MCC_TEXT)
+    # The reference's OWN loss helpers drive the reference run: utils/train_utils.py:19-49 imports as it is, semivl.py
+    # (whose top-level imports resolve through the shim) provides compute_mc_loss (:52-58), bound to its module globals
+    # `criterion_mc` / `mcc_loss_reduce` exactly as its __main__ block sets them (:156-162).
+    import semivl as ref_semivl
+    import utils.train_utils as ref_tu
+
+    def ref_cwl(loss, conf, ign, conf_mode, conf_thresh):
+        return ref_tu.confidence_weighted_loss(loss, conf, ign, dict(conf_mode=conf_mode, conf_thresh=conf_thresh))
+
+    def ref_mc(pred, mask, ign, reduce):
+        ref_semivl.mcc_loss_reduce = reduce
+        ref_semivl.criterion_mc = (torch.nn.CrossEntropyLoss(ignore_index=255) if reduce == "mean" else
+                                   torch.nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+        return ref_semivl.compute_mc_loss(pred, mask, ign)
+
+    REF_HELPERS = (ref_tu.cutmix_img_, ref_tu.cutmix_mask, ref_cwl, ref_mc)
     text = torch.from_numpy(np.load(TEXT))
     mcc = torch.from_numpy(np.load(MCC_TEXT))
 
@@ -178,7 +194,8 @@ def main():
                         def forward_maskclip(s, img, t):
                             return s.m.forward_maskclip(img, t)
                     loss, aux = O.semivl_step(Adapter(model), batch, iters, total_iters, conf_thresh=c["conf_thresh"],
-                                              conf_mode=c.get("conf_mode", "pixelwise"), fp_masks=fp_masks)
+                                              conf_mode=c.get("conf_mode", "pixelwise"), fp_masks=fp_masks,
+                                              helpers=REF_HELPERS)
                 finally:
                     F.dropout2d = orig
             else:
@@ -203,6 +220,26 @@ def main():
         print(f"[{name}] loss ref {rl.item():.8f} oracle {ol.item():.8f}  |d| {abs(rl.item() - ol.item()):.2e}")
         for k in ("loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "loss_mc_s2", "loss_mc_fp"):
             print(f"    {k:11s} ref {raux[k].item():.8f}  |d| {abs(raux[k].item() - oaux[k].item()):.2e}")
+            # reference modules + reference loss helpers vs the oracle's restatement of both
+            assert abs(raux[k].item() - oaux[k].item()) <= 1e-6 * max(1.0, abs(raux[k].item())), k
+        assert abs(rl.item() - ol.item()) <= 1e-6 * max(1.0, abs(rl.item()))
+        # the other reductions of the guidance loss and the other confidence modes, helper against helper on this
+        # fixture's own tensors (semivl.py:52-58,156-162; train_utils.py:30-49)
+        with torch.no_grad():
+            px, cw, ig = raux["pred_s1"].detach(), raux["conf_w"], batch["ignore_mask"]
+            ce = F.cross_entropy(px, raux["mask_w"], reduction="none")
+            for mode in ("pixelwise", "pixelratio", "pixelavg"):
+                a_, b_ = ref_cwl(ce, cw, ig, mode, c["conf_thresh"]), O.confidence_weighted_loss(ce, cw, ig, mode, c["conf_thresh"])
+                assert torch.equal(a_, b_), (mode, a_, b_)
+            for red in ("mean", "mean_valid", "mean_all"):
+                a_, b_ = ref_mc(px, raux["mclip"], ig, red), O.compute_mc_loss(px, raux["mclip"], ig, red)
+                assert torch.equal(a_, b_), (red, a_, b_)
+            m1 = ref_tu.cutmix_mask(raux["mask_w"], raux["mask_w_other"], batch["mix1"])
+            assert torch.equal(m1, O.cutmix_mask(raux["mask_w"], raux["mask_w_other"], batch["mix1"]))
+            i1, i2 = batch["img_s1"].clone(), batch["img_s1"].clone()
+            ref_tu.cutmix_img_(i1, batch["img_s1_other"], batch["mix1"])
+            O.cutmix_img_(i2, batch["img_s1_other"], batch["mix1"])
+            assert torch.equal(i1, i2)
         for k in ("mask_w", "mask_w_other", "mclip", "mclip_other"):
             assert torch.equal(raux[k], oaux[k]), f"{k} differs"
         # (the pseudo-label tie budget is a LOGIT gap: fixtures whose last conv is scaled by logit_gain scale it alike)

@@ -442,17 +442,23 @@ def test_head_memory_plan_is_exact(dev):
         losses = semivl_train_step(hip, batch, iters, total, dict(cfg0, **kw), fp_masks=masks)
         return losses.cpu(), {k: p.grad.clone() for k, p in hip.named_parameters() if p.grad is not None}
 
-    l_one, g_one = run(head_chunk_class_images=1 << 20, act_mem_fraction=None)       # one chunk per live range, all kept
-    l_chk, g_chk = run(head_chunk_class_images=21, act_mem_fraction=None)            # one sample per chunk, all kept
-    l_rec, g_rec = run(head_chunk_class_images=21, act_mem_fraction=0.0)             # ... nothing kept: all recomputed
-    assert torch.equal(l_one, l_chk) and torch.equal(l_chk, l_rec)                   # forward values never change
-    assert sorted(g_one) == sorted(g_chk) == sorted(g_rec)
+    l_one, g_one = run(head_chunk_class_images=1 << 20, act_mem_fraction=None, head_remat=False)   # one chunk per live range, all kept
+    l_chk, g_chk = run(head_chunk_class_images=21, act_mem_fraction=None, head_remat=False)        # one sample per chunk, all kept
+    l_rec, g_rec = run(head_chunk_class_images=21, act_mem_fraction=0.0, head_remat=False)         # ... nothing kept: all recomputed
+    # second level of the plan: GroupNorm / ConvTranspose outputs re-materialised in backward instead of kept
+    l_rm, g_rm = run(head_chunk_class_images=21, act_mem_fraction=None, head_remat=True)
+    l_rm1, g_rm1 = run(head_chunk_class_images=1 << 20, act_mem_fraction=None, head_remat=True)
+    assert torch.equal(l_one, l_chk) and torch.equal(l_chk, l_rec) and torch.equal(l_chk, l_rm) and torch.equal(l_one, l_rm1)
+    assert sorted(g_one) == sorted(g_chk) == sorted(g_rec) == sorted(g_rm)
     for k in g_one:
         assert torch.equal(g_chk[k], g_rec[k]), f"{k}: recompute must be bit-identical to keeping the activations"
+        assert torch.equal(g_chk[k], g_rm[k]), f"{k}: re-materialised GroupNorm / ConvTranspose outputs must be bit-identical"
+        assert torch.equal(g_one[k], g_rm1[k]), f"{k}: re-materialisation changed a gradient (single chunk)"
         scale = g_one[k].abs().max().item()
         floor = 1e-5 if k == "decode_head.head.bias" else 1e-9      # (exactly 0 in exact arithmetic: pure rounding noise)
         assert (g_chk[k] - g_one[k]).abs().max().item() <= 2e-5 * scale + floor, (k, (g_chk[k] - g_one[k]).abs().max().item(), scale)
     hip.decode_head.chunk_class_images = 1344
+    hip.decode_head.remat = None
 
 
 def test_extract_feat_and_fused_optimizer_ema(dev):

@@ -9,6 +9,13 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+# Gate of every bf16x6 kernel: its error against float64 must sit AT THE LEVEL of the exact fp32 MFMA chain's on the same
+# inputs (what bench.py's `dtype` string and the kernel headers claim).  Measured ratios: 0.85-1.0 where both arithmetics
+# accumulate in the same order; up to 1.15 for the split-K weight gradients, whose K slabs are longer in the split mode
+# (two resident blocks per CU instead of three): the six products carry 24 mantissa bits either way, what differs is the
+# length of the fp32 accumulation chain.  1.2 is the gate (round 3 allowed 1.5).
+EMU6_ERR_FACTOR = 1.2
+
 def rnd(*shape, dev, scale=1.0, seed=None):
     if seed is not None:
         torch.manual_seed(seed)
@@ -125,7 +132,7 @@ def test_gemm_bf16_split_emulation(dev, emu_mode, M, N, K):
         for k, fn in fns.items():
             err[(mode, k)] = _relerr(fn(), refs[k])
     for k in fns:
-        assert err[(6, k)] <= 1.5 * err[(0, k)] + 1e-8, (k, err)
+        assert err[(6, k)] <= EMU6_ERR_FACTOR * err[(0, k)] + 1e-8, (k, err)
         assert err[(3, k)] <= 2e-5, (k, err)
     # epilogue options go through the same code as the fp32 path
     emu_mode(6)
@@ -240,7 +247,7 @@ def test_gemm_planes_path(dev, emu_mode, M, N, K):
     emu_mode(6)
     xa, dya = ops.split_planes(x), ops.split_planes(dy)     # explicit planes: served by the planes kernel at any size
     y, dx = ops.linear(xa, w), ops.matmul_nn(dya, w)
-    assert _relerr(y, ref_nt) <= 1.5 * e0[0] + 1e-8 and _relerr(dx, ref_nn) <= 1.5 * e0[1] + 1e-8, (e0, _relerr(y, ref_nt))
+    assert _relerr(y, ref_nt) <= EMU6_ERR_FACTOR * e0[0] + 1e-8 and _relerr(dx, ref_nn) <= EMU6_ERR_FACTOR * e0[1] + 1e-8, (e0, _relerr(y, ref_nt))
     assert torch.equal(y, ops.linear(xa, w)), "deterministic"
     if ops.planes_eligible(M, N, K):
         assert torch.equal(y, ops.linear(x, w)), "fp32 inputs of eligible shapes take the same path (split pass first)"
@@ -337,7 +344,7 @@ def test_fused_attention(dev, Bn, T, H):
 @pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 17, 4), (2, 129, 3), (1, 161, 1), (1, 97, 2)])
 def test_fused_attention_split_emulation(dev, Bn, T, H):
     """svl_set_gemm_emulation(6) covers the attention products: the error vs fp64 stays at the level of the exact fp32
-    kernels' (bound: 1.5 x theirs + 1e-6), on the same ragged / spiky cases, and the result is deterministic."""
+    kernels' (bound: EMU6_ERR_FACTOR x theirs + 1e-6), on the same ragged / spiky cases, and the result is deterministic."""
     from semivl_amd import ops
     D, E = 64, 64 * H
     qkv = rnd(Bn * T, 3 * E, dev=dev, seed=51)
@@ -365,7 +372,7 @@ def test_fused_attention_split_emulation(dev, Bn, T, H):
         ops.set_gemm_emulation(0)
     lse_ulp = 1.2e-7 * float(torch.logsumexp(sc, -1).abs().max())     # LSE itself is O(100) on the spiky rows
     for e0, e6, what, slack in zip(res[0], res[6], ("out", "dqkv", "lse"), (1e-6, 1e-6, 2 * lse_ulp)):
-        assert e6 <= 1.5 * e0 + slack, (what, e0, e6)
+        assert e6 <= EMU6_ERR_FACTOR * e0 + slack, (what, e0, e6)
 
 
 @pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 260, 4), (2, 129, 3)])
@@ -436,6 +443,95 @@ def test_conv_fwd_dgrad_wgrad(dev, Ci, Co, k, dil, H):
     close(ops.unpack_conv_wgrad(dwf, Co, Ci, k, k), gw, atol=3e-5 * math.sqrt(n * H * W), what="conv wgrad")
 
 
+@pytest.mark.parametrize("C1,C2,Co,H,W,n,rep", [(64, 0, 64, 32, 32, 16, 1), (96, 32, 64, 16, 48, 24, 3), (64, 0, 32, 40, 24, 18, 1),
+                                                (32, 0, 32, 64, 64, 4, 1), (48, 16, 32, 16, 16, 66, 2)])
+def test_conv3x3_with_groupnorm_statistics(dev, emu_mode, C1, C2, Co, H, W, n, rep):
+    """svl_conv3x3_gn_f32: the tiled 3x3 convolution whose epilogue leaves the GroupNorm statistics (groups of 16
+    channels) -- in both arithmetics the convolution result is bit-identical to the plain launch, (mean, rstd) agree with
+    the statistics pass over that result (and with float64), ragged image edges and the two-source concat included; the
+    apply pass on those statistics reproduces torch's GroupNorm + ReLU."""
+    from semivl_amd import ops
+    a, b2 = rnd(n, C1, H, W, dev=dev, seed=36), (rnd(n // rep, C2, H, W, dev=dev) if C2 else None)
+    w = rnd(Co, C1 + C2, 3, 3, dev=dev, scale=0.1)
+    gamma, beta = rnd(Co, dev=dev) + 1.0, rnd(Co, dev=dev)
+    wf, _ = ops.pack_conv_w(w)
+    xcat = torch.cat([a, b2.repeat_interleave(rep, 0)], 1) if C2 else a
+    kw = dict(src2=nhwc(b2), ld2=C2, C2=C2, rep=rep) if C2 else {}
+    for mode in (0, 6):
+        emu_mode(mode)
+        got = ops.conv3x3_gn(nhwc(a), C1, n, H, W, C1, wf, Co, 1e-5, **kw)
+        assert got is not None, "the tiled kernel must take this shape"
+        pre, st = got
+        plain = ops.conv_fwd(nhwc(a), C1, n, H, W, C1, wf, Co, 3, 3, 1, 1, **kw)
+        assert torch.equal(pre, plain)
+        y0 = ops.empty(n * H * W, Co, device=dev)
+        st0 = ops.groupnorm_fwd(plain, Co, gamma, beta, 1e-5, n, H * W, Co, Co // 16, True, y0, Co)
+        g64 = plain.double().view(n, H * W, Co // 16, 16)
+        mean64, var64 = g64.mean(dim=(1, 3)), g64.var(dim=(1, 3), unbiased=False)
+        assert (st[..., 0].double() - mean64).abs().max() <= 2e-6 * (1 + mean64.abs().max())
+        assert ((st[..., 1].double() - (var64 + 1e-5).rsqrt()) / (var64 + 1e-5).rsqrt()).abs().max() <= 2e-6
+        assert (st - st0).abs().max() <= 2e-6 * (1 + st0.abs().max())
+        y = ops.groupnorm_apply(pre, Co, gamma, beta, n, H * W, Co, Co // 16, True, st, ops.empty(n * H * W, Co, device=dev), Co)
+        ref = F.relu(F.group_norm(F.conv2d(xcat, w, padding=1), Co // 16, gamma, beta, 1e-5))
+        close(nchw(y, n, H, W), ref, atol=3e-5 * math.sqrt(9 * (C1 + C2)) + 1e-5, what="conv+gn+relu")
+        again = ops.conv3x3_gn(nhwc(a), C1, n, H, W, C1, wf, Co, 1e-5, **kw)
+        assert torch.equal(again[1], st)                      # deterministic
+    # shapes the tiled kernel does not take are reported, not mis-run
+    assert ops.conv3x3_gn(nhwc(a)[: 4 * H * W], C1, 4, H, W, C1, wf, Co, 1e-5) is None or 4 * H * W >= 16384
+
+
+@pytest.mark.parametrize("Ci,Co,k,dil,H,W,n", [(128, 128, 3, 6, 32, 32, 3), (128, 128, 3, 18, 32, 32, 2), (640, 128, 1, 1, 32, 32, 2),
+                                               (128, 128, 3, 12, 24, 40, 2), (96, 64, 3, 2, 16, 48, 5), (128, 128, 1, 1, 32, 32, 2)])
+def test_conv_wgrad_split_emulation(dev, emu_mode, Ci, Co, k, dil, H, W, n):
+    """Weight gradient of the implicit-GEMM convolutions (A = dy^T, B = im2col(x)^T, split-K over the pixels) on the bf16x6
+    pipe (gemm_bf16x_kernel<3, 1, 2>: dilated ASPP layers, 1x1 projections): error vs fp64 at or below the fp32 MFMA
+    chain's, bf16x3 within 2^-16-ish; the library reports the split pipe for these launches."""
+    from semivl_amd import ops, lib as L
+    pad = dil * (k - 1) // 2
+    x, dy = rnd(n, Ci, H, W, dev=dev, seed=26), rnd(n, Co, H, W, dev=dev)
+    wz = torch.zeros(Co, Ci, k, k, device=dev, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x.double(), wz, padding=pad, dilation=dil), wz, dy.double())
+    xs, dys = nhwc(x), nhwc(dy)
+    err = {}
+    for mode in (0, 6, 3):
+        emu_mode(mode)
+        dwf = ops.conv_wgrad(dys, Co, xs, Ci, n, H, W, Ci, Co, k, k, dil, pad)
+        assert L.load().svl_last_gemm_path() == (1 if mode else 0)
+        err[mode] = _relerr(ops.unpack_conv_wgrad(dwf, Co, Ci, k, k), ref)
+    assert err[6] <= EMU6_ERR_FACTOR * err[0] + 1e-8, err
+    assert err[3] <= 2e-5, err
+    emu_mode(6)
+    again = ops.conv_wgrad(dys, Co, xs, Ci, n, H, W, Ci, Co, k, k, dil, pad)
+    assert torch.equal(again, ops.conv_wgrad(dys, Co, xs, Ci, n, H, W, Ci, Co, k, k, dil, pad))   # deterministic
+
+
+def test_conv_wgrad_split_emulation_two_sources_and_convT(dev, emu_mode):
+    """The same kernel on a dilated convolution over a two-source (class-repeated) concat input and on the ConvTranspose2d
+    weight gradient (stride-2 output grid), against float64."""
+    from semivl_amd import ops
+    n, rep, C1, C2, Co, H, W, dil = 6, 3, 64, 32, 128, 16, 24, 2
+    a, bsrc, dy = rnd(n, C1, H, W, dev=dev, seed=27), rnd(n // rep, C2, H, W, dev=dev), rnd(n, Co, H, W, dev=dev)
+    xcat = torch.cat([a, bsrc.repeat_interleave(rep, 0)], 1)
+    wz = torch.zeros(Co, C1 + C2, 3, 3, device=dev, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xcat.double(), wz, padding=dil, dilation=dil), wz, dy.double())
+    err = {}
+    for mode in (0, 6):
+        emu_mode(mode)
+        dwf = ops.conv_wgrad(nhwc(dy), Co, nhwc(a), C1, n, H, W, C1, Co, 3, 3, dil, dil, src2=nhwc(bsrc), ld2=C2, C2=C2, rep=rep)
+        err[mode] = _relerr(ops.unpack_conv_wgrad(dwf, Co, C1 + C2, 3, 3), ref)
+    assert err[6] <= EMU6_ERR_FACTOR * err[0] + 1e-8, err
+    # ConvTranspose2d(Ci -> Cu, k 2, s 2): dW[ci, cu, a, b] = sum_pix x[pix, ci] du[(2y + a, 2x + b), cu]
+    n, Ci, Cu, H, W = 4, 128, 96, 16, 16
+    x, du = rnd(n, Ci, H, W, dev=dev, seed=28), rnd(n, Cu, 2 * H, 2 * W, dev=dev)
+    wz = torch.zeros(Ci, Cu, 2, 2, device=dev, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv_transpose2d(x.double(), wz, stride=2), wz, du.double())
+    for mode in (0, 6):
+        emu_mode(mode)
+        dwb = ops.convT2x_wgrad(nhwc(x), Ci, nhwc(du), Cu, n, H, W, Ci, Cu)          # [Ci, (a, b, cu)]
+        err[mode] = _relerr(dwb.view(Ci, 2, 2, Cu).permute(0, 3, 1, 2), ref)
+    assert err[6] <= EMU6_ERR_FACTOR * err[0] + 1e-8, err
+
+
 @pytest.mark.parametrize("Ci,Co,k,dil,H,n", [(128, 128, 3, 1, 16, 3), (128, 128, 3, 6, 32, 2), (128, 128, 3, 18, 32, 2),
                                              (64, 96, 3, 1, 20, 2), (128, 160, 3, 12, 24, 1)])
 def test_conv_split_emulation(dev, emu_mode, Ci, Co, k, dil, H, n):
@@ -458,7 +554,7 @@ def test_conv_split_emulation(dev, emu_mode, Ci, Co, k, dil, H, n):
         dx = ops.conv_dgrad(dys, Co, n, H, W, Co, wd, Ci, k, k, dil, pad)
         err[mode] = (_relerr(nchw(y, n, H, W), ref_y), _relerr(nchw(dx, n, H, W), ref_dx))
     for i in (0, 1):
-        assert err[6][i] <= 1.5 * err[0][i] + 1e-8, err
+        assert err[6][i] <= EMU6_ERR_FACTOR * err[0][i] + 1e-8, err
         assert err[3][i] <= 2e-5, err
     emu_mode(6)
     b = rnd(Co, dev=dev)
@@ -1020,8 +1116,8 @@ def test_tiled_narrow_conv3x3_split_emulation(dev, emu_mode, b, N, H, W, C1, C2,
         dw = ops.unpack_conv_wgrad(dwf, Co, C1 + C2, 3, 3)
         assert torch.equal(dwf, ops.conv_wgrad(dy.view(-1, Co), Co, x1.view(-1, C1), C1, imgs, H, W, C1, Co, 3, 3, 1, 1, **kw))
         err[mode] = (_relerr(y.view(imgs, H, W, Co), ref), _relerr(dx.view(imgs, H, W, C1 + C2), gx), _relerr(dw, gw))
-    assert err[6][0] <= 1.5 * err[0][0] + 1e-8 and err[6][1] <= 1.5 * err[0][1] + 1e-8, err
-    assert err[6][2] <= 1.5 * err[0][2] + 1e-8, err      # weight gradient (conv3x3_wgrad_tiled_bf16x_kernel)
+    assert err[6][0] <= EMU6_ERR_FACTOR * err[0][0] + 1e-8 and err[6][1] <= EMU6_ERR_FACTOR * err[0][1] + 1e-8, err
+    assert err[6][2] <= EMU6_ERR_FACTOR * err[0][2] + 1e-8, err      # weight gradient (conv3x3_wgrad_tiled_bf16x_kernel)
     emu_mode(6)
     bias = rnd(Co, dev=dev)
     y = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, bias=bias, act=ops.ACT_RELU, **kw)

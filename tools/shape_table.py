@@ -9,6 +9,7 @@ from semivl_amd.model.builder import build_model
 from semivl_amd.synthetic import exp40_cfg, synthetic_batch
 from semivl_amd.train import FusedAdamW, GradAllReducer, semivl_train_step
 name = sys.argv[1] if len(sys.argv) > 1 else "pascal"
+name = {"voc": "pascal"}.get(name, name)
 shapes = {"pascal": (16, 512, 21), "cityscapes": (8, 801, 19), "ade": (16, 512, 150), "coco": (16, 512, 81)}
 B, crop, ncls = shapes[name]
 if len(sys.argv) > 2:
