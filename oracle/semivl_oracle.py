@@ -459,13 +459,19 @@ def compute_mc_loss(pred, mask, ign, reduce="mean_all"):  # semivl.py:52-58 with
 
 
 def semivl_step(model, batch, iters, total_iters, conf_thresh=0.95, conf_mode="pixelwise", mcc_lambda=(0.1, 0.0),
-                mcc_conf_thresh=0.9, fp_masks=None, mcc_loss_reduce="mean_all", helpers=None):
+                mcc_conf_thresh=0.9, fp_masks=None, mcc_loss_reduce="mean_all", helpers=None, label_override=None):
     """semivl.py:223-323 for method='semivl', criterion CELoss(ignore 255), criterion_u CELoss.
     `batch` holds the 12 step tensors.  Returns (loss, dict of intermediates).
     `helpers`: the loss helpers to drive the loop with -- the golden generator (tests/golden/gen_golden.py) passes the
     REFERENCE's own utils/train_utils.py functions and its semivl.py::compute_mc_loss here, so the fixtures pin this
     file's restatements of them (above) by execution; signature (cutmix_img_, cutmix_mask, confidence_weighted_loss(loss,
     conf, ign, conf_mode, conf_thresh), compute_mc_loss(pred, mask, ign, reduce))."""
+    """`label_override` (tests only): {'mask_w' / 'mask_w_other' / 'mclip' / 'mclip_other': int64 map} replaces the
+    hard label maps this loop derives itself.  A pseudo-label is an argmax: where the top-2 logit gap is below the
+    floating-point error of ANY implementation the decision is a tie, and at random init one flipped pixel moves a
+    gradient tensor by ~1/sqrt(#pixels) of its norm.  The full-size tests first assert that the product's maps differ
+    from this loop's only at such ties, then compare gradients under the SAME tie decisions."""
+    ov = label_override or {}
     cutmix_img_, cutmix_mask, confidence_weighted_loss, compute_mc_loss = helpers or (
         globals()["cutmix_img_"], globals()["cutmix_mask"], globals()["confidence_weighted_loss"],
         globals()["compute_mc_loss"])
@@ -484,6 +490,8 @@ def semivl_step(model, batch, iters, total_iters, conf_thresh=0.95, conf_mode="p
         mclip, mclip_other = mclip.split([nb, nb])
         mclip[b["ignore_mask"] == 255] = 255
         mclip_other[b["ignore_mask_other"] == 255] = 255
+        mask_w_other = ov.get("mask_w_other", mask_w_other)
+        mclip, mclip_other = ov.get("mclip", mclip), ov.get("mclip_other", mclip_other)
     model.train()
     preds, preds_fp = model(torch.cat((b["img_x"], b["img_w"])), need_fp=True, fp_masks=fp_masks)
     pred_x, pred_w = preds.chunk(2)
@@ -491,6 +499,7 @@ def semivl_step(model, batch, iters, total_iters, conf_thresh=0.95, conf_mode="p
     pred_s1, pred_s2 = model(torch.cat((b["img_s1"], b["img_s2"]))).chunk(2)
     pred_w = pred_w.detach()
     conf_w, mask_w = pred_w.softmax(dim=1).max(dim=1)
+    mask_w = ov.get("mask_w", mask_w)
     mw1, mw2 = cutmix_mask(mask_w, mask_w_other, b["mix1"]), cutmix_mask(mask_w, mask_w_other, b["mix2"])
     cw1, cw2 = cutmix_mask(conf_w, conf_w_other, b["mix1"]), cutmix_mask(conf_w, conf_w_other, b["mix2"])
     ig1 = cutmix_mask(b["ignore_mask"], b["ignore_mask_other"], b["mix1"])

@@ -1475,11 +1475,11 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       return emu_mode == 6 ? launch_emu<3>(q, 2, 0, 1, st) : launch_emu<2>(q, 2, 0, 1, st);
     }
     // weight gradients of the implicit-GEMM convolutions (A = dy^T, B = im2col(x)^T, split-K over the pixels): the
-    // dilated / 1x1 / transposed-conv layers of the decoder.  One 128-row tile holds all of Cout = 128 (64 wastes half a
-    // tile and still beats the fp32 pipe); a thread's 8 consecutive k must be pixels of one image row.
+    // dilated / 1x1 / transposed-conv layers of the decoder.  One 128-row tile holds all of Cout = 128 (Cout = 64 wastes half of
+    // every tile: measured slower than the fp32 kernel's 64-row tiles, 46 vs 53 TF, and left there); a thread's 8 consecutive k must be pixels of one image row.
     static const int emu_convw = getenv("SVL_GEMM_EMU_NO_CONVW") ? 0 : 1;
     if ((emu_mode == 3 || emu_mode == 6) && am == SVL_A_MCONTIG && bm == SVL_B_CONVW && d->out_mode == SVL_OUT_STRIDED &&
-        q.M >= 64 && q.N >= 96 && q.K >= 1024 && (q.K % 16) == 0 && (d->ksplit % 16) == 0 && (q.cv.Wo % 8) == 0 &&
+        q.M >= 96 && q.N >= 96 && q.K >= 1024 && (q.K % 16) == 0 && (d->ksplit % 16) == 0 && (q.cv.Wo % 8) == 0 &&
         q.A.vec && q.B.vec && emu_convw) {
       g_last_path = SVL_PATH_BF16X;
       return emu_mode == 6 ? launch_emu<3>(q, 1, 2, d->batch, st) : launch_emu<2>(q, 1, 2, d->batch, st);

@@ -107,9 +107,15 @@ struct CeP {
   long blocks_per_img;
 };
 
+// Round 4: the kernel moved 4.6 TB/s (0.58 of the 8 TB/s peak on its real PMC bytes).  It was latency-, not bandwidth-bound:
+// the tile loop issued ONE 16 B load per thread and waited for it before the LDS store (28 KB in flight per CU with seven
+// resident blocks), and the label / confidence maps were only requested after the barrier.  Now a thread requests up to 8
+// rows of its column quad before the first LDS store (no index division in the loop: thread = (row r, quad q), rows r, r +
+// R, ...), the maps are requested before the tile, the exponentials are computed once (the tile holds exp(x - max) for the
+// gradient pass) and the four block sums share one barrier.
 __global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [N][P]
-  __shared__ float red[4];
+  __shared__ float red[4][4];
   const int tid = threadIdx.x;
   const long blk = blockIdx.x;
   const long b = blk / p.blocks_per_img;
@@ -118,63 +124,78 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
   const float* src = p.logits + (long)b * p.N * p.HW + p0;
   const int P = p.P;
   const bool vec = ((p.HW & 3) == 0) && ((np & 3) == 0);
+  // per-pixel maps first: their latency hides under the tile loads
+  const long o = b * p.HW + p0 + tid;
+  const bool act = tid < np;
+  long t = 0, mm = 255, ig = 0;
+  float cf = 0.f;
+  if (act) {
+    t = p.target[o];
+    if (p.conf) { ig = p.ign[o]; cf = p.conf[o]; }
+    if (p.mc) mm = p.mc[o];
+  }
+  constexpr int LU = 8;
+  const int q4 = np >> 2;
+  const int R = vec ? 256 / q4 : 1;            // rows covered per pass by the (r, q) thread grid
+  const int r0 = vec ? tid / q4 : 0, q = vec ? tid - r0 * q4 : 0;
+  const bool ldr = vec && r0 < R;
   if (vec) {
-    const int q4 = np >> 2;
-    for (int i = tid; i < p.N * q4; i += 256) {
-      const int c = i / q4, q = i - c * q4;
-      *reinterpret_cast<float4*>(&tile[c * P + 4 * q]) = *reinterpret_cast<const float4*>(src + (long)c * p.HW + 4 * q);
+    if (ldr) {
+      const float* g = src + 4 * q;
+      float* d = tile + 4 * q;
+      for (int c0 = r0; c0 < p.N; c0 += R * LU) {
+        // branch-free: rows past N are CLAMPED to row N - 1 for the load AND the store (the same values land on the same
+        // address twice).  A load or a store under a per-lane condition becomes an exec-masked branch with the load sunk
+        // into it next to its own s_waitcnt -- the eight requests went out one at a time (2.1 TB/s instead of 4.6).
+        float4 v[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) v[u] = *reinterpret_cast<const float4*>(g + (long)min(c0 + u * R, p.N - 1) * p.HW);
+#pragma unroll
+        for (int u = 0; u < LU; ++u) *reinterpret_cast<float4*>(d + min(c0 + u * R, p.N - 1) * P) = v[u];
+      }
     }
   } else {
     for (int i = tid; i < p.N * np; i += 256) {
-      const int c = i / np, q = i - c * np;
-      tile[c * P + q] = src[(long)c * p.HW + q];
+      const int c = i / np, qq = i - c * np;
+      tile[c * P + qq] = src[(long)c * p.HW + qq];
     }
   }
   __syncthreads();
 
   float s_t = 0.f, s_m = 0.f, s_c = 0.f, n_v = 0.f;
-  if (tid < np) {
-    const long o = b * p.HW + p0 + tid;
+  if (act) {
     float m = -INFINITY;
     for (int c = 0; c < p.N; ++c) m = fmaxf(m, tile[c * P + tid]);
-    float s = 0.f;
-    for (int c = 0; c < p.N; ++c) s += expf(tile[c * P + tid] - m);
-    const float lse = m + logf(s);
-    const long t = p.target[o];
     const bool t_ok = !(p.use_ignore_t && t == 255);
+    const int ti = t_ok ? (int)t : -1;
+    const int mi = (p.mc && mm != 255) ? (int)mm : -1;
+    const float xt = ti >= 0 ? tile[ti * P + tid] : 0.f, xm = mi >= 0 ? tile[mi * P + tid] : 0.f;
+    float s = 0.f;
+    for (int c = 0; c < p.N; ++c) {
+      const float e = expf(tile[c * P + tid] - m);
+      s += e;
+      tile[c * P + tid] = e;
+    }
+    const float lse = m + logf(s);
     float w = 1.f;
     bool valid = t_ok;
     if (p.conf) {
-      const bool v = p.ign[o] != 255;
-      const float cf = p.conf[o];
+      const bool v = ig != 255;
       w = p.all_pixels ? 1.f : ((cf >= p.conf_thresh && v) ? 1.f : 0.f);
       if (p.img_weight) w *= p.img_weight[b];
       valid = v;
       s_c = v ? cf : 0.f;
     }
     n_v = valid ? 1.f : 0.f;
-    float ce_t = 0.f;
-    int ti = -1;
-    if (t_ok) {
-      ti = (int)t;
-      ce_t = lse - tile[ti * P + tid];
-    }
-    s_t = w * ce_t;
-    int mi = -1;
-    if (p.mc) {
-      const long mm = p.mc[o];
-      if (mm != 255) {
-        mi = (int)mm;
-        s_m = lse - tile[mi * P + tid];
-      }
-    }
+    s_t = t_ok ? w * (lse - xt) : 0.f;
+    s_m = mi >= 0 ? lse - xm : 0.f;
     if (p.dlogits) {
       const float gt = t_ok ? p.gscale[0] * w : 0.f;
       const float gm = (mi >= 0) ? p.gscale[1] : 0.f;
       const float gsum = gt + gm;
       const float inv = 1.f / s;
       for (int c = 0; c < p.N; ++c) {
-        const float pr = expf(tile[c * P + tid] - m) * inv;
+        const float pr = tile[c * P + tid] * inv;
         float d = gsum * pr;
         if (c == ti) d -= gt;
         if (c == mi) d -= gm;
@@ -182,28 +203,40 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
       }
     }
   }
-  // block partial sums (deterministic order: fixed tree, one slot per block)
-  const float r0 = block_sum_256(s_t, red);
-  const float r1 = block_sum_256(s_m, red);
-  const float r2 = block_sum_256(s_c, red);
-  const float r3 = block_sum_256(n_v, red);
-  if (tid == 0) {
-    float* pp = p.partials + blk * 4;
-    pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3;
+  // block partial sums (deterministic order: fixed shuffle tree per wave, waves in order; one slot per block)
+  {
+    float a0 = s_t, a1 = s_m, a2 = s_c, a3 = n_v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off, 64);
+      a1 += __shfl_xor(a1, off, 64);
+      a2 += __shfl_xor(a2, off, 64);
+      a3 += __shfl_xor(a3, off, 64);
+    }
+    if ((tid & 63) == 0) {
+      red[tid >> 6][0] = a0; red[tid >> 6][1] = a1; red[tid >> 6][2] = a2; red[tid >> 6][3] = a3;
+    }
   }
+  __syncthreads();     // (also: the tile now holds dlogits)
+  if (tid < 4) p.partials[blk * 4 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   if (p.dlogits) {
-    __syncthreads();
     float* dst = p.dlogits + (long)b * p.N * p.HW + p0;
     if (vec) {
-      const int q4 = np >> 2;
-      for (int i = tid; i < p.N * q4; i += 256) {
-        const int c = i / q4, q = i - c * q4;
-        *reinterpret_cast<float4*>(dst + (long)c * p.HW + 4 * q) = *reinterpret_cast<const float4*>(&tile[c * P + 4 * q]);
+      if (ldr) {
+        float* g = dst + 4 * q;
+        const float* d = tile + 4 * q;
+        for (int c0 = r0; c0 < p.N; c0 += R * LU) {
+          float4 v[LU];
+#pragma unroll
+          for (int u = 0; u < LU; ++u) v[u] = *reinterpret_cast<const float4*>(d + min(c0 + u * R, p.N - 1) * P);
+#pragma unroll
+          for (int u = 0; u < LU; ++u) *reinterpret_cast<float4*>(g + (long)min(c0 + u * R, p.N - 1) * p.HW) = v[u];
+        }
       }
     } else {
       for (int i = tid; i < p.N * np; i += 256) {
-        const int c = i / np, q = i - c * np;
-        dst[(long)c * p.HW + q] = tile[c * P + q];
+        const int c = i / np, qq = i - c * np;
+        dst[(long)c * p.HW + qq] = tile[c * P + qq];
       }
     }
   }

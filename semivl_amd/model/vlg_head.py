@@ -14,6 +14,10 @@ from .. import gradsync, ops
 from .vit import TransformerEncoderLayer
 
 
+import os as _os
+_MEM_DEBUG = bool(_os.environ.get("SVL_MEM_DEBUG"))
+
+
 # ------------------------------------------------------------------------------------------------ parameter containers
 class SemanticTransformer(nn.Module):
     def __init__(self, channels, text_channels, num_heads, pool_size):
@@ -91,15 +95,17 @@ class _LazyGN:
     """relu(groupnorm(pre)) of one conv + GN unit, described by what backward keeps anyway."""
 
     def __init__(self, sv, gn):
-        self.sv, self.gn = sv, gn
+        # (the fields, not `sv` itself: sv["lazy"] -> handle -> sv would be a reference cycle, and the tensors of a finished
+        # step would live until the cycle collector runs -- 90 GB at ADE)
+        self.pre, self.st, self.geom, self.gn = sv["pre"], sv["st"], sv["geom"], gn
 
     def get(self, out=None, ldo=None):
-        imgs, H, W, _C1, Co, _k, _dil, _pad = self.sv["geom"]
-        pre = self.sv["pre"]
+        imgs, H, W, _C1, Co, _k, _dil, _pad = self.geom
+        pre = self.pre
         if out is None:
             out, ldo = ops.empty(imgs * H * W, Co, device=pre.device), Co
         return ops.groupnorm_apply(pre, Co, self.gn.weight, self.gn.bias, imgs, H * W, Co, self.gn.num_groups, True,
-                                   self.sv["st"], out, ldo)
+                                   self.st, out, ldo)
 
 
 class _LazyCat:
@@ -370,6 +376,9 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, chunks_out):
             sv, over = None, True    # does not fit: drop, recompute this chunk (and the following ones) in backward
         if chunks_out is not None:
             chunks_out.append((s0, s1, live, sv))
+    if _MEM_DEBUG and chunks_out is not None:
+        print(f"[head fwd] b={b} N={N} remat={shared['remat']} chunks={[(c[0], c[1], c[2], c[3] is not None) for c in chunks_out]} "
+              f"allocated {torch.cuda.memory_allocated(dev) / 2**30:.1f} GB (limit {None if limit is None else round(limit / 2**30, 1)})", flush=True)
     return logits, shared
 
 
@@ -607,6 +616,9 @@ class _HeadFn(torch.autograd.Function):
                 sv = {}
                 _head_core_forward(m, sh, s0, s1, sv, None)
             a0, a4, ae = _head_backward_core(m, sv, dlogits[s0:s1], gc)
+            if _MEM_DEBUG:
+                print(f"[head bwd] chunk {s0}:{s1} allocated {torch.cuda.memory_allocated(dev) / 2**30:.1f} GB, peak "
+                      f"{torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GB", flush=True)
             ctx.chunks[i] = None
             del sv
             for full, part, hw_ in ((dsk0, a0, HW0), (dsk4, a4, HW), (demb, ae, HW)):

@@ -889,9 +889,9 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
         reduce_slabs(out, slabs)
         return out
     g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
-    # (the split-emulation kernel serves this launch when Cout >= 64, N >= 96 and the output rows are whole 8-pixel groups:
+    # (the split-emulation kernel serves this launch when Cout >= 96, N >= 96 and the output rows are whole 8-pixel groups:
     # 128-row tiles, two resident blocks per CU)
-    x6 = (get_gemm_emulation() in (3, 6) and Co >= 64 and N >= 96 and Wo % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0 and
+    x6 = (get_gemm_emulation() in (3, 6) and Co >= 96 and N >= 96 and Wo % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0 and
           not os.environ.get("SVL_GEMM_EMU_NO_CONVW"))
     s, ks = _ksplit_plan(Co, N, Kpix, emu_tiles=x6)
     out = empty(Co, N, device=dy.device)
@@ -958,7 +958,7 @@ def convT2x_wgrad(x, ldx, du, lddu, imgs, H, W, Ci, Co):
     Kpix = imgs * H * W
     N = 4 * Co
     g = conv_geom(2 * H, 2 * W, Co, 2, 2, 1, 0, 1, stride=2, Ho=H, Wo=W)
-    x6 = (get_gemm_emulation() in (3, 6) and Ci >= 64 and N >= 96 and W % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0 and
+    x6 = (get_gemm_emulation() in (3, 6) and Ci >= 96 and N >= 96 and W % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0 and
           not os.environ.get("SVL_GEMM_EMU_NO_CONVW"))
     s, ks = _ksplit_plan(Ci, N, Kpix, emu_tiles=x6)
     out = empty(Ci, N, device=x.device)

@@ -171,3 +171,17 @@ def test_optimizer_state_dict_is_index_compatible_with_the_reference(dev):
     t2 = torch.optim.AdamW(O.param_groups(build_oracle(c), 1e-3, 0.01, ck), lr=1e-3, weight_decay=0.01)
     t2.load_state_dict({k: fs[k] for k in ("state", "param_groups")})
     assert torch.equal(t2.state_dict()["state"][min(fs["state"])]["exp_avg"], fs["state"][min(fs["state"])]["exp_avg"])
+    # EVERY group (frozen tensors and clip_encoder.* included) carries `initial_lr` and a scheduled `lr`, so the reference's
+    # own loop (semivl.py:124-125 setdefault, :341-345 re-schedule of every group) runs on the loaded dict as it is
+    fo.poly_lr(3, 50)
+    fs2 = fo.state_dict()
+    f_ = (1 - 3 / 50) ** 0.9
+    for j, gf in enumerate(fs2["param_groups"]):
+        assert set(gf) >= {"lr", "initial_lr", "weight_decay", "betas", "eps", "amsgrad", "params"}, (names[j], sorted(gf))
+        assert abs(gf["lr"] - gf["initial_lr"] * f_) < 1e-15, names[j]
+    t2.load_state_dict({k: fs2[k] for k in ("state", "param_groups")})
+    for group in t2.param_groups:                               # the reference's poly schedule, verbatim in spirit
+        group["lr"] = group["initial_lr"] * (1 - 4 / 50) ** 0.9
+    f3 = FusedAdamW(build_hip(c).to(dev), ocfg)
+    f3.load_state_dict({k: fs2[k] for k in ("state", "param_groups")})
+    assert abs(f3._lr_factor - f_) < 1e-12 and f3.state_dict()["param_groups"][0]["lr"] == fs2["param_groups"][0]["lr"]

@@ -38,12 +38,12 @@ def build_pair(dev, nclass=21, dataset="pascal", crop=512, seed=4242):
     return cfg, hip.to(dev), orc
 
 
-def oracle_step(orc, cfg, batch, masks, conf_thresh):
+def oracle_step(orc, cfg, batch, masks, conf_thresh, label_override=None):
     from oracle import semivl_oracle as O
     for p_ in orc.parameters():
         p_.grad = None
     loss, aux = O.semivl_step(orc, batch, 100, 1000, conf_thresh=conf_thresh, conf_mode=cfg["conf_mode"],
-                              fp_masks=masks)
+                              fp_masks=masks, label_override=label_override)
     loss.backward()
     return loss, aux
 
@@ -100,6 +100,26 @@ def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stac
     og = {n: p.grad for n, p in orc.named_parameters() if p.grad is not None}
     hg = {n: p.grad for n, p in hip.named_parameters() if p.grad is not None}
     assert sorted(og) == sorted(hg) and len(og) > 100, sorted(set(og) ^ set(hg))
+
+    def worst_rel(ref):
+        return max(((hg[n].cpu() - ref[n]).norm() / (ref[n].norm() + 1e-20)).item() for n in ref
+                   if n != "decode_head.head.bias" and not any(s_ in n for s_ in bn_stack) and
+                   not any(s_ in n for s_ in after_bn))
+    # Pseudo-label ties.  The label maps above differ from the oracle's at a handful of pixels whose top-2 logit gap is
+    # below either implementation's rounding error -- legitimately, but at random init a gradient tensor is an incoherent
+    # sum over ~5e5 pixels, so ONE flipped target moves it by ~1/sqrt(#pixels) ~ 1.4e-3 of its norm, and WHICH ties flip
+    # changes with any reordering of a sum (round 4: statistics from a conv epilogue moved backbone.pos_embed from 2.9e-3
+    # to 5.2e-3 with 12 instead of 14 flips).  When the plain comparison is out of bounds and ties did flip, the gradients
+    # are compared under the SAME tie decisions: the oracle's step is repeated with the product's label maps.
+    if sum(flips.values()) > 0 and worst_rel(og) >= GRAD_REL_L2:
+        keep = {n: g.clone() for n, g in og.items()}
+        override = {k: haux[k].cpu() for k in ("mask_w", "mask_w_other", "mclip", "mclip_other")}
+        oracle_step(orc, cfg, batch, masks, cfg["conf_thresh"], label_override=override)
+        og = {n: p.grad.clone() for n, p in orc.named_parameters() if p.grad is not None}
+        for n, p_ in orc.named_parameters():      # (the module-scoped oracle serves the other arithmetic mode next)
+            if n in keep:
+                p_.grad = keep[n]
+        print(f"[gemm_mode {gemm_mode}] gradients compared under the product's tie decisions ({flips})")
     table = sorted(((hg[n].cpu() - og[n]).abs().max().item() / max(og[n].abs().max().item(), 1e-12), n) for n in og)
     t2_ = sorted((((hg[n].cpu() - og[n]).norm() / (og[n].norm() + 1e-20)).item(), n) for n in og)
     print(f"[gemm_mode {gemm_mode}] logit errs {errs}, label flips at ties {flips}; largest grad max-err / scale:",

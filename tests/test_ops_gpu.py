@@ -481,7 +481,7 @@ def test_conv3x3_with_groupnorm_statistics(dev, emu_mode, C1, C2, Co, H, W, n, r
 
 
 @pytest.mark.parametrize("Ci,Co,k,dil,H,W,n", [(128, 128, 3, 6, 32, 32, 3), (128, 128, 3, 18, 32, 32, 2), (640, 128, 1, 1, 32, 32, 2),
-                                               (128, 128, 3, 12, 24, 40, 2), (96, 64, 3, 2, 16, 48, 5), (128, 128, 1, 1, 32, 32, 2)])
+                                               (128, 128, 3, 12, 24, 40, 2), (96, 96, 3, 2, 16, 48, 5), (128, 128, 1, 1, 32, 32, 2)])
 def test_conv_wgrad_split_emulation(dev, emu_mode, Ci, Co, k, dil, H, W, n):
     """Weight gradient of the implicit-GEMM convolutions (A = dy^T, B = im2col(x)^T, split-K over the pixels) on the bf16x6
     pipe (gemm_bf16x_kernel<3, 1, 2>: dilated ASPP layers, 1x1 projections): error vs fp64 at or below the fp32 MFMA
