@@ -378,6 +378,9 @@ int svl_affine_planes_f32(const float* x, int64_t planes, int C, int64_t HW, con
  * (token slicing x[:, 1:], cls-row scatter, torch.cat into channel slices, batch broadcast, strided grad adds). */
 int svl_copy2d_f32(const float* src, int64_t sgrp, int64_t src_go, int64_t src_ld, float* dst, int64_t dgrp,
                    int64_t dst_go, int64_t dst_ld, int64_t rows, int C, int accumulate, svl_stream_t stream);
+/* Row permutation [outer, A, B, C] -> [outer, B, A, C] (C % 4 == 0): einops '(b n) (h w) c -> (b h w) n c' of the
+ * SemanticTransformer (vlg_head.py:44-62) when its class sequences run on svl_attention_fwd / _bwd (N >= 64). */
+int svl_permute_rows_f32(const float* src, int64_t outer, int A, int B, int C, float* dst, svl_stream_t stream);
 
 /* GroupNorm (+ optional ReLU) on NHWC class-images: x [imgs, HW, C] (pixel stride ldx), groups of C/G channels,
  * stats [imgs, G, 2] = (mean, rstd); y pixel stride ldy (lets the result land in a concat slice). vlg_head.py:74-137 */

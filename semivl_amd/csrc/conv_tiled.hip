@@ -21,12 +21,12 @@ constexpr int NPIX = IH * IW;  // 180
 // reads) becomes ~60 instructions per wave.  gn_finalize_kernel adds an image's tiles up (fixed order: deterministic,
 // independent of how many images share the launch).
 template <int TN>
-__device__ __forceinline__ void gn_tile_partials(const ConvTiledP& p, const float (&s)[TN], const float (&q)[TN], double* red,
+__device__ __forceinline__ void gn_tile_partials(const ConvTiledP& p, const double (&s)[TN], const double (&q)[TN], double* red,
                                                  int tid) {
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    double ds = (double)s[j], dq = (double)q[j];
+    double ds = s[j], dq = q[j];
 #pragma unroll
     for (int m = 1; m <= 8; m <<= 1) {
       ds += __shfl_xor(ds, m, 64);
@@ -168,9 +168,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   // C layout: column = output channel (l31 + 32 j), row i = (r & 3) + 8 (r >> 2) + 4 hi = pixel (i >> 4, i & 15) of the wave
   // Straight-line epilogue (see gemm_epilogue): uniform decisions once per 32-channel block, previous values (accumulate)
   // read before the first store, one pointer per block plus per-register pixel offsets.
-  float gs[TN], gq[TN];
+  double gs[TN], gq[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
+  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = l31 + 32 * j;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     if (p.gn_part) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float t = ok[r] ? v[r] : 0.f;
+        const double t = ok[r] ? (double)v[r] : 0.0;
         gs[j] += t;
         gq[j] += t * t;
       }
@@ -369,9 +369,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   // epilogue: identical to the fp32 kernel's (column = output channel, row = pixel of the wave)
-  float gs[TN], gq[TN];
+  double gs[TN], gq[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
+  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.0;
 #pragma unroll
   for (int u = 0; u < PT; ++u)
 #pragma unroll
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (p.gn_part) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float t = ok[r] ? v[r] : 0.f;
+        const double t = ok[r] ? (double)v[r] : 0.0;
         gs[j] += t;
         gq[j] += t * t;
       }
@@ -633,8 +633,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3
 // its three tx accumulators share every LDS read: 6 waves = 2 co tiles x 3 ty (Co = 64, 32-channel slab) or 2 ci tiles x
 // 3 ty (Co = 32, 64-channel slab; Ct = 32 stays on the fp32 kernel).
 constexpr int WPH = 4, WIH = WPH + 2;
-constexpr int DCH = 2 * WPH, DRS = (DCH + 1) * 8;      // dy^T: 8 slots per row, row stride 9 slots (bf16 elements)
-constexpr int XCH = 3 * WIH, XRS = (XCH + 1) * 8;      // x^T: 18 slots per row, row stride 19 slots
+// (per kernel shape: DCH = 2 rows' halves, DRS = (DCH + 1) * 8 elements: dy^T row stride, 9 or 17 slots; XCH = 3 x halo rows,
+//  XRS = (XCH + 1) * 8: x^T row stride, 19 or 31 slots -- odd strides: conflict-free 16 B accesses)
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -663,10 +663,17 @@ __device__ __forceinline__ void split3w(const float (&v)[8], u32x4_t (&h)[3]) { 
 // PRODUCERS (loads of patch i + 2, split + store of patch i + 1 into the other buffer) -- one barrier per patch, and on
 // every SIMD the matrix pipe and the VALU / memory pipes are fed by different waves at the same time.  (With six waves
 // doing both in turn, two barriers per patch, the kernel sat at 30 % MFMA-busy with 43 % of the wave time waiting.)
-template <int MT, int NT>
+// <1, 1, 2> (round 4): the 32 -> 32 layer (one co tile, one ci tile).  The two "tiles" are the two 4-row HALVES of an 8-row
+// patch (PR = 2): the producers stage 8 + 2 halo rows, consumer wave (half, ty) runs the half's four k-steps, and the two
+// halves' accumulators -- partial sums over different pixels -- leave as two slabs (the block writes slabs 2 g and 2 g + 1).
+// Same MFMA count per wave and barrier as the other two shapes; this layer ran on the fp32 kernel at 79-82 TF.
+template <int MT, int NT, int PR = 1>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_wgrad_tiled_bf16x_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
-  static_assert(MT * NT == 2, "six consumer waves = two tiles x three tap rows");
+  static_assert(MT * NT * PR == 2, "six consumer waves = two tiles x three tap rows");
   constexpr int Co = 32 * MT, SL = 32 * NT;
+  constexpr int WPHT = WPH * PR, WIHT = WPHT + 2;          // patch rows / halo rows staged per iteration
+  constexpr int DCH = 2 * WPHT, DRS = (DCH + 1) * 8;       // dy^T: 8 (16) slots per row, row stride an odd number of slots
+  constexpr int XCH = 3 * WIHT, XRS = (XCH + 1) * 8;       // x^T: 18 (30) slots per row
   constexpr int DPL = Co * DRS, XPL = SL * XRS;          // plane strides (elements)
   constexpr int NDC = DCH * Co, NXC = XCH * SL;           // thread-chunks per patch
   constexpr int ND = (NDC + 383) / 384, NX = (NXC + 383) / 384;
@@ -681,6 +688,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int c0 = slab * SL, Ct = p.C1 + p.C2;
   const int npatch = p.imgs * tiles_x * tiles_y;
   const int mt = MT == 2 ? (wave & 1) : 0, nt = NT == 2 ? (wave & 1) : 0, ty = wave >> 1;
+  const int pt = PR == 2 ? (wave & 1) : 0;                 // which 4-row half of the staged patch this consumer wave owns
 
   // The two roles run SEPARATE loops with the same number of barriers (one before the first patch, one per patch), so that
   // neither role's registers are live in the other's loop.
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     t /= tiles_x;
     const int tyi = t % tiles_y;
     img = t / tiles_y;
-    y0 = tyi * WPH; x0 = txi * PW;
+    y0 = tyi * WPHT; x0 = txi * PW;
   };
   auto gload = [&](int pi) {
     int img, y0, x0;
@@ -760,7 +768,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int img, y0, x0;
     coords(pi, img, y0, x0);
     // patches whose halo lies inside the image need no zeroing at all (uniform branch)
-    const bool inner = y0 >= 1 && y0 + WPH + 1 <= p.H && x0 >= 1 && x0 + PW + 1 <= p.W;
+    const bool inner = y0 >= 1 && y0 + WPHT + 1 <= p.H && x0 >= 1 && x0 + PW + 1 <= p.W;
 #pragma unroll
     for (int z = 0; z < ND; ++z) {
       u32x4_t h[3];
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const int fa = (l31 + 32 * mt) * DRS + hi * 8, fb = 3 * DPL + (l31 + 32 * nt) * XRS + (ty * 3 + hi) * 8;
+  const int fa = (l31 + 32 * mt) * DRS + (2 * WPH * pt + hi) * 8, fb = 3 * DPL + (l31 + 32 * nt) * XRS + (3 * WPH * pt + ty * 3 + hi) * 8;
   __syncthreads();
   for (int it = 0, pi = g; pi < npatch; pi += ngrp, ++it) {
     {
@@ -856,7 +864,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
   }
   // C layout: row i = co (within the tile), column = lane = ci; tap = 3 ty + tx
-  float* out = p.slabs + ((long)g * Co * gridDim.z + cz) * 9 * Ct;
+  float* out = p.slabs + ((long)(g * PR + pt) * Co * gridDim.z + cz) * 9 * Ct;
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -877,11 +885,13 @@ extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, in
   // value is valid for either kernel; the arithmetic switch is only read here to size the grid well)
   if (svl_get_gemm_emulation() == 6 && !getenv("SVL_CONV_TILED_NO_EMU")) {
     if (Co == 32 && Ct % 64 == 0) g = 256 / (Ct / 64);
+    if (Co == 32 && Ct == 32) g = 512;               // <1, 1, 2>: 256 blocks, each leaves two slabs
     if (Co == 64) g = 256 / (nslab < 1 ? 1 : nslab);
   }
   if (Co == 128) g = 128 / (nslab < 1 ? 1 : nslab);
   if (g < 1) g = 1;
   if (g > npatch) g = npatch;
+  if (Co == 32 && Ct == 32 && g > 1) g &= ~1L;      // (the 32 -> 32 split kernel writes slabs in pairs)
   return (int)g;
 }
 
@@ -905,7 +915,10 @@ extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, co
   const int tx = (W + PW - 1) / PW, ty = (H + PH - 1) / PH;
   dim3 grid((unsigned)groups, (unsigned)(Ct / 32));
   hipStream_t st = (hipStream_t)stream;
-  if (emu6 && (Co >= 64 || Ct % 64 == 0)) {   // the split emulation covers the weight gradient too
+  if (emu6 && Co == 32 && Ct == 32 && groups >= 2 && groups % 2 == 0 && H >= 2 * WPH) {
+    const int ty8 = (H + 2 * WPH - 1) / (2 * WPH);
+    hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 1, 2>), dim3((unsigned)(groups / 2), 1u), dim3(768), 0, st, p, tx, ty8);
+  } else if (emu6 && (Co >= 64 || Ct % 64 == 0)) {   // the split emulation covers the weight gradient too
     const int ty4 = (H + WPH - 1) / WPH;
     if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(768), 0, st, p, tx, ty4);
     else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<2, 1>), dim3((unsigned)groups, (unsigned)(Ct / 32), (unsigned)(Co / 64)), dim3(768), 0, st, p, tx, ty4);

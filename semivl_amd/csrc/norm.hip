@@ -861,6 +861,37 @@ extern "C" int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, 
   return SVL_OK;
 }
 
+// dst[o][b][a][:] = src[o][a][b][:]  (rows of 4 C4 floats): a wave per destination row, the index split once per row.
+namespace {
+__global__ __launch_bounds__(256) void permute_rows_kernel(const float4* __restrict__ src, long outer, int A, int B, int C4,
+                                                          float4* __restrict__ dst) {
+  const long rows = outer * A * B;
+  const int lane = threadIdx.x & 63;
+  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long r = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6); r < rows; r += nw) {
+    const long a = r % A, t = r / A, b = t % B, o = t / B;
+    const float4* s = src + ((o * A + a) * B + b) * C4;
+    float4* d = dst + r * C4;
+    for (int c = lane; c < C4; c += 64) d[c] = s[c];
+  }
+}
+}  // namespace
+
+// [outer, A, B, C] -> [outer, B, A, C] row permutation (C % 4 == 0, 16-byte aligned): the SemanticTransformer's
+// '(b n) (h w) c -> (b h w) n c' rearrange (vlg_head.py:44-62) for the class counts whose sequences go through the fused
+// attention kernels, which want a sequence's tokens in consecutive rows.
+extern "C" int svl_permute_rows_f32(const float* src, int64_t outer, int A, int B, int C, float* dst, svl_stream_t stream) {
+  SVL_CHECK_ARG(src && dst && outer > 0 && A > 0 && B > 0 && C > 0 && C % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
+                "svl_permute_rows_f32: bad args");
+  const long rows = outer * A * B;
+  long grid = (rows + 3) / 4;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(src), (long)outer, A, B, C / 4, reinterpret_cast<float4*>(dst));
+  SVL_LAUNCH_CHECK("svl_permute_rows_f32");
+  return SVL_OK;
+}
+
 extern "C" int svl_copy2d_f32(const float* src, int64_t sgrp, int64_t src_go, int64_t src_ld, float* dst, int64_t dgrp,
                               int64_t dst_go, int64_t dst_ld, int64_t rows, int C, int accumulate, svl_stream_t stream) {
   SVL_CHECK_ARG(src && dst && sgrp >= 1 && dgrp >= 1 && rows > 0 && C > 0, "svl_copy2d_f32: bad args");

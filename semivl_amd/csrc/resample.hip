@@ -150,25 +150,41 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_bwd_kernel(const float* __r
   }
 }
 
+// Round 4: one output float per thread ran the x4 logits upsampling at 1.15 TB/s of stores (the sources are cache-resident);
+// VEC = four consecutive output columns per thread, one 16 B store (same arithmetic per element).
+template <bool VEC>
 __global__ __launch_bounds__(256) void bilinear_planes_fwd_kernel(const float* __restrict__ x, long planes, int h, int w,
                                                                   int align, int H, int W, float* __restrict__ y) {
+  constexpr int V = VEC ? 4 : 1;
   const float sh = area_scale(h, H, align), sw = area_scale(w, W, align);
-  const long total = planes * H * W;
+  const int WV = W / V;
+  const long total = planes * H * WV;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int ox = (int)(i % W);
-    const long t = i / W;
+    const int oxq = (int)(i % WV) * V;
+    const long t = i / WV;
     const int oy = (int)(t % H);
     const long pl = t / H;
-    int y0, y1, x0, x1;
-    float ly0, ly1, lx0, lx1;
+    int y0, y1;
+    float ly0, ly1;
     src_index(oy, sh, h, align, y0, y1, ly0, ly1);
-    src_index(ox, sw, w, align, x0, x1, lx0, lx1);
     const float* b = x + pl * h * w;
-    y[i] = ly0 * (lx0 * b[y0 * w + x0] + lx1 * b[y0 * w + x1]) + ly1 * (lx0 * b[y1 * w + x0] + lx1 * b[y1 * w + x1]);
+    float o[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      int x0, x1;
+      float lx0, lx1;
+      src_index(oxq + j, sw, w, align, x0, x1, lx0, lx1);
+      o[j] = ly0 * (lx0 * b[y0 * w + x0] + lx1 * b[y0 * w + x1]) + ly1 * (lx0 * b[y1 * w + x0] + lx1 * b[y1 * w + x1]);
+    }
+    if constexpr (VEC) *reinterpret_cast<float4*>(y + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    else y[i] = o[0];
   }
 }
+// (round 4: the column taps of an input pixel do not depend on the output row: their weights are computed once per thread
+//  instead of once per candidate output pixel -- ~120 index computations became ~24; same products, same order)
 __global__ __launch_bounds__(256) void bilinear_planes_bwd_kernel(const float* __restrict__ dy, long planes, int h, int w,
                                                                   int align, int H, int W, float* __restrict__ dx) {
+  constexpr int MAXW = 16;
   const float sh = area_scale(h, H, align), sw = area_scale(w, W, align);
   const long total = planes * h * w;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -181,63 +197,130 @@ __global__ __launch_bounds__(256) void bilinear_planes_bwd_kernel(const float* _
     dst_range(ix, sw, W, align, xlo, xhi);
     const float* d = dy + pl * H * W;
     float acc = 0.f;
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      int y0, y1;
-      float ly0, ly1;
-      src_index(oy, sh, h, align, y0, y1, ly0, ly1);
-      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
-      if (wy == 0.f) continue;
-      for (int ox = xlo; ox <= xhi; ++ox) {
+    if (xhi - xlo < MAXW) {
+      float wxs[MAXW];
+#pragma unroll
+      for (int k = 0; k < MAXW; ++k) {
         int x0, x1;
         float lx0, lx1;
-        src_index(ox, sw, w, align, x0, x1, lx0, lx1);
-        const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
-        if (wx != 0.f) acc += wy * wx * d[(long)oy * W + ox];
+        src_index(min(xlo + k, W - 1), sw, w, align, x0, x1, lx0, lx1);
+        wxs[k] = (xlo + k <= xhi) ? (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f) : 0.f;
+      }
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        int y0, y1;
+        float ly0, ly1;
+        src_index(oy, sh, h, align, y0, y1, ly0, ly1);
+        const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+        if (wy == 0.f) continue;
+        const float* row = d + (long)oy * W;
+        float dv[MAXW];
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k) dv[k] = row[min(xlo + k, W - 1)];     // unconditional (cache-resident) loads
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k) acc = wxs[k] != 0.f ? acc + wy * wxs[k] * dv[k] : acc;
+      }
+    } else {
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        int y0, y1;
+        float ly0, ly1;
+        src_index(oy, sh, h, align, y0, y1, ly0, ly1);
+        const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          int x0, x1;
+          float lx0, lx1;
+          src_index(ox, sw, w, align, x0, x1, lx0, lx1);
+          const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+          if (wx != 0.f) acc += wy * wx * d[(long)oy * W + ox];
+        }
       }
     }
     dx[i] = acc;
   }
 }
 
+// Round 4: the two avgpool_cat kernels moved one float per thread with four integer divisions each (1.3 - 1.7 TB/s; 23 ms
+// per ADE step); now a thread owns a channel QUAD of one pooled token / one pixel: 16 B accesses, the index split once per
+// thread, the window read four loads at a time (same summation order as before: rows outer, columns inner).
+template <bool VEC>
 __global__ __launch_bounds__(256) void avgpool_cat_fwd_kernel(const float* __restrict__ x, int imgs, int H, int W, int C,
                                                               int P, int PW, const float* __restrict__ text, int Ct,
                                                               int nclass, float* __restrict__ y) {
-  const int Hp = H / P, Wp = W / PW, Co = C + Ct;
-  const long total = (long)imgs * Hp * Wp * Co;
+  constexpr int V = VEC ? 4 : 1;
+  const int Hp = H / P, Wp = W / PW, Co = C + Ct, CoV = Co / V;
+  const long total = (long)imgs * Hp * Wp * CoV;
   const float inv = 1.f / (float)(P * PW);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Co);
-    long t = i / Co;
+    const int c = (int)(i % CoV) * V;
+    long t = i / CoV;
     const int px = (int)(t % Wp);
     t /= Wp;
     const int py = (int)(t % Hp);
     const long img = t / Hp;
-    float v;
+    float v[V];
     if (c < C) {
-      float s = 0.f;
-      for (int a = 0; a < P; ++a)
-        for (int b = 0; b < PW; ++b) s += x[((img * H + py * P + a) * W + px * PW + b) * C + c];
-      v = s * inv;
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = 0.f;
+      const float* base = x + ((img * H + py * P) * W + px * PW) * C + c;
+      for (int a = 0; a < P; ++a) {
+        const float* row = base + (long)a * W * C;
+        int b = 0;
+        for (; b + 4 <= PW; b += 4) {              // four independent loads in flight, added in order
+          float r[4][V];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if constexpr (VEC) {
+              const float4 q = *reinterpret_cast<const float4*>(row + (long)(b + u) * C);
+              r[u][0] = q.x; r[u][1] = q.y; r[u][2] = q.z; r[u][3] = q.w;
+            } else {
+              r[u][0] = row[(long)(b + u) * C];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] += r[u][j];
+        }
+        for (; b < PW; ++b)
+#pragma unroll
+          for (int j = 0; j < V; ++j) v[j] += row[(long)b * C + j];
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] *= inv;
     } else {
-      v = text[(img % nclass) * Ct + (c - C)];
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = text[(img % nclass) * Ct + (c - C) + j];
     }
-    y[i] = v;
+    if constexpr (VEC) *reinterpret_cast<float4*>(y + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    else y[i] = v[0];
   }
 }
+template <bool VEC>
 __global__ __launch_bounds__(256) void avgpool_cat_bwd_kernel(const float* __restrict__ dy, int imgs, int H, int W, int C,
                                                               int P, int PW, int Ct, float* __restrict__ dx) {
-  const int Hp = H / P, Wp = W / PW, Co = C + Ct;
-  const long total = (long)imgs * H * W * C;
+  constexpr int V = VEC ? 4 : 1;
+  const int Hp = H / P, Wp = W / PW, Co = C + Ct, CV = C / V;
+  const long total = (long)imgs * H * W * CV;
   const float inv = 1.f / (float)(P * PW);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    long t = i / C;
+    const int c = (int)(i % CV) * V;
+    long t = i / CV;
     const int xx = (int)(t % W);
     t /= W;
     const int yy = (int)(t % H);
     const long img = t / H;
     const int py = yy / P, px = xx / PW;
-    dx[i] = (py < Hp && px < Wp) ? dy[((img * Hp + py) * Wp + px) * Co + c] * inv : 0.f;
+    const bool in = py < Hp && px < Wp;
+    if constexpr (VEC) {
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) {
+        q = *reinterpret_cast<const float4*>(dy + ((img * Hp + py) * Wp + px) * Co + c);
+        q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
+      }
+      *reinterpret_cast<float4*>(dx + i * 4) = q;
+    } else {
+      dx[i] = in ? dy[((img * Hp + py) * Wp + px) * Co + c] * inv : 0.f;
+    }
   }
 }
 
@@ -299,8 +382,12 @@ extern "C" int svl_sum_rep_f32(const float* src, int64_t ld, int64_t groups, int
 extern "C" int svl_bilinear_planes_fwd(const float* x, int64_t planes, int h, int w, int align_corners, int H, int W,
                                        float* y, svl_stream_t stream) {
   SVL_CHECK_ARG(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "svl_bilinear_planes_fwd: bad args");
-  hipLaunchKernelGGL(bilinear_planes_fwd_kernel, dim3(grid_for(planes * H * W)), dim3(256), 0, (hipStream_t)stream, x,
-                     (long)planes, h, w, align_corners, H, W, y);
+  if (W % 4 == 0 && ((uintptr_t)y & 15) == 0)
+    hipLaunchKernelGGL(bilinear_planes_fwd_kernel<true>, dim3(grid_for(planes * H * (W / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                       (long)planes, h, w, align_corners, H, W, y);
+  else
+    hipLaunchKernelGGL(bilinear_planes_fwd_kernel<false>, dim3(grid_for(planes * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long)planes, h, w, align_corners, H, W, y);
   SVL_LAUNCH_CHECK("svl_bilinear_planes_fwd");
   return SVL_OK;
 }
@@ -316,9 +403,12 @@ extern "C" int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C
                                    int Ct, int nclass, float* y, svl_stream_t stream) {
   SVL_CHECK_ARG(x && y && imgs > 0 && PH > 0 && PW > 0 && H >= PH && W >= PW && C > 0 && (Ct == 0 || (text && nclass > 0)),
                 "svl_avgpool_cat_fwd: bad args");
-  const long total = (long)imgs * (H / PH) * (W / PW) * (C + Ct);
-  hipLaunchKernelGGL(avgpool_cat_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, imgs, H, W, C,
-                     PH, PW, text, Ct, nclass > 0 ? nclass : 1, y);
+  const bool vec = C % 4 == 0 && Ct % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+  const long total = (long)imgs * (H / PH) * (W / PW) * ((C + Ct) / (vec ? 4 : 1));
+  if (vec) hipLaunchKernelGGL(avgpool_cat_fwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, imgs, H, W, C,
+                              PH, PW, text, Ct, nclass > 0 ? nclass : 1, y);
+  else hipLaunchKernelGGL(avgpool_cat_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, imgs, H, W, C,
+                          PH, PW, text, Ct, nclass > 0 ? nclass : 1, y);
   SVL_LAUNCH_CHECK("svl_avgpool_cat_fwd");
   return SVL_OK;
 }
@@ -326,9 +416,12 @@ extern "C" int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int 
                                    svl_stream_t stream) {
   SVL_CHECK_ARG(dy && dx && imgs > 0 && PH > 0 && PW > 0 && H >= PH && W >= PW && C > 0 && Ct >= 0,
                 "svl_avgpool_cat_bwd: bad args");
-  const long total = (long)imgs * H * W * C;
-  hipLaunchKernelGGL(avgpool_cat_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, imgs, H, W,
-                     C, PH, PW, Ct, dx);
+  const bool vec = C % 4 == 0 && Ct % 4 == 0 && ((((uintptr_t)dy | (uintptr_t)dx) & 15) == 0);
+  const long total = (long)imgs * H * W * (C / (vec ? 4 : 1));
+  if (vec) hipLaunchKernelGGL(avgpool_cat_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, imgs, H, W,
+                              C, PH, PW, Ct, dx);
+  else hipLaunchKernelGGL(avgpool_cat_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, imgs, H, W,
+                          C, PH, PW, Ct, dx);
   SVL_LAUNCH_CHECK("svl_avgpool_cat_bwd");
   return SVL_OK;
 }

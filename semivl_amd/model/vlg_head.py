@@ -467,7 +467,18 @@ def _semtr_forward(lyr, x, tp, imgs, b, N, h, w, Ch, Ct, sv):
     y1, st1 = ops.layernorm_fwd(tok, p["ln1w"], p["ln1b"], t.eps)
     qkv = ops.linear(y1, p["win"], p["bin"])
     G = hp * wp
-    o, probs = ops.seqattn_fwd(qkv, b * G, G, N, t.num_heads, N * G, 1, G)
+    E3 = qkv.shape[1]
+    mfma_seq = N >= ops.SEQATTN_MFMA_MIN and (E3 // 3) == 64 * t.num_heads and qkv.is_cuda
+    if mfma_seq:
+        # long class sequences (COCO / ADE): '(b n) (h w) c -> (b h w) n c' as one row permutation, then the fused MFMA
+        # attention of the ViT blocks on b*G sequences of N tokens (flash-style: log-sum-exp rows instead of the
+        # [N, N] probabilities; the wave-per-query kernel ran these at ~9 TF)
+        qkv = ops.permute_rows(qkv, b, N, G, E3)                  # kept in THIS layout for backward
+        o_t, probs = ops.attention_fwd(qkv, b * G, N, t.num_heads)   # (`probs` slot: the LSE rows)
+        o = ops.permute_rows(o_t, b, G, N, E3 // 3)
+        del o_t
+    else:
+        o, probs = ops.seqattn_fwd(qkv, b * G, G, N, t.num_heads, N * G, 1, G)
     t2 = ops.linear(o, p["wout"], p["bout"], resid=tok)
     y2, st2 = ops.layernorm_fwd(t2, p["ln2w"], p["ln2b"], t.eps)
     h_pre = ops.empty(y2.shape[0], p["w1"].shape[0], device=x.device) if sv is not None else None
@@ -477,7 +488,7 @@ def _semtr_forward(lyr, x, tp, imgs, b, N, h, w, Ch, Ct, sv):
     ops.bilinear_nhwc_fwd(t3, E, imgs, hp, wp, Ch, True, 1, h, w, x, Ch, accumulate=True)
     if sv is not None:
         sv.update(tok=tok, y1=y1, st1=st1, qkv=qkv, o=o, probs=probs, t2=t2, y2=y2, st2=st2, h_pre=h_pre, hh=hh,
-                  dims=(hp, wp, G, E))
+                  dims=(hp, wp, G, E), mfma_seq=mfma_seq)
     return x
 
 
@@ -509,7 +520,14 @@ def _semtr_backward(lyr, dx, dtp_acc, imgs, b, N, h, w, Ch, Ct, sv, gc):
         gc.put(a.out_proj.weight, lambda d, acc: ops.matmul_tn(dt2, sv["o"], out=d, accumulate=acc))
         gc.put(a.out_proj.bias, lambda d, acc: ops.colsum(dt2, out=d, accumulate=acc))
     do = ops.matmul_nn(dt2, p["wout"])
-    dqkv = ops.seqattn_bwd(do, sv["qkv"], sv["probs"], b * G, G, N, t.num_heads, N * G, 1, G)
+    if sv["mfma_seq"]:
+        Ee = do.shape[1]
+        dqkv_t = ops.attention_bwd(ops.permute_rows(do, b, N, G, Ee), sv["qkv"], ops.permute_rows(sv["o"], b, N, G, Ee),
+                                   sv["probs"], b * G, N, t.num_heads)
+        dqkv = ops.permute_rows(dqkv_t, b, G, N, 3 * Ee)
+        del dqkv_t
+    else:
+        dqkv = ops.seqattn_bwd(do, sv["qkv"], sv["probs"], b * G, G, N, t.num_heads, N * G, 1, G)
     with ops.wgrad_side(dqkv, sv["y1"]):
         gc.put(a.in_proj_weight, lambda d, acc: ops.matmul_tn(dqkv, sv["y1"], out=d, accumulate=acc))
         gc.put(a.in_proj_bias, lambda d, acc: ops.colsum(dqkv, out=d, accumulate=acc))

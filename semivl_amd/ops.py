@@ -776,6 +776,18 @@ def vit_attention_bwd(dout, qkv, P, Bn, T, H, D):
 
 
 # ------------------------------------------------------------------------------------------------ SemanticTransformer attention
+def permute_rows(x, outer, A, Bd, Cc):
+    """[outer, A, Bd, Cc] -> [outer, Bd, A, Cc] (rows of Cc floats)."""
+    out = empty(outer * A * Bd, Cc, device=x.device)
+    L.check(L.load().svl_permute_rows_f32(_p(x), outer, A, Bd, Cc, _p(out), _st()), "svl_permute_rows_f32")
+    return out
+
+
+# class sequences of at least this length go through the fused (flash-style, MFMA) attention kernels of the ViT instead of
+# the wave-per-query VALU kernel (seqattn.hip): N = 81 / 150 (COCO / ADE); N = 19 / 21 would idle 7 of 8 waves of a block
+SEQATTN_MFMA_MIN = int(os.environ.get("SVL_SEQATTN_MFMA_MIN", "64"))
+
+
 def seqattn_fwd(qkv, groups, inner, seq, heads, outer_stride, inner_stride, seq_stride):
     rows, E3 = qkv.shape
     E = E3 // 3
@@ -883,7 +895,7 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
         L.check(lib.svl_conv3x3_wgrad_tiled(_p(dy), lddy, Co, _p(x), ldx, C1, _p(src2), ld2, C2, rep, imgs, H, W,
                                             _p(slabs), groups, _st()), "svl_conv3x3_wgrad_tiled")
         x6 = (get_gemm_emulation() == 6 and not os.environ.get("SVL_CONV_TILED_NO_EMU") and
-              (Co >= 64 or (C1 + C2) % 64 == 0))       # the dispatch rule of svl_conv3x3_wgrad_tiled
+              (Co >= 64 or (C1 + C2) % 64 == 0 or (C1 + C2 == 32 and H >= 8 and groups >= 2)))   # the dispatch rule of svl_conv3x3_wgrad_tiled
         _prof_end("gemm_bf16x" if x6 else "gemm", e0, 2.0 * Co * N * Kpix, ("wgrad3x3_tiled", Co, N, Kpix, 1))
         out = empty(Co, N, device=dy.device)
         reduce_slabs(out, slabs)

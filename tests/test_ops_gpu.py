@@ -1089,7 +1089,8 @@ def test_tiled_narrow_conv3x3(dev, b, N, H, W, C1, C2, Co):
 
 
 @pytest.mark.parametrize("b,N,H,W,C1,C2,Co", [(2, 6, 32, 48, 48, 16, 32), (2, 4, 40, 56, 96, 32, 64), (1, 3, 72, 80, 64, 0, 64),
-                                              (3, 8, 19, 37, 16, 16, 32), (2, 8, 32, 32, 96, 32, 128), (1, 5, 61, 70, 32, 0, 32)])
+                                              (3, 8, 19, 37, 16, 16, 32), (2, 8, 32, 32, 96, 32, 128), (1, 5, 61, 70, 32, 0, 32),
+                                              (2, 4, 64, 64, 32, 0, 32)])
 def test_tiled_narrow_conv3x3_split_emulation(dev, emu_mode, b, N, H, W, C1, C2, Co):
     """conv3x3_tiled_bf16x_kernel (mode 6: forward and mirrored-tap input gradient of the narrow 3x3 convolutions on the
     bf16 pipe): error vs fp64 at or below the fp32 tiled kernel's; two concat sources, ragged patches, bias / ReLU /
@@ -1128,6 +1129,34 @@ def test_tiled_narrow_conv3x3_split_emulation(dev, emu_mode, b, N, H, W, C1, C2,
     close(acc, want, atol=2e-4, what="accumulate")
     y2 = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, bias=bias, act=ops.ACT_RELU, **kw)
     assert torch.equal(y, y2), "deterministic"
+
+
+@pytest.mark.parametrize("b,N,G,heads", [(2, 81, 16, 4), (1, 150, 9, 4), (3, 64, 4, 2)])
+def test_class_sequences_on_fused_attention(dev, emu_mode, b, N, G, heads):
+    """SemanticTransformer attention over the N classes (vlg_head.py:44-62) for long sequences: the row permutation
+    '(b n) g c -> (b g) n c' + the ViT's fused attention kernels (both arithmetics) against the wave-per-query kernel of
+    seqattn.hip on the strided layout and against torch -- output and dqkv."""
+    from semivl_amd import ops
+    E = 64 * heads
+    qkv = rnd(b * N * G, 3 * E, dev=dev, seed=71)
+    do = rnd(b * N * G, E, dev=dev, seed=72)
+    o_ref, probs = ops.seqattn_fwd(qkv, b * G, G, N, heads, N * G, 1, G)
+    dq_ref = ops.seqattn_bwd(do, qkv, probs, b * G, G, N, heads, N * G, 1, G)
+    x = qkv.view(b, N, G, 3, heads, 64).permute(0, 2, 4, 3, 1, 5).double().requires_grad_(True)     # [b, G, h, 3, N, 64]
+    att = torch.softmax(x[:, :, :, 0] @ x[:, :, :, 1].transpose(-1, -2) / 8.0, -1) @ x[:, :, :, 2]     # [b, G, h, N, 64]
+    o64 = att.permute(0, 3, 1, 2, 4).reshape(b * N * G, E)
+    (g64,) = torch.autograd.grad(o64, x, do.double())
+    dq64 = g64.permute(0, 4, 1, 3, 2, 5).reshape(b * N * G, 3 * E)
+    assert _relerr(o_ref, o64) < 2e-6 and _relerr(dq_ref, dq64) < 2e-6
+    for mode in (0, 6):
+        emu_mode(mode)
+        qt = ops.permute_rows(qkv, b, N, G, 3 * E)
+        assert torch.equal(qt.view(b, G, N, 3 * E), qkv.view(b, N, G, 3 * E).transpose(1, 2))
+        o_t, lse = ops.attention_fwd(qt, b * G, N, heads)
+        o = ops.permute_rows(o_t, b, G, N, E)
+        dqt = ops.attention_bwd(ops.permute_rows(do, b, N, G, E), qt, o_t, lse, b * G, N, heads)
+        dq = ops.permute_rows(dqt, b, G, N, 3 * E)
+        assert _relerr(o, o64) < 2e-6 and _relerr(dq, dq64) < 2e-6, (mode, _relerr(o, o64), _relerr(dq, dq64))
 
 
 # ------------------------------------------------------------------------------------------------ ABI contract: re-entrancy

@@ -23,7 +23,7 @@ for (C1, C2, Co, H, W, n, rep) in cases:
         g = plain.double().view(n, H * W, Co // 16, 16)
         m64, v64 = g.mean(dim=(1, 3)), g.var(dim=(1, 3), unbiased=False)
         r64 = (v64 + 1e-5).rsqrt()
-        print(f"C1={C1} C2={C2} Co={Co} {H}x{W} n={n} mode {mode}: pre equal {torch.equal(pre, plain)}; "
+        print(f"C1={C1} C2={C2} Co={Co} {H}x{W} n={n} mode {mode}: pre equal {torch.equal(pre, plain)}; stats differ in {int((st != st0).sum())} of {st.numel()}; "
               f"mean err fused {((st[..., 0].double() - m64).abs() / (m64.abs() + v64.sqrt())).max().item():.2e} two-pass {((st0[..., 0].double() - m64).abs() / (m64.abs() + v64.sqrt())).max().item():.2e}; "
               f"rstd rel err fused {((st[..., 1].double() - r64).abs() / r64).max().item():.2e} two-pass {((st0[..., 1].double() - r64).abs() / r64).max().item():.2e}; "
               f"mean/std max {(m64.abs() / v64.sqrt()).max().item():.2f}")
