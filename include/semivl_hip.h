@@ -216,9 +216,12 @@ int svl_gemm_planes_f32(const svl_pgemm_desc* d, svl_stream_t stream);
  * Co = 128 (an error in mode 0); svl_conv3x3_wgrad_tiled_groups sizes `groups` for the kernel the current mode selects
  * (any groups >= 1 is valid for either). */
 int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, int Co);
+/* gn_in (may be NULL; both entry points that take it): a [imgs][2][C1] table of svl_groupnorm_scale_shift -- src1 then holds
+ * the PRE-normalisation output of the previous convolution and the operand relu(fma(src1, scale, shift)) = GroupNorm + ReLU
+ * (vlg_head.py:122-123) is formed while the tile is staged: the normalised tensor is never written (round 4). */
 int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, const float* src1, int64_t ld1, int C1,
                             const float* src2, int64_t ld2, int C2, int rep, int imgs, int H, int W, float* slabs,
-                            int groups, svl_stream_t stream);
+                            int groups, const float* gn_in, svl_stream_t stream);
 
 /* out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s*count + i]  — deterministic split-K combine. */
 int svl_reduce_slabs_f32(float* out, const float* slabs, int nslab, int64_t count, int accumulate,
@@ -396,7 +399,11 @@ int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
 int64_t svl_conv3x3_gn_ws_doubles(int imgs, int H, int W, int N);
 int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const float* src2, int64_t ld2, int C2, int rep,
                        const float* w, int imgs, int H, int W, int N, float* out, int64_t ldo, float eps, double* ws,
-                       float* stats, svl_stream_t stream);
+                       float* stats, const float* gn_in, svl_stream_t stream);
+/* scsh [imgs][2][C]: the per-(image, channel) affine form of GroupNorm, y = fma(x, scsh[img][0][c], scsh[img][1][c]), from
+ * statistics [imgs, G, 2] -- the table the tiled convolutions apply (+ ReLU) to a pre-normalisation operand (gn_in). */
+int svl_groupnorm_scale_shift(const float* stats, const float* gamma, const float* beta, int imgs, int C, int G, float* scsh,
+                              svl_stream_t stream);
 /* The apply pass of svl_groupnorm_fwd alone, on given statistics: bit-identical y.  Backward uses it to re-materialise a
  * normalised activation from the kept pre-normalisation tensor instead of keeping both (no reference counterpart: autograd
  * keeps every intermediate, vlg_head.py:84-137). */
@@ -447,13 +454,16 @@ int svl_seqattn_bwd(const svl_seqattn_desc* d, svl_stream_t stream);
  * ---------------------------------------------------------------------------------------------- */
 /* Conv2d(C -> 1): y[pix] = bias[0] + sum_{tap,ci} x[pix + off(tap)][ci] * w[tap*C + ci]  (vlg_head.py:190,239; w is the
  * forward pack [1, KH*KW*C]). */
+/* gn_in (NULL or the [imgs][2][C] table of svl_groupnorm_scale_shift; both entry points): x is the PRE-normalisation output
+ * of the last Up convolution and relu(fma(x, scale, shift)) = GroupNorm + ReLU (vlg_head.py:126-127) is formed on the way
+ * in -- the forward through an LDS-tiled kernel (3x3, pad 1, C = 16 / 32 / 64: one HBM read per input element). */
 int svl_conv_cout1_fwd(const float* x, int64_t ldx, int imgs, int H, int W, int C, int KH, int KW, int dil, int pad,
-                       const float* w, const float* bias, float* y, svl_stream_t stream);
+                       const float* w, const float* bias, const float* gn_in, float* y, svl_stream_t stream);
 /* Weight gradient of Conv2d(C -> 1, 3x3): per-block partial sums slabs[nblocks][9*C] (nblocks =
  * svl_conv_cout1_wgrad_blocks); combine with svl_reduce_slabs_f32. */
 int svl_conv_cout1_wgrad_blocks(int imgs, int H, int W);
 int svl_conv_cout1_wgrad(const float* dy, const float* x, int64_t ldx, int imgs, int H, int W, int C, int dil, int pad,
-                         float* slabs, svl_stream_t stream);
+                         const float* gn_in, float* slabs, svl_stream_t stream);
 /* out[p] = sum_tap T[p - sign*off(tap)][tap] with T [pix, KH*KW]: the shifted-tap sum that completes a Cin=1 input
  * gradient (conv1 7x7, vlg_head.py:169,221) after the GEMM T = dY . W. */
 int svl_tap_gather(const float* T, int imgs, int H, int W, int KH, int KW, int dil, int pad, int sign, float* out,

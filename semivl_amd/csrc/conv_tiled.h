@@ -12,6 +12,9 @@ struct ConvTiledP {
   int sign;                                         // +1: correlation taps, -1: mirrored taps (input-gradient form)
   double* gn_part;                                  // null, or [blocks][N / 16][2]: per-tile (sum, sum of squares) of the
                                                     // result per 16-channel GroupNorm group (svl_conv3x3_gn_f32)
+  const float* gn_in;                               // null, or [imgs][2][C1] (scale, shift): src1 holds PRE-normalisation
+                                                    // values, the operand is relu(fma(x, scale, shift)) (GroupNorm + ReLU
+                                                    // applied while the tile is staged: svl_groupnorm_scale_shift)
 };
 
 bool svl_conv3x3_tiled_eligible(const ConvTiledP& p);

@@ -13,6 +13,16 @@ namespace {
 constexpr int PH = 8, PW = 16, IH = PH + 2, IW = PW + 2, SLAB = 16, XS = SLAB + 1;
 constexpr int NPIX = IH * IW;  // 180
 
+// GroupNorm + ReLU of a staged operand quad (gn_in): the apply kernel's own expression, fmaxf(fma(x, sc, sh), 0).
+__device__ __forceinline__ float4 gn_relu4(const float4 v, const float4 sc, const float4 sh, unsigned in_image) {
+  float4 o;
+  o.x = in_image ? fmaxf(__builtin_fmaf(v.x, sc.x, sh.x), 0.f) : 0.f;
+  o.y = in_image ? fmaxf(__builtin_fmaf(v.y, sc.y, sh.y), 0.f) : 0.f;
+  o.z = in_image ? fmaxf(__builtin_fmaf(v.z, sc.z, sh.z), 0.f) : 0.f;
+  o.w = in_image ? fmaxf(__builtin_fmaf(v.w, sc.w, sh.w), 0.f) : 0.f;
+  return o;
+}
+
 // GroupNorm statistics in the convolution's epilogue (vlg_head.py:116-137: every narrow 3x3 convolution feeds a
 // GroupNorm over groups of 16 channels).  A wave's accumulator columns are channels (lane & 31: two groups per 32-column
 // tile), its rows pixels: every lane adds up its own valid pixels in fp32 (<= 32 values), the 32 lanes of a group (16
@@ -96,21 +106,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 
   float4 rx[XP];
   float4 rw[(9 * N * 4 + 255) / 256];
+  float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f), gsh = make_float4(0.f, 0.f, 0.f, 0.f);   // gn_in: this thread's channel quad
+  unsigned rxok = 0;                                                                      // in-image flags of rx[]
+  bool gnow = false;                                                                      // the staged slab is normalised
   auto gload = [&](int s) {
     const int c0 = s * SLAB;
     const bool first = c0 < p.C1;
     const float* base = first ? p.src1 + ((long)img * p.H) * p.W * p.ld1 + c0
                               : p.src2 + ((long)(img / p.rep) * p.H) * p.W * p.ld2 + (c0 - p.C1);
     const long ld = first ? p.ld1 : p.ld2;
+    gnow = p.gn_in != nullptr && first;
+    if (gnow) {   // (4 q = 4 (tid & 3): the quad is the same for all of a thread's pieces)
+      gsc = *reinterpret_cast<const float4*>(p.gn_in + ((long)img * 2 + 0) * p.C1 + c0 + 4 * (tid & 3));
+      gsh = *reinterpret_cast<const float4*>(p.gn_in + ((long)img * 2 + 1) * p.C1 + c0 + 4 * (tid & 3));
+    }
+    rxok = 0;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int f = tid + 256 * i;
       const int pix = f >> 2, q = f & 3;
       const int iy = pix / IW, ix = pix - iy * IW;
       const int y = y0 - 1 + iy, x = x0 - 1 + ix;
-      rx[i] = (f < NPIX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W)
-                  ? *reinterpret_cast<const float4*>(base + ((long)y * p.W + x) * ld + 4 * q)
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool in = f < NPIX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      rxok |= in ? (1u << i) : 0u;
+      rx[i] = in ? *reinterpret_cast<const float4*>(base + ((long)y * p.W + x) * ld + 4 * q)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < (9 * N * 4 + 255) / 256; ++i) {
@@ -126,7 +146,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       const int f = tid + 256 * i;
       if (f < NPIX * 4) {
         float* d = xs + (f >> 2) * XS + 4 * (f & 3);
-        d[0] = rx[i].x; d[1] = rx[i].y; d[2] = rx[i].z; d[3] = rx[i].w;
+        float4 v = rx[i];
+        if (gnow) v = gn_relu4(v, gsc, gsh, (rxok >> i) & 1u);   // zero padding stays zero: it pads y, not pre
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       }
     }
 #pragma unroll
@@ -274,21 +296,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   float4 rx[XP];
   float4 rw[WP];
+  float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f), gsh = make_float4(0.f, 0.f, 0.f, 0.f);   // gn_in: this thread's channel quad
+  unsigned rxok = 0;                                                                      // in-image flags of rx[]
+  bool gnow = false;                                                                      // the staged slab is normalised
   auto gload = [&](int s) __attribute__((always_inline)) {
     const int c0 = s * SLAB;
     const bool first = c0 < p.C1;
     const float* base = first ? p.src1 + ((long)img * p.H) * p.W * p.ld1 + c0
                               : p.src2 + ((long)(img / p.rep) * p.H) * p.W * p.ld2 + (c0 - p.C1);
     const long ld = first ? p.ld1 : p.ld2;
+    gnow = p.gn_in != nullptr && first;
+    if (gnow) {
+      gsc = *reinterpret_cast<const float4*>(p.gn_in + ((long)img * 2 + 0) * p.C1 + c0 + 4 * (tid & 3));
+      gsh = *reinterpret_cast<const float4*>(p.gn_in + ((long)img * 2 + 1) * p.C1 + c0 + 4 * (tid & 3));
+    }
+    rxok = 0;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int f = tid + 256 * i;
       const int pix = f >> 2, q = f & 3;
       const int iy = pix / IW, ix = pix - iy * IW;
       const int y = y0 - 1 + iy, x = x0 - 1 + ix;
-      rx[i] = (f < NPX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W)
-                  ? *reinterpret_cast<const float4*>(base + ((long)y * p.W + x) * ld + 4 * q)
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool in = f < NPX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      rxok |= in ? (1u << i) : 0u;
+      rx[i] = in ? *reinterpret_cast<const float4*>(base + ((long)y * p.W + x) * ld + 4 * q)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
@@ -304,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int f = tid + 256 * i;
       if (f < NPX * 4) {
         bf16x4 h0, h1, h2;
-        split3x4(rx[i], h0, h1, h2);
+        split3x4(gnow ? gn_relu4(rx[i], gsc, gsh, (rxok >> i) & 1u) : rx[i], h0, h1, h2);
         const int o = swz(f >> 2, f & 3);
         *reinterpret_cast<bf16x4*>(xs + o) = h0;
         *reinterpret_cast<bf16x4*>(xs + XPL + o) = h1;
@@ -462,13 +494,14 @@ extern "C" int64_t svl_conv3x3_gn_ws_doubles(int imgs, int H, int W, int N) {
 
 extern "C" int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const float* src2, int64_t ld2, int C2, int rep,
                                   const float* w, int imgs, int H, int W, int N, float* out, int64_t ldo, float eps,
-                                  double* ws, float* stats, svl_stream_t stream) {
+                                  double* ws, float* stats, const float* gn_in, svl_stream_t stream) {
   SVL_CHECK_ARG(src1 && w && out && ws && stats && imgs > 0 && N % 16 == 0, "svl_conv3x3_gn_f32: bad args");
   ConvTiledP t;
   t.src1 = src1; t.ld1 = ld1; t.C1 = C1; t.src2 = src2; t.ld2 = ld2; t.C2 = C2; t.rep = rep < 1 ? 1 : rep;
   t.w = w; t.K = 9 * (C1 + C2); t.out = out; t.ldo = ldo; t.bias = nullptr; t.act = SVL_ACT_NONE; t.accumulate = 0;
-  t.imgs = imgs; t.H = H; t.W = W; t.N = N; t.sign = 1; t.gn_part = ws;
+  t.imgs = imgs; t.H = H; t.W = W; t.N = N; t.sign = 1; t.gn_part = ws; t.gn_in = gn_in;
   if (!svl_conv3x3_tiled_eligible(t)) return SVL_ERR_UNSUPPORTED;
+  SVL_CHECK_ARG(!gn_in || (((uintptr_t)gn_in & 15) == 0 && C1 % 4 == 0), "svl_conv3x3_gn_f32: gn_in must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   int tiles = 0;
   const int rc = svl_conv3x3_tiled_launch(t, st, &tiles);
@@ -497,6 +530,8 @@ struct WgradTiledP {
   const float* src2; long ld2; int C2; int rep;
   float* slabs;                         // [groups][Co][9 * (C1 + C2)]
   int imgs, H, W, groups;
+  const float* gn_in;                   // null, or [imgs][2][C1]: src1 is a PRE-normalisation tensor, x = relu(fma(src1, scale,
+                                        // shift)) is formed while the tile is staged (as ConvTiledP::gn_in)
 };
 
 template <int MT, int SL>
@@ -529,6 +564,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3
   }
 
   float4 rd[DP], rx[XP];
+  float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f), gsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned rxok = 0;
+  const int gq = tid % (SL / 4);                      // this thread's channel quad of the slab (the same for all its pieces)
+  const bool gn = p.gn_in != nullptr && c0 + 4 * gq < p.C1;
   auto gload = [&](int pi) {
     int t = pi;
     const int txi = t % tiles_x;
@@ -546,6 +585,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3
     }
     const float* b1 = p.src1 + ((long)img * p.H) * p.W * p.ld1;
     const float* b2 = p.C2 > 0 ? p.src2 + ((long)(img / p.rep) * p.H) * p.W * p.ld2 : nullptr;
+    if (gn) {
+      gsc = *reinterpret_cast<const float4*>(p.gn_in + ((long)img * 2 + 0) * p.C1 + c0 + 4 * gq);
+      gsh = *reinterpret_cast<const float4*>(p.gn_in + ((long)img * 2 + 1) * p.C1 + c0 + 4 * gq);
+    }
+    rxok = 0;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int f = tid + 256 * i;
@@ -554,8 +598,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3
       const int y = y0 - 1 + iy, x = x0 - 1 + ix;
       const int c = c0 + 4 * q;                      // a slab may straddle the two concat sources (C1 % 4 == 0)
       const float* src = c < p.C1 ? b1 + ((long)y * p.W + x) * p.ld1 + c : b2 + ((long)y * p.W + x) * p.ld2 + (c - p.C1);
-      rx[i] = (pix < NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W) ? *reinterpret_cast<const float4*>(src)
-                                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool in = pix < NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      rxok |= in ? (1u << i) : 0u;
+      rx[i] = in ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto sstore = [&]() {
@@ -567,7 +612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int f = tid + 256 * i;
-      if (f < NPIX * SL / 4) *reinterpret_cast<float4*>(xs + 4 * f) = rx[i];
+      if (f < NPIX * SL / 4) *reinterpret_cast<float4*>(xs + 4 * f) = gn ? gn_relu4(rx[i], gsc, gsh, (rxok >> i) & 1u) : rx[i];
     }
   };
 
@@ -705,6 +750,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const char* xsrc[NX];   // (channel 0 of) this thread's concat source -- selected ONCE: a per-lane choice of source inside
                           // the loop would turn every load into a branch
   long ximg[NX];          // bytes per image of that source
+  bool xgn[NX];           // gn_in: this thread's channel belongs to the pre-normalisation source (scale / shift per patch image)
+  float rsc[NX], rsh[NX];
   const int dld4 = (int)p.lddy * 4;
 #pragma unroll
   for (int z = 0; z < ND; ++z) {
@@ -725,6 +772,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     xdiv[z] = second ? p.rep : 1;
     ximg[z] = (long)p.H * p.W * xld4[z];
     xch4[z] = (second ? c0 + xci[z] - p.C1 : c0 + xci[z]) * 4;
+    xgn[z] = p.gn_in != nullptr && !second;
+    rsc[z] = 1.f; rsh[z] = 0.f;
     const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
     xtp[z] = (hr - 1) * p.W + 8 * cg - 1;                      // pixel offset of element 0 from the patch origin
     xmax[z] = (p.H * p.W - 1) * xld4[z] + xch4[z];
@@ -753,6 +802,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 #pragma unroll
     for (int z = 0; z < NX; ++z) {
+      if (xgn[z]) {
+        rsc[z] = p.gn_in[((long)img * 2 + 0) * p.C1 + (xch4[z] >> 2)];
+        rsh[z] = p.gn_in[((long)img * 2 + 1) * p.C1 + (xch4[z] >> 2)];
+      }
       const char* ximgp = xsrc[z] + (long)(img / xdiv[z]) * ximg[z];
       int o = (spix + xtp[z]) * xld4[z] + xch4[z];
 #pragma unroll
@@ -792,6 +845,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = rx[z][j];
+      if (xgn[z]) {         // GroupNorm + ReLU of the pre-normalisation operand (before the zero padding of y below)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(__builtin_fmaf(v[j], rsc[z], rsh[z]), 0.f);
+      }
       if (!inner) {
         const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
         const int y = y0 - 1 + hr, xb = x0 - 1 + 8 * cg;
@@ -897,7 +954,7 @@ extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, in
 
 extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, const float* src1, int64_t ld1, int C1,
                                        const float* src2, int64_t ld2, int C2, int rep, int imgs, int H, int W,
-                                       float* slabs, int groups, svl_stream_t stream) {
+                                       float* slabs, int groups, const float* gn_in, svl_stream_t stream) {
   auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
   const bool emu6 = emu_ok && svl_get_gemm_emulation() == 6;
@@ -911,7 +968,8 @@ extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, co
   WgradTiledP p;
   p.dy = dy; p.lddy = lddy; p.Co = Co;
   p.src1 = src1; p.ld1 = ld1; p.C1 = C1; p.src2 = src2; p.ld2 = ld2; p.C2 = C2; p.rep = rep < 1 ? 1 : rep;
-  p.slabs = slabs; p.imgs = imgs; p.H = H; p.W = W; p.groups = groups;
+  p.slabs = slabs; p.imgs = imgs; p.H = H; p.W = W; p.groups = groups; p.gn_in = gn_in;
+  SVL_CHECK_ARG(!gn_in || ((uintptr_t)gn_in & 15) == 0, "svl_conv3x3_wgrad_tiled: gn_in must be 16-byte aligned");
   const int tx = (W + PW - 1) / PW, ty = (H + PH - 1) / PH;
   dim3 grid((unsigned)groups, (unsigned)(Ct / 32));
   hipStream_t st = (hipStream_t)stream;

@@ -1554,6 +1554,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     t.imgs = (int)((long)d->M / ((long)cv.H * cv.W)); t.H = cv.H; t.W = cv.W; t.N = d->N;
     t.sign = cv.sign;
     t.gn_part = nullptr;
+    t.gn_in = nullptr;
     if ((d->bias == nullptr || d->bias_mod == 0) && svl_conv3x3_tiled_eligible(t)) {
       static const int temu = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
       g_last_path = (temu && emu_mode == 6) ? SVL_PATH_BF16X : SVL_PATH_F32;

@@ -470,6 +470,15 @@ __global__ __launch_bounds__(NT) void groupnorm_stats_kernel(const float* __rest
     stats[(img * G + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
+// The per-(image, channel) affine form of GroupNorm: y = fma(x, sc, sh) with sc = rstd * gamma, sh = fma(-mean, sc, beta).
+// ONE definition for the apply kernel, the two backward kernels (which re-derive the ReLU mask from x) and the table the
+// convolution kernels apply while they stage a normalised operand (svl_groupnorm_scale_shift): the sign of y must come out
+// bit-identical everywhere, so the contraction is written out instead of left to the compiler.
+__device__ __forceinline__ void gn_scale_shift(float mean, float rstd, const float4 ga, const float4 be, float4& sc, float4& sh) {
+  sc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
+  sh = make_float4(__builtin_fmaf(-mean, sc.x, be.x), __builtin_fmaf(-mean, sc.y, be.y), __builtin_fmaf(-mean, sc.z, be.z),
+                   __builtin_fmaf(-mean, sc.w, be.w));
+}
 // Apply passes: grid = (pixel slabs, images); a thread keeps ONE channel quad (256 % CQ == 0), so the group statistics,
 // gamma/beta (and in backward the two group sums) are loop-invariant registers and the loop body is load/fma/store.
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, long ldx,
@@ -484,8 +493,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
   const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
   const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
   const float4 be = *reinterpret_cast<const float4*>(beta + c);
-  const float4 sc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
-  const float4 sh = make_float4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+  float4 sc, sh;
+  gn_scale_shift(mean, rstd, ga, be, sc, sh);
   const float* xi = x + img * HW * ldx + c;
   float* yi = y + img * HW * ldy + c;
   for (long p = (long)blockIdx.x * PR + pr; p < HW; p += (long)gridDim.x * PR) {
@@ -522,8 +531,7 @@ __global__ __launch_bounds__(NT) void groupnorm_bwd_sums_kernel(const float* __r
   float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;
   if (remask) {
     const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * cq), be = *reinterpret_cast<const float4*>(beta + 4 * cq);
-    msc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
-    msh = make_float4(be.x - mean * msc.x, be.y - mean * msc.y, be.z - mean * msc.z, be.w - mean * msc.w);
+    gn_scale_shift(mean, rstd, ga, be, msc, msh);
   }
   auto body = [&](float4 d, const float4 v, float4 o) {
     if (remask)
@@ -610,8 +618,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_apply_kernel(const float* _
   float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;
   if (remask) {
     const float4 be = *reinterpret_cast<const float4*>(beta + c);
-    msc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
-    msh = make_float4(be.x - mean * msc.x, be.y - mean * msc.y, be.z - mean * msc.z, be.w - mean * msc.w);
+    gn_scale_shift(mean, rstd, ga, be, msc, msh);
   }
   float* oi = dx + img * HW * lddx + c;
   for (long p = (long)blockIdx.x * PR + pr; p < HW; p += (long)gridDim.x * PR) {
@@ -821,6 +828,35 @@ extern "C" int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma
   hipLaunchKernelGGL(groupnorm_apply_kernel, gn_apply_grid(imgs, HW, C), dim3(256), 0, st, x, (long)ldx, gamma, beta,
                      npix, (long)HW, C, G, relu, stats, y, (long)ldy);
   SVL_LAUNCH_CHECK("svl_groupnorm_fwd/apply");
+  return SVL_OK;
+}
+
+// scsh[img][0][c] = sc, scsh[img][1][c] = sh of gn_scale_shift: the table a convolution applies to a GroupNorm'ed operand
+// it reads in its PRE-normalisation form (conv_tiled.hip, gn_in), so that y = relu(gn(pre)) is never written.
+namespace {
+__global__ void gn_table_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                long imgs, int C, int G, float* __restrict__ scsh) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (img, channel quad)
+  const int CQ = C >> 2;
+  if (i >= imgs * CQ) return;
+  const long img = i / CQ;
+  const int c = (int)(i - img * CQ) * 4;
+  const int g = c / (C / G);
+  const float mean = stats[(img * G + g) * 2], rstd = stats[(img * G + g) * 2 + 1];
+  float4 sc, sh;
+  gn_scale_shift(mean, rstd, *reinterpret_cast<const float4*>(gamma + c), *reinterpret_cast<const float4*>(beta + c), sc, sh);
+  *reinterpret_cast<float4*>(scsh + (img * 2 + 0) * C + c) = sc;
+  *reinterpret_cast<float4*>(scsh + (img * 2 + 1) * C + c) = sh;
+}
+}  // namespace
+
+extern "C" int svl_groupnorm_scale_shift(const float* stats, const float* gamma, const float* beta, int imgs, int C, int G,
+                                         float* scsh, svl_stream_t stream) {
+  SVL_CHECK_ARG(stats && gamma && beta && scsh && imgs > 0 && gn_shape_ok(C, G), "svl_groupnorm_scale_shift: bad args");
+  const long n = (long)imgs * (C / 4);
+  hipLaunchKernelGGL(gn_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta,
+                     (long)imgs, C, G, scsh);
+  SVL_LAUNCH_CHECK("svl_groupnorm_scale_shift");
   return SVL_OK;
 }
 

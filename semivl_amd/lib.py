@@ -77,7 +77,7 @@ SIGNATURES = {
     "svl_split_planes_bf16x3": (_I, [_P, _L, _L, _L, _I, _P, _L, _L, _P]),
     "svl_gemm_planes_f32": (_I, [C.POINTER(PGemmDesc), _P]),
     "svl_conv3x3_wgrad_tiled_groups": (_I, [_I, _I, _I, _I, _I]),
-    "svl_conv3x3_wgrad_tiled": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "svl_conv3x3_wgrad_tiled": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "svl_reduce_slabs_f32": (_I, [_P, _P, _I, _L, _I, _P]),
     "svl_softmax_max_f32": (_I, [_P, _I, _I, _L, _P, _P, _P]),
     "svl_cutmix_f32": (_I, [_P, _P, _P, _P, _I, _I, _L, _P]),
@@ -120,7 +120,8 @@ SIGNATURES = {
     "svl_copy2d_f32": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _P]),
     "svl_groupnorm_fwd": (_I, [_P, _L, _P, _P, _F, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_conv3x3_gn_ws_doubles": (_L, [_I, _I, _I, _I]),
-    "svl_conv3x3_gn_f32": (_I, [_P, _L, _I, _P, _L, _I, _I, _P, _I, _I, _I, _I, _P, _L, _F, _P, _P, _P]),
+    "svl_conv3x3_gn_f32": (_I, [_P, _L, _I, _P, _L, _I, _I, _P, _I, _I, _I, _I, _P, _L, _F, _P, _P, _P, _P]),
+    "svl_groupnorm_scale_shift": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "svl_groupnorm_apply": (_I, [_P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _P, _L, _P]),
     "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_bn_ws_doubles": (_L, [_L, _I]),
@@ -139,9 +140,9 @@ SIGNATURES = {
     "svl_aug_gaussian_blur_u8": (_I, [_P, _I, _I, _F, _P, _P, _P]),
     "svl_attention_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P]),
     "svl_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P]),
-    "svl_conv_cout1_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "svl_conv_cout1_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "svl_conv_cout1_wgrad_blocks": (_I, [_I, _I, _I]),
-    "svl_conv_cout1_wgrad": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "svl_conv_cout1_wgrad": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "svl_tap_gather": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "svl_seqattn_fwd": (_I, [C.POINTER(SeqAttnDesc), _P]),
     "svl_seqattn_bwd": (_I, [C.POINTER(SeqAttnDesc), _P]),

@@ -137,36 +137,80 @@ class _LazyConvT:
         return u
 
 
+class _GNDeferred:
+    """Output of a conv + GroupNorm + ReLU unit that is NOT written (round 4): the pre-normalisation tensor plus the
+    [imgs, 2, C] (scale, shift) table.  The next 3x3 convolution -- forward and weight gradient -- forms relu(gn(pre)) while
+    it stages its operand tiles (`gn_in` of the tiled kernels); .get() materialises the tensor for anything else."""
+
+    def __init__(self, pre, st, gn, table, imgs, HW, Co):
+        self.pre, self.st, self.gn, self.table, self.dims = pre, st, gn, table, (imgs, HW, Co)
+
+    def get(self, out=None, ldo=None):
+        imgs, HW, Co = self.dims
+        if out is None:
+            out, ldo = ops.empty(imgs * HW, Co, device=self.pre.device), Co
+        return ops.groupnorm_apply(self.pre, Co, self.gn.weight, self.gn.bias, imgs, HW, Co, self.gn.num_groups, True,
+                                   self.st, out, ldo)
+
+
 def _mat(x):
     return x if (x is None or isinstance(x, torch.Tensor)) else x.get()
 
 
 # ------------------------------------------------------------------------------------------------ conv + GN (+ReLU) unit
 def _conv_gn_fwd(x, ldx, imgs, H, W, C1, conv, gn, k, dil, sv, src2=None, ld2=0, C2=0, rep=1, y=None, ldy=None,
-                 remat=False, x_keep=None):
+                 remat=False, x_keep=None, defer_for=None):
     """`remat`: y is not kept in `sv` (callers keep `sv["lazy"]`, a _LazyGN, instead of the tensor); `x_keep`: what to
-    remember as this unit's input in place of the tensor x (a lazy handle of the producer)."""
+    remember as this unit's input in place of the tensor x (a lazy handle of the producer).  `x` may be a _GNDeferred (the
+    previous unit's unwritten output).  `defer_for` = output channels of the 3x3 conv + GN unit that is this unit's ONLY
+    consumer (or "cout1": the head's Conv2d(C -> 1)): when that consumer's kernels can apply GroupNorm + ReLU to their
+    operand themselves, y is not written and a _GNDeferred is returned in its place."""
     Co = conv.weight.shape[0]
     wf, wd = ops.pack_conv_w(conv.weight)
     pad = dil * (k - 1) // 2
-    if y is None:
-        y = ops.empty(imgs * H * W, Co, device=x.device)
-        ldy = Co
-    # the narrow 3x3 layers: GroupNorm statistics come out of the convolution's epilogue (one tensor pass less)
-    fused = (ops.conv3x3_gn(x, ldx, imgs, H, W, C1, wf, Co, gn.eps, src2=src2, ld2=ld2, C2=C2, rep=rep)
-             if (k == 3 and dil == 1 and gn.num_groups * 16 == Co) else None)
-    if fused is not None:
+    fusable = k == 3 and dil == 1 and gn.num_groups * 16 == Co
+    gn_in, dev = None, (x.pre.device if isinstance(x, _GNDeferred) else x.device)
+    fused = None
+    if isinstance(x, _GNDeferred):     # the operand is relu(gn(x.pre)), applied by the convolution's own staging
+        fused = ops.conv3x3_gn(x.pre, ldx, imgs, H, W, C1, wf, Co, gn.eps, gn_in=x.table) if (fusable and C2 == 0) else None
+        if fused is not None:
+            gn_in = x.table
+        else:                           # (a consumer the tiled kernel does not take after all: write the tensor)
+            x = x.get()
+    if fused is None and fusable:
+        # the narrow 3x3 layers: GroupNorm statistics come out of the convolution's epilogue (one tensor pass less)
+        fused = ops.conv3x3_gn(x, ldx, imgs, H, W, C1, wf, Co, gn.eps, src2=src2, ld2=ld2, C2=C2, rep=rep)
+    deferred = None
+    can_defer = False
+    if fused is not None and defer_for is not None and y is None and ops.GN_DEFER:
+        if defer_for == "cout1":        # the head's Conv2d(C -> 1): LDS-tiled forward + channel-lane weight gradient
+            can_defer = ops.conv_cout1_gn_ok(H, W, Co)
+        else:                           # a 3x3 conv + GN unit with `defer_for` output channels (tiled forward and wgrad)
+            can_defer = defer_for in (32, 64) and ops.conv_wgrad_tiled_ok(imgs, H, W, Co, 0, defer_for, defer_for, Co)
+    if can_defer:
         pre, st = fused
-        ops.groupnorm_apply(pre, Co, gn.weight, gn.bias, imgs, H * W, Co, gn.num_groups, True, st, y, ldy)
+        deferred = _GNDeferred(pre, st, gn, ops.groupnorm_scale_shift(st, gn.weight, gn.bias, imgs, Co, gn.num_groups),
+                               imgs, H * W, Co)
+        ldy = Co
     else:
-        pre = ops.conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, k, k, dil, pad, src2=src2, ld2=ld2, C2=C2, rep=rep)
-        st = ops.groupnorm_fwd(pre, Co, gn.weight, gn.bias, gn.eps, imgs, H * W, Co, gn.num_groups, True, y, ldy)
+        if y is None:
+            y = ops.empty(imgs * H * W, Co, device=dev)
+            ldy = Co
+        if fused is not None:
+            pre, st = fused
+            ops.groupnorm_apply(pre, Co, gn.weight, gn.bias, imgs, H * W, Co, gn.num_groups, True, st, y, ldy)
+        else:
+            pre = ops.conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, k, k, dil, pad, src2=src2, ld2=ld2, C2=C2, rep=rep)
+            st = ops.groupnorm_fwd(pre, Co, gn.weight, gn.bias, gn.eps, imgs, H * W, Co, gn.num_groups, True, y, ldy)
     if sv is not None:
-        sv.update(x=x if x_keep is None else x_keep, ldx=ldx, pre=pre, y=None if remat else y, ldy=ldy, st=st, wd=wd,
-                  geom=(imgs, H, W, C1, Co, k, dil, pad), src2=src2, ld2=ld2, C2=C2, rep=rep)
+        # the unit's input as backward will read it: the deferred producer's `pre` + table when the forward consumed it
+        # that way, else the tensor / the lazy handle of the memory plan
+        xs = x if gn_in is not None else (x if x_keep is None else x_keep)
+        sv.update(x=xs, gn_in=gn_in, ldx=ldx, pre=pre, y=None if (remat or deferred is not None) else y, ldy=ldy, st=st,
+                  wd=wd, geom=(imgs, H, W, C1, Co, k, dil, pad), src2=src2, ld2=ld2, C2=C2, rep=rep)
         if remat:
             sv["lazy"] = _LazyGN(sv, gn)
-    return y
+    return deferred if deferred is not None else y
 
 
 def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None, x=None):
@@ -180,10 +224,15 @@ def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None, x=None):
     gc.put_tensor(gn.weight, dg)
     gc.put_tensor(gn.bias, db)
     C2 = sv["C2"]
-    x = _mat(sv["x"]) if x is None else x
-    with ops.wgrad_side(dpre, x, sv["src2"]):     # off the dependency chain: weight-gradient stream (ops.wgrad_side)
+    gn_in = sv.get("gn_in")
+    if gn_in is not None and x is None:    # the input was never written: the weight gradient normalises `pre` on the fly
+        x = sv["x"].pre
+    else:
+        gn_in = None
+        x = _mat(sv["x"]) if x is None else x
+    with ops.wgrad_side(dpre, x, sv["src2"], gn_in):     # off the dependency chain: weight-gradient stream (ops.wgrad_side)
         dwf = ops.conv_wgrad(dpre, Co, x, sv["ldx"], imgs, H, W, C1, Co, k, k, dil, pad, src2=sv["src2"],
-                             ld2=sv["ld2"], C2=C2, rep=sv["rep"])
+                             ld2=sv["ld2"], C2=C2, rep=sv["rep"], gn_in=gn_in)
         gc.put_tensor(conv.weight, ops.unpack_conv_wgrad(dwf, Co, C1 + C2, k, k))
     if not need_dx:
         return None
@@ -439,20 +488,22 @@ def _head_core_forward(m, shared, s0, s1, sv, logits_out):
     g2 = _up_forward(m.up1, x, imgs, h, w, skips[0], h, w, b, N, s_up1, remat)
     s_up2 = {} if sv is not None else None
     g4 = _up_forward(m.up2, g2, imgs, 2 * h, 2 * w, skips[1], h0, w0, b, N, s_up2, remat,
-                     x_keep=s_up1["b"]["lazy"] if remat else None)
-    C4 = g4.shape[1]
+                     x_keep=s_up1["b"]["lazy"] if remat else None, out_for="cout1")   # (the head conv is g4's only consumer)
+    g4d = g4 if isinstance(g4, _GNDeferred) else None     # never written: the head conv normalises up2's last `pre` itself
+    C4 = g4d.dims[2] if g4d is not None else g4.shape[1]
     whf, whd = ops.pack_conv_w(m.head.weight)
     if logits_out is not None:
         direct = out_size == (4 * h, 4 * w)
-        lg = ops.conv_cout1_fwd(g4, C4, imgs, 4 * h, 4 * w, C4, whf, 3, 3, 1, 1, bias=m.head.bias,
-                                out=logits_out.view(-1, 1) if direct else None)  # [(b n), 4h, 4w, 1]
+        lg = ops.conv_cout1_fwd(g4d.pre if g4d is not None else g4, C4, imgs, 4 * h, 4 * w, C4, whf, 3, 3, 1, 1,
+                                bias=m.head.bias, out=logits_out.view(-1, 1) if direct else None,
+                                gn_in=g4d.table if g4d is not None else None)  # [(b n), 4h, 4w, 1]
         if not direct:
             ops.bilinear_planes_fwd(lg.view(b, N, 4 * h, 4 * w), 4 * h, 4 * w, m.align_corners, out_size[0], out_size[1],
                                     out=logits_out)
     if sv is not None:
         sv.update(dims=(b, N, h, w, HW, imgs, Ch, Ct, Ce, Cv, C0, HW0), embn=embn,
                   inv_e=inv_e, textn=textn, sim=sim, w1d=w1d, x1=x1, aspp=aspp_sv, gap=s_gap, pooled=pooled, proj=s_proj,
-                  tp=tp, tr=tr_sv, up1=s_up1, up2=s_up2, g4=s_up2["b"]["lazy"] if remat else g4, whd=whd,
+                  tp=tp, tr=tr_sv, up1=s_up1, up2=s_up2, g4=g4d if g4d is not None else (s_up2["b"]["lazy"] if remat else g4), whd=whd,
                   out_size=out_size)
 
 
@@ -540,7 +591,7 @@ def _semtr_backward(lyr, dx, dtp_acc, imgs, b, N, h, w, Ch, Ct, sv, gc):
     return ops.add(dx, dxin_pool, out=dxin_pool)
 
 
-def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv, remat=False, x_keep=None):
+def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv, remat=False, x_keep=None, out_for=None):
     """vlg_head.py:129-137.  x [(b n) h w, Cin]; skip [b sh sw, Cs] -> [(b n) 2h 2w, Cout].  `remat` (memory plan): the
     ConvTranspose output and the two GroupNorm outputs are not kept; `x_keep`: lazy handle of x when x itself is one."""
     Cin = up.up.weight.shape[0]
@@ -556,12 +607,14 @@ def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv, remat=False, x_keep=N
     remat = remat and sv is not None
     xk = x if x_keep is None else x_keep
     sa = {} if sv is not None else None
+    Cm = up.conv[0].weight.shape[0]
     g1 = _conv_gn_fwd(u, Cu, imgs, 2 * h, 2 * w, Cu, up.conv[0], up.conv[1], 3, 1, sa, src2=sup, ld2=Cs, C2=Cs, rep=N,
-                      remat=remat, x_keep=_LazyConvT(xk, Cin, imgs, h, w, wp_, Cu, up.up.bias) if remat else None)
+                      remat=remat, x_keep=_LazyConvT(xk, Cin, imgs, h, w, wp_, Cu, up.up.bias) if remat else None,
+                      defer_for=up.conv[3].weight.shape[0])     # (conv b is g1's only consumer)
     del u
     sb = {} if sv is not None else None
-    g2 = _conv_gn_fwd(g1, g1.shape[1], imgs, 2 * h, 2 * w, g1.shape[1], up.conv[3], up.conv[4], 3, 1, sb, remat=remat,
-                      x_keep=sa["lazy"] if remat else None)
+    g2 = _conv_gn_fwd(g1, Cm, imgs, 2 * h, 2 * w, Cm, up.conv[3], up.conv[4], 3, 1, sb, remat=remat,
+                      x_keep=sa["lazy"] if remat else None, defer_for=out_for)
     if sv is not None:
         sv.update(x=xk, wp=wp_, a=sa, b=sb, dims=(Cin, Cu, Cs, sh, sw))
     return g2
@@ -691,11 +744,13 @@ def _head_backward_core(m, sv, dlogits, gc):
             dlg = dlogits
         dlg = dlg.view(imgs * 16 * HW, 1)
         # ---- head conv
-        g4 = _mat(sv["g4"])
+        g4d = sv["g4"] if isinstance(sv["g4"], _GNDeferred) else None
+        g4 = g4d.pre if g4d is not None else _mat(sv["g4"])
         C4 = g4.shape[1]
-        with ops.wgrad_side(dlg, g4):
+        g4t = g4d.table if g4d is not None else None
+        with ops.wgrad_side(dlg, g4, g4t):
             gc.put(m.head.bias, lambda d, acc: ops.colsum(dlg, out=d, accumulate=acc))
-            dwh = ops.conv_cout1_wgrad(dlg, g4, C4, imgs, 4 * h, 4 * w, C4, 1, 1)
+            dwh = ops.conv_cout1_wgrad(dlg, g4, C4, imgs, 4 * h, 4 * w, C4, 1, 1, gn_in=g4t)
             gc.put_tensor(m.head.weight, ops.unpack_conv_wgrad(dwh, 1, C4, 3, 3))
         dg4 = ops.conv_dgrad(dlg, 1, imgs, 4 * h, 4 * w, 1, sv["whd"], C4, 3, 3, 1, 1)
         # ---- up2, up1

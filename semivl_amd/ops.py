@@ -647,9 +647,18 @@ def groupnorm_fwd(x, ldx, gamma, beta, eps, imgs, HW, Cc, G, relu, y, ldy):
 
 
 CONV_GN_FUSED = not os.environ.get("SVL_NO_CONV_GN_FUSED")
+GN_DEFER = not os.environ.get("SVL_NO_GN_DEFER")     # GroupNorm + ReLU applied by the consuming convolution (model/vlg_head.py)
 
 
-def conv3x3_gn(x, ldx, imgs, H, W, C1, wf, Co, eps, src2=None, ld2=0, C2=0, rep=1):
+def groupnorm_scale_shift(stats, gamma, beta, imgs, Cc, G):
+    """[imgs, 2, C] (scale, shift) table of a GroupNorm from its statistics (the `gn_in` operand of the tiled convolutions)."""
+    t = empty(imgs, 2, Cc, device=stats.device)
+    L.check(L.load().svl_groupnorm_scale_shift(_p(stats), _p(gamma), _p(beta), imgs, Cc, G, _p(t), _st()),
+            "svl_groupnorm_scale_shift")
+    return t
+
+
+def conv3x3_gn(x, ldx, imgs, H, W, C1, wf, Co, eps, src2=None, ld2=0, C2=0, rep=1, gn_in=None):
     """3x3 / pad 1 convolution fused with the statistics of the following GroupNorm (groups of 16 channels): returns
     (pre [imgs*H*W, Co], stats [imgs, Co/16, 2]), or None when the tiled kernel does not take the shape (the caller then
     runs conv_fwd + groupnorm_fwd)."""
@@ -661,7 +670,7 @@ def conv3x3_gn(x, ldx, imgs, H, W, C1, wf, Co, eps, src2=None, ld2=0, C2=0, rep=
     stats = empty(imgs, Co // 16, 2, device=x.device)
     e0 = _prof_begin()
     rc = lib.svl_conv3x3_gn_f32(_p(x), ldx, C1, _p(src2), ld2, C2, rep, _p(wf), imgs, H, W, Co, _p(pre), Co, float(eps),
-                                _p(ws), _p(stats), _st())
+                                _p(ws), _p(stats), _p(gn_in), _st())
     if rc == -3:            # SVL_ERR_UNSUPPORTED: nothing was launched
         return None
     L.check(rc, "svl_conv3x3_gn_f32")
@@ -878,8 +887,16 @@ def conv_dgrad(dy, lddy, imgs, H, W, Co, wd, Ci, KH, KW, dil, pad, out=None, ldo
     return out
 
 
-def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None, ld2=0, C2=0, rep=1, stride=1):
-    """dWf[Co, KH*KW*(C1+C2)] = dy^T im2col(x), deterministic split-K over (output) pixels."""
+def conv_wgrad_tiled_ok(imgs, H, W, C1, C2, Co, lddy, ldx, ld2=0):
+    """The spatially tiled 3x3 weight-gradient kernels (conv_tiled.hip) take this layer (they also accept `gn_in`)."""
+    co_ok = Co in (32, 64) or (Co == 128 and get_gemm_emulation() == 6 and not os.environ.get("SVL_CONV_TILED_NO_EMU"))
+    return (CONV_TILED and co_ok and C1 % 4 == 0 and C2 % 4 == 0 and (C1 + C2) % 32 == 0 and H >= 8 and W >= 16 and
+            imgs * H * W >= 16384 and lddy % 4 == 0 and ldx % 4 == 0 and (C2 == 0 or ld2 % 4 == 0))
+
+
+def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None, ld2=0, C2=0, rep=1, stride=1, gn_in=None):
+    """dWf[Co, KH*KW*(C1+C2)] = dy^T im2col(x), deterministic split-K over (output) pixels.  `gn_in`: x is a
+    pre-normalisation tensor, the operand is relu(groupnorm(x)) (tiled kernels only: conv_wgrad_tiled_ok)."""
     Ho, Wo = conv_out_size(H, W, KH, KW, dil, pad, stride) if stride != 1 else (H, W)
     Kpix = imgs * Ho * Wo
     N = KH * KW * (C1 + C2)
@@ -893,13 +910,14 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
         slabs = empty(groups, Co, N, device=dy.device)
         e0 = _prof_begin()
         L.check(lib.svl_conv3x3_wgrad_tiled(_p(dy), lddy, Co, _p(x), ldx, C1, _p(src2), ld2, C2, rep, imgs, H, W,
-                                            _p(slabs), groups, _st()), "svl_conv3x3_wgrad_tiled")
+                                            _p(slabs), groups, _p(gn_in), _st()), "svl_conv3x3_wgrad_tiled")
         x6 = (get_gemm_emulation() == 6 and not os.environ.get("SVL_CONV_TILED_NO_EMU") and
               (Co >= 64 or (C1 + C2) % 64 == 0 or (C1 + C2 == 32 and H >= 8 and groups >= 2)))   # the dispatch rule of svl_conv3x3_wgrad_tiled
         _prof_end("gemm_bf16x" if x6 else "gemm", e0, 2.0 * Co * N * Kpix, ("wgrad3x3_tiled", Co, N, Kpix, 1))
         out = empty(Co, N, device=dy.device)
         reduce_slabs(out, slabs)
         return out
+    assert gn_in is None, "gn_in needs the tiled weight-gradient kernel (conv_wgrad_tiled_ok)"
     g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
     # (the split-emulation kernel serves this launch when Cout >= 96, N >= 96 and the output rows are whole 8-pixel groups:
     # 128-row tiles, two resident blocks per CU)
@@ -916,21 +934,28 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
     return out
 
 
-def conv_cout1_fwd(x, ldx, imgs, H, W, Cc, wf, KH, KW, dil, pad, bias=None, out=None):
-    """Conv2d(C -> 1) forward, HBM-bound direct kernel; wf = forward pack [1, KH*KW*C]; returns [imgs*H*W, 1]."""
+def conv_cout1_gn_ok(H, W, Cc, KH=3, KW=3, dil=1, pad=1):
+    """The LDS-tiled Conv2d(C -> 1) kernel takes this layer (the form that accepts `gn_in`)."""
+    return (KH == 3 and KW == 3 and dil == 1 and pad == 1 and Cc in (16, 32, 64) and H >= 8 and W >= 16 and
+            not os.environ.get("SVL_COUT1_NO_TILED"))
+
+
+def conv_cout1_fwd(x, ldx, imgs, H, W, Cc, wf, KH, KW, dil, pad, bias=None, out=None, gn_in=None):
+    """Conv2d(C -> 1) forward, HBM-bound direct kernel; wf = forward pack [1, KH*KW*C]; returns [imgs*H*W, 1].
+    `gn_in`: x is a pre-normalisation tensor, the operand is relu(groupnorm(x)) (conv_cout1_gn_ok)."""
     y = empty(imgs * H * W, 1, device=x.device) if out is None else out
     assert y.is_contiguous() and y.numel() == imgs * H * W
-    L.check(L.load().svl_conv_cout1_fwd(_p(x), ldx, imgs, H, W, Cc, KH, KW, dil, pad, _p(wf), _p(bias), _p(y), _st()),
-            "svl_conv_cout1_fwd")
+    L.check(L.load().svl_conv_cout1_fwd(_p(x), ldx, imgs, H, W, Cc, KH, KW, dil, pad, _p(wf), _p(bias), _p(gn_in), _p(y),
+                                        _st()), "svl_conv_cout1_fwd")
     return y
 
 
-def conv_cout1_wgrad(dy, x, ldx, imgs, H, W, Cc, dil, pad):
-    """Weight gradient of Conv2d(C -> 1, 3x3): returns the forward-pack layout [1, 9*C]."""
+def conv_cout1_wgrad(dy, x, ldx, imgs, H, W, Cc, dil, pad, gn_in=None):
+    """Weight gradient of Conv2d(C -> 1, 3x3): returns the forward-pack layout [1, 9*C] (`gn_in` as in conv_cout1_fwd)."""
     lib = L.load()
     nb = lib.svl_conv_cout1_wgrad_blocks(imgs, H, W)
     slabs = empty(nb, 9 * Cc, device=x.device)
-    L.check(lib.svl_conv_cout1_wgrad(_p(dy), _p(x), ldx, imgs, H, W, Cc, dil, pad, _p(slabs), _st()),
+    L.check(lib.svl_conv_cout1_wgrad(_p(dy), _p(x), ldx, imgs, H, W, Cc, dil, pad, _p(gn_in), _p(slabs), _st()),
             "svl_conv_cout1_wgrad")
     out = empty(1, 9 * Cc, device=x.device)
     reduce_slabs(out, slabs)

@@ -448,6 +448,19 @@ def test_head_memory_plan_is_exact(dev):
     # second level of the plan: GroupNorm / ConvTranspose outputs re-materialised in backward instead of kept
     l_rm, g_rm = run(head_chunk_class_images=21, act_mem_fraction=None, head_remat=True)
     l_rm1, g_rm1 = run(head_chunk_class_images=1 << 20, act_mem_fraction=None, head_remat=True)
+    # third level: GroupNorm + ReLU of the Up blocks' first unit applied by the consuming convolution's staging (forward and
+    # weight gradient) instead of written -- on / off must not change a bit
+    from semivl_amd import ops
+    assert ops.GN_DEFER
+    ops.GN_DEFER = False
+    try:
+        l_nd, g_nd = run(head_chunk_class_images=1 << 20, act_mem_fraction=None, head_remat=False)
+        l_ndr, g_ndr = run(head_chunk_class_images=1 << 20, act_mem_fraction=None, head_remat=True)
+    finally:
+        ops.GN_DEFER = True
+    assert torch.equal(l_one, l_nd) and torch.equal(l_one, l_ndr)
+    for k in g_one:
+        assert torch.equal(g_one[k], g_nd[k]) and torch.equal(g_one[k], g_ndr[k]), f"{k}: deferred GroupNorm changed a gradient"
     assert torch.equal(l_one, l_chk) and torch.equal(l_chk, l_rec) and torch.equal(l_chk, l_rm) and torch.equal(l_one, l_rm1)
     assert sorted(g_one) == sorted(g_chk) == sorted(g_rec) == sorted(g_rm)
     for k in g_one:

@@ -480,6 +480,36 @@ def test_conv3x3_with_groupnorm_statistics(dev, emu_mode, C1, C2, Co, H, W, n, r
     assert ops.conv3x3_gn(nhwc(a)[: 4 * H * W], C1, 4, H, W, C1, wf, Co, 1e-5) is None or 4 * H * W >= 16384
 
 
+@pytest.mark.parametrize("C,Co,H,W,n", [(64, 64, 32, 32, 16), (32, 32, 40, 24, 18), (64, 32, 64, 64, 5), (32, 32, 19, 37, 24)])
+def test_groupnorm_applied_by_the_consuming_conv(dev, emu_mode, C, Co, H, W, n):
+    """`gn_in`: a tiled 3x3 convolution (forward + GroupNorm statistics, and the weight gradient) whose operand is the
+    PRE-normalisation tensor of the previous unit plus the (scale, shift) table -- relu(groupnorm(pre)) is formed in the
+    staging and never written.  Bit-identical to running the same kernels on the materialised tensor, both arithmetics,
+    ragged image edges (the zero padding pads y, not pre)."""
+    from semivl_amd import ops
+    pre = rnd(n * H * W, C, dev=dev, seed=81)
+    gamma, beta = rnd(C, dev=dev) + 1.0, rnd(C, dev=dev)
+    w = rnd(Co, C, 3, 3, dev=dev, scale=0.1)
+    dy = rnd(n * H * W, Co, dev=dev, seed=82)
+    wf, _ = ops.pack_conv_w(w)
+    G = C // 16
+    y = ops.empty(n * H * W, C, device=dev)
+    st = ops.groupnorm_fwd(pre, C, gamma, beta, 1e-5, n, H * W, C, G, True, y, C)
+    table = ops.groupnorm_scale_shift(st, gamma, beta, n, C, G)
+    ref = F.relu(F.group_norm(nchw(pre, n, H, W), G, gamma, beta, 1e-5))
+    close(nchw(y, n, H, W), ref, atol=2e-5, what="groupnorm + relu")
+    for mode in (0, 6):
+        emu_mode(mode)
+        a = ops.conv3x3_gn(y, C, n, H, W, C, wf, Co, 1e-5)
+        b = ops.conv3x3_gn(pre, C, n, H, W, C, wf, Co, 1e-5, gn_in=table)
+        assert a is not None and b is not None
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), mode
+        assert ops.conv_wgrad_tiled_ok(n, H, W, C, 0, Co, Co, C)
+        wa = ops.conv_wgrad(dy, Co, y, C, n, H, W, C, Co, 3, 3, 1, 1)
+        wb = ops.conv_wgrad(dy, Co, pre, C, n, H, W, C, Co, 3, 3, 1, 1, gn_in=table)
+        assert torch.equal(wa, wb), mode
+
+
 @pytest.mark.parametrize("Ci,Co,k,dil,H,W,n", [(128, 128, 3, 6, 32, 32, 3), (128, 128, 3, 18, 32, 32, 2), (640, 128, 1, 1, 32, 32, 2),
                                                (128, 128, 3, 12, 24, 40, 2), (96, 96, 3, 2, 16, 48, 5), (128, 128, 1, 1, 32, 32, 2)])
 def test_conv_wgrad_split_emulation(dev, emu_mode, Ci, Co, k, dil, H, W, n):
@@ -583,6 +613,32 @@ def test_conv_cout1_thin_kernels(dev, C, H):
     (gw,) = torch.autograd.grad(ref, w, dy)
     dwf = ops.conv_cout1_wgrad(nhwc(dy), nhwc(x.detach()), C, n, H, H, C, 1, 1)
     close(ops.unpack_conv_wgrad(dwf, 1, C, 3, 3), gw, atol=1e-3, what="cout1 wgrad")
+
+
+@pytest.mark.parametrize("C,H,W,n", [(32, 128, 128, 5), (32, 37, 50, 7), (16, 24, 40, 3), (64, 16, 32, 4)])
+def test_conv_cout1_with_groupnorm_input(dev, C, H, W, n):
+    """Head conv on a PRE-normalisation input (`gn_in`): the LDS-tiled forward and the channel-lane weight gradient form
+    relu(groupnorm(pre)) themselves -- bit-identical to the same kernels on the written tensor; ragged image edges (the zero
+    padding pads y, not pre); the tiled forward against torch."""
+    from semivl_amd import ops
+    pre = rnd(n * H * W, C, dev=dev, seed=91)
+    gamma, beta = rnd(C, dev=dev) + 1.0, rnd(C, dev=dev)
+    w, b = rnd(1, C, 3, 3, dev=dev, scale=0.2), rnd(1, dev=dev)
+    dy = rnd(n * H * W, 1, dev=dev, seed=92)
+    wf, _ = ops.pack_conv_w(w)
+    G = C // 16
+    y = ops.empty(n * H * W, C, device=dev)
+    st = ops.groupnorm_fwd(pre, C, gamma, beta, 1e-5, n, H * W, C, G, True, y, C)
+    table = ops.groupnorm_scale_shift(st, gamma, beta, n, C, G)
+    assert ops.conv_cout1_gn_ok(H, W, C)
+    a = ops.conv_cout1_fwd(y, C, n, H, W, C, wf, 3, 3, 1, 1, bias=b)
+    c = ops.conv_cout1_fwd(pre, C, n, H, W, C, wf, 3, 3, 1, 1, bias=b, gn_in=table)
+    assert torch.equal(a, c)
+    ref = F.conv2d(F.relu(F.group_norm(nchw(pre, n, H, W), G, gamma, beta, 1e-5)), w, b, padding=1)
+    close(nchw(a, n, H, W), ref, atol=2e-4, what="gn + relu + cout1")
+    wa = ops.conv_cout1_wgrad(dy, y, C, n, H, W, C, 1, 1)
+    wb = ops.conv_cout1_wgrad(dy, pre, C, n, H, W, C, 1, 1, gn_in=table)
+    assert torch.equal(wa, wb)
 
 
 def test_conv_cin1_fwd_elementwise(dev):
