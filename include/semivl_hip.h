@@ -42,7 +42,9 @@ typedef enum svl_status {
   SVL_ERR_UNSUPPORTED = -3
 } svl_status;
 
-int svl_version(void); /* 300: round-3 ABI (packed-planes operands; planes outputs of LayerNorm / attention; loss-mode arguments of
+int svl_version(void); /* 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
+                           svl_stream_prepare, svl_last_gemm_path; gn_in arguments of the tiled weight gradient and the Conv2d(C -> 1)
+                           entries, `accumulate` of svl_avgpool_cat_bwd); 300: round-3 ABI (packed-planes operands; planes outputs of LayerNorm / attention; loss-mode arguments of
                            the pixel-loss entries; 200 = round 2: helper-stream contexts, caller-owned scratch everywhere) */
 /* Destroys the helper stream/events this library created for `stream` on the current device (no-op if none), or for
  * every stream.  Call after the stream has been synchronised; not required before process exit. */
@@ -494,9 +496,10 @@ int svl_bilinear_planes_bwd(const float* dy, int64_t planes, int h, int w, int a
  * average pool of ASPPPooling, vlg_head.py:70-81, on any map shape). text may be NULL (Ct=0). */
 int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C, int PH, int PW, const float* text, int Ct,
                         int nclass, float* y, svl_stream_t stream);
-/* dx [imgs,H,W,C] = avgpool backward of dy[..., :C] (ld = C+Ct); pixels outside the floor region get 0. */
+/* dx [imgs,H,W,C] (=|+=) avgpool backward of dy[..., :C] (ld = C+Ct); pixels outside the floor region get 0 (accumulate:
+ * the pooled gradient is ADDED to dx -- the residual sum of SemanticTransformer / ASPP pooling without an extra pass). */
 int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int C, int PH, int PW, int Ct, float* dx,
-                        svl_stream_t stream);
+                        int accumulate, svl_stream_t stream);
 /* dtext [nclass, Ct] = sum over images of class n (img % nclass == n) and pooled pixels of dy[..., C + ct]. */
 int svl_avgpool_cat_bwd_text(const float* dy, int imgs, int64_t HWp, int C, int Ct, int nclass, float* dtext,
                              svl_stream_t stream);

@@ -1306,12 +1306,23 @@ int launch_emu(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
   return SVL_OK;
 }
 
+// (eight slab loads in flight per thread, added in slab order -- the same sum, bit for bit, as one load at a time, which left
+//  the 50-to-500-slab reductions of the decoder's weight gradients at the pace of one HBM round trip per slab: 14 ms of
+//  exposed time per ADE step)
 __global__ void reduce_slabs_kernel(float* out, const float* slabs, int nslab, long count, int accumulate) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < count; i += stride) {
     float s = accumulate ? out[i] : 0.f;
-    for (int k = 0; k < nslab; ++k) s += slabs[(long)k * count + i];
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slabs[(long)(k + u) * count + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nslab; ++k) s += slabs[(long)k * count + i];
     out[i] = s;
   }
 }

@@ -116,6 +116,7 @@ struct CeP {
 __global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [N][P]
   __shared__ float red[4][4];
+  __shared__ float part[2][256];          // per-(class part, pixel) partial max / partial sum when P < 256
   const int tid = threadIdx.x;
   const long blk = blockIdx.x;
   const long b = blk / p.blocks_per_img;
@@ -124,9 +125,13 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
   const float* src = p.logits + (long)b * p.N * p.HW + p0;
   const int P = p.P;
   const bool vec = ((p.HW & 3) == 0) && ((np & 3) == 0);
+  // P < 256 (N > 64: the tile holds fewer pixels): K = 256 / P threads share a pixel, thread (pixel tid % P, part tid / P)
+  // owns the classes c = part, part + K, ... -- every lane of the block works in the three class loops (at N = 150 three
+  // waves of four used to idle: 2.3 TB/s) and the partial max / sum of a pixel meet in LDS in part order (deterministic).
+  const int K = 256 / P, pix = tid % P, prt = tid / P;
   // per-pixel maps first: their latency hides under the tile loads
-  const long o = b * p.HW + p0 + tid;
-  const bool act = tid < np;
+  const long o = b * p.HW + p0 + pix;
+  const bool act = pix < np;
   long t = 0, mm = 255, ig = 0;
   float cf = 0.f;
   if (act) {
@@ -163,19 +168,35 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
   __syncthreads();
 
   float s_t = 0.f, s_m = 0.f, s_c = 0.f, n_v = 0.f;
+  float m = -INFINITY, s = 0.f, xt = 0.f, xm = 0.f;
+  const bool t_ok = !(p.use_ignore_t && t == 255);
+  const int ti = (act && t_ok) ? (int)t : -1;
+  const int mi = (act && p.mc && mm != 255) ? (int)mm : -1;
   if (act) {
-    float m = -INFINITY;
-    for (int c = 0; c < p.N; ++c) m = fmaxf(m, tile[c * P + tid]);
-    const bool t_ok = !(p.use_ignore_t && t == 255);
-    const int ti = t_ok ? (int)t : -1;
-    const int mi = (p.mc && mm != 255) ? (int)mm : -1;
-    const float xt = ti >= 0 ? tile[ti * P + tid] : 0.f, xm = mi >= 0 ? tile[mi * P + tid] : 0.f;
-    float s = 0.f;
-    for (int c = 0; c < p.N; ++c) {
-      const float e = expf(tile[c * P + tid] - m);
+    for (int c = prt; c < p.N; c += K) m = fmaxf(m, tile[c * P + pix]);
+    xt = ti >= 0 ? tile[ti * P + pix] : 0.f;      // (read before the exp pass overwrites the tile)
+    xm = mi >= 0 ? tile[mi * P + pix] : 0.f;
+  }
+  if (K > 1) {                                    // (block-uniform)
+    part[0][tid] = m;
+    __syncthreads();
+    m = part[0][pix];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, part[0][k * P + pix]);
+  }
+  if (act) {
+    for (int c = prt; c < p.N; c += K) {
+      const float e = expf(tile[c * P + pix] - m);
       s += e;
-      tile[c * P + tid] = e;
+      tile[c * P + pix] = e;
     }
+  }
+  if (K > 1) {
+    part[1][tid] = s;
+    __syncthreads();
+    s = part[1][pix];
+    for (int k = 1; k < K; ++k) s += part[1][k * P + pix];
+  }
+  if (act) {
     const float lse = m + logf(s);
     float w = 1.f;
     bool valid = t_ok;
@@ -186,20 +207,24 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const CeP p) {
       valid = v;
       s_c = v ? cf : 0.f;
     }
-    n_v = valid ? 1.f : 0.f;
-    s_t = t_ok ? w * (lse - xt) : 0.f;
-    s_m = mi >= 0 ? lse - xm : 0.f;
+    if (prt == 0) {                               // the pixel's scalars are counted once
+      n_v = valid ? 1.f : 0.f;
+      s_t = t_ok ? w * (lse - xt) : 0.f;
+      s_m = mi >= 0 ? lse - xm : 0.f;
+    } else {
+      s_c = 0.f;
+    }
     if (p.dlogits) {
       const float gt = t_ok ? p.gscale[0] * w : 0.f;
       const float gm = (mi >= 0) ? p.gscale[1] : 0.f;
       const float gsum = gt + gm;
       const float inv = 1.f / s;
-      for (int c = 0; c < p.N; ++c) {
-        const float pr = tile[c * P + tid] * inv;
+      for (int c = prt; c < p.N; c += K) {
+        const float pr = tile[c * P + pix] * inv;
         float d = gsum * pr;
         if (c == ti) d -= gt;
         if (c == mi) d -= gm;
-        tile[c * P + tid] = d;
+        tile[c * P + pix] = d;
       }
     }
   }
@@ -460,11 +485,9 @@ inline int grid_for(long n, int per_thread = 1) {
   if (g > 256 * 16) g = 256 * 16;
   return (int)g;
 }
-inline int ce_tile_pixels(int N) {
+inline int ce_tile_pixels(int N) {     // 256, 128 or 64 pixels: the [N][P] tile stays within 64 KB and 256 % P == 0
   int P = (64 * 1024) / (4 * N);
-  if (P > 256) P = 256;
-  P &= ~63;
-  return P;
+  return P >= 256 ? 256 : (P >= 128 ? 128 : (P >= 64 ? 64 : 0));
 }
 
 }  // namespace

@@ -180,11 +180,13 @@ __global__ __launch_bounds__(256) void bilinear_planes_fwd_kernel(const float* _
     else y[i] = o[0];
   }
 }
-// (round 4: the column taps of an input pixel do not depend on the output row: their weights are computed once per thread
-//  instead of once per candidate output pixel -- ~120 index computations became ~24; same products, same order)
+// (round 4: the column taps of an input pixel do not depend on the output row: the first contributing output column and
+//  the <= MAXW tap weights from there are found once per thread (~14 index computations instead of ~120 per thread; a
+//  window of 16 unconditional loads per row was tried first and was SLOWER, 2.06 vs 1.64 ms at N = 150: the loads, not
+//  the index math, set the pace, so only the contributing columns are read).  Same products, same order.
 __global__ __launch_bounds__(256) void bilinear_planes_bwd_kernel(const float* __restrict__ dy, long planes, int h, int w,
                                                                   int align, int H, int W, float* __restrict__ dx) {
-  constexpr int MAXW = 16;
+  constexpr int MAXW = 9;     // contributing output columns of one input column: <= 2 x scale (scale 4: 8) + 1
   const float sh = area_scale(h, H, align), sw = area_scale(w, W, align);
   const long total = planes * h * w;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -197,14 +199,28 @@ __global__ __launch_bounds__(256) void bilinear_planes_bwd_kernel(const float* _
     dst_range(ix, sw, W, align, xlo, xhi);
     const float* d = dy + pl * H * W;
     float acc = 0.f;
-    if (xhi - xlo < MAXW) {
+    // first / last contributing output column
+    int xf = xlo, xl = xhi;
+    for (; xf <= xhi; ++xf) {
+      int x0, x1;
+      float lx0, lx1;
+      src_index(xf, sw, w, align, x0, x1, lx0, lx1);
+      if ((x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f) != 0.f) break;
+    }
+    for (; xl > xf; --xl) {
+      int x0, x1;
+      float lx0, lx1;
+      src_index(xl, sw, w, align, x0, x1, lx0, lx1);
+      if ((x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f) != 0.f) break;
+    }
+    if (xf <= xhi && xl - xf < MAXW) {
       float wxs[MAXW];
 #pragma unroll
       for (int k = 0; k < MAXW; ++k) {
         int x0, x1;
         float lx0, lx1;
-        src_index(min(xlo + k, W - 1), sw, w, align, x0, x1, lx0, lx1);
-        wxs[k] = (xlo + k <= xhi) ? (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f) : 0.f;
+        src_index(min(xf + k, W - 1), sw, w, align, x0, x1, lx0, lx1);
+        wxs[k] = (xf + k <= xl) ? (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f) : 0.f;
       }
       for (int oy = ylo; oy <= yhi; ++oy) {
         int y0, y1;
@@ -215,11 +231,11 @@ __global__ __launch_bounds__(256) void bilinear_planes_bwd_kernel(const float* _
         const float* row = d + (long)oy * W;
         float dv[MAXW];
 #pragma unroll
-        for (int k = 0; k < MAXW; ++k) dv[k] = row[min(xlo + k, W - 1)];     // unconditional (cache-resident) loads
+        for (int k = 0; k < MAXW; ++k) dv[k] = row[min(xf + k, W - 1)];     // unconditional (cache-resident) loads
 #pragma unroll
         for (int k = 0; k < MAXW; ++k) acc = wxs[k] != 0.f ? acc + wy * wxs[k] * dv[k] : acc;
       }
-    } else {
+    } else if (xf <= xhi) {
       for (int oy = ylo; oy <= yhi; ++oy) {
         int y0, y1;
         float ly0, ly1;
@@ -297,7 +313,7 @@ __global__ __launch_bounds__(256) void avgpool_cat_fwd_kernel(const float* __res
 }
 template <bool VEC>
 __global__ __launch_bounds__(256) void avgpool_cat_bwd_kernel(const float* __restrict__ dy, int imgs, int H, int W, int C,
-                                                              int P, int PW, int Ct, float* __restrict__ dx) {
+                                                              int P, int PW, int Ct, float* __restrict__ dx, int accumulate) {
   constexpr int V = VEC ? 4 : 1;
   const int Hp = H / P, Wp = W / PW, Co = C + Ct, CV = C / V;
   const long total = (long)imgs * H * W * CV;
@@ -317,9 +333,14 @@ __global__ __launch_bounds__(256) void avgpool_cat_bwd_kernel(const float* __res
         q = *reinterpret_cast<const float4*>(dy + ((img * Hp + py) * Wp + px) * Co + c);
         q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
       }
+      if (accumulate) {
+        const float4 a = *reinterpret_cast<const float4*>(dx + i * 4);
+        q.x += a.x; q.y += a.y; q.z += a.z; q.w += a.w;
+      }
       *reinterpret_cast<float4*>(dx + i * 4) = q;
     } else {
-      dx[i] = in ? dy[((img * Hp + py) * Wp + px) * Co + c] * inv : 0.f;
+      const float v = in ? dy[((img * Hp + py) * Wp + px) * Co + c] * inv : 0.f;
+      dx[i] = accumulate ? dx[i] + v : v;
     }
   }
 }
@@ -413,15 +434,15 @@ extern "C" int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C
   return SVL_OK;
 }
 extern "C" int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int C, int PH, int PW, int Ct, float* dx,
-                                   svl_stream_t stream) {
+                                   int accumulate, svl_stream_t stream) {
   SVL_CHECK_ARG(dy && dx && imgs > 0 && PH > 0 && PW > 0 && H >= PH && W >= PW && C > 0 && Ct >= 0,
                 "svl_avgpool_cat_bwd: bad args");
   const bool vec = C % 4 == 0 && Ct % 4 == 0 && ((((uintptr_t)dy | (uintptr_t)dx) & 15) == 0);
   const long total = (long)imgs * H * W * (C / (vec ? 4 : 1));
   if (vec) hipLaunchKernelGGL(avgpool_cat_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, imgs, H, W,
-                              C, PH, PW, Ct, dx);
+                              C, PH, PW, Ct, dx, accumulate);
   else hipLaunchKernelGGL(avgpool_cat_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, imgs, H, W,
-                          C, PH, PW, Ct, dx);
+                          C, PH, PW, Ct, dx, accumulate);
   SVL_LAUNCH_CHECK("svl_avgpool_cat_bwd");
   return SVL_OK;
 }

@@ -336,33 +336,43 @@ def _chunk_plan(m, b, N):
     return out
 
 
-def _kept_bytes_per_class_image(m, HW):
-    """What backward keeps per class-image WITHOUT re-materialisation (fp32): conv1 out, 4 ASPP pre + the concat, project
-    pre / out, the residual sum (13 Ch maps at h x w), ~1.8 MB of SemanticTransformer tokens per 1024 pixels, and per Up
-    block at 4x / 16x the pixels: ConvTranspose out + 2 x (pre, out)."""
+def _kept_bytes_per_class_image(m, HW, level=0):
+    """What backward keeps per class-image (fp32) at re-materialisation level 0 / 1 / 2: conv1 out, 4 ASPP pre + the concat,
+    project pre, the residual sum (12 Ch maps at h x w), ~1.8 MB of SemanticTransformer tokens per 1024 pixels, and per Up
+    block at 4x / 16x the pixels: ConvTranspose out + 2 x pre + the second unit's output (the first unit's output -- and
+    up2's second, consumed by the head conv -- are never written: _GNDeferred; counted as kept when those kernels cannot
+    take the layer would be pessimistic by < 15 %).  Level 1 drops the ConvTranspose outputs and up1's output, level 2 the
+    ASPP concat as well."""
     Ch = m.channels
     c_up1, c_up2 = m.up1.conv[0].weight.shape[0], m.up2.conv[0].weight.shape[0]
     cu1, cu2 = m.up1.up.weight.shape[1], m.up2.up.weight.shape[1]
-    return 4 * HW * (13 * Ch + 450 + 4 * (cu1 + 4 * c_up1) + 16 * (cu2 + 4 * c_up2))
+    maps = 12 * Ch + 450 + 4 * (cu1 + 3 * c_up1) + 16 * (cu2 + 2 * c_up2)
+    if level >= 1:
+        maps -= 4 * (cu1 + c_up1) + 16 * cu2
+    if level >= 2:
+        maps -= 5 * Ch
+    return 4 * HW * maps
 
 
 def _remat_decision(m, plan, N, HW, dev):
-    """Re-materialise (see _LazyGN) instead of keeping?  `m.remat`: True / False, or None = decide: on when everything the
-    step's grad-carrying decodes would keep does not fit under the activation budget (then no chunk has to be re-run as a
-    whole).  The training step announces the class-image count of ALL its live decodes (`m._live_class_images`) and the
-    decision of the step's first decode holds for the others (`m._remat_step`)."""
+    """Re-materialisation level (see _LazyGN): 0 keep everything, 1 re-create the Up blocks' ConvTranspose / GroupNorm outputs
+    in backward, 2 the ASPP concat too.  `m.remat`: False / True (= 2) / a level, or None = decide: the LOWEST level at which
+    everything the step's grad-carrying decodes keep fits under the activation budget (then no chunk has to be re-run as a
+    whole; ADE N = 150 at B = 16: level 1).  The training step announces the class-image count of ALL its live decodes
+    (`m._live_class_images`) and the decision of the step's first decode holds for the others (`m._remat_step`)."""
     mode = getattr(m, "remat", None)
     if mode is not None:
-        return bool(mode)
+        return 2 if mode is True else int(mode)
     step = getattr(m, "_remat_step", None)
     if isinstance(step, dict) and "on" in step:
         return step["on"]
     limit = getattr(m, "act_limit_bytes", None)
-    on = False
+    on = 0
     if limit is not None and dev.type == "cuda":
         live = getattr(m, "_live_class_images", None) or sum(s1 - s0 for s0, s1, lv in plan if lv) * N
-        need = live * _kept_bytes_per_class_image(m, HW)
-        on = need > 0.9 * (limit - torch.cuda.memory_allocated(dev))
+        room = 0.9 * (limit - torch.cuda.memory_allocated(dev))
+        while on < 2 and live * _kept_bytes_per_class_image(m, HW, on) > room:
+            on += 1
     if isinstance(step, dict):
         step["on"] = on
     return on
@@ -454,14 +464,15 @@ def _head_core_forward(m, shared, s0, s1, sv, logits_out):
     w1f, w1d = ops.pack_conv_w(m.conv1.weight)
     x1 = ops.conv_fwd(sim, 1, imgs, h, w, 1, w1f, Ch, k1, k1, 1, (k1 - 1) // 2, bias=m.conv1.bias)
     # ---- ASPP ----------------------------------------------------------------------------------------------
-    remat = bool(shared.get("remat")) and sv is not None
+    level = int(shared.get("remat") or 0) if sv is not None else 0
+    remat, remat_aspp = level >= 1, level >= 2
     cat = ops.empty(imgs * HW, 5 * Ch, device=dev)
     aspp_sv = []
     for j, d in enumerate(m.aspp.rates):
         seq = m.aspp.aspp_convs[j]
         s_ = {} if sv is not None else None
         _conv_gn_fwd(x1, Ch, imgs, h, w, Ch, seq[0], seq[1], 1 if d == 1 else 3, d, s_, y=cat[:, j * Ch:], ldy=5 * Ch,
-                     remat=remat)
+                     remat=remat_aspp)
         aspp_sv.append(s_)
     gap = m.aspp.aspp_convs[4].gap
     pooled = ops.avgpool_cat_fwd(x1, imgs, h, w, Ch, (h, w), None, 1)      # AdaptiveAvgPool2d(1) on any map shape
@@ -470,7 +481,7 @@ def _head_core_forward(m, shared, s0, s1, sv, logits_out):
     ops.bilinear_nhwc_fwd(gy, Ch, imgs, 1, 1, Ch, True, 1, h, w, cat[:, 4 * Ch:], 5 * Ch)
     s_proj = {} if sv is not None else None
     x2 = _conv_gn_fwd(cat, 5 * Ch, imgs, h, w, 5 * Ch, m.aspp.project[0], m.aspp.project[1], 1, 1, s_proj, remat=remat,
-                      x_keep=_LazyCat([a_["lazy"] for a_ in aspp_sv], gy, imgs, h, w, Ch) if remat else None)
+                      x_keep=_LazyCat([a_["lazy"] for a_ in aspp_sv], gy, imgs, h, w, Ch) if remat_aspp else None)
     # y = x + project(cat).  (x2 is not needed again: the project GN's ReLU mask is re-derived from its `pre`; without
     # remat a new buffer is used all the same so that the unit's kept `y` stays what it was.)
     x = ops.add(x2, x1, out=x2) if remat else ops.add(x2, x1)
@@ -586,9 +597,9 @@ def _semtr_backward(lyr, dx, dtp_acc, imgs, b, N, h, w, Ch, Ct, sv, gc):
     dtok, dg1, db1 = ops.layernorm_bwd(dy1, sv["tok"], sv["st1"], p["ln1w"], dx_add=dt2, want_wgrad=True)
     gc.put_tensor(t.ln1.weight, dg1)
     gc.put_tensor(t.ln1.bias, db1)
-    dxin_pool, dtext = ops.avgpool_cat_bwd(dtok, imgs, h, w, Ch, lyr.pool_size, Ct, N)
+    dx, dtext = ops.avgpool_cat_bwd(dtok, imgs, h, w, Ch, lyr.pool_size, Ct, N, add_to=dx)   # dx += pooled gradient
     ops.add(dtp_acc, dtext, out=dtp_acc)
-    return ops.add(dx, dxin_pool, out=dxin_pool)
+    return dx
 
 
 def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv, remat=False, x_keep=None, out_for=None):
@@ -778,8 +789,7 @@ def _head_backward_core(m, sv, dlogits, gc):
         ops.bilinear_nhwc_bwd(dcat[:, 4 * Ch:], 5 * Ch, imgs, 1, 1, Ch, True, 1, h, w, dgy, Ch)
         dpooled = _conv_gn_bwd(dgy, Ch, gap[1], gap[2], sv["gap"], gc)  # [imgs, Ch]
         # avgpool over the whole map: every pixel gets dpooled / HW
-        dgap, _ = ops.avgpool_cat_bwd(dpooled, imgs, h, w, Ch, (h, w), 0, 1)
-        ops.add(dx1, dgap, out=dx1)
+        ops.avgpool_cat_bwd(dpooled, imgs, h, w, Ch, (h, w), 0, 1, add_to=dx1)   # dx1 += dpooled / HW
         sv["aspp"] = sv["proj"] = None
         # ---- conv1
         k1 = m.conv1_ksize

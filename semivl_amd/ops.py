@@ -528,6 +528,12 @@ def colsum(x2d, out=None, accumulate=False, C_=None, ld=None):
     if out is None:
         out = empty(Cc, device=x2d.device)
         accumulate = False
+    if Cc == 1 and ldd == 1 and rows >= 65536 and rows % 1024 == 0:
+        # the sum of one long column (the head conv's bias gradient: 19.6 M dlogits per ADE chunk) has ONE column of
+        # parallelism in the column kernel -- 2.9 ms at 27 GB/s; as a [rows / 1024, 1024] matrix it is a 16 B-wide column
+        # sum (full bandwidth) followed by a 1024-element one.  Fixed summation order either way.
+        part = colsum(x2d.reshape(rows // 1024, 1024))
+        return colsum(part.view(1024, 1), out=out, accumulate=accumulate)
     lib = L.load()
     ws = empty(int(lib.svl_colsum_ws_floats(rows, Cc)), device=x2d.device)
     L.check(lib.svl_colsum_f32(_p(x2d), rows, Cc, ldd, _p(out), 1 if accumulate else 0, _p(ws), _st()),
@@ -1051,11 +1057,13 @@ def avgpool_cat_fwd(x, imgs, H, W, Cc, P, text, nclass):
     return y
 
 
-def avgpool_cat_bwd(dy, imgs, H, W, Cc, P, Ct, nclass):
+def avgpool_cat_bwd(dy, imgs, H, W, Cc, P, Ct, nclass, add_to=None):
+    """`add_to`: an existing [imgs*H*W, Cc] gradient the pooled gradient is added to in place (returned as dx)."""
     PH, PW = (P, P) if isinstance(P, int) else P
-    dx = empty(imgs * H * W, Cc, device=dy.device)
+    dx = empty(imgs * H * W, Cc, device=dy.device) if add_to is None else add_to
     lib = L.load()
-    L.check(lib.svl_avgpool_cat_bwd(_p(dy), imgs, H, W, Cc, PH, PW, Ct, _p(dx), _st()), "svl_avgpool_cat_bwd")
+    L.check(lib.svl_avgpool_cat_bwd(_p(dy), imgs, H, W, Cc, PH, PW, Ct, _p(dx), 0 if add_to is None else 1, _st()),
+            "svl_avgpool_cat_bwd")
     dtext = None
     if Ct > 0:
         dtext = empty(nclass, Ct, device=dy.device)

@@ -507,16 +507,32 @@ class GradAllReducer:
         on_gpu = optimizer.g.is_cuda
         if on_gpu and self.world > 1:
             step_streams = create_step_streams(optimizer.g.device)
-        self._comm = torch.cuda.Stream() if (self._async and on_gpu) else None
+        self._comm = None
         if on_gpu and self.world > 1 and not os.environ.get("SVL_NO_QUEUE_PROBE"):
-            # (blocking backends have no communication stream: probe what one created at this point WOULD share)
-            probe = self._comm if self._comm is not None else torch.cuda.Stream()
+            # The communication stream is PICKED, not taken as it comes: up to six fresh streams are probed against the
+            # step's streams and the first one that shares a hardware queue with none of them is kept (the runtime's
+            # stream -> queue assignment is not round-robin once library helper streams exist: with 8 queues the first
+            # fresh stream landed on the main stream's queue, measured).  Blocking backends have no communication stream:
+            # the same search reports what one created at this point WOULD get.
             names = ["main", "second"] + (["weight_gradient"] if len(step_streams) > 2 else [])
-            shared = [n_ for n_, s_ in zip(names, step_streams) if ops.streams_share_queue(s_, probe)]
+            tried, pick, shared = [], None, None
+            for _ in range(6):
+                cand = torch.cuda.Stream()
+                sh_ = [n_ for n_, s_ in zip(names, step_streams) if ops.streams_share_queue(s_, cand)]
+                tried.append(cand)               # (kept alive: a destroyed stream's queue slot would be handed out again)
+                if pick is None or len(sh_) < len(shared):
+                    pick, shared = cand, sh_
+                if not sh_:
+                    break
+            self._probed_streams = tried
+            if self._async:
+                self._comm = pick
             self.queue_info = dict(gpu_max_hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                                    comm_stream_shares_queue=bool(shared), shares_queue_with=shared,
-                                   weight_gradient_stream=bool(ops.WGRAD_STREAM),
-                                   comm_stream="dedicated" if self._comm is not None else "none (blocking backend; probed a stand-in)")
+                                   streams_probed=len(tried), weight_gradient_stream=bool(ops.WGRAD_STREAM),
+                                   comm_stream="dedicated" if self._async else "none (blocking backend; probed a stand-in)")
+        elif self._async and on_gpu:
+            self._comm = torch.cuda.Stream()
         self._works, self._fired, self._complete = [], set(), [0] * len(self.buckets)
         self.early_fires = 0
         if self.world > 1 and groups:

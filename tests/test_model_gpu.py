@@ -448,6 +448,8 @@ def test_head_memory_plan_is_exact(dev):
     # second level of the plan: GroupNorm / ConvTranspose outputs re-materialised in backward instead of kept
     l_rm, g_rm = run(head_chunk_class_images=21, act_mem_fraction=None, head_remat=True)
     l_rm1, g_rm1 = run(head_chunk_class_images=1 << 20, act_mem_fraction=None, head_remat=True)
+    l_rmA, g_rmA = run(head_chunk_class_images=1 << 20, act_mem_fraction=None, head_remat=1)       # level 1: the Up blocks only
+    assert torch.equal(l_one, l_rmA) and all(torch.equal(g_one[k], g_rmA[k]) for k in g_one)
     # third level: GroupNorm + ReLU of the Up blocks' first unit applied by the consuming convolution's staging (forward and
     # weight gradient) instead of written -- on / off must not change a bit
     from semivl_amd import ops

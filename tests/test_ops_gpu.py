@@ -910,6 +910,10 @@ def test_avgpool_cat(dev, H, P):
     dx, dt = ops.avgpool_cat_bwd(nhwc(dy), b * N, H, H, C, P, Ct, N)
     close(nchw(dx, b * N, H, H), gx, atol=1e-6)
     close(dt, gt, atol=1e-4)
+    base = rnd(b * N * H * H, C, dev=dev, seed=18)     # add_to: the pooled gradient lands on an existing residual gradient
+    want = base + dx
+    got, _ = ops.avgpool_cat_bwd(nhwc(dy), b * N, H, H, C, P, Ct, N, add_to=base)
+    assert got.data_ptr() == base.data_ptr() and torch.equal(got, want)
 
 
 # ------------------------------------------------------------------------------------------------ pixel losses

@@ -1,6 +1,6 @@
-# End-of-round evidence run on the 1-GPU box (profiles/README.md):  gpurun -- 'TAG=r3_x bash tools/round_end_run.sh'
+# End-of-round evidence run on the 1-GPU box (profiles/README.md):  gpurun -- 'TAG=r4_x bash tools/round_end_run.sh'
 cd $GRAFT_REPO_ROOT
-T=${TAG:-r3}
+T=${TAG:-r4}
 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -25 > gpurun_out/${T}_pytest.log
 # PMC records of the dominant launches (quoted by bench.py as roofline.traffic / roofline_hbm.traffic)
 bash tools/pmc_x6p.sh 32800 3072 768 4 > gpurun_out/${T}_pmc_x6p_ffn1.txt 2>&1   # mode 4 = FFN-1 as the step launches it (no fp32 C)
@@ -19,6 +19,13 @@ for m in bf16x6 f32; do
   if [ $m = bf16x6 ]; then python tools/rocpd_dispatches.py $DB gemm_x6p_kernelILi256ELi1E 1548 > gpurun_out/${T}_dominant_dispatches.csv; fi
   rm -rf gpurun_out/prof_$m
 done
+# the N > 1 code path on this one-GPU box: two ranks over gloo (blocking all-reduce) -- the `allreduce` object with the
+# stream -> hardware-queue probe of the reducer
+SVL_DIST_BACKEND=gloo python bench.py --gpus 2 --batch 4 --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode --no-profile > gpurun_out/${T}_bench_gloo2.json 2> gpurun_out/${T}_bench_gloo2.err
+# every MFMA launch shape of the VOC and ADE steps (solo HIP-event durations)
+python tools/shape_table.py voc > gpurun_out/${T}_shapes_voc.txt 2>/dev/null
+python tools/shape_table.py ade > gpurun_out/${T}_shapes_ade.txt 2>/dev/null
+for c in ade coco cityscapes; do TAG=${T}_$c bash tools/prof_step.sh --config $c > /dev/null 2>&1; done
 tail -4 gpurun_out/${T}_pytest.log
 for f in default cityscapes ade coco exact_f32; do python -c "
 import json; d=json.loads(open('gpurun_out/${T}_bench_$f.json').read().strip().splitlines()[-1]); r=d.get('roofline',{}); print('$f', d['value'], d['ms_per_step'], d['config']['peak_mem_gb'], r.get('frac'), r.get('avg_ms'), (d.get('exact_f32') or {}).get('value'))"; done
