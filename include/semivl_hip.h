@@ -500,8 +500,9 @@ int svl_avgpool_cat_fwd(const float* x, int imgs, int H, int W, int C, int PH, i
  * the pooled gradient is ADDED to dx -- the residual sum of SemanticTransformer / ASPP pooling without an extra pass). */
 int svl_avgpool_cat_bwd(const float* dy, int imgs, int H, int W, int C, int PH, int PW, int Ct, float* dx,
                         int accumulate, svl_stream_t stream);
-/* dtext [nclass, Ct] = sum over images of class n (img % nclass == n) and pooled pixels of dy[..., C + ct]. */
-int svl_avgpool_cat_bwd_text(const float* dy, int imgs, int64_t HWp, int C, int Ct, int nclass, float* dtext,
+/* dtext [nclass, Ct] = sum over images of class n (img % nclass == n) and pooled pixels of dy[..., C + ct]; part: imgs * Ct
+ * floats of scratch (per-image partial sums, added up per class in image order). */
+int svl_avgpool_cat_bwd_text(const float* dy, int imgs, int64_t HWp, int C, int Ct, int nclass, float* part, float* dtext,
                              svl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

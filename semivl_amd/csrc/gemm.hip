@@ -1522,7 +1522,11 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     const bool a_dense = am == SVL_A_KCONTIG ||
                          (a_conv && cv.KH == 1 && cv.KW == 1 && cv.pad == 0 && p.cv.stride == 1 && cv.C2 == 0 &&
                           p.cv.Ho == cv.H && p.cv.Wo == cv.W);
-    if (shortk && a_dense && bm == SVL_B_KCONTIG && d->batch == 1 && d->ksplit == 0 && d->K % 64 == 0 && d->K >= 64 &&
+    // (SVL_SHORTK_EMU_MAXK, A/B aid: in the split-emulation modes row-major outputs with K above it go to the bf16 pipe
+    //  kernel instead -- K = 128 with N = 128 / 640 is 2 N FLOP per operand byte, more matrix- than store-bound)
+    static const int sk_emu_maxk = env_int("SVL_SHORTK_EMU_MAXK", 128);
+    const bool sk_to_emu = (emu_mode == 3 || emu_mode == 6) && d->out_mode == SVL_OUT_STRIDED && d->K > sk_emu_maxk;
+    if (shortk && !sk_to_emu && a_dense && bm == SVL_B_KCONTIG && d->batch == 1 && d->ksplit == 0 && d->K % 64 == 0 && d->K >= 64 &&
         d->K <= 128 && d->M >= 32768 && d->N >= 96 && p.A.vec && p.B.vec &&
         (d->out_mode == SVL_OUT_STRIDED || d->out_mode == SVL_OUT_CONVT2X)) {
       const bool fast = (d->ldc_n == 1 || d->out_mode == SVL_OUT_CONVT2X) && !d->resid && !d->preact && !d->accumulate &&

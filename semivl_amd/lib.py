@@ -153,7 +153,7 @@ SIGNATURES = {
     "svl_bilinear_planes_bwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _P, _P]),
     "svl_avgpool_cat_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
     "svl_avgpool_cat_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
-    "svl_avgpool_cat_bwd_text": (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
+    "svl_avgpool_cat_bwd_text": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _P]),
     "svl_adamw_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _I, _F, _P, _F, _P]),
 }
 

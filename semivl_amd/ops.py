@@ -1066,8 +1066,8 @@ def avgpool_cat_bwd(dy, imgs, H, W, Cc, P, Ct, nclass, add_to=None):
             "svl_avgpool_cat_bwd")
     dtext = None
     if Ct > 0:
-        dtext = empty(nclass, Ct, device=dy.device)
-        L.check(lib.svl_avgpool_cat_bwd_text(_p(dy), imgs, (H // PH) * (W // PW), Cc, Ct, nclass, _p(dtext), _st()),
+        dtext, part = empty(nclass, Ct, device=dy.device), empty(imgs, Ct, device=dy.device)
+        L.check(lib.svl_avgpool_cat_bwd_text(_p(dy), imgs, (H // PH) * (W // PW), Cc, Ct, nclass, _p(part), _p(dtext), _st()),
                 "svl_avgpool_cat_bwd_text")
     return dx, dtext
 
