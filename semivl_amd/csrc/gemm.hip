@@ -1475,6 +1475,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     g_emu_mode.store(emu_mode, std::memory_order_relaxed);
   }
   static const int emu_conv = getenv("SVL_GEMM_EMU_NO_CONV") ? 0 : 1;
+  static const int sk_emu_maxk_g = env_int("SVL_SHORTK_EMU_MAXK", 64);   // (see the short-K dispatch below)
   g_last_path = SVL_PATH_F32;
   auto launch = [&](const GemmP& q) -> int {
     // implicit-GEMM convolutions (NHWC im2col on the fly, forward and mirrored-tap input gradient) join the split
@@ -1495,8 +1496,13 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       g_last_path = SVL_PATH_BF16X;
       return emu_mode == 6 ? launch_emu<3>(q, 1, 2, d->batch, st) : launch_emu<2>(q, 1, 2, d->batch, st);
     }
+    // (the pixel-shuffle store of ConvTranspose2d(k 2, s 2) is one of the shared epilogue's store forms: the K = 128
+    //  ConvTranspose of up1 joins the dense launches on the split pipe)
+    const bool emu_out_ok = d->out_mode == SVL_OUT_STRIDED ||
+                            (d->out_mode == SVL_OUT_CONVT2X && am == SVL_A_KCONTIG && bm == SVL_B_KCONTIG && d->batch == 1 &&
+                             d->ksplit == 0 && d->K > sk_emu_maxk_g);
     if ((emu_mode == 3 || emu_mode == 6) && (am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) &&
-        (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && q.M >= 256 && q.N >= 96 &&
+        (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && emu_out_ok && q.M >= 256 && q.N >= 96 &&
         q.K >= 64) {
       g_last_path = SVL_PATH_BF16X;
       return emu_mode == 6 ? launch_emu<3>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
@@ -1522,10 +1528,13 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     const bool a_dense = am == SVL_A_KCONTIG ||
                          (a_conv && cv.KH == 1 && cv.KW == 1 && cv.pad == 0 && p.cv.stride == 1 && cv.C2 == 0 &&
                           p.cv.Ho == cv.H && p.cv.Wo == cv.W);
-    // (SVL_SHORTK_EMU_MAXK, A/B aid: in the split-emulation modes row-major outputs with K above it go to the bf16 pipe
-    //  kernel instead -- K = 128 with N = 128 / 640 is 2 N FLOP per operand byte, more matrix- than store-bound)
-    static const int sk_emu_maxk = env_int("SVL_SHORTK_EMU_MAXK", 128);
-    const bool sk_to_emu = (emu_mode == 3 || emu_mode == 6) && d->out_mode == SVL_OUT_STRIDED && d->K > sk_emu_maxk;
+    // In the split-emulation modes the row-major K = 128 launches (ASPP 1x1 convolution and its input gradient, the
+    // projection's input gradient N = 640: 2 N FLOP per operand byte, more matrix- than store-bound) go to the bf16-pipe
+    // kernel instead: 94 -> 109 TF and 80 -> 87 TF solo, ADE 24.86 -> 25.40 img/s, VOC 77.50 -> 77.84 in the step (same
+    // box, round 4).  K = 64 (ConvTranspose of up2) and the pixel-shuffle stores stay here.  SVL_SHORTK_EMU_MAXK=128 undoes it.
+    const int sk_emu_maxk = sk_emu_maxk_g;
+    const bool sk_to_emu = (emu_mode == 3 || emu_mode == 6) && d->K > sk_emu_maxk &&
+                           (d->out_mode == SVL_OUT_STRIDED || (d->out_mode == SVL_OUT_CONVT2X && am == SVL_A_KCONTIG));
     if (shortk && !sk_to_emu && a_dense && bm == SVL_B_KCONTIG && d->batch == 1 && d->ksplit == 0 && d->K % 64 == 0 && d->K >= 64 &&
         d->K <= 128 && d->M >= 32768 && d->N >= 96 && p.A.vec && p.B.vec &&
         (d->out_mode == SVL_OUT_STRIDED || d->out_mode == SVL_OUT_CONVT2X)) {
