@@ -42,7 +42,7 @@ typedef enum svl_status {
   SVL_ERR_UNSUPPORTED = -3
 } svl_status;
 
-int svl_version(void); /* 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
+int svl_version(void); /* 401: + svl_conv3x3_weight_planes, svl_gemm_desc::conv_w_planes, w_planes of svl_conv3x3_gn_f32; 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
                            svl_stream_prepare, svl_last_gemm_path; gn_in arguments of the tiled weight gradient and the Conv2d(C -> 1)
                            entries, `accumulate` of svl_avgpool_cat_bwd); 300: round-3 ABI (packed-planes operands; planes outputs of LayerNorm / attention; loss-mode arguments of
                            the pixel-loss entries; 200 = round 2: helper-stream contexts, caller-owned scratch everywhere) */
@@ -143,6 +143,10 @@ typedef struct svl_gemm_desc {
   const float* resid; /* addressed like C for SVL_OUT_STRIDED (own strides below); see SVL_OUT_PATCH */
   int64_t ldr_m, ldr_n, r_bs_outer, r_bs_inner;
   int accumulate;
+  const void* conv_w_planes; /* optional, SVL_A_CONV with a 3x3 / pad 1 / dilation 1 / stride 1 geometry and N = 32 / 64 only: the
+                              * weights B once more as svl_conv3x3_weight_planes(B, N, C1 + C2) wrote them.  Used when the
+                              * spatially tiled kernel serves the launch in emulation mode 6 (identical results, the
+                              * kernel copies the planes instead of splitting the weights in every block); ignored otherwise. */
 } svl_gemm_desc;
 
 int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream);
@@ -401,7 +405,15 @@ int svl_groupnorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
 int64_t svl_conv3x3_gn_ws_doubles(int imgs, int H, int W, int N);
 int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const float* src2, int64_t ld2, int C2, int rep,
                        const float* w, int imgs, int H, int W, int N, float* out, int64_t ldo, float eps, double* ws,
-                       float* stats, const float* gn_in, svl_stream_t stream);
+                       float* stats, const float* gn_in, const void* w_planes, svl_stream_t stream);
+/* The weights of a narrow 3x3 convolution (forward pack [N, 9 Ct], or the input-gradient pack [Cin, 9 Cout]; N = 32 / 64,
+ * Ct % 16 == 0) split ONCE into the three bf16 planes of emulation mode 6, in the LDS image of the tiled kernel (per slab of
+ * 16 input channels: [plane][tap N + n][16]) -- svl_conv3x3_weight_planes_bytes(N, Ct) = 6 bytes per weight.  Optional
+ * operand `w_planes` of svl_conv3x3_gn_f32 and `conv_w_planes` of svl_gemm_desc (null = the kernel splits the fp32 weights
+ * in every block: same bits, ~20 % slower).  Build it once per weight version (the reference has no counterpart: cuDNN
+ * re-lays its filters out internally).  Replaces nothing of the reference by itself: vlg_head.py:120-127's Conv2d weights. */
+int64_t svl_conv3x3_weight_planes_bytes(int N, int Ct);
+int svl_conv3x3_weight_planes(const float* w, int N, int Ct, void* planes, svl_stream_t stream);
 /* scsh [imgs][2][C]: the per-(image, channel) affine form of GroupNorm, y = fma(x, scsh[img][0][c], scsh[img][1][c]), from
  * statistics [imgs, G, 2] -- the table the tiled convolutions apply (+ ReLU) to a pre-normalisation operand (gn_in). */
 int svl_groupnorm_scale_shift(const float* stats, const float* gamma, const float* beta, int imgs, int C, int G, float* scsh,

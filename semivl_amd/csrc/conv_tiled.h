@@ -15,6 +15,9 @@ struct ConvTiledP {
   const float* gn_in;                               // null, or [imgs][2][C1] (scale, shift): src1 holds PRE-normalisation
                                                     // values, the operand is relu(fma(x, scale, shift)) (GroupNorm + ReLU
                                                     // applied while the tile is staged: svl_groupnorm_scale_shift)
+  const void* w_planes;                             // null, or the weights pre-split into the bf16 planes image of the split
+                                                    // kernel's LDS weight buffer (svl_conv3x3_weight_planes): staging a
+                                                    // slab's weights is then a copy instead of 9 N 16 splits per block
 };
 
 bool svl_conv3x3_tiled_eligible(const ConvTiledP& p);

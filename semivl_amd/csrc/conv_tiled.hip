@@ -32,7 +32,7 @@ __device__ __forceinline__ float4 gn_relu4(const float4 v, const float4 sc, cons
 // independent of how many images share the launch).
 template <int TN>
 __device__ __forceinline__ void gn_tile_partials(const ConvTiledP& p, const double (&s)[TN], const double (&q)[TN], double* red,
-                                                 int tid) {
+                                                 int tid, long slot) {
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -58,7 +58,7 @@ __device__ __forceinline__ void gn_tile_partials(const ConvTiledP& p, const doub
       ts += red[(w * 2 * TN + tid) * 2];
       tq += red[(w * 2 * TN + tid) * 2 + 1];
     }
-    double* o = p.gn_part + ((long)blockIdx.x * (2 * TN) + tid) * 2;
+    double* o = p.gn_part + (slot * (2 * TN) + tid) * 2;
     o[0] = ts;
     o[1] = tq;
   }
@@ -124,20 +124,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int f = tid + 256 * i;
-      const int pix = f >> 2, q = f & 3;
+      const int pix = min(f >> 2, NPIX - 1), q = f & 3;
       const int iy = pix / IW, ix = pix - iy * IW;
       const int y = y0 - 1 + iy, x = x0 - 1 + ix;
       const bool in = f < NPIX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W;
       rxok |= in ? (1u << i) : 0u;
-      rx[i] = in ? *reinterpret_cast<const float4*>(base + ((long)y * p.W + x) * ld + 4 * q)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      // UNCONDITIONAL load from a clamped pixel, masked when the piece is stored: a load under a per-lane condition
+      // becomes an exec-masked branch, and the s_waitcnt the compiler then needs before re-defining the destination
+      // registers at the next piece exposed the whole HBM latency of the prefetch once per slab (round 4 counters)
+      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);
+      rx[i] = *reinterpret_cast<const float4*>(base + ((long)yc * p.W + xc) * ld + 4 * q);
     }
 #pragma unroll
     for (int i = 0; i < (9 * N * 4 + 255) / 256; ++i) {
-      const int f = tid + 256 * i;                 // co fastest: consecutive lanes -> consecutive LDS columns
+      const int f = min(tid + 256 * i, nwp - 1);    // co fastest: consecutive lanes -> consecutive LDS columns
       const int co = f % N, rest = f / N, q = rest & 3, tap = rest >> 2;
-      rw[i] = f < nwp ? *reinterpret_cast<const float4*>(p.w + (long)co * p.K + tap * Ct + c0 + 4 * q)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[i] = *reinterpret_cast<const float4*>(p.w + (long)co * p.K + tap * Ct + c0 + 4 * q);
     }
   };
   auto sstore = [&]() {
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       const int f = tid + 256 * i;
       if (f < NPIX * 4) {
         float* d = xs + (f >> 2) * XS + 4 * (f & 3);
-        float4 v = rx[i];
+        float4 v = ((rxok >> i) & 1u) ? rx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (gnow) v = gn_relu4(v, gsc, gsh, (rxok >> i) & 1u);   // zero padding stays zero: it pads y, not pre
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       }
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     for (int r = 0; r < 16; ++r)
       if (ok[r]) ob[off[r]] = v[r];
   }
-  if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, reinterpret_cast<double*>(ws), tid);   // (the K loop ended with a barrier)
+  if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, reinterpret_cast<double*>(ws), tid, blockIdx.x);   // (the K loop ended with a barrier)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -244,11 +246,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 // A 16-channel slab is exactly one MFMA k-group: per tap a wave reads 3 A fragments (its 32 pixels, shifted by the tap) and
 // 3 TN B fragments (the tap's weights) and issues 6 TN MFMAs -- 54 TN per slab against 72 TN of the twice-as-long fp32
 // instruction.  Values are split ONCE when a slab is staged (the halo tile serves 9 taps, the weights 4 waves).
-// LDS rows are 32 B (16 bf16) with the two 16 B halves swapped on bit 3 of the row index: any 16 consecutive rows (pixels
-// of a patch row, output channels) then cover all 64 banks once -- conflict-free ds_read_b128 without padding, which keeps
-// the image at 17 + 55 KB (N = 64): two blocks per CU.
+// LDS rows are 32 B (16 bf16).  Weight rows: the two 16 B halves swapped on bit 3 of the row index -- the lane groups a
+// ds_read_b128 serves together ({0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} of consecutive rows) then cover all 64 banks
+// once without padding; pixel rows: see XROW in the kernel.  The image is 17 + 55 KB (N = 64): two blocks per CU.
+//
+// What bounds this kernel family (round-4 measurements: s_memtime phases with one and two blocks per CU, SQ counters): on
+// a SIMD the cycles of the wave-level ds_read_b128 (1 KiB each, ~32 cycles) and of the MFMAs (32 cycles each) ADD --
+// efficiency = MFMAs / (MFMAs + reads), whichever wave issued them.  Per tap a wave issues 3 (PT + TN) reads for 6 PT TN
+// MFMAs: 9 / 12 here (57 % of the pipe at its clock: measured 52 - 59 %), 6 / 6 with one tile per wave (the 119 - 133 TF of
+// round 3), 12 / 24 for the 64 x 64 wave tiles of gemm_bf16x_kernel (67 %), 21 / 72 for the packed-planes GEMM (77 %).
+// Splitting the weights outside the kernel, requesting fragments a tap ahead, branch-free global loads and persistent
+// blocks each removed their cost from the profile and left the time where it was; only fewer reads per MFMA move it
+// (a 2 x 2 register tile needs 86 KB of LDS at N = 64: one block per CU, staging exposed -- not taken).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32q __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split3x4(const float4 v, bf16x4& h0, bf16x4& h1, bf16x4& h2) {
   float x[4] = {v.x, v.y, v.z, v.w};
@@ -268,21 +280,55 @@ __device__ __forceinline__ int swz(int row, int q) { return row * 16 + ((((q >> 
 // PT = 32-pixel tiles per wave: PT = 2 (a 16 x 16 patch per block) doubles the MFMA work per staged weight fragment and
 // per barrier -- used for N = 32, where one tile per wave left only 54 MFMAs between two barriers (119-133 TF vs 167-171
 // at N = 64).
-template <int TN, int PT>
+//
+// WPRE: the weights arrive pre-split (ConvTiledP::w_planes).  Every block of a launch stages the same 9 x N x 16 weights
+// per slab, so splitting them in the kernel repeats ~8 VALU per element in every block: at N = 64 that is 9 of the 12
+// float4 pieces a thread splits per slab, and the split instructions share the SIMD's issue slots with the 108 MFMAs of
+// the slab (measured round 4: 165 - 183 TF, the ratio MFMA / (MFMA + split) cycles predicts).  With the planes image
+// prepared once per weight version a slab's weights are 54 N 16-byte pieces copied global -> LDS verbatim.
+#ifdef SVL_CONV_PHASE_TIMING
+__device__ unsigned long long g_conv_phase[8];   // measurement build only (tools/conv_phases.py)
+#define SVL_PH(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tl_; tl_ = tn_; }
+#else
+#define SVL_PH(i)
+#endif
+template <int TN, int PT, bool WPRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_tiled_bf16x_kernel(const ConvTiledP p, int tiles_x, int tiles_y) {
   constexpr int N = 32 * TN;
   constexpr int PHT = PH * PT, IHT = PHT + 2, NPX = IHT * IW;   // patch rows, halo rows, staged pixels
   constexpr int XP = (NPX * 4 + 255) / 256;         // input float4 pieces per thread (3 / 6)
-  constexpr int WP = (9 * N * 4 + 255) / 256;       // weight float4 pieces per thread (5 / 9)
-  constexpr int XPL = NPX * 16, WPL = 9 * N * 16;   // plane strides (bf16 elements)
+  constexpr int WP = WPRE ? 1 : (9 * N * 4 + 255) / 256;   // weight float4 pieces per thread (5 / 9)
+  // x tile in LDS: 32-byte pixels, patch rows IW * 32 + 16 bytes apart and NO swizzle.  A ds_read_b128 serves lanes
+  // {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (and the same + 32) together -- 8 pixels of patch row r and the 8 OTHER
+  // columns of row r + 1: within a row the 8 pixels cover the 8 residues (mod 8) once = banks 8 k + [0, 4) for the lanes'
+  // 16-byte half, and the odd number of 16-byte units per row puts row r + 1 on banks 8 k + [4, 8): all 64 banks once,
+  // for every tap shift.  (The round-3 layout, rows 18 pixels apart with the halves swapped on bit 3 of the pixel index,
+  // was conflict-free for 16 CONSECUTIVE lanes only: 19 % of the LDS cycles of this kernel were conflict cycles.)
+  constexpr int XROW = IW * 16 + 8;                 // bf16 elements per staged patch row
+  constexpr int XPL = IHT * XROW, WPL = 9 * N * 16; // plane strides (bf16 elements)
+  constexpr int NWQ = 3 * WPL / 8;                  // 16-byte pieces of a slab's weight planes image (54 N)
+  constexpr int WQ = WPRE ? (NWQ + 255) / 256 : 1;  // of those per thread (7 / 14)
   __shared__ __attribute__((aligned(16))) __bf16 xs[3 * XPL];
   __shared__ __attribute__((aligned(16))) __bf16 ws[3 * WPL];
+  __shared__ double gred[4 * TN * 2 * 2];           // GroupNorm partials of the four waves (ws holds the NEXT tile's weights by then)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  int t = blockIdx.x;
-  const int txi = t % tiles_x;
-  t /= tiles_x;
-  const int tyi = t % tiles_y, img = t / tiles_y;
-  const int y0 = tyi * PHT, x0 = txi * PW;
+  // PERSISTENT blocks: a block walks tiles blockIdx.x, + gridDim.x, ... and the (tile, slab) pairs form ONE pipeline -- the
+  // first slab of the next tile is requested during the last MFMA phase of this one and the result stores drain under the
+  // next tile's work.  One tile per block cost 14 % (128 -> 64 channels) to 57 % (32 -> 32) of a block's cycles in the
+  // exposed first fetch and the store tail (s_memtime phases, round 4).
+  const int ntiles = p.imgs * tiles_x * tiles_y;
+  int tile = blockIdx.x;                             // the tile being computed
+  int img, y0, x0;                                   // ... and its image / origin
+  int limg, ly0, lx0;                                // the same of the tile whose slab is being STAGED
+  auto decode = [&](int t, int& im, int& yy, int& xx) __attribute__((always_inline)) {
+    const int txi = t % tiles_x;
+    t /= tiles_x;
+    const int tyi = t % tiles_y;
+    im = t / tiles_y;
+    yy = tyi * PHT; xx = txi * PW;
+  };
+  decode(tile, img, y0, x0);
+  limg = img; ly0 = y0; lx0 = x0;
   const int Ct = p.C1 + p.C2, nslab = Ct / SLAB;
   const int nwp = 9 * N * 4;
 
@@ -296,38 +342,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   float4 rx[XP];
   float4 rw[WP];
+  u32q rq[WQ];
   float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f), gsh = make_float4(0.f, 0.f, 0.f, 0.f);   // gn_in: this thread's channel quad
   unsigned rxok = 0;                                                                      // in-image flags of rx[]
   bool gnow = false;                                                                      // the staged slab is normalised
   auto gload = [&](int s) __attribute__((always_inline)) {
     const int c0 = s * SLAB;
     const bool first = c0 < p.C1;
-    const float* base = first ? p.src1 + ((long)img * p.H) * p.W * p.ld1 + c0
-                              : p.src2 + ((long)(img / p.rep) * p.H) * p.W * p.ld2 + (c0 - p.C1);
+    const float* base = first ? p.src1 + ((long)limg * p.H) * p.W * p.ld1 + c0
+                              : p.src2 + ((long)(limg / p.rep) * p.H) * p.W * p.ld2 + (c0 - p.C1);
     const long ld = first ? p.ld1 : p.ld2;
     gnow = p.gn_in != nullptr && first;
-    if (gnow) {
-      gsc = *reinterpret_cast<const float4*>(p.gn_in + ((long)img * 2 + 0) * p.C1 + c0 + 4 * (tid & 3));
-      gsh = *reinterpret_cast<const float4*>(p.gn_in + ((long)img * 2 + 1) * p.C1 + c0 + 4 * (tid & 3));
-    }
     rxok = 0;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int f = tid + 256 * i;
-      const int pix = f >> 2, q = f & 3;
+      const int pix = min(f >> 2, NPX - 1), q = f & 3;
       const int iy = pix / IW, ix = pix - iy * IW;
-      const int y = y0 - 1 + iy, x = x0 - 1 + ix;
+      const int y = ly0 - 1 + iy, x = lx0 - 1 + ix;
       const bool in = f < NPX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W;
       rxok |= in ? (1u << i) : 0u;
-      rx[i] = in ? *reinterpret_cast<const float4*>(base + ((long)y * p.W + x) * ld + 4 * q)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);   // (unconditional: see the fp32 kernel)
+      rx[i] = *reinterpret_cast<const float4*>(base + ((long)yc * p.W + xc) * ld + 4 * q);
     }
+    if (WPRE) {
+      const u32q* wq = reinterpret_cast<const u32q*>(p.w_planes) + (long)s * NWQ;
 #pragma unroll
-    for (int i = 0; i < WP; ++i) {
-      const int f = tid + 256 * i;                 // quad fastest: 4 lanes cover the 64 contiguous bytes of one (co, tap)
-      const int q = f & 3, rest = f >> 2, co = rest % N, tap = rest / N;
-      rw[i] = f < nwp ? *reinterpret_cast<const float4*>(p.w + (long)co * p.K + tap * Ct + c0 + 4 * q)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < WQ; ++i) {
+        const int f = tid + 256 * i;
+        rq[i] = wq[f < NWQ ? f : NWQ - 1];         // (clamped, not conditional: the loads stay batched)
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WP; ++i) {
+        const int f = min(tid + 256 * i, nwp - 1);   // quad fastest: 4 lanes cover the 64 contiguous bytes of one (co, tap)
+        const int q = f & 3, rest = f >> 2, co = rest % N, tap = rest / N;
+        rw[i] = *reinterpret_cast<const float4*>(p.w + (long)co * p.K + tap * Ct + c0 + 4 * q);
+      }
+    }
+    if (gnow) {   // (last: the wait that protects the table registers then sits behind the issue of the big loads)
+      gsc = *reinterpret_cast<const float4*>(p.gn_in + ((long)limg * 2 + 0) * p.C1 + c0 + 4 * (tid & 3));
+      gsh = *reinterpret_cast<const float4*>(p.gn_in + ((long)limg * 2 + 1) * p.C1 + c0 + 4 * (tid & 3));
     }
   };
   auto sstore = [&]() __attribute__((always_inline)) {
@@ -336,56 +391,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int f = tid + 256 * i;
       if (f < NPX * 4) {
         bf16x4 h0, h1, h2;
-        split3x4(gnow ? gn_relu4(rx[i], gsc, gsh, (rxok >> i) & 1u) : rx[i], h0, h1, h2);
-        const int o = swz(f >> 2, f & 3);
+        const unsigned in = (rxok >> i) & 1u;
+        split3x4(gnow ? gn_relu4(rx[i], gsc, gsh, in) : (in ? rx[i] : make_float4(0.f, 0.f, 0.f, 0.f)), h0, h1, h2);
+        const int spx = f >> 2, siy = spx / IW;
+        const int o = siy * XROW + (spx - siy * IW) * 16 + 4 * (f & 3);
         *reinterpret_cast<bf16x4*>(xs + o) = h0;
         *reinterpret_cast<bf16x4*>(xs + XPL + o) = h1;
         *reinterpret_cast<bf16x4*>(xs + 2 * XPL + o) = h2;
       }
     }
+    if (WPRE) {
 #pragma unroll
-    for (int i = 0; i < WP; ++i) {
-      const int f = tid + 256 * i;
-      if (f < nwp) {
-        const int q = f & 3, rest = f >> 2, co = rest % N, tap = rest / N;
-        bf16x4 h0, h1, h2;
-        split3x4(rw[i], h0, h1, h2);
-        const int o = swz(tap * N + co, q);        // (N is a multiple of 8: bit 3 of the row index is bit 3 of co)
-        *reinterpret_cast<bf16x4*>(ws + o) = h0;
-        *reinterpret_cast<bf16x4*>(ws + WPL + o) = h1;
-        *reinterpret_cast<bf16x4*>(ws + 2 * WPL + o) = h2;
+      for (int i = 0; i < WQ; ++i) {
+        const int f = tid + 256 * i;
+        if (f < NWQ) reinterpret_cast<u32q*>(ws)[f] = rq[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WP; ++i) {
+        const int f = tid + 256 * i;
+        if (f < nwp) {
+          const int q = f & 3, rest = f >> 2, co = rest % N, tap = rest / N;
+          bf16x4 h0, h1, h2;
+          split3x4(rw[i], h0, h1, h2);
+          const int o = swz(tap * N + co, q);        // (N is a multiple of 8: bit 3 of the row index is bit 3 of co)
+          *reinterpret_cast<bf16x4*>(ws + o) = h0;
+          *reinterpret_cast<bf16x4*>(ws + WPL + o) = h1;
+          *reinterpret_cast<bf16x4*>(ws + 2 * WPL + o) = h2;
+        }
       }
     }
   };
 
   const int pr = wave * 2 * PT + (l31 >> 4), pc = l31 & 15;   // this lane's A-operand pixel of its first tile
+#ifdef SVL_CONV_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
   gload(0);
   sstore();
   __syncthreads();
+  SVL_PH(0)
+  // The fragments of tap t + 1 are requested BEFORE the MFMAs of tap t and the two groups are fenced: left alone the
+  // scheduler sinks every ds_read to just above its first use (register pressure), and the wave sits in s_waitcnt for
+  // the LDS latency once per MFMA pair (round 4 counters: matrix pipe 52 % busy, a quarter of the wave cycles parked).
+  bf16x8 a[2][3][PT], b[2][3][TN];
+  auto lfrag = [&](int tap, int fb) __attribute__((always_inline)) {
+    const int dy = p.sign * (tap / 3 - 1), dx = p.sign * (tap % 3 - 1);
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      const int oa = (pr + 2 * u + 1 + dy) * XROW + (pc + 1 + dx) * 16 + 8 * hi;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[fb][pl][u] = *reinterpret_cast<const bf16x8*>(xs + pl * XPL + oa);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int rb = tap * N + 32 * j + l31;
+      const int ob = rb * 16 + (((hi ^ (rb >> 3)) & 1) << 3);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[fb][pl][j] = *reinterpret_cast<const bf16x8*>(ws + pl * WPL + ob);
+    }
+  };
+  for (;;) {
   for (int s = 0; s < nslab; ++s) {
-    if (s + 1 < nslab) gload(s + 1);
+    // the next piece of the pipeline: this tile's next slab, or slab 0 of the block's next tile
+    const bool last = s + 1 == nslab;
+    const bool more = !last || tile + (int)gridDim.x < ntiles;
+    if (last && more) decode(tile + (int)gridDim.x, limg, ly0, lx0);
+    if (more) gload(last ? 0 : s + 1);
+    lfrag(0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int dy = p.sign * (tap / 3 - 1), dx = p.sign * (tap % 3 - 1);
-      bf16x8 a[3][PT], b[3][TN];
-#pragma unroll
-      for (int u = 0; u < PT; ++u) {
-        const int pa = (pr + 2 * u + 1 + dy) * IW + (pc + 1 + dx);
-        const int oa = pa * 16 + (((hi ^ (pa >> 3)) & 1) << 3);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[pl][u] = *reinterpret_cast<const bf16x8*>(xs + pl * XPL + oa);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int rb = tap * N + 32 * j + l31;
-        const int ob = rb * 16 + (((hi ^ (rb >> 3)) & 1) << 3);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[pl][j] = *reinterpret_cast<const bf16x8*>(ws + pl * WPL + ob);
-      }
+      const int fb = tap & 1;
+      if (tap + 1 < 9) lfrag(tap + 1, fb ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
       // smallest cross terms first: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
 #define SVL_CT(PA, PB)                                                                     \
   _Pragma("unroll") for (int u = 0; u < PT; ++u) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[u][j] = \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][u], b[PB][j], acc[u][j], 0, 0, 0);
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fb][PA][u], b[fb][PB][j], acc[u][j], 0, 0, 0);
       SVL_CT(2, 0)
       SVL_CT(0, 2)
       SVL_CT(1, 1)
@@ -393,14 +475,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       SVL_CT(0, 1)
       SVL_CT(0, 0)
 #undef SVL_CT
+      __builtin_amdgcn_sched_barrier(0);
     }
+    SVL_PH(1)
     __syncthreads();
-    if (s + 1 < nslab) {
-      sstore();
+    SVL_PH(2)
+    if (more) sstore();
+    SVL_PH(3)
+    if (!last) {
       __syncthreads();
+      SVL_PH(4)
     }
   }
-  // epilogue: identical to the fp32 kernel's (column = output channel, row = pixel of the wave)
+  // epilogue of the tile (its stores drain under the next tile's first MFMA phase): identical to the fp32 kernel's
+  // (column = output channel, row = pixel of the wave)
   double gs[TN], gq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.0;
@@ -421,6 +509,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       ok[r] = y < p.H && x < p.W;
       off[r] = ((long)y * p.W + x) * p.ldo;
       v[r] = acc[u][j][r] + bv;
+      acc[u][j][r] = 0.f;
     }
     if (p.gn_part) {
 #pragma unroll
@@ -448,10 +537,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int r = 0; r < 16; ++r)
       if (ok[r]) ob[off[r]] = v[r];
   }
-  if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, reinterpret_cast<double*>(ws), tid);   // (the K loop ended with a barrier)
+  if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, gred, tid, tile);   // (one barrier inside; gred is not touched by the staging)
+  SVL_PH(5)
+  tile += (int)gridDim.x;
+  if (tile >= ntiles) break;
+  img = limg; y0 = ly0; x0 = lx0;
+  __syncthreads();                                   // the staged slab 0 of the next tile is complete
+  }
+#ifdef SVL_CONV_PHASE_TIMING
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[i], ph[i]);
+    atomicAdd(&g_conv_phase[7], 1ull);
+  }
+#endif
+}
+
+// The weight planes image of conv3x3_tiled_bf16x_kernel<.., WPRE = true>: for slab s (16 input channels) the three planes
+// [pl][tap * N + co][16 channels, halves swapped by swz] exactly as the kernel lays a slab's weights out in LDS -- the same
+// split3x4 on the same values, so both forms of the kernel compute identical bits.
+__global__ __launch_bounds__(256) void conv_w_planes_kernel(const float* __restrict__ w, int N, int Ct, __bf16* __restrict__ out) {
+  const int nslab = Ct / SLAB;
+  const long total = (long)nslab * 9 * N * 4;
+  const long f = (long)blockIdx.x * 256 + threadIdx.x;
+  if (f >= total) return;
+  const int q = (int)(f & 3);
+  long rest = f >> 2;
+  const int co = (int)(rest % N);
+  rest /= N;
+  const int tap = (int)(rest % 9), s = (int)(rest / 9);
+  const float4 v = *reinterpret_cast<const float4*>(w + (long)co * (9 * Ct) + tap * Ct + s * SLAB + 4 * q);
+  bf16x4 h0, h1, h2;
+  split3x4(v, h0, h1, h2);
+  const int WPL = 9 * N * 16;
+  __bf16* o = out + (long)s * 3 * WPL + swz(tap * N + co, q);
+  *reinterpret_cast<bf16x4*>(o) = h0;
+  *reinterpret_cast<bf16x4*>(o + WPL) = h1;
+  *reinterpret_cast<bf16x4*>(o + 2 * WPL) = h2;
 }
 
 }  // namespace
+
+#ifdef SVL_CONV_PHASE_TIMING
+extern "C" int svl_debug_conv_phases(unsigned long long* out8, int reset) {
+  if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_phase), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_conv_phase), z, sizeof(z)); }
+  return SVL_OK;
+}
+#endif
+extern "C" int64_t svl_conv3x3_weight_planes_bytes(int N, int Ct) { return (int64_t)3 * 9 * N * Ct * 2; }
+
+extern "C" int svl_conv3x3_weight_planes(const float* w, int N, int Ct, void* planes, svl_stream_t stream) {
+  SVL_CHECK_ARG(w && planes && (N == 32 || N == 64) && Ct > 0 && Ct % SLAB == 0, "svl_conv3x3_weight_planes: N must be 32 / 64, Ct a multiple of 16");
+  SVL_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)planes & 15) == 0, "svl_conv3x3_weight_planes: 16-byte aligned pointers");
+  const long total = (long)(Ct / SLAB) * 9 * N * 4;
+  hipLaunchKernelGGL(conv_w_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, Ct,
+                     reinterpret_cast<__bf16*>(planes));
+  SVL_LAUNCH_CHECK("svl_conv3x3_weight_planes");
+  return SVL_OK;
+}
 
 bool svl_conv3x3_tiled_eligible(const ConvTiledP& p) {
   auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
@@ -471,12 +615,33 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st, int* tiles_per
   static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
   static const int pt2 = getenv("SVL_CONV_TILED_PT1") ? 0 : 1;
   if (emu_ok && svl_get_gemm_emulation() == 6) {   // the split emulation covers the narrow convolutions too
+    static const int wpre_ok = getenv("SVL_CONV_TILED_NO_WPLANES") ? 0 : 1;
+    const bool wpre = wpre_ok && p.w_planes != nullptr;
+    // persistent blocks: two per CU (the LDS image allows two), each walking tiles b, b + grid, ...
+    static const long resident = [] {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const char* e = getenv("SVL_CONV_TILED_BLOCKS_PER_CU");
+      const int per_cu = e ? atoi(e) : 2;
+      return (long)(cus > 0 ? cus : 256) * (per_cu > 0 ? per_cu : 2);
+    }();
     if (p.N == 32 && pt2 && p.H >= 2 * PH) {        // 16 x 16 patches: two pixel tiles per wave
       const int ty2 = (p.H + 2 * PH - 1) / (2 * PH);
       if (tiles_per_img) *tiles_per_img = tx * ty2;
-      hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 2>), dim3((unsigned)((long)p.imgs * tx * ty2)), dim3(256), 0, st, p, tx, ty2);
-    } else if (p.N == 32) hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
-    else hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
+      const long nt2 = (long)p.imgs * tx * ty2;
+      const dim3 grid2((unsigned)(nt2 < resident ? nt2 : resident));
+      if (wpre) hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 2, true>), grid2, dim3(256), 0, st, p, tx, ty2);
+      else hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 2, false>), grid2, dim3(256), 0, st, p, tx, ty2);
+    } else {
+      const dim3 grid1((unsigned)(blocks < resident ? blocks : resident));
+      if (p.N == 32) {
+        if (wpre) hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 1, true>), grid1, dim3(256), 0, st, p, tx, ty);
+        else hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 1, false>), grid1, dim3(256), 0, st, p, tx, ty);
+      } else {
+        if (wpre) hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<2, 1, true>), grid1, dim3(256), 0, st, p, tx, ty);
+        else hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<2, 1, false>), grid1, dim3(256), 0, st, p, tx, ty);
+      }
+    }
   } else if (p.N == 32) hipLaunchKernelGGL(conv3x3_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   else hipLaunchKernelGGL(conv3x3_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p, tx, ty);
   SVL_LAUNCH_CHECK("svl_gemm_f32 (tiled 3x3 conv)");
@@ -494,12 +659,12 @@ extern "C" int64_t svl_conv3x3_gn_ws_doubles(int imgs, int H, int W, int N) {
 
 extern "C" int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const float* src2, int64_t ld2, int C2, int rep,
                                   const float* w, int imgs, int H, int W, int N, float* out, int64_t ldo, float eps,
-                                  double* ws, float* stats, const float* gn_in, svl_stream_t stream) {
+                                  double* ws, float* stats, const float* gn_in, const void* w_planes, svl_stream_t stream) {
   SVL_CHECK_ARG(src1 && w && out && ws && stats && imgs > 0 && N % 16 == 0, "svl_conv3x3_gn_f32: bad args");
   ConvTiledP t;
   t.src1 = src1; t.ld1 = ld1; t.C1 = C1; t.src2 = src2; t.ld2 = ld2; t.C2 = C2; t.rep = rep < 1 ? 1 : rep;
   t.w = w; t.K = 9 * (C1 + C2); t.out = out; t.ldo = ldo; t.bias = nullptr; t.act = SVL_ACT_NONE; t.accumulate = 0;
-  t.imgs = imgs; t.H = H; t.W = W; t.N = N; t.sign = 1; t.gn_part = ws; t.gn_in = gn_in;
+  t.imgs = imgs; t.H = H; t.W = W; t.N = N; t.sign = 1; t.gn_part = ws; t.gn_in = gn_in; t.w_planes = w_planes;
   if (!svl_conv3x3_tiled_eligible(t)) return SVL_ERR_UNSUPPORTED;
   SVL_CHECK_ARG(!gn_in || (((uintptr_t)gn_in & 15) == 0 && C1 % 4 == 0), "svl_conv3x3_gn_f32: gn_in must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -565,7 +730,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3
 
   float4 rd[DP], rx[XP];
   float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f), gsh = make_float4(0.f, 0.f, 0.f, 0.f);
-  unsigned rxok = 0;
+  unsigned rxok = 0, rdok = 0;
   const int gq = tid % (SL / 4);                      // this thread's channel quad of the slab (the same for all its pieces)
   const bool gn = p.gn_in != nullptr && c0 + 4 * gq < p.C1;
   auto gload = [&](int pi) {
@@ -574,14 +739,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3
     t /= tiles_x;
     const int tyi = t % tiles_y, img = t / tiles_y;
     const int y0 = tyi * PH, x0 = txi * PW;
+    rdok = 0;
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
       const int f = tid + 256 * i;
-      const int pix = f / (Co / 4), q = f - pix * (Co / 4);
+      const int pix = min(f / (Co / 4), 127), q = f % (Co / 4);
       const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
-      rd[i] = (pix < 128 && y < p.H && x < p.W)
-                  ? *reinterpret_cast<const float4*>(p.dy + (((long)img * p.H + y) * p.W + x) * p.lddy + 4 * q)
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      rdok |= (y < p.H && x < p.W) ? (1u << i) : 0u;      // (unconditional loads from clamped pixels, masked at the store:
+      const int yc = min(y, p.H - 1), xc = min(x, p.W - 1);   //  see conv3x3_tiled_kernel)
+      rd[i] = *reinterpret_cast<const float4*>(p.dy + (((long)img * p.H + yc) * p.W + xc) * p.lddy + 4 * q);
     }
     const float* b1 = p.src1 + ((long)img * p.H) * p.W * p.ld1;
     const float* b2 = p.C2 > 0 ? p.src2 + ((long)(img / p.rep) * p.H) * p.W * p.ld2 : nullptr;
@@ -593,26 +759,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int f = tid + 256 * i;
-      const int pix = f / (SL / 4), q = f - pix * (SL / 4);
+      const int pix = min(f / (SL / 4), NPIX - 1), q = f % (SL / 4);
       const int iy = pix / IW, ix = pix - iy * IW;
       const int y = y0 - 1 + iy, x = x0 - 1 + ix;
       const int c = c0 + 4 * q;                      // a slab may straddle the two concat sources (C1 % 4 == 0)
-      const float* src = c < p.C1 ? b1 + ((long)y * p.W + x) * p.ld1 + c : b2 + ((long)y * p.W + x) * p.ld2 + (c - p.C1);
-      const bool in = pix < NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);
+      const float* src = c < p.C1 ? b1 + ((long)yc * p.W + xc) * p.ld1 + c : b2 + ((long)yc * p.W + xc) * p.ld2 + (c - p.C1);
+      const bool in = y >= 0 && y < p.H && x >= 0 && x < p.W;
       rxok |= in ? (1u << i) : 0u;
-      rx[i] = in ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[i] = *reinterpret_cast<const float4*>(src);
     }
   };
   auto sstore = [&]() {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
       const int f = tid + 256 * i;
-      if (f < 128 * Co / 4) *reinterpret_cast<float4*>(ds + 4 * f) = rd[i];
+      if (f < 128 * Co / 4) *reinterpret_cast<float4*>(ds + 4 * f) = ((rdok >> i) & 1u) ? rd[i] : z4;
     }
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int f = tid + 256 * i;
-      if (f < NPIX * SL / 4) *reinterpret_cast<float4*>(xs + 4 * f) = gn ? gn_relu4(rx[i], gsc, gsh, (rxok >> i) & 1u) : rx[i];
+      const unsigned in = (rxok >> i) & 1u;
+      if (f < NPIX * SL / 4) *reinterpret_cast<float4*>(xs + 4 * f) = gn ? gn_relu4(rx[i], gsc, gsh, in) : (in ? rx[i] : z4);
     }
   };
 

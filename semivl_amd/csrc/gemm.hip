@@ -1496,13 +1496,10 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       g_last_path = SVL_PATH_BF16X;
       return emu_mode == 6 ? launch_emu<3>(q, 1, 2, d->batch, st) : launch_emu<2>(q, 1, 2, d->batch, st);
     }
-    // (the pixel-shuffle store of ConvTranspose2d(k 2, s 2) is one of the shared epilogue's store forms: the K = 128
-    //  ConvTranspose of up1 joins the dense launches on the split pipe)
-    const bool emu_out_ok = d->out_mode == SVL_OUT_STRIDED ||
-                            (d->out_mode == SVL_OUT_CONVT2X && am == SVL_A_KCONTIG && bm == SVL_B_KCONTIG && d->batch == 1 &&
-                             d->ksplit == 0 && d->K > sk_emu_maxk_g);
+    // (the pixel-shuffle store of ConvTranspose2d(k 2, s 2) stays with the short-K stream kernel, whose epilogue writes
+    //  whole rows: through this kernel's 32 x 32 accumulator layout the K = 128 ConvTranspose of up1 ran at 31 TF, 88 there)
     if ((emu_mode == 3 || emu_mode == 6) && (am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) &&
-        (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && emu_out_ok && q.M >= 256 && q.N >= 96 &&
+        (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && q.M >= 256 && q.N >= 96 &&
         q.K >= 64) {
       g_last_path = SVL_PATH_BF16X;
       return emu_mode == 6 ? launch_emu<3>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
@@ -1533,8 +1530,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     // kernel instead: 94 -> 109 TF and 80 -> 87 TF solo, ADE 24.86 -> 25.40 img/s, VOC 77.50 -> 77.84 in the step (same
     // box, round 4).  K = 64 (ConvTranspose of up2) and the pixel-shuffle stores stay here.  SVL_SHORTK_EMU_MAXK=128 undoes it.
     const int sk_emu_maxk = sk_emu_maxk_g;
-    const bool sk_to_emu = (emu_mode == 3 || emu_mode == 6) && d->K > sk_emu_maxk &&
-                           (d->out_mode == SVL_OUT_STRIDED || (d->out_mode == SVL_OUT_CONVT2X && am == SVL_A_KCONTIG));
+    const bool sk_to_emu = (emu_mode == 3 || emu_mode == 6) && d->K > sk_emu_maxk && d->out_mode == SVL_OUT_STRIDED;
     if (shortk && !sk_to_emu && a_dense && bm == SVL_B_KCONTIG && d->batch == 1 && d->ksplit == 0 && d->K % 64 == 0 && d->K >= 64 &&
         d->K <= 128 && d->M >= 32768 && d->N >= 96 && p.A.vec && p.B.vec &&
         (d->out_mode == SVL_OUT_STRIDED || d->out_mode == SVL_OUT_CONVT2X)) {
@@ -1579,6 +1575,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     t.sign = cv.sign;
     t.gn_part = nullptr;
     t.gn_in = nullptr;
+    t.w_planes = d->conv_w_planes;
     if ((d->bias == nullptr || d->bias_mod == 0) && svl_conv3x3_tiled_eligible(t)) {
       static const int temu = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
       g_last_path = (temu && emu_mode == 6) ? SVL_PATH_BF16X : SVL_PATH_F32;

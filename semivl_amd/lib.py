@@ -38,7 +38,7 @@ class GemmDesc(C.Structure):
                 ("alpha", C.c_float), ("bias", C.c_void_p), ("bias_mod", C.c_int), ("act", C.c_int),
                 ("preact", C.c_void_p), ("resid", C.c_void_p),
                 ("ldr_m", C.c_int64), ("ldr_n", C.c_int64), ("r_bs_outer", C.c_int64), ("r_bs_inner", C.c_int64),
-                ("accumulate", C.c_int)]
+                ("accumulate", C.c_int), ("conv_w_planes", C.c_void_p)]
 
 
 class PGemmDesc(C.Structure):
@@ -120,7 +120,9 @@ SIGNATURES = {
     "svl_copy2d_f32": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _P]),
     "svl_groupnorm_fwd": (_I, [_P, _L, _P, _P, _F, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_conv3x3_gn_ws_doubles": (_L, [_I, _I, _I, _I]),
-    "svl_conv3x3_gn_f32": (_I, [_P, _L, _I, _P, _L, _I, _I, _P, _I, _I, _I, _I, _P, _L, _F, _P, _P, _P, _P]),
+    "svl_conv3x3_gn_f32": (_I, [_P, _L, _I, _P, _L, _I, _I, _P, _I, _I, _I, _I, _P, _L, _F, _P, _P, _P, _P, _P]),
+    "svl_conv3x3_weight_planes_bytes": (_L, [_I, _I]),
+    "svl_conv3x3_weight_planes": (_I, [_P, _I, _I, _P, _P]),
     "svl_groupnorm_scale_shift": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "svl_groupnorm_apply": (_I, [_P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _P, _L, _P]),
     "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),

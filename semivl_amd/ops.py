@@ -90,8 +90,9 @@ class Op:
 
 def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batch=1, batch_inner=1, ksplit=0,
          c_bso=0, c_bsi=0, alpha=1.0, bias=None, bias_mod=0, act=ACT_NONE, resid=None, r_off=0, ldr_m=None, ldr_n=1,
-         r_bso=0, r_bsi=0, accumulate=False, out_mode=OUT_STRIDED, conv=None, ct=(0, 0, 0), preact=None):
+         r_bso=0, r_bsi=0, accumulate=False, out_mode=OUT_STRIDED, conv=None, ct=(0, 0, 0), preact=None, w_planes=None):
     d = L.GemmDesc()
+    d.conv_w_planes = _p(w_planes)
     d.a_mode, d.b_mode, d.M, d.N, d.K = a_mode, b_mode, M, N, K
     d.batch, d.batch_inner, d.ksplit = batch, batch_inner, ksplit
     d.A, d.B = A.c(), B.c()
@@ -676,7 +677,7 @@ def conv3x3_gn(x, ldx, imgs, H, W, C1, wf, Co, eps, src2=None, ld2=0, C2=0, rep=
     stats = empty(imgs, Co // 16, 2, device=x.device)
     e0 = _prof_begin()
     rc = lib.svl_conv3x3_gn_f32(_p(x), ldx, C1, _p(src2), ld2, C2, rep, _p(wf), imgs, H, W, Co, _p(pre), Co, float(eps),
-                                _p(ws), _p(stats), _p(gn_in), _st())
+                                _p(ws), _p(stats), _p(gn_in), _p(w_planes_of(wf)), _st())
     if rc == -3:            # SVL_ERR_UNSUPPORTED: nothing was launched
         return None
     L.check(rc, "svl_conv3x3_gn_f32")
@@ -846,13 +847,43 @@ def cached_pack(W, tag, fn):
     return out
 
 
+CONV_W_PLANES = not os.environ.get("SVL_CONV_TILED_NO_WPLANES")
+
+
+def conv3x3_weight_planes(pack, N, Ct):
+    """bf16 x 3 planes of a narrow 3x3 convolution's packed weights [N, 9 Ct] in the tiled kernel's LDS image
+    (svl_conv3x3_weight_planes), or None when the tiled split kernel cannot use one."""
+    if not (CONV_W_PLANES and pack.is_cuda and N in (32, 64) and Ct % 16 == 0):
+        return None
+    lib = L.load()
+    pl = torch.empty(lib.svl_conv3x3_weight_planes_bytes(N, Ct), dtype=torch.uint8, device=pack.device)
+    L.check(lib.svl_conv3x3_weight_planes(_p(pack), N, Ct, _p(pl), _st()), "svl_conv3x3_weight_planes")
+    return pl
+
+
+def w_planes_of(pack):
+    """The planes image that travels with a packed weight (pack_conv_w), if any."""
+    return getattr(pack, "_svl_planes", None)
+
+
 def pack_conv_w(W):
-    """[Co, Ci, kh, kw] -> forward pack [Co, (kh kw) Ci] and dgrad pack [Ci, (kh kw) Co] (weight-sized permutes, cached)."""
+    """[Co, Ci, kh, kw] -> forward pack [Co, (kh kw) Ci] and dgrad pack [Ci, (kh kw) Co] (weight-sized permutes, cached).
+    The packs of the narrow 3x3 layers carry their pre-split planes (`w_planes_of`): built with the pack, once per
+    parameter version, kept alive and stream-tracked with it."""
     def build(w):
         Co, Ci, kh, kw = w.shape
-        return (w.permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci).contiguous(),
-                w.permute(1, 2, 3, 0).reshape(Ci, kh * kw * Co).contiguous())
-    return cached_pack(W, "conv", build)
+        wf = w.permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci).contiguous()
+        wd = w.permute(1, 2, 3, 0).reshape(Ci, kh * kw * Co).contiguous()
+        out = [wf, wd]
+        if kh == 3 and kw == 3:
+            for pk, n, ct in ((wf, Co, Ci), (wd, Ci, Co)):
+                pl = conv3x3_weight_planes(pk, n, ct)
+                if pl is not None:
+                    pk._svl_planes = pl
+                    out.append(pl)
+        return tuple(out)
+    r = cached_pack(W, "conv", build)
+    return r[0], r[1]
 
 
 def unpack_conv_wgrad(dwf, Co, Ci, kh, kw):
@@ -877,7 +908,7 @@ def conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, KH, KW, dil, pad, bias=None, act=AC
         ldo = Co
     g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
     gemm(A_CONV, B_KC, M, Co, K, Op(x, ldx), Op(wf, K), out, ldc_m=ldo, bias=bias, act=act, conv=g, resid=resid,
-         ldr_m=ldr)
+         ldr_m=ldr, w_planes=w_planes_of(wf) if (KH, dil, pad, stride) == (3, 1, 1, 1) else None)
     return out
 
 
@@ -889,7 +920,8 @@ def conv_dgrad(dy, lddy, imgs, H, W, Co, wd, Ci, KH, KW, dil, pad, out=None, ldo
         out = empty(M, Ci, device=dy.device)
         ldo = Ci
     g = conv_geom(H, W, Co, KH, KW, dil, pad, -1)
-    gemm(A_CONV, B_KC, M, Ci, K, Op(dy, lddy), Op(wd, K), out, ldc_m=ldo, conv=g, accumulate=accumulate)
+    gemm(A_CONV, B_KC, M, Ci, K, Op(dy, lddy), Op(wd, K), out, ldc_m=ldo, conv=g, accumulate=accumulate,
+         w_planes=w_planes_of(wd) if (KH, dil, pad) == (3, 1, 1) else None)
     return out
 
 

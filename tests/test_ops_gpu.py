@@ -480,6 +480,53 @@ def test_conv3x3_with_groupnorm_statistics(dev, emu_mode, C1, C2, Co, H, W, n, r
     assert ops.conv3x3_gn(nhwc(a)[: 4 * H * W], C1, 4, H, W, C1, wf, Co, 1e-5) is None or 4 * H * W >= 16384
 
 
+@pytest.mark.parametrize("C1,C2,Co,H,W,n,rep", [(64, 0, 64, 32, 32, 16, 1), (96, 32, 64, 16, 48, 24, 3), (64, 0, 32, 40, 24, 18, 1),
+                                                (32, 0, 32, 19, 37, 24, 1), (48, 16, 32, 16, 16, 66, 2)])
+def test_conv3x3_presplit_weight_planes(dev, emu_mode, C1, C2, Co, H, W, n, rep):
+    """svl_conv3x3_weight_planes: the packed weights of a narrow 3x3 convolution split once into the tiled kernel's LDS
+    image.  Forward, forward + GroupNorm statistics and the input gradient compute the same bits with the planes (a copy
+    per slab) as with the fp32 weights (a split per block and slab); the planes travel with the cached pack."""
+    from semivl_amd import ops, lib as L
+    a, b2 = rnd(n, C1, H, W, dev=dev, seed=91), (rnd(n // rep, C2, H, W, dev=dev) if C2 else None)
+    w = rnd(Co, C1 + C2, 3, 3, dev=dev, scale=0.1)
+    dy = rnd(n * H * W, Co, dev=dev, seed=92)
+    wf, wd = ops.pack_conv_w(w)
+    assert ops.w_planes_of(wf) is not None
+    assert ops.w_planes_of(wf).numel() == L.load().svl_conv3x3_weight_planes_bytes(Co, C1 + C2)
+    bare_f, bare_d = wf.clone(), wd.clone()                # the same values without a planes image
+    assert ops.w_planes_of(bare_f) is None
+    kw = dict(src2=nhwc(b2), ld2=C2, C2=C2, rep=rep) if C2 else {}
+    emu_mode(6)
+    y1 = ops.conv_fwd(nhwc(a), C1, n, H, W, C1, wf, Co, 3, 3, 1, 1, **kw)
+    assert L.load().svl_last_gemm_path() == 1
+    y0 = ops.conv_fwd(nhwc(a), C1, n, H, W, C1, bare_f, Co, 3, 3, 1, 1, **kw)
+    assert torch.equal(y0, y1)
+    g1 = ops.conv3x3_gn(nhwc(a), C1, n, H, W, C1, wf, Co, 1e-5, **kw)
+    g0 = ops.conv3x3_gn(nhwc(a), C1, n, H, W, C1, bare_f, Co, 1e-5, **kw)
+    assert torch.equal(g0[0], g1[0]) and torch.equal(g0[1], g1[1]) and torch.equal(g1[0], y1)
+    if (C1 + C2) in (32, 64):                              # the input gradient of this layer is a narrow convolution too
+        assert ops.w_planes_of(wd) is not None
+        d1 = ops.conv_dgrad(dy, Co, n, H, W, Co, wd, C1 + C2, 3, 3, 1, 1)
+        d0 = ops.conv_dgrad(dy, Co, n, H, W, Co, bare_d, C1 + C2, 3, 3, 1, 1)
+        assert torch.equal(d0, d1)
+        xg = torch.cat([a, b2.repeat_interleave(rep, 0)], 1).requires_grad_(True) if C2 else a.clone().requires_grad_(True)
+        F.conv2d(xg, w, padding=1).backward(nchw(dy, n, H, W))
+        close(nchw(d1, n, H, W), xg.grad, atol=3e-5 * math.sqrt(9 * Co) + 1e-5, what="dgrad with planes")
+    else:
+        assert ops.w_planes_of(wd) is None
+    # a parameter's planes are rebuilt with its pack when the weights change
+    par = torch.nn.Parameter(w.clone())
+    p1, _ = ops.pack_conv_w(par)
+    assert ops.pack_conv_w(par)[0] is p1 and ops.w_planes_of(p1) is not None
+    with torch.no_grad():
+        par.mul_(2.0)
+    ops.weights_changed()
+    p2, _ = ops.pack_conv_w(par)
+    assert p2 is not p1
+    y2 = ops.conv_fwd(nhwc(a), C1, n, H, W, C1, p2, Co, 3, 3, 1, 1, **kw)
+    close(y2, 2.0 * y1, atol=1e-5 * (1 + y1.abs().max().item()), what="planes of the updated weights")
+
+
 @pytest.mark.parametrize("C,Co,H,W,n", [(64, 64, 32, 32, 16), (32, 32, 40, 24, 18), (64, 32, 64, 64, 5), (32, 32, 19, 37, 24)])
 def test_groupnorm_applied_by_the_consuming_conv(dev, emu_mode, C, Co, H, W, n):
     """`gn_in`: a tiled 3x3 convolution (forward + GroupNorm statistics, and the weight gradient) whose operand is the
