@@ -52,6 +52,18 @@ LOGIT_ERR_BOUND = 1.5e-5     # asserted on every logit tensor below (measured: 4
 TIE_EPS = 2 * LOGIT_ERR_BOUND   # a pseudo-label may differ only where the ORACLE's top-2 logit gap is below this constant
 GRAD_REL_L2 = 4e-3            # per-tensor ||g - g_ref|| / ||g_ref|| (measured <= 3.0e-3: skip_proj.1 / layer-0 attention / pos_embed,
 GRAD_MAX_ERR = 6e-3           # the far ends of the chains); element-wise bound in units of the tensor's largest entry (<= 4.1e-3)
+# The tensors BEHIND the class-shared features at the far end of the backward chain: the gradient of a skip feature is the
+# sum of N class-images' input gradients that nearly cancel at random init, so the ~1e-6 rounding differences between two
+# valid fp32 evaluations come out multiplied by ~3e3 in these four (and only these) tensors.  Measured on this step, same
+# data, the product's own arithmetic variants against the fp32 oracle: exact fp32 MFMA 2.1 - 2.7e-3; split products with
+# the K = 128 row streams on the fp32 pipe 2.8 - 3.5e-3, with them on the split pipe 5.1 - 7.0e-3; one GroupNorm statistic
+# moved by 1 ulp 2.9 -> 5.2e-3 (round 4) -- a draw per rounding pattern, not an accuracy ranking: against float64
+# (test_fullsize_gradient_error_against_fp64, its own seed) both arithmetic modes stay within the asserted 3e-3 on every
+# tensor with either routing of those launches, and the fp32 oracle itself is 1.5e-3 away on skip_proj.1.0.weight.  They
+# get their own bound; every other tensor keeps GRAD_REL_L2.
+SHARED_FAR_END = ("backbone.pos_embed", "backbone.layers.0.attn.attn.in_proj_weight", "backbone.layers.0.attn.attn.out_proj.weight",
+                  "decode_head.skip_proj.1.0.weight")
+GRAD_REL_L2_SHARED = 1.2e-2
 
 
 def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stack=(), after_bn=(), after_bn_tol=None):
@@ -104,7 +116,7 @@ def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stac
     def worst_rel(ref):
         return max(((hg[n].cpu() - ref[n]).norm() / (ref[n].norm() + 1e-20)).item() for n in ref
                    if n != "decode_head.head.bias" and not any(s_ in n for s_ in bn_stack) and
-                   not any(s_ in n for s_ in after_bn))
+                   not any(s_ in n for s_ in after_bn) and n not in SHARED_FAR_END)
     # Pseudo-label ties.  The label maps above differ from the oracle's at a handful of pixels whose top-2 logit gap is
     # below either implementation's rounding error -- legitimately, but at random init a gradient tensor is an incoherent
     # sum over ~5e5 pixels, so ONE flipped target moves it by ~1/sqrt(#pixels) ~ 1.4e-3 of its norm, and WHICH ties flip
@@ -137,6 +149,8 @@ def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stac
             assert rel2 < 3e-2 or ref.norm().item() < 1e-7, f"{n}: rel L2 {rel2}"
             continue
         tol2 = after_bn_tol if (after_bn_tol is not None and any(s_ in n for s_ in after_bn)) else GRAD_REL_L2
+        if n in SHARED_FAR_END:
+            tol2 = max(tol2, GRAD_REL_L2_SHARED)
         assert rel2 < tol2, f"{n}: grad rel L2 {rel2} (bound {tol2})"
         assert err < (GRAD_MAX_ERR if tol2 == GRAD_REL_L2 else 1.5 * tol2) * scale + 1e-8, f"{n}: grad max err {err} vs scale {scale}"
     return haux
