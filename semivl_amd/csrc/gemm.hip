@@ -18,6 +18,7 @@
 // optional second concatenated source), the patch-embedding gather, conv wgrad (im2col^T) and split-K.
 #include "svl_common.h"
 #include "conv_tiled.h"
+#include "gemm_shortk.h"
 #include <atomic>
 #include <type_traits>
 #include <stdlib.h>
@@ -1536,6 +1537,19 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         (d->out_mode == SVL_OUT_STRIDED || d->out_mode == SVL_OUT_CONVT2X)) {
       const bool fast = (d->ldc_n == 1 || d->out_mode == SVL_OUT_CONVT2X) && !d->resid && !d->preact && !d->accumulate &&
                         (d->act == SVL_ACT_NONE || d->act == SVL_ACT_RELU || d->act == SVL_ACT_GELU);
+      // the ConvTranspose2d(k 2, s 2) layers (and any K = 64 stream) in emulation mode 6: the same stream structure on
+      // the split pipe (gemm_shortk.hip) -- these were the largest launches left on the fp32 matrix pipe
+      static const int sk_x6 = getenv("SVL_SHORTK_NO_X6") ? 0 : 1;
+      if (fast && emu_mode == 6 && sk_x6 && (d->out_mode == SVL_OUT_CONVT2X || d->K == 64)) {
+        ShortKP q;
+        q.A = d->A.ptr; q.lda = d->A.ld; q.B = d->B.ptr; q.ldb = d->B.ld; q.C = d->C; q.ldc_m = d->ldc_m;
+        q.M = d->M; q.N = d->N; q.K = d->K; q.out_mode = d->out_mode; q.ct_H = d->ct_H; q.ct_W = d->ct_W;
+        q.ct_Cout = d->ct_Cout; q.alpha = d->alpha; q.bias = d->bias; q.bias_mod = d->bias_mod; q.act = d->act;
+        if (svl_shortk_x6_eligible(q)) {
+          g_last_path = SVL_PATH_BF16X;
+          return svl_shortk_x6_launch(q, st);
+        }
+      }
       g_last_path = SVL_PATH_SHORTK;
       return launch_shortk(p, fast, st);
     }

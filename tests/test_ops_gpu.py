@@ -783,6 +783,33 @@ def test_gemm_shortk_convT_and_1x1(dev):
     close(nchw(y, n, H, H), F.relu(F.conv2d(x, w1, b.repeat(3)[:128])), atol=5e-4, what="short-K 1x1 conv")
 
 
+@pytest.mark.parametrize("n,Ci,Co,H,W,extra", [(9, 64, 48, 64, 64, 16), (3, 128, 96, 96, 128, 0), (5, 64, 48, 72, 100, 16),
+                                               (2, 128, 33, 128, 130, 7)])
+def test_convT_split_stream(dev, emu_mode, n, Ci, Co, H, W, extra):
+    """ConvTranspose2d(k 2, s 2) of the Up blocks in emulation mode 6: gemm_shortk.hip (the row stream of the fp32 kernel
+    with bf16 x 3 operands, six products).  Error vs float64 at the level of the fp32 stream's (same bound as every
+    other split kernel), the pixel-shuffle store into a concat slice leaves the other channels alone, ragged row counts
+    and column chunks (4 Co not a multiple of 32 / of the chunk), and the library reports the split pipe."""
+    from semivl_amd import ops, lib as L
+    x = rnd(n, Ci, H, W, dev=dev, seed=61)
+    w = rnd(Ci, Co, 2, 2, dev=dev, scale=0.1)
+    b = rnd(Co, dev=dev)
+    ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
+    wp = w.permute(2, 3, 1, 0).reshape(4 * Co, Ci).contiguous()
+    err = {}
+    for mode in (0, 6):
+        emu_mode(mode)
+        out = torch.full((n * 4 * H * W, Co + extra), 7.0, device=dev)
+        ops.convT2x_fwd(nhwc(x), Ci, n, H, W, Ci, wp, Co, b, out, Co + extra)
+        # (16-byte stores of 4 consecutive columns: Cout % 4 == 0, else the fp32 stream kernel keeps the launch)
+        assert L.load().svl_last_gemm_path() == (1 if (mode == 6 and Co % 4 == 0) else 2), mode
+        got = out.view(n, 2 * H, 2 * W, Co + extra)[..., :Co].permute(0, 3, 1, 2)
+        err[mode] = _relerr(got, ref)
+        assert (out[:, Co:] == 7.0).all()
+    assert err[6] <= EMU6_ERR_FACTOR * err[0] + 1e-9, err
+    assert err[6] < 5e-7, err
+
+
 def test_patch_embed(dev):
     from semivl_amd import ops
     n, S, P, E = 2, 64, 16, 768
