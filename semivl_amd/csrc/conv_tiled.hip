@@ -64,42 +64,6 @@ __device__ __forceinline__ void gn_tile_partials(const ConvTiledP& p, const doub
   }
 }
 
-// The same for TRANSPOSED accumulators (rows = channels, columns = the wave's 32 pixels: conv3x3_tiled_bf16x_kernel): a lane
-// holds one pixel and, per 32-channel tile, 8 values of each of its two groups; all 64 lanes are combined.
-template <int TN>
-__device__ __forceinline__ void gn_tile_partials_t(const ConvTiledP& p, const double (&s)[TN][2], const double (&q)[TN][2],
-                                                   double* red, int tid, long slot) {
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      double ds = s[j][h], dq = q[j][h];
-#pragma unroll
-      for (int m = 1; m <= 32; m <<= 1) {
-        ds += __shfl_xor(ds, m, 64);
-        dq += __shfl_xor(dq, m, 64);
-      }
-      if (lane == 0) {
-        double* d = red + ((wave * TN + j) * 2 + h) * 2;
-        d[0] = ds;
-        d[1] = dq;
-      }
-    }
-  __syncthreads();
-  if (tid < 2 * TN) {                             // group tid = 2 j + half
-    double ts = 0.0, tq = 0.0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      ts += red[(w * 2 * TN + tid) * 2];
-      tq += red[(w * 2 * TN + tid) * 2 + 1];
-    }
-    double* o = p.gn_part + (slot * (2 * TN) + tid) * 2;
-    o[0] = ts;
-    o[1] = tq;
-  }
-}
-
 __global__ void gn_finalize_kernel(const double* __restrict__ part, int tiles, int G, double n, float eps, long count,
                                    float* __restrict__ stats) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;    // (img, group)
@@ -503,7 +467,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // smallest cross terms first: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
 #define SVL_CT(PA, PB)                                                                     \
   _Pragma("unroll") for (int u = 0; u < PT; ++u) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[u][j] = \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[fb][PB][j], a[fb][PA][u], acc[u][j], 0, 0, 0);
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fb][PA][u], b[fb][PB][j], acc[u][j], 0, 0, 0);
       SVL_CT(2, 0)
       SVL_CT(0, 2)
       SVL_CT(1, 1)
@@ -523,52 +487,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       SVL_PH(4)
     }
   }
-  // epilogue of the tile (its stores drain under the next tile's first MFMA phase).  The products are issued with the
-  // WEIGHTS as the MFMA's A operand: accumulator rows are output channels, columns the wave's 32 pixels -- a lane owns one
-  // pixel and 4 consecutive channels per accumulator quad: 16-byte stores (4 TN per pixel tile instead of 16 TN dword
-  // stores; the store tail was 5 - 19 % of a block's cycles and store-ISSUE-bound, gemm_shortk.hip).
-  double gs[TN][2], gq[TN][2];
+  // epilogue of the tile (its stores drain under the next tile's first MFMA phase): identical to the fp32 kernel's
+  // (column = output channel, row = pixel of the wave)
+  double gs[TN], gq[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) gs[j][0] = gs[j][1] = gq[j][0] = gq[j][1] = 0.0;
+  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.0;
 #pragma unroll
-  for (int u = 0; u < PT; ++u) {
-    const int y = y0 + wave * 2 * PT + 2 * u + (l31 >> 4), x = x0 + (l31 & 15);
-    const bool ok = y < p.H && x < p.W;
-    float* ob = p.out + (((long)img * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1)) * p.ldo;
+  for (int u = 0; u < PT; ++u)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+  for (int j = 0; j < TN; ++j) {
+    const int co = l31 + 32 * j;
+    const float bv = p.bias ? p.bias[co] : 0.f;
+    float* ob = p.out + (long)img * p.H * p.W * p.ldo + co;
+    float v[16];
+    long off[16];
+    bool ok[16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = 32 * j + 8 * q + 4 * hi;
-        float v[4];
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int y = y0 + wave * 2 * PT + 2 * u + (i >> 4), x = x0 + (i & 15);
+      ok[r] = y < p.H && x < p.W;
+      off[r] = ((long)y * p.W + x) * p.ldo;
+      v[r] = acc[u][j][r] + bv;
+      acc[u][j][r] = 0.f;
+    }
+    if (p.gn_part) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[u][j][4 * q + e] + (p.bias ? p.bias[co + e] : 0.f);
-          acc[u][j][4 * q + e] = 0.f;
-        }
-        if (p.gn_part) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const double t = ok ? (double)v[e] : 0.0;
-            gs[j][q >> 1] += t;
-            gq[j][q >> 1] += t * t;
-          }
-        }
-        if (p.act == SVL_ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-        } else if (p.act == SVL_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (p.accumulate) {
-          const float4 prev = *reinterpret_cast<const float4*>(ob + co);   // (clamped pixel: always readable)
-          v[0] += prev.x; v[1] += prev.y; v[2] += prev.z; v[3] += prev.w;
-        }
-        if (ok) *reinterpret_cast<float4*>(ob + co) = make_float4(v[0], v[1], v[2], v[3]);
+      for (int r = 0; r < 16; ++r) {
+        const double t = ok[r] ? (double)v[r] : 0.0;
+        gs[j] += t;
+        gq[j] += t * t;
       }
+    }
+    if (p.act == SVL_ACT_GELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+    } else if (p.act == SVL_ACT_RELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (p.accumulate) {
+      float prev[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[r] = ok[r] ? ob[off[r]] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += prev[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) ob[off[r]] = v[r];
   }
-  if (p.gn_part) gn_tile_partials_t<TN>(p, gs, gq, gred, tid, tile);   // (one barrier inside; gred is not touched by the staging)
+  if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, gred, tid, tile);   // (one barrier inside; gred is not touched by the staging)
   SVL_PH(5)
   tile += (int)gridDim.x;
   if (tile >= ntiles) break;
@@ -633,7 +602,6 @@ bool svl_conv3x3_tiled_eligible(const ConvTiledP& p) {
   if (!(p.N == 32 || p.N == 64)) return false;
   if (p.C1 <= 0 || p.C1 % SLAB || p.C2 % SLAB || p.K != 9 * (p.C1 + p.C2) || p.K % 4) return false;
   if (p.ld1 % 4 || !a16(p.src1) || !a16(p.w)) return false;
-  if (p.ldo % 4 || !a16(p.out)) return false;                     // (the split kernel stores 4 consecutive channels at once)
   if (p.C2 > 0 && (!p.src2 || p.rep < 1 || p.ld2 % 4 || !a16(p.src2))) return false;
   if (p.act != SVL_ACT_NONE && p.act != SVL_ACT_GELU && p.act != SVL_ACT_RELU) return false;
   return (long)p.imgs * p.H * p.W >= 16384 && p.H >= PH && p.W >= PW;
