@@ -156,7 +156,8 @@ int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream);
  *   6  fp32-accurate emulation on the bf16 matrix pipe: every operand element is split into 3 bf16 terms and the 6
  *      leading cross products are accumulated in fp32 (error <= the fp32 path's, 2.7x the MFMA rate).  Mode 6 also
  *      covers svl_attention_{fwd,bwd} (all five products of the fused attention; S is recomputed bit-identically in
- *      the backward) and the forward / input gradient of the spatially tiled 3x3 convolutions;
+ *      the backward), the forward / input gradient of the spatially tiled 3x3 convolutions, and the K = 64 / 128 row
+ *      streams with the ConvTranspose2d(k 2, s 2) pixel-shuffle store (SVL_OUT_CONVT2X; csrc/gemm_shortk.hip);
  *   3  2-term split, 3 products (~16 mantissa bits, 5.3x the MFMA rate); dense GEMMs only.
  * Initial value: environment variable SVL_GEMM_EMU (0 if unset).  Inputs, outputs and accumulation stay fp32.
  * A/B switches (read once per process): SVL_ATTN_NO_EMU, SVL_CONV_TILED_NO_EMU keep those kernels on the fp32 pipe. */
