@@ -250,14 +250,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 // ds_read_b128 serves together ({0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} of consecutive rows) then cover all 64 banks
 // once without padding; pixel rows: see XROW in the kernel.  The image is 17 + 55 KB (N = 64): two blocks per CU.
 //
-// What bounds this kernel family (round-4 measurements: s_memtime phases with one and two blocks per CU, SQ counters): on
-// a SIMD the cycles of the wave-level ds_read_b128 (1 KiB each, ~32 cycles) and of the MFMAs (32 cycles each) ADD --
-// efficiency = MFMAs / (MFMAs + reads), whichever wave issued them.  Per tap a wave issues 3 (PT + TN) reads for 6 PT TN
-// MFMAs: 9 / 12 here (57 % of the pipe at its clock: measured 52 - 59 %), 6 / 6 with one tile per wave (the 119 - 133 TF of
-// round 3), 12 / 24 for the 64 x 64 wave tiles of gemm_bf16x_kernel (67 %), 21 / 72 for the packed-planes GEMM (77 %).
-// Splitting the weights outside the kernel, requesting fragments a tap ahead, branch-free global loads and persistent
-// blocks each removed their cost from the profile and left the time where it was; only fewer reads per MFMA move it
-// (a 2 x 2 register tile needs 86 KB of LDS at N = 64: one block per CU, staging exposed -- not taken).
+// What bounds this kernel family (round-4 measurements: s_memtime phases with one and two blocks per CU, SQ counters).  A
+// wave issues in order, and a wave-level ds_read_b128 (1 KiB) costs it about as many cycles as an MFMA (32): alone on its
+// SIMD a wave runs the 108 MFMAs + 81 reads of a slab in 6192 cycles = 57 per MFMA = 32 (1 + 81 / 108) -- for a wave that
+// mixes the two, efficiency <= MFMAs / (MFMAs + reads): 9 reads / 12 MFMAs per tap here, 6 / 6 with one tile per wave (the
+// 119 - 133 TF of round 3), 12 / 24 for the 64 x 64 wave tiles of gemm_bf16x_kernel.  The second wave of the SIMD (the other
+// block of the CU) fills the gaps only partly while it is itself a mix of reads and MFMAs: 38.5 cycles per MFMA when both
+// are in their MFMA phase, 52 - 59 % of the pipe over the whole kernel.  gemm_planes.hip shows what full overlap takes: the two
+// waves of a SIMD in STRICT alternation (one issues only MFMAs while the other only reads and copies, a barrier interval
+// apart): 33 cycles per MFMA.  Splitting the weights outside the kernel, requesting fragments a tap ahead, branch-free
+// global loads and persistent blocks each removed their cost from the profile and left the time where it was (the MFMA
+// phase stretched by the same amount); only the conflict-free pixel rows moved it.  Next: either fewer reads per MFMA
+// (a 2 x 2 register tile needs 86 KB of LDS at N = 64: one block per CU) or the role split of gemm_planes.hip in one
+// 8-wave block per CU (two patches, shared weights: 90 KB).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32q __attribute__((ext_vector_type(4)));

@@ -12,7 +12,8 @@
 //   * six cross products per (k-group, 32-column tile), smallest terms first, fp32 accumulate: error vs float64 at the
 //     level of the fp32 chain's (tests/test_ops_gpu.py);
 //   * the panel is the MFMA's A operand, so a lane owns 4 consecutive output columns of one row: 16-byte stores.
-// Reads per MFMA (conv_tiled.hip has the measured law): 3 B fragments for 6 MFMAs, the A operand never touches LDS.
+// Reads per MFMA (conv_tiled.hip: what a wave that mixes the two can reach): 3 B fragments for 6 MFMAs, the A operand
+// never touches LDS.
 #include "gemm_shortk.h"
 #include <stdlib.h>
 #include <atomic>
