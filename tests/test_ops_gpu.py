@@ -1,6 +1,7 @@
 """Per-kernel parity of the HIP C-ABI against plain PyTorch fp32 ops on the same device (ATen is only the checker
 here).  Everything goes through semivl_amd.ops -> ctypes -> libsemivl_hip.so."""
 import math
+import os
 
 import pytest
 import torch
@@ -525,6 +526,54 @@ def test_conv3x3_presplit_weight_planes(dev, emu_mode, C1, C2, Co, H, W, n, rep)
     assert p2 is not p1
     y2 = ops.conv_fwd(nhwc(a), C1, n, H, W, C1, p2, Co, 3, 3, 1, 1, **kw)
     close(y2, 2.0 * y1, atol=1e-5 * (1 + y1.abs().max().item()), what="planes of the updated weights")
+
+
+def test_role_split_tiled_conv_is_bit_identical(dev):
+    """conv3x3_tiled_rs_kernel (SVL_CONV_TILED_RS=1, off by default: an 8-wave block per CU whose two groups alternate
+    between a memory phase and a pure MFMA phase): same accumulation order per accumulator as the default
+    kernel, so forward, forward + GroupNorm statistics (+ gn_in) and the input gradient must agree BIT FOR BIT with it --
+    ragged edges, odd tile counts (one group idles at the end) and both channel widths.  The switch is read once per
+    process: the check runs in a child."""
+    import subprocess, sys
+    code = r"""
+import torch, sys
+sys.path.insert(0, %r)
+from semivl_amd import ops
+dev = torch.device('cuda:0')
+ops.set_gemm_emulation(6)
+torch.manual_seed(5)
+for (C1, C2, Co, H, W, n, rep) in [(64, 0, 64, 32, 32, 16, 1), (96, 32, 64, 16, 48, 24, 3), (64, 0, 32, 40, 24, 18, 1),
+                                   (32, 0, 32, 19, 37, 24, 1), (48, 16, 32, 16, 16, 66, 2), (64, 0, 64, 24, 40, 19, 1)]:
+    a = torch.randn(n * H * W, C1, device=dev)
+    b2 = torch.randn((n // rep) * H * W, C2, device=dev) if C2 else None
+    w = torch.randn(Co, C1 + C2, 3, 3, device=dev) * 0.1
+    wf, wd = ops.pack_conv_w(w)
+    bare_f, bare_d = wf.clone(), wd.clone()          # no planes image: the default kernel serves these launches
+    kw = dict(src2=b2, ld2=C2, C2=C2, rep=rep) if C2 else {}
+    y1 = ops.conv_fwd(a, C1, n, H, W, C1, wf, Co, 3, 3, 1, 1, **kw)
+    y0 = ops.conv_fwd(a, C1, n, H, W, C1, bare_f, Co, 3, 3, 1, 1, **kw)
+    assert torch.equal(y0, y1), ('fwd', C1, C2, Co)
+    g1 = ops.conv3x3_gn(a, C1, n, H, W, C1, wf, Co, 1e-5, **kw)
+    g0 = ops.conv3x3_gn(a, C1, n, H, W, C1, bare_f, Co, 1e-5, **kw)
+    assert torch.equal(g0[0], g1[0]) and torch.equal(g0[1], g1[1]), ('gn', C1, C2, Co)
+    if not C2:
+        gam, bet = torch.rand(C1, device=dev) + 0.5, torch.randn(C1, device=dev)
+        yy = ops.empty(n * H * W, C1, device=dev)
+        st = ops.groupnorm_fwd(a, C1, gam, bet, 1e-5, n, H * W, C1, C1 // 16, True, yy, C1)
+        tab = ops.groupnorm_scale_shift(st, gam, bet, n, C1, C1 // 16)
+        h1 = ops.conv3x3_gn(a, C1, n, H, W, C1, wf, Co, 1e-5, gn_in=tab)
+        h0 = ops.conv3x3_gn(a, C1, n, H, W, C1, bare_f, Co, 1e-5, gn_in=tab)
+        assert torch.equal(h0[0], h1[0]) and torch.equal(h0[1], h1[1]), ('gn_in', C1, Co)
+    if (C1 + C2) in (32, 64):
+        dy = torch.randn(n * H * W, Co, device=dev)
+        d1 = ops.conv_dgrad(dy, Co, n, H, W, Co, wd, C1 + C2, 3, 3, 1, 1)
+        d0 = ops.conv_dgrad(dy, Co, n, H, W, Co, bare_d, C1 + C2, 3, 3, 1, 1)
+        assert torch.equal(d0, d1), ('dgrad', C1, C2, Co)
+print('role-split ok')
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVL_CONV_TILED_RS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "role-split ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("C,Co,H,W,n", [(64, 64, 32, 32, 16), (32, 32, 40, 24, 18), (64, 32, 64, 64, 5), (32, 32, 19, 37, 24)])
