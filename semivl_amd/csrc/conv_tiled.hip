@@ -623,26 +623,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned rxok = 0;
   bool gnow = false;
   int limg, ly0, lx0;                                 // patch of the tile being STAGED
-  decode(t0 + grp, limg, ly0, lx0);
+  int pixo[XP];                                       // ... its pieces' clamped pixel index inside the image, in-image flags
+  unsigned tok = 0;
+  auto xtile = [&](int t) __attribute__((always_inline)) {     // once per tile: everything of a piece's address but the channel
+    decode(t, limg, ly0, lx0);
+    tok = 0;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int f = gt + 256 * i;
+      const int pix = min(f >> 2, NPX - 1);
+      const int iy = pix / IW, ix = pix - iy * IW;
+      const int y = ly0 - 1 + iy, x = lx0 - 1 + ix;
+      const bool in = f < NPX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      tok |= in ? (1u << i) : 0u;
+      pixo[i] = min(max(y, 0), p.H - 1) * p.W + min(max(x, 0), p.W - 1);
+    }
+  };
+  xtile(t0 + grp);
   auto xload = [&](int ls) __attribute__((always_inline)) {
     const int c0 = ls * SLAB;
     const bool first = c0 < p.C1;
     const float* base = first ? p.src1 + ((long)limg * p.H) * p.W * p.ld1 + c0
                               : p.src2 + ((long)(limg / p.rep) * p.H) * p.W * p.ld2 + (c0 - p.C1);
-    const long ld = first ? p.ld1 : p.ld2;
+    const int ld = (int)(first ? p.ld1 : p.ld2);
     gnow = p.gn_in != nullptr && first;
-    rxok = 0;
+    rxok = tok;
+    base += 4 * (gt & 3);
 #pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      const int f = gt + 256 * i;
-      const int pix = min(f >> 2, NPX - 1), q = f & 3;
-      const int iy = pix / IW, ix = pix - iy * IW;
-      const int y = ly0 - 1 + iy, x = lx0 - 1 + ix;
-      const bool in = f < NPX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W;
-      rxok |= in ? (1u << i) : 0u;
-      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);
-      rx[i] = *reinterpret_cast<const float4*>(base + ((long)yc * p.W + xc) * ld + 4 * q);
-    }
+    for (int i = 0; i < XP; ++i) rx[i] = *reinterpret_cast<const float4*>(base + (long)pixo[i] * ld);
     if (gnow) {
       gsc = *reinterpret_cast<const float4*>(p.gn_in + ((long)limg * 2 + 0) * p.C1 + c0 + 4 * (gt & 3));
       gsh = *reinterpret_cast<const float4*>(p.gn_in + ((long)limg * 2 + 1) * p.C1 + c0 + 4 * (gt & 3));
@@ -744,32 +752,56 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         double gs[TN], gq[TN];
 #pragma unroll
         for (int jj = 0; jj < TN; ++jj) gs[jj] = gq[jj] = 0.0;
+        float* obase = p.out + (long)img * p.H * p.W * p.ldo + l31;
+        const int ldo = (int)p.ldo;
 #pragma unroll
-        for (int u = 0; u < PT; ++u)
+        for (int u = 0; u < PT; ++u) {
+          int off[16];                                  // (the fragment registers are dead here: room for the whole tile's offsets)
+          unsigned okm = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int y = y0 + gw * 2 * PT + 2 * u + (i >> 4), x = x0 + (i & 15);
+            okm |= (tvalid && y < p.H && x < p.W) ? (1u << r) : 0u;
+            off[r] = (min(y, p.H - 1) * p.W + min(x, p.W - 1)) * ldo;
+          }
 #pragma unroll
           for (int jj = 0; jj < TN; ++jj) {
-            const int co = l31 + 32 * jj;
-            const float bv = p.bias ? p.bias[co] : 0.f;
-            float* ob = p.out + (long)img * p.H * p.W * p.ldo + co;
+            const float bv = p.bias ? p.bias[l31 + 32 * jj] : 0.f;
+            float* ob = obase + 32 * jj;
+            float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-              const int y = y0 + gw * 2 * PT + 2 * u + (i >> 4), x = x0 + (i & 15);
-              const bool ok = tvalid && y < p.H && x < p.W;
-              float* op = ob + ((long)min(y, p.H - 1) * p.W + min(x, p.W - 1)) * p.ldo;
-              float v = acc[u][jj][r] + bv;
+              v[r] = acc[u][jj][r] + bv;
               acc[u][jj][r] = 0.f;
-              if (p.gn_part) {
-                const double t = ok ? (double)v : 0.0;
-                gs[jj] += t;
-                gq[jj] += t * t;
-              }
-              if (p.act == SVL_ACT_GELU) v = gelu_erf(v);
-              else if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
-              if (p.accumulate) v += *op;
-              if (ok) *op = v;
             }
+            if (p.gn_part) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const double t_ = ((okm >> r) & 1u) ? (double)v[r] : 0.0;
+                gs[jj] += t_;
+                gq[jj] += t_ * t_;
+              }
+            }
+            if (p.act == SVL_ACT_GELU) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+            } else if (p.act == SVL_ACT_RELU) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (p.accumulate) {
+              float prev[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) prev[r] = ob[off[r]];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] += prev[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if ((okm >> r) & 1u) ob[off[r]] = v[r];
           }
+        }
         if (p.gn_part) {                                // wave partials (the order of gn_tile_partials)
 #pragma unroll
           for (int jj = 0; jj < TN; ++jj) {
@@ -802,12 +834,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           if (lks == nslab) {                           // the next slab opens this group's next tile
             lks = 0;
             lkk = lkk + 1;
-            decode(t0 + grp + lkk * tstride, limg, ly0, lx0);
+            xtile(t0 + grp + lkk * tstride);
           }
           xload(lks);
         }
-        SVL_PH(1)
-        // fragments of this row
+      }
+      SVL_PH(1)
+      {
+        // fragments of this row (unconditionally -- past the last row they are never used, but a conditional definition
+        // would keep the previous row's 108 registers alive through the epilogue above)
         const __bf16* xs = xs0 + (size_t)cpar * 3 * XPL;
         const int dyo = p.sign * (cr - 1) * XROW, dxs = p.sign * 16;
         const __bf16* wr = ws + bbase + cr * 3 * N * 16;

@@ -26,6 +26,6 @@ for (C, Co, Hh) in [(128, 64, 64), (64, 64, 64), (64, 32, 128), (32, 32, 128)]:
     fn(ctypes.cast(buf, ctypes.c_void_p), 0)
     nb, ni = max(1, buf[7]), max(1, buf[6])
     per = ni / nb
-    names = ["epilogue", "staging", "reads+wait", "mfma", "barrier"]
+    names = ["epilogue", "wstore", "wload", "xstore", "xload", "reads+wait"]
     print(f"{C:3d}->{Co:3d} {Hh}x{Hh}: blocks {nb}, intervals/block {per:.0f}; group 0, cycles per interval PAIR: " +
           "  ".join(f"{n} {2 * buf[i] / ni:6.0f}" for i, n in enumerate(names)), flush=True)
