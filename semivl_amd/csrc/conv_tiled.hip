@@ -574,6 +574,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   a tile's epilogue runs at the start of the MEM phase after its last row; the GroupNorm partials of the four waves are
 //   summed one MEM phase later (the interval barriers order the two steps).
 // Accumulation order per accumulator = taps in order, six terms each: bit-identical to conv3x3_tiled_bf16x_kernel.
+// STATUS (round 4): opt-in (SVL_CONV_TILED_RS=1), 139 - 149 TF at N = 64 against the default kernel's 150 - 160.  s_memtime
+// per MEM phase (tools/conv_phases_rs.py): the 27 fragment reads + their wait 555 cycles, the MFMA phase 1463 -- but every
+// VALU instruction of a MEM phase waits for a gap in the partner's back-to-back MFMAs (~30 cycles each): the pixel split
+// costs 1650 cycles per slab, the address arithmetic of its loads 1070, the tile epilogue (~600 VALU) 12 k cycles on the
+// interval's critical path.  gemm_planes.hip's memory phase has no VALU at all.  To finish this kernel the VALU work has
+// to move into the MFMA phase of the SAME wave (the split and the epilogue as fillers between its own MFMAs, accumulators
+// copied aside), leaving reads, LDS writes and loads at precomputed addresses for the MEM phase.
 template <int TN, int PT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_tiled_rs_kernel(const ConvTiledP p, int tiles_x, int tiles_y) {
   constexpr int N = 32 * TN;
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
   for (int it = 0; it < nint; ++it) {
     const int j = it - grp;
-    SVL_PH(4)
+    SVL_PH(6)
     if (j >= 0 && (j & 1) == 0) {
       // ------------------------------------------------------------------ MEM(m)
       if (pend_tile >= 0) {                             // (written one MEM phase = two barriers ago)
@@ -826,9 +833,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (m < Q) {
         // staging: weights of row m + 2 (requested in the previous MEM phase), request row m + 3 (= row cr of the next slab)
         if (m + 2 < Q) wstore(cr == 0 ? 2 : cr - 1);
+        SVL_PH(1)
         if (m + 3 < Q) wload(cs + 1 == nslab ? 0 : cs + 1, cr);
+        SVL_PH(2)
         // pixels of the next slab: request in the slab's first row, split + write in its last
         if (cr == 2 && m + 1 < Q) xstore(cpar ^ 1);
+        SVL_PH(3)
         if (cr == 0 && m + 3 < Q) {
           lks = lks + 1;
           if (lks == nslab) {                           // the next slab opens this group's next tile
@@ -839,7 +849,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           xload(lks);
         }
       }
-      SVL_PH(1)
+      SVL_PH(4)
       {
         // fragments of this row (unconditionally -- past the last row they are never used, but a conditional definition
         // would keep the previous row's 108 registers alive through the epilogue above)
@@ -865,7 +875,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifdef SVL_CONV_PHASE_TIMING
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-      SVL_PH(2)
+      SVL_PH(5)
       // advance the row counters
       m = m + 1;
       cr = cr + 1;
@@ -892,7 +902,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef SVL_RS
         }
       }
-      SVL_PH(3)
+      SVL_PH(6)
     }
     // interval barrier: LDS traffic drained, but NOT the global loads in flight for later phases (__syncthreads() would
     // add s_waitcnt vmcnt(0): the whole L2 / HBM latency of the staging loads inside every MEM phase)
@@ -902,7 +912,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifdef SVL_CONV_PHASE_TIMING
   if (tid == 0) {                                   // (group 0's first wave)
 #pragma unroll
-    for (int i = 0; i < 5; ++i) atomicAdd(&g_conv_phase[i], ph[i]);
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[i], ph[i]);   // epilogue | wstore | wload | xstore | xload | reads (6: MFMA + barrier, not reported)
     atomicAdd(&g_conv_phase[6], (unsigned long long)nint);
     atomicAdd(&g_conv_phase[7], 1ull);
   }
