@@ -493,55 +493,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       SVL_PH(4)
     }
   }
-  // epilogue of the tile (its stores drain under the next tile's first MFMA phase): identical to the fp32 kernel's
-  // (column = output channel, row = pixel of the wave)
+  // epilogue of the tile (its stores drain under the next tile's first MFMA phase): the fp32 kernel's (column = output
+  // channel, row = pixel of the wave), with the pixel offsets formed once per pixel tile in 32 bits -- the epilogue's VALU
+  // instructions wait for gaps in the other block's MFMA stream like every VALU instruction of a staging phase
   double gs[TN], gq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.0;
+  {
+    float* obase = p.out + (long)img * p.H * p.W * p.ldo + l31;
+    const int ldo = (int)p.ldo;
 #pragma unroll
-  for (int u = 0; u < PT; ++u)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = l31 + 32 * j;
-    const float bv = p.bias ? p.bias[co] : 0.f;
-    float* ob = p.out + (long)img * p.H * p.W * p.ldo + co;
-    float v[16];
-    long off[16];
-    bool ok[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int y = y0 + wave * 2 * PT + 2 * u + (i >> 4), x = x0 + (i & 15);
-      ok[r] = y < p.H && x < p.W;
-      off[r] = ((long)y * p.W + x) * p.ldo;
-      v[r] = acc[u][j][r] + bv;
-      acc[u][j][r] = 0.f;
-    }
-    if (p.gn_part) {
+    for (int u = 0; u < PT; ++u) {
+      int off[16];
+      unsigned okm = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const double t = ok[r] ? (double)v[r] : 0.0;
-        gs[j] += t;
-        gq[j] += t * t;
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int y = y0 + wave * 2 * PT + 2 * u + (i >> 4), x = x0 + (i & 15);
+        okm |= (y < p.H && x < p.W) ? (1u << r) : 0u;
+        off[r] = (min(y, p.H - 1) * p.W + min(x, p.W - 1)) * ldo;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float bv = p.bias ? p.bias[l31 + 32 * j] : 0.f;
+        float* ob = obase + 32 * j;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = acc[u][j][r] + bv;
+          acc[u][j][r] = 0.f;
+        }
+        if (p.gn_part) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const double t = ((okm >> r) & 1u) ? (double)v[r] : 0.0;
+            gs[j] += t;
+            gq[j] += t * t;
+          }
+        }
+        if (p.act == SVL_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+        } else if (p.act == SVL_ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.accumulate) {
+          float prev[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) prev[r] = ob[off[r]];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += prev[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if ((okm >> r) & 1u) ob[off[r]] = v[r];
       }
     }
-    if (p.act == SVL_ACT_GELU) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
-    } else if (p.act == SVL_ACT_RELU) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-    }
-    if (p.accumulate) {
-      float prev[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) prev[r] = ok[r] ? ob[off[r]] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] += prev[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (ok[r]) ob[off[r]] = v[r];
   }
   if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, gred, tid, tile);   // (one barrier inside; gred is not touched by the staging)
   SVL_PH(5)
