@@ -814,6 +814,32 @@ def test_gemm_shortk_stream(dev, M, N, K, act):
     close(out2, lin + res, atol=2e-4, what="short-K resid")
 
 
+@pytest.mark.parametrize("M,N,K,act", [(40003, 192, 64, 0), (36000, 96, 64, 1), (33333, 200, 64, 2), (32768, 128, 64, 0)])
+def test_gemm_shortk_stream_split(dev, emu_mode, M, N, K, act):
+    """The K = 64 row streams with a row-major result in emulation mode 6 (shortk_x6_kernel: 16-byte stores of 4 consecutive
+    columns, bias from LDS, GELU / ReLU): error vs float64 at the level of the fp32 stream's, ragged row counts, column
+    counts that are not a multiple of the chunk, and the general epilogue (residual / pre-activation) still served by the
+    other kernels."""
+    from semivl_amd import ops, lib as L
+    x, w, b = rnd(M, K, dev=dev, seed=71), rnd(N, K, dev=dev, scale=0.2), rnd(N, dev=dev)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+    err = {}
+    for mode in (0, 6):
+        emu_mode(mode)
+        out = ops.linear(x, w, b, act=act)
+        assert L.load().svl_last_gemm_path() == (1 if mode == 6 else 2), mode
+        err[mode] = _relerr(out, ref)
+    assert err[6] <= EMU6_ERR_FACTOR * err[0] + 1e-9, err
+    emu_mode(6)
+    res = rnd(M, N, dev=dev, seed=72)
+    pre = torch.empty(M, N, device=dev)
+    out2 = ops.linear(x, w, b, resid=res, preact=pre)
+    lin = (x.double() @ w.double().t() + b.double()).float()
+    close(pre, lin, atol=2e-4, what="short-K preact (mode 6)")
+    close(out2, lin + res, atol=2e-4, what="short-K resid (mode 6)")
+
+
 def test_gemm_shortk_convT_and_1x1(dev):
     from semivl_amd import ops
     n, Ci, Co, H = 9, 64, 48, 64  # 36864 pixels: ConvTranspose2d k2 s2 as [pix, 64] x [4*48, 64]^T with scatter epilogue
