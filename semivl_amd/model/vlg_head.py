@@ -213,6 +213,9 @@ def _conv_gn_fwd(x, ldx, imgs, H, W, C1, conv, gn, k, dil, sv, src2=None, ld2=0,
     return deferred if deferred is not None else y
 
 
+_WGRAD_AFTER_DGRAD = bool(int(_os.environ.get("SVL_WGRAD_AFTER_DGRAD", "1")))
+
+
 def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None, x=None):
     """`dx_acc`: an existing input-gradient buffer the convolution's dgrad is ADDED to in the GEMM epilogue (the branches of a
     residual / multi-branch node) instead of returned as a new tensor and added by a separate pass.  `x`: the unit's input
@@ -230,16 +233,26 @@ def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None, x=None):
     else:
         gn_in = None
         x = _mat(sv["x"]) if x is None else x
-    with ops.wgrad_side(dpre, x, sv["src2"], gn_in):     # off the dependency chain: weight-gradient stream (ops.wgrad_side)
-        dwf = ops.conv_wgrad(dpre, Co, x, sv["ldx"], imgs, H, W, C1, Co, k, k, dil, pad, src2=sv["src2"],
-                             ld2=sv["ld2"], C2=C2, rep=sv["rep"], gn_in=gn_in)
-        gc.put_tensor(conv.weight, ops.unpack_conv_wgrad(dwf, Co, C1 + C2, k, k))
+    def wgrad():
+        with ops.wgrad_side(dpre, x, sv["src2"], gn_in):     # off the dependency chain: weight-gradient stream (ops.wgrad_side)
+            dwf = ops.conv_wgrad(dpre, Co, x, sv["ldx"], imgs, H, W, C1, Co, k, k, dil, pad, src2=sv["src2"],
+                                 ld2=sv["ld2"], C2=C2, rep=sv["rep"], gn_in=gn_in)
+            gc.put_tensor(conv.weight, ops.unpack_conv_wgrad(dwf, Co, C1 + C2, k, k))
+    # WGRAD_AFTER_DGRAD: the weight gradient is ordered behind the input gradient -- two matrix-bound kernels side by side
+    # share one pipe and finish no earlier, while the NEXT unit's GroupNorm backward (bandwidth-bound, on the chain) then has
+    # a matrix-bound partner
+    if not (_WGRAD_AFTER_DGRAD and need_dx):
+        wgrad()
     if not need_dx:
         return None
     if dx_acc is not None:
-        return ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad, out=dx_acc, ldo=dx_acc.stride(0),
-                              accumulate=True)
-    return ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad)  # [pix, C1+C2]
+        dx = ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad, out=dx_acc, ldo=dx_acc.stride(0),
+                            accumulate=True)
+    else:
+        dx = ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad)  # [pix, C1+C2]
+    if _WGRAD_AFTER_DGRAD:
+        wgrad()
+    return dx
 
 
 # ------------------------------------------------------------------------------------------------ head
@@ -645,12 +658,17 @@ def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
     dskip = ops.empty(b * sh * sw, Cs, device=dev)
     ops.bilinear_nhwc_bwd(dcat[:, Cu:], ld, b, sh, sw, Cs, True, N, 2 * h, 2 * w, dskip, Cs)
     # ConvTranspose half
-    with ops.wgrad_side(dcat, xin):
-        gc.put(up.up.bias, lambda d, acc: ops.colsum(dcat, out=d, accumulate=acc, C_=Cu, ld=ld))
-        dwb = ops.convT2x_wgrad(xin, Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
-        gc.put_tensor(up.up.weight, dwb.view(Cin, 2, 2, Cu).permute(0, 3, 1, 2).contiguous())
+    def wgrad():
+        with ops.wgrad_side(dcat, xin):
+            gc.put(up.up.bias, lambda d, acc: ops.colsum(dcat, out=d, accumulate=acc, C_=Cu, ld=ld))
+            dwb = ops.convT2x_wgrad(xin, Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
+            gc.put_tensor(up.up.weight, dwb.view(Cin, 2, 2, Cu).permute(0, 3, 1, 2).contiguous())
+    if not _WGRAD_AFTER_DGRAD:
+        wgrad()
     wb = ops.cached_pack(up.up.weight, "convT_bwd", lambda w_: w_.permute(0, 2, 3, 1).reshape(Cin, 4 * Cu).contiguous())
     dx = ops.convT2x_dgrad(dcat, ld, imgs, h, w, Cu, wb, Cin)
+    if _WGRAD_AFTER_DGRAD:
+        wgrad()                         # (behind the input gradient: see _conv_gn_bwd)
     return dx, dskip
 
 
