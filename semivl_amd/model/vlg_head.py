@@ -578,23 +578,38 @@ def _semtr_backward(lyr, dx, dtp_acc, imgs, b, N, h, w, Ch, Ct, sv, gc):
     dt3 = ops.zeros(rows, E, device=dev)
     ops.bilinear_nhwc_bwd(dx, Ch, imgs, hp, wp, Ch, True, 1, h, w, dt3, E)
     # t3 = t2 + W2 hh + b2
-    with ops.wgrad_side(dt3, sv["hh"]):
-        gc.put(f[1].weight, lambda d, acc: ops.matmul_tn(dt3, sv["hh"], out=d, accumulate=acc))
-        gc.put(f[1].bias, lambda d, acc: ops.colsum(dt3, out=d, accumulate=acc))
+    def wg_f2():
+        with ops.wgrad_side(dt3, sv["hh"]):
+            gc.put(f[1].weight, lambda d, acc: ops.matmul_tn(dt3, sv["hh"], out=d, accumulate=acc))
+            gc.put(f[1].bias, lambda d, acc: ops.colsum(dt3, out=d, accumulate=acc))
+    if not _WGRAD_AFTER_DGRAD:
+        wg_f2()
     dh = ops.matmul_nn(dt3, p["w2"])
+    if _WGRAD_AFTER_DGRAD:              # (weight gradients behind their input gradient: see _conv_gn_bwd)
+        wg_f2()
     dhp = ops.eltwise(1, dh, sv["h_pre"], out=dh)
-    with ops.wgrad_side(dhp, sv["y2"]):
-        gc.put(f[0][0].weight, lambda d, acc: ops.matmul_tn(dhp, sv["y2"], out=d, accumulate=acc))
-        gc.put(f[0][0].bias, lambda d, acc: ops.colsum(dhp, out=d, accumulate=acc))
+    def wg_f1():
+        with ops.wgrad_side(dhp, sv["y2"]):
+            gc.put(f[0][0].weight, lambda d, acc: ops.matmul_tn(dhp, sv["y2"], out=d, accumulate=acc))
+            gc.put(f[0][0].bias, lambda d, acc: ops.colsum(dhp, out=d, accumulate=acc))
+    if not _WGRAD_AFTER_DGRAD:
+        wg_f1()
     dy2 = ops.matmul_nn(dhp, p["w1"])
+    if _WGRAD_AFTER_DGRAD:
+        wg_f1()
     dt2, dg2, db2 = ops.layernorm_bwd(dy2, sv["t2"], sv["st2"], p["ln2w"], dx_add=dt3, want_wgrad=True)
     gc.put_tensor(t.ln2.weight, dg2)
     gc.put_tensor(t.ln2.bias, db2)
     # t2 = tok + Wout o + bout
-    with ops.wgrad_side(dt2, sv["o"]):
-        gc.put(a.out_proj.weight, lambda d, acc: ops.matmul_tn(dt2, sv["o"], out=d, accumulate=acc))
-        gc.put(a.out_proj.bias, lambda d, acc: ops.colsum(dt2, out=d, accumulate=acc))
+    def wg_o():
+        with ops.wgrad_side(dt2, sv["o"]):
+            gc.put(a.out_proj.weight, lambda d, acc: ops.matmul_tn(dt2, sv["o"], out=d, accumulate=acc))
+            gc.put(a.out_proj.bias, lambda d, acc: ops.colsum(dt2, out=d, accumulate=acc))
+    if not _WGRAD_AFTER_DGRAD:
+        wg_o()
     do = ops.matmul_nn(dt2, p["wout"])
+    if _WGRAD_AFTER_DGRAD:
+        wg_o()
     if sv["mfma_seq"]:
         Ee = do.shape[1]
         dqkv_t = ops.attention_bwd(ops.permute_rows(do, b, N, G, Ee), sv["qkv"], ops.permute_rows(sv["o"], b, N, G, Ee),
@@ -603,10 +618,15 @@ def _semtr_backward(lyr, dx, dtp_acc, imgs, b, N, h, w, Ch, Ct, sv, gc):
         del dqkv_t
     else:
         dqkv = ops.seqattn_bwd(do, sv["qkv"], sv["probs"], b * G, G, N, t.num_heads, N * G, 1, G)
-    with ops.wgrad_side(dqkv, sv["y1"]):
-        gc.put(a.in_proj_weight, lambda d, acc: ops.matmul_tn(dqkv, sv["y1"], out=d, accumulate=acc))
-        gc.put(a.in_proj_bias, lambda d, acc: ops.colsum(dqkv, out=d, accumulate=acc))
+    def wg_in():
+        with ops.wgrad_side(dqkv, sv["y1"]):
+            gc.put(a.in_proj_weight, lambda d, acc: ops.matmul_tn(dqkv, sv["y1"], out=d, accumulate=acc))
+            gc.put(a.in_proj_bias, lambda d, acc: ops.colsum(dqkv, out=d, accumulate=acc))
+    if not _WGRAD_AFTER_DGRAD:
+        wg_in()
     dy1 = ops.matmul_nn(dqkv, p["win"])
+    if _WGRAD_AFTER_DGRAD:
+        wg_in()
     dtok, dg1, db1 = ops.layernorm_bwd(dy1, sv["tok"], sv["st1"], p["ln1w"], dx_add=dt2, want_wgrad=True)
     gc.put_tensor(t.ln1.weight, dg1)
     gc.put_tensor(t.ln1.bias, db1)
