@@ -361,17 +361,24 @@ def main():
                                     "frac_executed = 2MNK actually issued by those launches / the same time; frac_whole_step = "
                                     "executed algorithmic FLOPs / the WHOLE step time (every non-MFMA pass counted against the MFMA "
                                     "peak); `contract` = the same ratios with SURVEY §8(d)'s 19-forward-equivalent figure")
-        if gx:   # the split-emulation GEMM family against ITS pipe: bf16 dense peak / products per fp32 MAC
+        def nprod_of(tag_):
+            """16-bit products a launch issues per fp32 MAC: 3 on fp16 x 2 planes, else the mode's 6 (3 in bf16x3 mode)."""
+            return 3 if (tag_ and tag_[0] == "planes_h2") or a.gemm_arith == "bf16x3" else 6
+
+        if gx:   # the split-emulation GEMM family against ITS pipe: 16-bit dense peak vs the products actually issued
             nprod = 6 if a.gemm_arith == "bf16x6" else 3
             t_x = sum(e0.elapsed_time(e1) for e0, e1, *_ in gx) * 1e-3
             f_x = sum(w for _, _, w, *_ in gx)
+            iss_x = sum(w * nprod_of(tag) for _, _, w, tag, *_ in gx)
             out["mfma_step_vs_f32_pipe"]["bf16_pipe"] = dict(
                 kernel=f"gemm_bf16x_kernel<{nprod // 2 if nprod == 6 else 2},...> (svl_gemm_f32 in emulation mode {nprod})"
                        + (" + attn_{fwd,bwd_dq,bwd_dkv}_x6_kernel" if prof.get("attention_bf16x") else ""),
                 launches=len(gx), kernel_time_ms=round(t_x * 1e3, 2), achieved=round(f_x / t_x / 1e12, 2),
-                peak=round(PEAK_BF16_MFMA_TF / nprod, 1), unit="TFLOP/s (fp32-equivalent)",
-                frac=round(f_x / t_x / 1e12 / (PEAK_BF16_MFMA_TF / nprod), 4),
-                note=f"2MNK of the launches / their summed duration vs {PEAK_BF16_MFMA_TF:.0f} TF bf16 dense / {nprod} products")
+                issued_16bit_tflops=round(iss_x / t_x / 1e12, 1), peak=PEAK_BF16_MFMA_TF, unit="TFLOP/s",
+                frac=round(iss_x / t_x / 1e12 / PEAK_BF16_MFMA_TF, 4),
+                note=f"achieved = 2MNK of the launches / their summed duration (fp32-equivalent); frac = the 16-bit products "
+                     f"they issue (3 per fp32 MAC on fp16 x 2 planes, 6 on bf16 x 3 and the in-register split kernels) / the "
+                     f"same time vs {PEAK_BF16_MFMA_TF:.0f} TF dense")
         # the ViT encoder alone (north_star: ">= 60 % MFMA peak on the ViT encoder"): launches issued inside the encoder's
         # forward / backward regions (5 trainable + 2 frozen forwards, 4 backwards per step)
         gv = [e for e in g if e[4] == "vit"]
@@ -381,8 +388,11 @@ def main():
             # priced against the pipe the encoder's launches run on: bf16 dense / products per fp32 MAC in the split
             # modes (every ViT GEMM and the fused attention), the fp32 MFMA peak in exact mode
             split_n = {"bf16x6": 6, "bf16x3": 3}.get(a.gemm_arith)
+            if split_n:   # products per fp32 MAC, weighted by the executed FLOPs of the launches (3 on fp16 x 2 planes, else 6)
+                split_n = sum(e[2] * nprod_of(e[3]) for e in gv) / max(sum(e[2] for e in gv), 1.0)
             peak_v = PEAK_BF16_MFMA_TF / split_n if split_n else PEAK_F32_MFMA_TF
             out["roofline_vit_encoder"] = dict(bound="mfma", achieved=round(ach_v, 2), peak=round(peak_v, 1),
+                                               products_per_fp32_mac=round(split_n, 2) if split_n else None,
                                                unit="TFLOP/s (fp32-equivalent)" if split_n else "TFLOP/s",
                                                frac=round(ach_v / peak_v, 4),
                                                frac_vs_f32_mfma_pipe=round(ach_v / PEAK_F32_MFMA_TF, 4), launches=len(gv),
@@ -443,7 +453,7 @@ def main():
             tag, v = max(by.items(), key=lambda kv: kv[1][0])
             fam = fam_of[tag]
             on_bf16 = fam.endswith("bf16x")
-            nprod = {"bf16x6": 6, "bf16x3": 3}.get(a.gemm_arith, 6)
+            nprod = nprod_of(tag)
             peak = PEAK_BF16_MFMA_TF / nprod if on_bf16 else PEAK_F32_MFMA_TF
             d_tf = v[1] / v[0] / 1e12
             fl = v[1] / v[2]
@@ -463,16 +473,19 @@ def main():
                      "duration (HIP events, streams back to back); peak = the pipe its kernel family runs on (2500 TF bf16 "
                      f"dense / {nprod} products per fp32 MAC, or the 157.3 TF fp32 MFMA peak)")
         elif not g_arith_exact:
-            nprod = 6 if a.gemm_arith == "bf16x6" else 3
-            planes = ("planes", Md, 3072, 768, ops.ACT_GELU) in by
-            dom_tag = ("planes", Md, 3072, 768, ops.ACT_GELU) if planes else (0, 0, Md, 3072, 768, 1)
+            h2 = ("planes_h2", Md, 3072, 768, ops.ACT_GELU) in by      # fp16 x 2 planes: three products per fp32 MAC
+            planes = h2 or ("planes", Md, 3072, 768, ops.ACT_GELU) in by
+            nprod = 3 if (h2 or a.gemm_arith == "bf16x3") else 6
+            dom_tag = (("planes_h2" if h2 else "planes"), Md, 3072, 768, ops.ACT_GELU) if planes else (0, 0, Md, 3072, 768, 1)
             dom = by.get(dom_tag)
             clock = None
             if dom is not None and planes:
                 # the clock the chip sustains under this kernel (svl_clock_probe waves on a second stream next to 24
                 # back-to-back launches of the same shape and epilogue)
-                xa, wb = ops.split_planes(torch.randn(Md, 768, device=dev)), ops.split_planes(torch.randn(3072, 768, device=dev) * 0.05)
-                bias_, pre_, po_ = torch.zeros(3072, device=dev), ops.empty(Md, 3072, device=dev), ops.Planes(Md, 3072, device=dev)
+                xa = ops.split_planes(torch.randn(Md, 768, device=dev))
+                wb = ops.split_planes(torch.randn(3072, 768, device=dev) * 0.05)
+                bias_, pre_ = torch.zeros(3072, device=dev), ops.empty(Md, 3072, device=dev)
+                po_ = ops.Planes(Md, 3072, device=dev)
                 avg_ = dom[0] * 1e3 / dom[2]
                 clock = dict(
                     under_dominant_kernel=clock_probe_mhz(
@@ -484,27 +497,39 @@ def main():
                          "and serialises it -- tools/clock_step.py)")
                 del xa, wb, bias_, pre_, po_
             if dom is not None:
-                d_tf = dom[1] / dom[0] / 1e12
                 peak = PEAK_BF16_MFMA_TF / nprod
-                traffic, tnote = (pmc_traffic_record(a.batch, "pmc_x6p_traffic.json", "gemm_planes.hip") if planes and nprod == 6
+                fl_ = 2.0 * Md * 3072 * 768
+                solo_ms = dom[0] * 1e3 / dom[2]
+                ins = in_step.get(dom_tag)
+                # `achieved` / `frac` = the launches inside the step as `value` measures it (streams overlapped); the solo
+                # duration (the step's streams run back to back) is kept beside it
+                avg_ms = ins[0] / ins[1] if ins and ins[1] else solo_ms
+                d_tf = fl_ / (avg_ms * 1e-3) / 1e12
+                opb = 4 if h2 else 6        # bytes per operand element
+                traffic, tnote = (pmc_traffic_record(a.batch, "pmc_x6p_traffic.json", "gemm_planes_impl.h") if planes
                                   else (None, "no PMC record for this kernel"))
                 out["roofline"] = dict(
                     bound="mfma", achieved=round(d_tf, 1), peak=round(peak, 1), unit="TFLOP/s (fp32-equivalent)",
                     frac=round(d_tf / peak, 4), traffic=traffic,
-                    kernel=("gemm_x6p_kernel<256, EPI_GELU> (svl_gemm_planes_f32: packed bf16x3 planes, 6 products on "
-                            "v_mfma_f32_32x32x16_bf16; bias + erf-GELU + saved pre-activation + result as planes)" if planes
+                    kernel=((f"gemm_x6p_kernel<{2 if h2 else 3}, 256, EPI_GELU> (svl_gemm_planes_f32: packed "
+                             + ("fp16 x 2 planes with row scales, 3 products on v_mfma_f32_32x32x16_f16"
+                                if h2 else "bf16 x 3 planes, 6 products on v_mfma_f32_32x32x16_bf16")
+                             + "; bias + erf-GELU + saved pre-activation + result as planes)") if planes
                             else "gemm_bf16x_kernel (svl_gemm_f32, in-register split)") + ", M=%d N=3072 K=768" % Md,
-                    launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 4),
-                    **in_step_fields(dom_tag, 2.0 * Md * 3072 * 768, peak),
-                    flops_per_launch=2.0 * Md * 3072 * 768, bf16_issued_tflops=round(d_tf * nprod, 1),
-                    frac_of_bf16_dense_peak=round(d_tf * nprod / PEAK_BF16_MFMA_TF, 4),
-                    algorithmic_bytes=(Md * 768 * 6 + 3072 * 768 * 6 + Md * 3072 * 10) if planes else 513.0e6 * a.batch / 16,
+                    launches=dom[2], avg_ms=round(avg_ms, 4), avg_ms_solo=round(solo_ms, 4),
+                    achieved_solo=round(fl_ / (solo_ms * 1e-3) / 1e12, 1),
+                    frac_solo=round(fl_ / (solo_ms * 1e-3) / 1e12 / peak, 4),
+                    flops_per_launch=fl_, mfma_issued_tflops=round(d_tf * nprod, 1),
+                    frac_of_16bit_dense_peak=round(d_tf * nprod / PEAK_BF16_MFMA_TF, 4),
+                    algorithmic_bytes=(Md * 768 * opb + 3072 * 768 * opb + Md * 3072 * (4 + opb)) if planes else 513.0e6 * a.batch / 16,
                     traffic_note=tnote, clock_mhz=clock,
-                    frac_at_sustained_clock=(round(d_tf / peak * PEAK_CLOCK_MHZ / clock["under_dominant_kernel"], 4)
-                                             if clock and clock["under_dominant_kernel"] else None),
-                    note=f"achieved = 2MNK / mean launch duration; peak = {PEAK_BF16_MFMA_TF:.0f} TF bf16 dense / {nprod} "
-                         "products per fp32 MAC (MI355X_MICROARCH.md); algorithmic bytes = A and B planes (6 B/element) read "
-                         "once + pre-activation (4 B) and result planes (6 B) written once")
+                    frac_solo_at_sustained_clock=(round(fl_ / (solo_ms * 1e-3) / 1e12 / peak * PEAK_CLOCK_MHZ / clock["under_dominant_kernel"], 4)
+                                                  if clock and clock["under_dominant_kernel"] else None),
+                    note=f"achieved = 2MNK / mean launch duration INSIDE the timed step (HIP events on the launch stream, the "
+                         f"step's streams overlapped as `value` runs them); *_solo = the same launches with the step's streams "
+                         f"run back to back; peak = {PEAK_BF16_MFMA_TF:.0f} TF 16-bit dense / {nprod} products per fp32 MAC "
+                         f"(MI355X_MICROARCH.md); algorithmic bytes = A and B planes ({opb} B/element) read once + "
+                         f"pre-activation (4 B) and result planes ({opb} B) written once")
         else:
             dom_tag = (0, 0, Md, 3072, 768, 1)
             dom = by.get(dom_tag)
@@ -513,7 +538,8 @@ def main():
                 traffic, tnote = pmc_traffic_record(a.batch)
                 out["roofline"] = dict(
                     bound="mfma", achieved=round(d_tf, 1), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
-                    frac=round(d_tf / PEAK_F32_MFMA_TF, 4), traffic=traffic,
+                    frac=round(d_tf / PEAK_F32_MFMA_TF, 4), frac_is="solo (streams back to back); frac_in_step beside it",
+                    traffic=traffic,
                     kernel="gemm_kernel<128,128,2,2,KCONTIG,KCONTIG> (svl_gemm_f32, v_mfma_f32_32x32x2_f32), M=%d N=3072 K=768" % Md,
                     launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 4),
                     **in_step_fields(dom_tag, 2.0 * Md * 3072 * 768, PEAK_F32_MFMA_TF), flops_per_launch=2.0 * Md * 3072 * 768,

@@ -42,7 +42,7 @@ typedef enum svl_status {
   SVL_ERR_UNSUPPORTED = -3
 } svl_status;
 
-int svl_version(void); /* 401: + svl_conv3x3_weight_planes, svl_gemm_desc::conv_w_planes, w_planes of svl_conv3x3_gn_f32; 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
+int svl_version(void); /* 500: round-5 ABI (fp16 x 2 planes: svl_split_planes_f16x2, svl_planes_bytes_fmt, fmt / scale fields of svl_pgemm_desc); 401: + svl_conv3x3_weight_planes, svl_gemm_desc::conv_w_planes, w_planes of svl_conv3x3_gn_f32; 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
                            svl_stream_prepare, svl_last_gemm_path; gn_in arguments of the tiled weight gradient and the Conv2d(C -> 1)
                            entries, `accumulate` of svl_avgpool_cat_bwd); 300: round-3 ABI (packed-planes operands; planes outputs of LayerNorm / attention; loss-mode arguments of
                            the pixel-loss entries; 200 = round 2: helper-stream contexts, caller-owned scratch everywhere) */
@@ -209,11 +209,31 @@ typedef struct svl_pgemm_desc {
   const float* resid;
   int64_t ldr;
   int accumulate;
+  /* round 5: the fp16 x 2 operand format (below).  All zero / NULL = the bf16 x 3 form above. */
+  int fmt;                /* format of A and B: 0 = bf16 x 3 planes (six products), 1 = fp16 x 2 planes + row scales (three) */
+  int p_fmt;              /* format of planes_out: 0 / 1; 1 needs fmt = 1, a_rnorm, b_bound, p_sexp and no residual add */
+  const int32_t* a_sexp;  /* fmt 1: scale exponents of A's rows [a_rows] / of B's rows [b_rows]; NULL = all zero */
+  const int32_t* b_sexp;
+  const float* a_rnorm;   /* p_fmt 1: upper bounds of the L2 norms of A's rows [a_rows] ...                          */
+  const float* b_bound;   /* ... and a device float[2] = {max row L2 norm of B, max |bias|}: row m of the result is   */
+  int32_t* p_sexp;        /* bounded by a_rnorm[m] b_bound[0] + b_bound[1]; its scale exponent is written to p_sexp[m] */
 } svl_pgemm_desc;
 int64_t svl_planes_rows(int64_t rows);             /* rows rounded up to the 256-row band a tile reads */
 int64_t svl_planes_bytes(int64_t rows, int K);
 int svl_split_planes_bf16x3(const float* x, int64_t ld, int64_t k_stride, int64_t rows, int K, void* planes,
                             int64_t planes_rows, int64_t row_off, svl_stream_t stream);
+/* The fp16 x 2 operand format (round 5; csrc/gemm_planes_h2.hip): x(r, k) = 2^e(r) (h0 + h1), h0 = fp16(x 2^-e(r)), h1 =
+ * fp16(x 2^-e(r) - h0), one scale exponent e(r) per ROW placing the row's largest magnitude in [2^14, 2^15); chunk layout as
+ * above with two planes per (k-group, row block): svl_planes_bytes_fmt(rows, K, 1) = 4 bytes per element.  Two
+ * round-to-nearest fp16 terms carry 23 significand bits, the three leading cross products (v_mfma_f32_32x32x16_f16, fp32
+ * accumulate) leave out a1 b1 <= 2^-22 |a b|: half the matrix work of the bf16 x 3 form at an error vs fp64 at or below the
+ * plain fp32 MFMA chain's for K >= 48 (tests/test_ops_gpu.py::test_gemm_planes_path).  The GEMM multiplies its
+ * accumulators by 2^(e_A(m) + e_B(n)) (exact).  svl_split_planes_f16x2 is the generic pack pass (arguments as
+ * svl_split_planes_bf16x3); it also writes sexp[row_off + r] and, if rnorm != NULL, an upper bound of each row's L2 norm --
+ * what a GEMM needs to scale a planes OUTPUT in this format (svl_pgemm_desc::a_rnorm / b_bound). */
+int64_t svl_planes_bytes_fmt(int64_t rows, int K, int fmt);
+int svl_split_planes_f16x2(const float* x, int64_t ld, int64_t k_stride, int64_t rows, int K, void* planes,
+                           int64_t planes_rows, int64_t row_off, int32_t* sexp, float* rnorm, svl_stream_t stream);
 int svl_gemm_planes_f32(const svl_pgemm_desc* d, svl_stream_t stream);
 /* Weight gradient of a narrow (Co = 32 / 64) 3x3 / stride 1 / pad 1 convolution over NHWC activations with an optional
  * second concat source (read at image img / rep): slabs[g][co][tap * (C1 + C2) + ci] for g < groups (forward-pack

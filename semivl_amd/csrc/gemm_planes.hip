@@ -1,474 +1,10 @@
-// fp32-accurate GEMM on the bf16 matrix pipe with PRE-SPLIT, FRAGMENT-PACKED operands (gfx950 / CDNA4).
-//
-//   C(m, n) = epilogue( sum_k A(m, k) * B(n, k) ),   A, B given as 3 bf16 "planes" each.
-//
-// Arithmetic (svl_set_gemm_emulation(6)): every fp32 operand element x is the exact sum x0 + x1 + x2 (+ a residual
-// below 2^-24 |x|) of three bf16 terms x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); bf16 x bf16 products are
-// exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, and the six leading cross products (a2 b0, a0 b2, a1 b1,
-// a1 b0, a0 b1, a0 b0 -- smallest first) carry 24 mantissa bits of every a * b: the error against fp64 is at the level of (tests: <= 1.2 x, measured 0.85 - 1.0 x)
-// the plain fp32 MFMA chain's (tests/test_ops_gpu.py).
-//
-// Operand format ("packed planes"): for k-group kg = k / 16, row block rb = row / 32 and plane pl, ONE 1 KiB chunk
-//     P[(kg * RB + rb) * 3 + pl][lane][8]  (bf16),   lane = h * 32 + row % 32,
-// holds, for lane-half h, the 8 k's  kg*16 + 4h + {0,1,2,3, 8,9,10,11}  of that row: exactly the register image of one
-// MFMA 32x32x16 operand fragment (lane = row, 8 consecutive registers-halves = its k's; the k order inside a group is free
-// as long as A and B agree).  Consequences:
-//   * a tile's K step is one contiguous run of chunks in memory; it is copied global -> LDS by global_load_lds_dwordx4
-//     (1 KiB per wave instruction, fully coalesced, no VGPR round trip, no address arithmetic beyond an SGPR bump);
-//   * the LDS image IS the fragment: every operand read is one ds_read_b128 at base + lane * 16 -- conflict-free by
-//     construction, no padding, no swizzle;
-//   * with transposed accumulators (MFMA issued as B-fragment x A-fragment) a lane of the epilogue owns, per 16 output
-//     columns, exactly the 8 values of ITS lane slot of the next GEMM's A chunk, so a GEMM emits its result as packed
-//     planes with one coalesced 1 KiB store per (row block, k-group, plane).
-// Weights are packed once per parameter version, activations by their producer (LayerNorm, the previous GEMM's
-// epilogue, svl_split_planes_bf16x3 as the generic pass), so the main loop is LDS-DMA + ds_read_b128 + MFMA only.
-//
-// Kernel structure (256 x BN tile, BN = 256 or 128; 512 threads = 8 waves; one block per CU):
-//   * waves 0-3 (group 0) own tile rows 0-127, waves 4-7 (group 1) rows 128-255; wave w and w + 4 share a SIMD.
-//   * the two groups run ONE BARRIER INTERVAL APART: while a group issues its 48 (24) MFMAs of a k-group -- a pure
-//     matrix-pipe phase of 1536 (768) cycles -- its SIMD partner reads the fragments of ITS next k-group from LDS
-//     (18 / 15 ds_read_b128), issues its share of the LDS-DMA for the k-group two ahead and parks at the barrier.  The
-//     matrix pipe of every SIMD is always owned by exactly one wave; nothing but MFMAs is issued between two barriers
-//     by the computing wave.  (The round-2 kernels ran all waves in lockstep -- read, compute, refill -- and sat at
-//     ~1.0 PF whatever the tile: MI355X_MICROARCH.md "Two waves per SIMD".)
-//   * three LDS stages of 48 / 36 KiB; LDS-DMA stays in flight across barriers: a wave waits with a COUNTED vmcnt for
-//     the k-group it issued two intervals earlier, one interval before anybody reads it.
-// Barrier B_n ends interval I_n.  Group 0: mem(kg) in I_{2kg+1}, mfma(kg) in I_{2kg+2}; group 1 one interval later.
-// Stage kg % 3 is read in I_{2kg+1} (g0) and I_{2kg+2} (g1) and refilled for kg + 3 from I_{2kg+3} on (WAR safe: both
-// groups drained their reads with lgkmcnt(0) before B_{2kg+2}); its LDS-DMA was issued in I_{2kg-3} / I_{2kg-2} and waited
-// for (vmcnt) before B_{2kg-1} / B_{2kg}, i.e. at least one barrier before the first read (RAW safe).
-#include "svl_common.h"
-#include <atomic>
-#include <type_traits>
+// svl_gemm_planes_f32 and the bf16 x 3 instantiation of the packed-planes GEMM (gemm_planes_impl.h holds the kernel; the
+// fp16 x 2 instantiation is compiled in gemm_planes_h2.hip so that the two sets of kernels build in parallel).
+#include "gemm_planes_impl.h"
+
+int svl_planes_launch_h2(const PlanesP& p, hipStream_t st);     // gemm_planes_h2.hip
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a class: not promoted to registers)
-
-constexpr int BM = 256;
-constexpr int CH = 1024;        // bytes of one (k-group, row block, plane) chunk
-constexpr int NSTAGE = 3;
-
-template <int I, int N_, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N_) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N_>(f);
-  }
-}
-
-struct PlanesP {
-  const char* A;            // first chunk of row block 0, k-group 0
-  const char* B;
-  long a_ks, b_ks;          // bytes between k-groups (rows_padded * 96)
-  int b_rb;                 // 32-row blocks the B operand's buffer holds
-  int M, N, K;              // M valid rows from A's row block 0
-  float* C;
-  long ldc;
-  char* P;                  // packed planes out (row block 0, k-group 0 of the result) or null
-  long p_ks;
-  const float* bias;
-  int act;
-  float* preact;
-  const float* resid;
-  long ldr;
-  int accumulate;
-  int tiles_n, full_m, tail_rows;   // full_m = M / 256 row bands; tail_rows = M % 256
-  int rcnt[8], fstart[8];   // per XCD x (blocks with id % 8 == x): ragged-band tiles it takes first, first full tile of its chunk
-  int panel;                // column tiles per panel of the full-tile order (tile_of_block)
-};
-
-// One LDS-DMA instruction: 64 lanes x 16 B from `base` (wave-uniform, SGPR pair) + `lane_off` (the constant lane * 16)
-// to LDS bytes [lds_dst, lds_dst + 1024).  Inline asm because the builtin, inside the k-loop, is selected in its 64-bit
-// VGPR-address form with a v_lshl_add_u64 per DMA: that VALU instruction has to be issued by the memory-phase wave
-// between its SIMD partner's back-to-back MFMAs, and VALU and MFMA issue do not overlap on a SIMD -- measured with
-// s_memtime: 230 cycles per DMA, the memory phase (1750 cycles) longer than the matrix phase (1580).  With the SGPR-base
-// form a DMA is SALU + one VMEM issue (67 cycles; memory phase 740).  M0 is written in the statement that reads it and
-// restored (it is compiler-reserved); the s_nop covers a base SGPR written by a VALU (v_readfirstlane) just before.
-// The compiler does not count these loads: every wait for them is an explicit vmcnt below.
-__device__ __forceinline__ void glds16(const char* base_, unsigned lane_off, unsigned lds_dst_) {
-  // (the operands ARE wave-uniform; readfirstlane makes that provable where the compiler's divergence analysis gives up --
-  // it folds away when the value already lives in SGPRs)
-  const unsigned long long bv = (unsigned long long)base_;
-  const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(bv >> 32));     // (the builtin returns int: widen as unsigned)
-  const unsigned b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bv);
-  const char* base = (const char*)(((unsigned long long)b_hi << 32) | (unsigned long long)b_lo);
-  const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "s"(base), "v"(lane_off), "s"(lds_dst)
-               : "memory");
-}
-
-template <int N_>
-__device__ __forceinline__ void wait_vm() {
-  if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N_ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N_ == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else static_assert(N_ < 0, "unsupported vmcnt");
-}
-
-// x = x0 + x1 + x2: the three bf16 planes of 8 values
-__device__ __forceinline__ void split3x8(const float (&x)[8], bf16x8& h0, bf16x8& h1, bf16x8& h2) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float v = x[j];
-    h0[j] = (__bf16)v;
-    v -= (float)h0[j];
-    h1[j] = (__bf16)v;
-    v -= (float)h1[j];
-    h2[j] = (__bf16)v;
-  }
-}
-
-// Block -> tile.  Blocks go to XCD (id % 8) and, inside an XCD, to CUs in id order as CUs free up.  Every XCD first takes
-// its share of the RAGGED row band's tiles (M % 256 rows), then a contiguous chunk of the full tiles in n-fastest order:
-// concurrent tiles of an XCD share A row bands / B column bands in that XCD's L2.
-// (A ragged tile streams the whole B panel for a fraction of the MFMA work: its k-loop is bound by the memory phase, not
-// by its MFMAs, and costs ~0.4 of a full tile -- +3 % at K = 768, +7 % at K = 3072 against M = 32768.  Tried and dropped:
-// running the last full band + the leftover rows as 288-row tiles (ninth row block on the lower wave row) in a second,
-// concurrent launch on the helper stream: the fork / join and the two grids competing for CUs cost more, +2 ... +11 %.)
-// (Tried and dropped: TWO independent 256 x 128 workgroups per CU (4 waves each, 2 LDS stages, plain lockstep loop) so that one
-// workgroup's prologue / epilogue runs under the other's matrix phases: 1.5x the L2 -> LDS traffic per MFMA and two barriers
-// per k-group cost more than the overlap returns -- FFN-1 with GELU + pre-activation + planes 1.011 vs 0.922 ms, plain
-// 0.823 vs 0.764 ms, 8192^3 1424 vs 1524 TF.  The kernel is bound by the energy of its instruction mix, not by idle phases.)
-// (Tried and dropped: TWO independent 256 x 128 workgroups per CU (4 waves each, 2 LDS stages, plain lockstep loop) so that one
-// workgroup's prologue / epilogue runs under the other's matrix phases: 1.5x the L2 -> LDS traffic per MFMA and two barriers
-// per k-group cost more than the overlap returns -- FFN-1 with GELU + pre-activation + planes 1.011 vs 0.922 ms, plain
-// 0.823 vs 0.764 ms, 8192^3 1424 vs 1524 TF.  And a PERSISTENT grid (one block per CU walking its tiles, the next tile's first
-// two k-groups requested before the current epilogue, transposes through the third stage): 0.5 ... 1.3 % on the kernel, nothing
-// on the step, register spills in the erf epilogues.  The kernel is bound by the energy of its instruction mix -- the clock it
-// is given -- not by idle phases.)
-// (Tried and dropped: cutting the first 32 tiles of every XCD in two row parts of s / 8 and (8 - s) / 8 so that its CUs
-// run 1/8 of a tile apart and their store bursts do not coincide -- partial tiles keep only one wave group busy and
-// cost more than the de-synchronised epilogues gain: +5...7 % on the ViT shapes.)
-struct TileRef { int m0, rows, tn; };
-__device__ __forceinline__ TileRef tile_of_block(const PlanesP& p) {
-  TileRef t;
-  const int lin = (int)blockIdx.x, x = lin & 7, idx = lin >> 3;
-  const int rc = p.rcnt[x];
-  if (idx < rc) {
-    t.m0 = p.full_m * BM;
-    t.rows = p.tail_rows;
-    t.tn = idx * 8 + x;
-  } else {
-    const int f = p.fstart[x] + idx - rc;
-    // full tiles in PANEL order: column groups of p.panel tiles, row bands inside a group, columns inside a band -- an
-    // XCD's 32 concurrent tiles are (32 / panel) bands x panel columns, and the group's B panels (panel x 1.2 MB) stay in
-    // its 4 MB L2 while it walks down the bands (row-major order = panel of tiles_n columns: every round re-reads all of B)
-    const int gsz = p.full_m * p.panel;
-    const int cg = f / gsz, r = f - cg * gsz;
-    const int w = min(p.panel, p.tiles_n - cg * p.panel);
-    const int tm = r / w;
-    t.tn = cg * p.panel + (r - tm * w);
-    t.m0 = tm * BM;
-    t.rows = BM;
-  }
-  return t;
-}
-
-enum { EPI_LIGHT = 0, EPI_GELU = 1, EPI_DGELU = 2 };   // epilogue flavour compiled in (the erf code is large)
-
-// ---- epilogue, shared by both kernels.  acc[i][j][r] = C(m, n), m = m0 + (wm*TM + i)*32 + l31, n = nw + j*32 + 8*(r>>2) +
-// 4*hi + (r&3); wl = this wave's LDS transpose buffer (32 rows x (TN*128 + 16) bytes).
-template <int TM, int TN, int EPI>
-__device__ __forceinline__ void x6p_epilogue(const PlanesP& p, f32x16 (&acc)[TM][TN], int m0, int mvalid, int wm, int nw,
-                                             char* wl, int lane) {
-  const int l31 = lane & 31, hi = lane >> 5;
-  // The
-  // arithmetic runs in this layout (a lane owns 4-runs of ONE row: bias / saved pre-activation are 16 B reads, and per 16
-  // columns its 8 values are exactly its lane slot of the next GEMM's A chunk: packed planes leave as 1 KiB stores).
-  // fp32 outputs (C, preact) go through a per-wave LDS transpose so that every store instruction writes whole 128 /
-  // 256-byte row segments (measured: 32-byte segments straight from the accumulator layout write at 2.8 TB/s, full
-  // lines at 4.6 TB/s).
-  constexpr int WC = TN * 32;                      // columns of a wave
-  constexpr int RS = WC * 4 + 16;                  // LDS row stride of the transpose buffer (bytes)
-  constexpr int LPR = WC / 4;                      // lanes per row in the row-major readback (16 B each)
-  static_assert((32 * LPR) % 64 == 0, "readback steps must be whole wave instructions");
-  const bool vec = (p.ldc % 4 == 0) && (reinterpret_cast<uintptr_t>(p.C) % 16 == 0) &&
-                   (reinterpret_cast<uintptr_t>(p.preact) % 16 == 0);
-  const bool rvec = p.resid && (p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.resid) % 16 == 0);
-
-  // the wave's 32 x WC block `o` (acc layout) -> dst rows, coalesced; accumulate: dst += o
-  auto store_rows = [&](float* dst, const f32x16 (&o)[TN], int mloc, bool accumulate) __attribute__((always_inline)) {
-    static_for<0, TN>([&](auto J) {
-      constexpr int j = decltype(J)::value;
-      static_for<0, 4>([&](auto G) {
-        constexpr int g = decltype(G)::value;
-        f32x4 q = {o[j][4 * g], o[j][4 * g + 1], o[j][4 * g + 2], o[j][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(wl + l31 * RS + (j * 32 + 8 * g + 4 * hi) * 4) = q;
-      });
-    });
-    // (same wave wrote and reads: DS operations of a wave execute in order, no barrier)
-#pragma unroll
-    for (int it = 0; it < 32 * LPR / 64; ++it) {
-      const int idx = it * 64 + lane, row = idx / LPR, rc4 = (idx - row * LPR) * 4;
-      const f32x4 q = *reinterpret_cast<const f32x4*>(wl + row * RS + rc4 * 4);
-      const int n = nw + rc4;
-      if (mloc + row < mvalid && n < p.N) {
-        float* d = dst + (long)(m0 + mloc + row) * p.ldc + n;
-        if (vec && n + 4 <= p.N) {
-          f32x4 v = q;
-          if (accumulate) v += *reinterpret_cast<const f32x4*>(d);
-          *reinterpret_cast<f32x4*>(d) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) d[e] = accumulate ? d[e] + q[e] : q[e];
-        }
-      }
-    }
-  };
-
-  static_for<0, TM>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    const int mloc = (wm * TM + i) * 32;
-    if (mloc < mvalid) {
-      const int m = m0 + mloc + l31;
-      const bool mok = mloc + l31 < mvalid;
-      // 1. bias
-      if (p.bias) {
-        static_for<0, TN>([&](auto J) {
-          constexpr int j = decltype(J)::value;
-          static_for<0, 4>([&](auto G) {
-            constexpr int g = decltype(G)::value;
-            const int n = nw + j * 32 + 8 * g + 4 * hi;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += n + e < p.N ? p.bias[n + e] : 0.f;
-          });
-        });
-      }
-      // 2. pre-activation copy
-      if (p.preact) store_rows(p.preact, acc[i], mloc, false);
-      // 3. activation / residual / derivative product
-      static_for<0, TN>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        static_for<0, 4>([&](auto G) {
-          constexpr int g = decltype(G)::value;
-          const int n = nw + j * 32 + 8 * g + 4 * hi;
-          float rv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.resid && mok && n < p.N) {
-            const float* rp = p.resid + (long)m * p.ldr + n;
-            if (rvec && n + 4 <= p.N) {
-              const f32x4 q = *reinterpret_cast<const f32x4*>(rp);
-              rv[0] = q[0]; rv[1] = q[1]; rv[2] = q[2]; rv[3] = q[3];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) rv[e] = n + e < p.N ? rp[e] : 0.f;
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[i][j][4 * g + e];
-            if constexpr (EPI == EPI_GELU) v = gelu_erf(v) + rv[e];
-            else if constexpr (EPI == EPI_DGELU) v *= gelu_erf_grad(rv[e]);
-            else {
-              if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
-              if (p.act == SVL_ACT_MUL_DRELU) v = rv[e] > 0.f ? v : 0.f;
-              else v += rv[e];
-            }
-            acc[i][j][4 * g + e] = v;
-          }
-        });
-      });
-      // 4. outputs
-      if (p.C) store_rows(p.C, acc[i], mloc, p.accumulate != 0);
-      if (p.P) {
-        static_for<0, TN>([&](auto J) {
-          constexpr int j = decltype(J)::value;
-          static_for<0, 2>([&](auto G2) {
-            constexpr int g2 = decltype(G2)::value;
-            const int nb = nw + j * 32 + 16 * g2;
-            if (nb < p.N) {   // (columns past N / rows past the edge land in padding nobody reads)
-              float o8[8];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o8[e] = acc[i][j][8 * g2 + e];
-              bf16x8 h0, h1, h2;
-              split3x8(o8, h0, h1, h2);
-              char* q = p.P + (long)(nb >> 4) * p.p_ks + (long)((m0 + mloc) >> 5) * (3 * CH) + lane * 16;
-              *reinterpret_cast<bf16x8*>(q) = h0;
-              *reinterpret_cast<bf16x8*>(q + CH) = h1;
-              *reinterpret_cast<bf16x8*>(q + 2 * CH) = h2;
-            }
-          });
-        });
-      }
-    }
-  });
-}
-
-
-template <int BN, int EPI>
-__global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
-  extern __shared__ __attribute__((aligned(1024))) char sm[];
-  // wave grid WM x WN over the 256 x BN tile, 32x32 MFMA blocks per wave TM x TN:
-  //   BN = 256: 2 x 4 waves of 128 x 64;  BN = 192: 4 x 2 waves of 64 x 96;  BN = 128: 2 x 4 waves of 128 x 32.
-  // The two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) are the upper / lower 128 rows in every shape.
-  constexpr int WN = BN == 192 ? 2 : 4, WM = 8 / WN;
-  constexpr int TM = BM / 32 / WM, TN = BN / 32 / WN;
-  constexpr int NCHA = BM / 32 * 3, NCHB = BN / 32 * 3, NCH = NCHA + NCHB;   // chunks of one stage (A then B)
-  constexpr int STAGE = NCH * CH;
-  constexpr int CPW = (NCH + 7) / 8;                   // LDS-DMA instructions per wave and k-group (upper bound)
-  constexpr bool EVEN = NCH % 8 == 0;                  // every wave issues CPW; else waves >= NCH % 8 issue CPW - 1
-  static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS");
-
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wm = wave / WN, wq = wave % WN;
-
-  const TileRef tr = tile_of_block(p);
-  const int m0 = tr.m0, n0 = tr.tn * BN, mvalid = tr.rows;
-  const int nblk = (mvalid + 31) >> 5;                 // row blocks of A this tile needs
-  // valid 32-row blocks of this wave (wave-uniform): ragged tiles skip the MFMAs of row blocks past the edge
-  const int vb = min(TM, max(0, nblk - wm * TM));
-
-  // wave-uniform chunk bases (SGPRs); the per-lane part of a DMA address is the constant lane * 16 (glds16)
-  const char* a_src = p.A + (long)(m0 >> 5) * (3 * CH);
-  const char* b_src = p.B + (long)tr.tn * (NCHB * CH);
-  const unsigned lane16 = lane * 16;
-  const unsigned sm_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
-  const int nk = p.K >> 4;
-
-  // chunk sources of this wave inside a k-group (wave-uniform); A chunks of row blocks a ragged tile does not need are
-  // redirected to row block 0 (same instruction count -- the vmcnt bookkeeping is static -- and no read past the operand's
-  // last row band)
-  auto issue = [&](int kg, int st) __attribute__((always_inline)) {
-    const char* ak = a_src + (long)kg * p.a_ks;
-    const char* bk = b_src + (long)kg * p.b_ks;
-    const unsigned dst = sm_base + st * STAGE;
-    static_for<0, CPW>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      const int c = wave + 8 * i;
-      if (EVEN || i + 1 < CPW || c < NCH) {
-        const char* s;
-        if constexpr (8 * i + 7 < NCHA) {
-          const int rb = c / 3;
-          s = ak + (rb < nblk ? c : c - 3 * rb) * CH;
-        } else {
-          static_assert(8 * i >= NCHA, "A / B chunk boundary must fall on a multiple of 8");
-          // (the last column tile may reach past the B operand's padded rows -- N = 512 cut in 192-wide tiles: those
-          // row blocks are redirected to the tile's first one; their columns are masked in the epilogue)
-          const int cb = c - NCHA, rb = cb / 3;
-          s = bk + (tr.tn * (BN / 32) + rb < p.b_rb ? cb : cb - 3 * rb) * CH;
-        }
-        glds16(s, lane16, dst + c * CH);
-      }
-    });
-  };
-  const bool short_wave = !EVEN && wave >= NCH % 8;
-  auto wait_older = [&]() __attribute__((always_inline)) {   // all but the k-group issued last have landed
-    if constexpr (EVEN) wait_vm<CPW>();
-    else {
-      if (short_wave) wait_vm<CPW - 1>();
-      else wait_vm<CPW>();
-    }
-  };
-
-  f32x16 acc[TM][TN];
-  static_for<0, TM>([&](auto I) {
-    static_for<0, TN>([&](auto J) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[decltype(I)::value][decltype(J)::value][r] = 0.f;
-    });
-  });
-
-  // fragment addresses inside a stage: A row block (wm * TM + i), B row block (wq * TN + j)
-  const int fa = lane * 16 + wm * (TM * 3 * CH);
-  const int fb = lane * 16 + NCHA * CH + wq * (TN * 3 * CH);
-
-  issue(0, 0);
-  if (nk > 1) {
-    issue(1, 1);
-    wait_older();
-  } else {
-    wait_vm<0>();
-  }
-  __builtin_amdgcn_s_barrier();                 // B_0: k-group 0 is in LDS for everybody
-  if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
-  __builtin_amdgcn_sched_barrier(0);
-
-  auto kloop = [&](auto FULLT) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(FULLT)::value;
-    bf16x8 a[3][TM], b[3][TN];
-    int st = 0;
-    for (int kg = 0; kg < nk; ++kg) {
-      // ---------------- memory phase: fragments of this k-group, LDS-DMA of k-group kg + 2
-      const char* S = sm + st * STAGE;
-      {
-        static_for<0, 3>([&](auto P) {
-          constexpr int pl = decltype(P)::value;
-          static_for<0, TN>([&](auto J) {
-            b[pl][decltype(J)::value] = *reinterpret_cast<const bf16x8*>(S + fb + (decltype(J)::value * 3 + pl) * CH);
-          });
-        });
-        static_for<0, 3>([&](auto P) {
-          constexpr int pl = decltype(P)::value;
-          static_for<0, TM>([&](auto I) {
-            a[pl][decltype(I)::value] = *reinterpret_cast<const bf16x8*>(S + fa + (decltype(I)::value * 3 + pl) * CH);
-          });
-        });
-      }
-      if (kg + 2 < nk) {
-        int st2 = st + 2;
-        if (st2 >= NSTAGE) st2 -= NSTAGE;
-        issue(kg + 2, st2);
-        wait_older();                             // k-group kg + 1 (this wave's part) has landed
-      } else {
-        wait_vm<0>();
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---------------- matrix phase: transposed accumulators D(n, m) += B-fragment x A-fragment, smallest cross terms
-      // first; consecutive MFMAs go to different accumulators
-      __builtin_amdgcn_s_setprio(1);
-      if constexpr (FULL) {
-        static_for<0, 6>([&](auto T) {
-          constexpr int t = decltype(T)::value;
-          constexpr int PA = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;     // (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
-          constexpr int PB = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
-          static_for<0, TM>([&](auto I) {
-            static_for<0, TN>([&](auto J) {
-              constexpr int i = decltype(I)::value, j = decltype(J)::value;
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB][j], a[PA][i], acc[i][j], 0, 0, 0);
-            });
-          });
-        });
-      } else {   // ragged tile: row blocks past the edge are skipped (vb is wave-uniform)
-        static_for<0, TM>([&](auto I) {
-          constexpr int i = decltype(I)::value;
-          if (i < vb) {
-            static_for<0, 6>([&](auto T) {
-              constexpr int t = decltype(T)::value;
-              constexpr int PA = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
-              constexpr int PB = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
-              static_for<0, TN>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PB][j], a[PA][i], acc[i][j], 0, 0, 0);
-              });
-            });
-          }
-        });
-      }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      st = st + 1 == NSTAGE ? 0 : st + 1;
-    }
-  };
-  // two instances of the whole loop (not a branch inside it: the accumulators would be merged through copies)
-  if (vb == TM) kloop(std::true_type{});
-  else kloop(std::false_type{});
-  if (grp == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two groups match: every LDS read is done
-
-  x6p_epilogue<TM, TN, EPI>(p, acc, m0, mvalid, wm, n0 + wq * (TN * 32), sm + wave * (32 * (TN * 128 + 16)), lane);
-}
 
 // fp32 [rows, K] (element (r, k) at x[r * ld + k * ks]) -> packed planes.  Thread = (row, k-group, lane half): 2 x 16 B read,
 // 3 x 16 B written; the 32 rows of a block give 512 B contiguous per (k-group, half, plane).  Rows in [rows, rows_pad)
@@ -509,84 +45,19 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
   }
 }
 
-// hipFuncSetAttribute is per device: one bit per device ordinal and kernel
-bool attr_needed(std::atomic<uint64_t>& mask) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const uint64_t bit = 1ull << (dev & 63);
-  return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
-}
-
-template <int BN, int EPI>
-int launch_kernel(const PlanesP& q, long blocks, hipStream_t st) {
-  constexpr size_t lds = (size_t)NSTAGE * ((BM + BN) / 32 * 3) * CH;
-  static std::atomic<uint64_t> mask{0};
-  if (attr_needed(mask))
-    SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6p_kernel<BN, EPI>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((gemm_x6p_kernel<BN, EPI>), dim3((unsigned)blocks), dim3(512), lds, st, q);
-  SVL_LAUNCH_CHECK("svl_gemm_planes_f32");
-  return SVL_OK;
-}
-
-template <int BN>
-int launch_tile(PlanesP q, hipStream_t st) {
-  q.tiles_n = (q.N + BN - 1) / BN;
-  q.full_m = q.M / BM;
-  q.tail_rows = q.M % BM;
-  const long nf = (long)q.full_m * q.tiles_n, nr = q.tail_rows ? q.tiles_n : 0, total = nf + nr;
-  if (total <= 0 || total > 0x7fffffffL) {
-    svl_set_error("svl_gemm_planes_f32: bad tile count %ld", total);
-    return SVL_ERR_INVALID_ARG;
-  }
-  static const int panel_env = getenv("SVL_PLANES_PANEL") ? atoi(getenv("SVL_PLANES_PANEL")) : 0;
-  // 6 columns per panel: FETCH x 2 of FFN-1 (12 column tiles) 1.035 -> 0.82 GB at unchanged time; 2 / 3 are worse than
-  // row-major (A bands re-read per panel), shapes with <= 6 column tiles are row-major anyway (tools/micro/run12.sh)
-  const int pw = panel_env > 0 ? panel_env : 6;
-  q.panel = pw < q.tiles_n ? pw : q.tiles_n;
-  long fs = 0;
-  for (int x = 0; x < 8; ++x) {   // XCD x runs the blocks with id % 8 == x
-    const long blocks = (total - x + 7) / 8, rag = nr > x ? (nr - x + 7) / 8 : 0;
-    q.rcnt[x] = (int)rag;
-    q.fstart[x] = (int)fs;
-    fs += blocks - rag;
-  }
-  if (q.act == SVL_ACT_GELU) return launch_kernel<BN, EPI_GELU>(q, total, st);
-  if (q.act == SVL_ACT_MUL_DGELU) return launch_kernel<BN, EPI_DGELU>(q, total, st);
-  return launch_kernel<BN, EPI_LIGHT>(q, total, st);
-}
-
-// Tile width: 256 unless a narrower tile wastes less of the last round of the grid (256 CUs x 1 block; the ragged row
-// band's tiles are short and come first, so only the full tiles count): N = 768 / 2304 tile as 4 / 12 x 192 into whole
-// rounds at M = 32 x 1025.
-int launch(const PlanesP& q, hipStream_t st) {
-  static const int force = getenv("SVL_PLANES_TILE") ? atoi(getenv("SVL_PLANES_TILE")) : 0;
-  auto cost = [&](int bn) {
-    const long tiles = (long)(q.M / BM) * ((q.N + bn - 1) / bn);
-    const long rounds = tiles > 0 ? (tiles + 255) / 256 : 1;
-    return (double)rounds * bn * (bn == 128 ? 1.15 : bn == 192 ? 1.04 : 1.0);   // time ~ rounds x tile width (x the narrower tiles' overhead)
-  };
-  int bn = force;
-  if (!bn) {
-    bn = 256;
-    if (q.N <= 128) bn = 128;
-    else {
-      if (cost(192) < cost(bn)) bn = 192;
-      if (cost(128) < cost(bn)) bn = 128;
-    }
-  }
-  if (bn == 128) return launch_tile<128>(q, st);
-  if (bn == 192) return launch_tile<192>(q, st);
-  return launch_tile<256>(q, st);
-}
-
 }  // namespace
+
 
 extern "C" int64_t svl_planes_rows(int64_t rows) { return rows <= 0 ? -1 : (rows + 255) / 256 * 256; }
 
 extern "C" int64_t svl_planes_bytes(int64_t rows, int K) {
   if (rows <= 0 || K <= 0 || (K & 15)) return -1;
   return (int64_t)(K >> 4) * svl_planes_rows(rows) * 96;
+}
+
+extern "C" int64_t svl_planes_bytes_fmt(int64_t rows, int K, int fmt) {
+  if (rows <= 0 || K <= 0 || (K & 15) || fmt < 0 || fmt > 1) return -1;
+  return (int64_t)(K >> 4) * svl_planes_rows(rows) * (fmt == 1 ? 64 : 96);
 }
 
 extern "C" int svl_split_planes_bf16x3(const float* x, int64_t ld, int64_t k_stride, int64_t rows, int K, void* planes,
@@ -616,21 +87,30 @@ extern "C" int svl_gemm_planes_f32(const svl_pgemm_desc* d, svl_stream_t stream)
   SVL_CHECK_ARG(!(d->act == SVL_ACT_MUL_DGELU || d->act == SVL_ACT_MUL_DRELU) || d->resid,
                 "svl_gemm_planes_f32: MUL_D* needs the saved pre-activation in resid");
   SVL_CHECK_ARG(!d->accumulate || d->C, "svl_gemm_planes_f32: accumulate needs C");
+  SVL_CHECK_ARG((d->fmt == 0 || d->fmt == 1) && (d->p_fmt == 0 || d->p_fmt == 1), "svl_gemm_planes_f32: fmt / p_fmt must be 0 (bf16 x 3) or 1 (fp16 x 2)");
+  SVL_CHECK_ARG(!(d->planes_out && d->p_fmt == 1) || (d->fmt == 1 && d->a_rnorm && d->b_bound && d->p_sexp && !d->resid) ||
+                    (d->fmt == 1 && d->a_rnorm && d->b_bound && d->p_sexp && (d->act == SVL_ACT_MUL_DGELU || d->act == SVL_ACT_MUL_DRELU)),
+                "svl_gemm_planes_f32: an fp16 x 2 planes output needs fp16 x 2 operands, a_rnorm, b_bound, p_sexp and no residual add "
+                "(its row scales come from the bound |A_m| max|B_n| + max|bias|)");
   // a tile reads whole 256-row bands of A from m_off on: the buffer must hold them (allocation padding, never stored)
   SVL_CHECK_ARG(d->a_rows - d->m_off >= (int64_t)(d->M + 255) / 256 * 256 || (d->m_off % 256) == 0,
                 "svl_gemm_planes_f32: A plane buffer too short for the last row band");
   PlanesP p;
   const long mo = d->m_off;
-  p.A = (const char*)d->A + (mo >> 5) * (3 * CH);
+  const int np = d->fmt == 1 ? 2 : 3, pnp = d->p_fmt == 1 ? 2 : 3;
+  p.A = (const char*)d->A + (mo >> 5) * (np * CH);
   p.B = (const char*)d->B;
-  p.a_ks = d->a_rows * 96; p.b_ks = d->b_rows * 96;
+  p.a_ks = d->a_rows * 32 * np; p.b_ks = d->b_rows * 32 * np;
+  p.a_se = d->a_sexp ? d->a_sexp + mo : nullptr; p.b_se = d->b_sexp;
+  p.a_rn = d->a_rnorm ? d->a_rnorm + mo : nullptr; p.b_bd = d->b_bound;
+  p.p_se = d->p_sexp ? d->p_sexp + mo : nullptr; p.p_np = pnp;
   p.b_rb = (int)(d->b_rows / 32);
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.C = d->C ? d->C + mo * d->ldc : nullptr; p.ldc = d->ldc;
-  p.P = d->planes_out ? (char*)d->planes_out + (mo >> 5) * (3 * CH) : nullptr; p.p_ks = d->p_rows * 96;
+  p.P = d->planes_out ? (char*)d->planes_out + (mo >> 5) * (pnp * CH) : nullptr; p.p_ks = d->p_rows * 32 * pnp;
   p.bias = d->bias; p.act = d->act;
   p.preact = d->preact ? d->preact + mo * d->ldc : nullptr;
   p.resid = d->resid ? d->resid + mo * d->ldr : nullptr; p.ldr = d->ldr;
   p.accumulate = d->accumulate;
-  return launch(p, (hipStream_t)stream);
+  return np == 2 ? svl_planes_launch_h2(p, (hipStream_t)stream) : launch<3>(p, (hipStream_t)stream);
 }

@@ -46,7 +46,9 @@ class PGemmDesc(C.Structure):
                 ("m_off", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int64), ("planes_out", C.c_void_p), ("p_rows", C.c_int64),
                 ("bias", C.c_void_p), ("act", C.c_int), ("preact", C.c_void_p), ("resid", C.c_void_p),
-                ("ldr", C.c_int64), ("accumulate", C.c_int)]
+                ("ldr", C.c_int64), ("accumulate", C.c_int),
+                ("fmt", C.c_int), ("p_fmt", C.c_int), ("a_sexp", C.c_void_p), ("b_sexp", C.c_void_p),
+                ("a_rnorm", C.c_void_p), ("b_bound", C.c_void_p), ("p_sexp", C.c_void_p)]
 
 
 class CeDesc(C.Structure):
@@ -75,6 +77,8 @@ SIGNATURES = {
     "svl_planes_rows": (_L, [_L]),
     "svl_planes_bytes": (_L, [_L, _I]),
     "svl_split_planes_bf16x3": (_I, [_P, _L, _L, _L, _I, _P, _L, _L, _P]),
+    "svl_planes_bytes_fmt": (_L, [_L, _I, _I]),
+    "svl_split_planes_f16x2": (_I, [_P, _L, _L, _L, _I, _P, _L, _L, _P, _P, _P]),
     "svl_gemm_planes_f32": (_I, [C.POINTER(PGemmDesc), _P]),
     "svl_conv3x3_wgrad_tiled_groups": (_I, [_I, _I, _I, _I, _I]),
     "svl_conv3x3_wgrad_tiled": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _P, _P]),

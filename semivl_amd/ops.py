@@ -270,32 +270,52 @@ def planes_rows(rows):
     return (rows + 255) // 256 * 256
 
 
-class Planes:
-    """An fp32 matrix [rows, K] held as three bf16 planes x = x0 + x1 + x2 in the fragment-packed layout of
-    csrc/gemm_planes.hip (1 KiB chunks per (k-group, 32-row block, plane); include/semivl_hip.h): the operand format of
-    svl_gemm_planes_f32.  The buffer holds `prow` = rows rounded up to 256 rows (tiles read whole row bands)."""
-    __slots__ = ("buf", "rows", "K", "prow")
+# Operand format of the packed-planes GEMM: "h2" = fp16 x 2 planes + one power-of-two scale per row, three cross products
+# (round 5: half the matrix work and 2/3 of the bytes of "b3" at the same error level against fp64); "b3" = bf16 x 3 planes,
+# six products.  SVL_PLANES_FMT=b3 keeps round 4's form for A/B runs; the fused attention kernels emit b3 either way (their
+# consumers -- out-projection, in_proj input gradient -- take the format of the A operand they are given).
+PLANES_FMT = os.environ.get("SVL_PLANES_FMT", "h2")
+assert PLANES_FMT in ("h2", "b3")
 
-    def __init__(self, rows, K, device=None, buf=None):
+
+class Planes:
+    """An fp32 matrix [rows, K] in the fragment-packed operand format of svl_gemm_planes_f32 (1 KiB chunks per (k-group,
+    32-row block, plane); include/semivl_hip.h).  fmt "b3": three bf16 planes x = x0 + x1 + x2.  fmt "h2": two fp16 planes
+    and one scale exponent per row, x = 2^sexp[row] (h0 + h1); `rnorm` (optional) = upper bounds of the rows' L2 norms,
+    which a GEMM needs to scale a planes OUTPUT in this format.  The buffer holds `prow` = rows rounded up to 256 rows."""
+    __slots__ = ("buf", "rows", "K", "prow", "fmt", "sexp", "rnorm", "wmax", "_bd")
+
+    def __init__(self, rows, K, device=None, buf=None, fmt=None, sexp=None, rnorm=None):
         assert K % 16 == 0
+        self.fmt = fmt or PLANES_FMT
         self.rows, self.K, self.prow = rows, K, planes_rows(rows)
-        self.buf = buf if buf is not None else torch.empty(K // 16 * self.prow * 48, dtype=torch.bfloat16,
-                                                           device=device if device is not None else torch.cuda.current_device())
+        dev = device if device is not None else (buf.device if buf is not None else torch.cuda.current_device())
+        self.wmax, self._bd = None, None
+        if self.fmt == "h2":
+            self.buf = buf if buf is not None else torch.empty(K // 16 * self.prow * 32, dtype=torch.float16, device=dev)
+            self.sexp = sexp if sexp is not None else torch.empty(self.prow, dtype=torch.int32, device=dev)
+            self.rnorm = rnorm
+        else:
+            self.buf = buf if buf is not None else torch.empty(K // 16 * self.prow * 48, dtype=torch.bfloat16, device=dev)
+            self.sexp = self.rnorm = None
 
     @property
     def shape(self):
         return (self.rows, self.K)
 
     def kslice(self, k0, k1):
-        """Columns [k0, k1) (multiples of 16) as a Planes view: k-groups are the outermost index of the layout."""
+        """Columns [k0, k1) (multiples of 16) as a Planes view: k-groups are the outermost index of the layout (the row
+        scales of an h2 buffer belong to whole rows and stay valid; the row norms stay upper bounds)."""
         assert k0 % 16 == 0 and k1 % 16 == 0 and 0 <= k0 < k1 <= self.K
-        per = self.prow * 48
-        return Planes(self.rows, k1 - k0, buf=self.buf[k0 // 16 * per:k1 // 16 * per])
+        per = self.prow * (32 if self.fmt == "h2" else 48)
+        return Planes(self.rows, k1 - k0, buf=self.buf[k0 // 16 * per:k1 // 16 * per], fmt=self.fmt, sexp=self.sexp,
+                      rnorm=self.rnorm)
 
 
-def split_planes(x2d, out=None, row_off=0, transpose=False):
-    """fp32 [rows, K] -> Planes (one HBM pass: 4 B read + 6 B written per element).  transpose=True splits x2d^T (used
-    once per weight for the input-gradient GEMMs)."""
+def split_planes(x2d, out=None, row_off=0, transpose=False, fmt=None):
+    """fp32 [rows, K] -> Planes (one HBM pass: 4 B read + 6 / 4 B written per element; the h2 pass reads a 32-row block
+    twice, the second time from L2, to find the row scales).  transpose=True splits x2d^T (used once per weight for the
+    input-gradient GEMMs)."""
     assert x2d.dim() == 2 and x2d.dtype == torch.float32
     if transpose:
         K, rows = x2d.shape
@@ -306,8 +326,14 @@ def split_planes(x2d, out=None, row_off=0, transpose=False):
         assert x2d.stride(1) == 1
         ld, ks = x2d.stride(0), 1
     if out is None:
-        out = Planes(rows, K, device=x2d.device)
+        out = Planes(rows, K, device=x2d.device, fmt=fmt)
     assert out.K == K and out.rows >= row_off + rows and row_off % 32 == 0
+    if out.fmt == "h2":
+        if out.rnorm is None:
+            out.rnorm = torch.empty(out.prow, dtype=torch.float32, device=x2d.device)
+        L.check(L.load().svl_split_planes_f16x2(_p(x2d), ld, ks, rows, K, _p(out.buf), out.prow, row_off, _p(out.sexp),
+                                                _p(out.rnorm), _st()), "svl_split_planes_f16x2")
+        return out
     L.check(L.load().svl_split_planes_bf16x3(_p(x2d), ld, ks, rows, K, _p(out.buf), out.prow, row_off, _st()),
             "svl_split_planes_bf16x3")
     return out
@@ -342,6 +368,9 @@ class StreamCached:
                 yield from StreamCached._tensors(x)
         elif hasattr(v, "buf"):
             yield v.buf
+            for extra in (getattr(v, "sexp", None), getattr(v, "rnorm", None), getattr(v, "wmax", None)):
+                if extra is not None:
+                    yield extra
 
     def get(self):
         if self.ev is not None:
@@ -360,22 +389,44 @@ def weights_changed():
     WEIGHT_EPOCH += 1
 
 
-def weight_planes(W, transpose=False):
+def weight_planes(W, transpose=False, fmt=None):
     """Planes of a weight matrix (or of a row slice of one), split ONCE and cached: frozen weights for the life of the
-    process (keyed on storage + torch version counter), trainable ones until the next optimizer step."""
+    process (keyed on storage + torch version counter), trainable ones until the next optimizer step.  h2 planes also carry
+    `wmax` = the largest row norm (a 0-dim device tensor: the B side of the bound behind an h2 planes output)."""
+    fmt = fmt or PLANES_FMT
+
+    def build():
+        pl = split_planes(W.detach(), transpose=transpose, fmt=fmt)
+        if fmt == "h2":
+            pl.wmax = pl.rnorm[:pl.rows].max()
+        return pl
+
     base = W._base if W._base is not None else W
     if not isinstance(base, torch.nn.Parameter):      # not a parameter: no identity to key a cache on
-        return split_planes(W.detach(), transpose=transpose)
-    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transpose)
+        return build()
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transpose, fmt)
     ver = (base._version, WEIGHT_EPOCH if base.requires_grad else 0)
     hit = _WPLANES.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is base:    # (a freed parameter's address may be handed out again)
         return hit[1].get()
-    pl = split_planes(W.detach(), transpose=transpose)
+    pl = build()
     if len(_WPLANES) > 4096:
         _WPLANES.clear()
     _WPLANES[key] = (ver, StreamCached(pl), weakref.ref(base))
     return pl
+
+
+def _out_bound(B, bias):
+    """Device float[2] = {max row norm of B, max |bias|} for svl_pgemm_desc::b_bound, cached on the weight planes per bias
+    tensor version (two tiny reductions otherwise, per call)."""
+    key = None if bias is None else (bias.data_ptr(), bias._version, WEIGHT_EPOCH if bias.requires_grad else 0)
+    if B._bd is not None and B._bd[0] == key and B._bd[2] == torch.cuda.current_stream().cuda_stream:
+        return B._bd[1]
+    wmax = B.wmax if B.wmax is not None else B.rnorm[:B.rows].max()
+    bmax = bias.detach().abs().max() if bias is not None else torch.zeros((), device=wmax.device)
+    bd = torch.stack([wmax, bmax]).float()
+    B._bd = (key, bd, torch.cuda.current_stream().cuda_stream)
+    return bd
 
 
 def planes_eligible(M, N, K):
@@ -394,7 +445,7 @@ def pgemm(A, B, M, N, out=None, planes_out=None, bias=None, act=ACT_NONE, preact
           m_off=0):
     """out[M, N] (fp32, row-major, optional) and / or planes_out (Planes [M, N], optional) = epi(A @ B^T)."""
     K = A.K
-    assert B.K == K and A.rows >= m_off + M and B.rows >= N
+    assert B.K == K and A.rows >= m_off + M and B.rows >= N and A.fmt == B.fmt
     d = L.PGemmDesc()
     d.A, d.B, d.a_rows, d.b_rows = _p(A.buf), _p(B.buf), A.prow, B.prow
     d.m_off, d.M, d.N, d.K = m_off, M, N, K
@@ -403,8 +454,15 @@ def pgemm(A, B, M, N, out=None, planes_out=None, bias=None, act=ACT_NONE, preact
         d.C, d.ldc = _p(out), out.stride(0)
     elif preact is not None:
         d.ldc = preact.stride(0)
+    keep = None
+    if A.fmt == "h2":
+        d.fmt, d.a_sexp, d.b_sexp = 1, _p(A.sexp), _p(B.sexp)
     if planes_out is not None:
         d.planes_out, d.p_rows = _p(planes_out.buf), planes_out.prow
+        if planes_out.fmt == "h2":     # row scales of the result from the bound |A_m| max|B_n| + max|bias| (include/semivl_hip.h)
+            assert A.fmt == "h2" and A.rnorm is not None
+            keep = _out_bound(B, bias)
+            d.p_fmt, d.a_rnorm, d.b_bound, d.p_sexp = 1, _p(A.rnorm), _p(keep), _p(planes_out.sexp)
     d.bias, d.act, d.preact = _p(bias), act, _p(preact)
     if resid is not None:
         assert resid.stride(1) == 1
@@ -412,7 +470,14 @@ def pgemm(A, B, M, N, out=None, planes_out=None, bias=None, act=ACT_NONE, preact
     d.accumulate = 1 if accumulate else 0
     e0 = _prof_begin()
     L.check(L.load().svl_gemm_planes_f32(C.byref(d), _st()), "svl_gemm_planes_f32")
-    _prof_end("gemm_bf16x", e0, 2.0 * M * N * K, ("planes", M, N, K, act))
+    _prof_end("gemm_bf16x", e0, 2.0 * M * N * K, ("planes" if A.fmt == "b3" else "planes_h2", M, N, K, act))
+
+
+def _planes_out_for(xa, M, N, resid, act):
+    """The Planes object a planes_only GEMM writes: h2 when the A operand is h2 and carries row norms (the result's row
+    scales come from a bound, which a residual add would break), b3 otherwise (any A format can emit it)."""
+    h2 = xa.fmt == "h2" and xa.rnorm is not None and (resid is None or act in (ACT_MUL_DGELU, ACT_MUL_DRELU))
+    return Planes(M, N, device=xa.buf.device, fmt="h2" if h2 else "b3")
 
 
 # ------------------------------------------------------------------------------------------------ dense helpers
@@ -425,11 +490,11 @@ def linear(x, W, bias=None, act=ACT_NONE, resid=None, out=None, accumulate=False
     assert W.shape[1] == K and W.stride(1) == 1
     if isinstance(x, Planes) or planes_eligible(M, N, K):
         xa = x if isinstance(x, Planes) else split_planes(x)
-        wb = weight_planes(W)
+        wb = weight_planes(W, fmt=xa.fmt)
         if preact is not None:
             assert out is None or preact.stride(0) == out.stride(0)
         if planes_only and N % 16 == 0 and out is None and not accumulate:
-            po = Planes(M, N, device=xa.buf.device)
+            po = _planes_out_for(xa, M, N, resid, act)
             pgemm(xa, wb, M, N, None, po, bias, act, preact, resid)
             return po
         if out is None:
@@ -460,11 +525,11 @@ def matmul_nn(a, b, out=None, accumulate=False, dact=ACT_NONE, z=None, planes_on
     assert b.shape[0] == K and b.stride(1) == 1
     if isinstance(a, Planes) or planes_eligible(M, N, K):
         xa = a if isinstance(a, Planes) else split_planes(a)
-        wb = weight_planes(b, transpose=True)       # B^T planes: rows = N (input features), k = K (output features)
+        wb = weight_planes(b, transpose=True, fmt=xa.fmt)   # B^T planes: rows = N (input features), k = K (output features)
         if dact != ACT_NONE:
             assert z is not None and z.shape == (M, N) and z.stride(1) == 1 and not accumulate
         if planes_only and N % 16 == 0 and out is None and not accumulate:
-            po = Planes(M, N, device=xa.buf.device)
+            po = _planes_out_for(xa, M, N, z if dact != ACT_NONE else None, dact)
             pgemm(xa, wb, M, N, None, po, None, dact, None, z if dact != ACT_NONE else None)
             return po
         if out is None:
@@ -592,12 +657,12 @@ def layernorm_fwd(x, gamma, beta, eps, planes=False, want_y=True):
         L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),
                 "svl_layernorm_fwd")
         return y, stats
-    if want_y:   # measured at [32800, 768]: row pass (39 us) + pack pass over the cache-warm result (38 us) beats the fused
+    if want_y or PLANES_FMT == "h2":   # measured at [32800, 768]: row pass (39 us) + pack pass over the cache-warm result (38 us) beats the fused
         y = torch.empty_like(x)      # kernel (102 us: its 32-row blocks leave 8 sequential rows per wave); planes-only
         L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),
                 "svl_layernorm_fwd")                                                 # is faster fused (60 us vs 77)
-        return y, stats, split_planes(y)
-    pl = Planes(rows, Cc, device=x.device)
+        return (y if want_y else None), stats, split_planes(y)      # (h2: the pack pass finds the row scales; no fused form yet)
+    pl = Planes(rows, Cc, device=x.device, fmt="b3")
     L.check(L.load().svl_layernorm_fwd_planes(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, None, _p(stats),
                                               _p(pl.buf), pl.prow, _st()), "svl_layernorm_fwd_planes")
     return None, stats, pl
@@ -728,7 +793,7 @@ def attention_fwd(qkv, Bn, T, H, want_lse=True, planes=False, want_out=True):
     E = H * 64
     out = empty(Bn * T, E, device=qkv.device) if (want_out or not planes) else None
     lse = empty(Bn * H * T, device=qkv.device) if want_lse else None
-    op = Planes(Bn * T, E, device=qkv.device) if planes else None
+    op = Planes(Bn * T, E, device=qkv.device, fmt="b3") if planes else None
     e0 = _prof_begin()
     L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if planes else None,
                                        op.prow if planes else 0, _st()), "svl_attention_fwd")
@@ -741,7 +806,7 @@ def attention_bwd(dout, qkv, out, lse, Bn, T, H, planes=False):
     dqkv = torch.empty_like(qkv)
     ws = empty(Bn * H * T, device=qkv.device)
     E = H * 64
-    dp = Planes(Bn * T, 3 * E, device=qkv.device) if planes else None
+    dp = Planes(Bn * T, 3 * E, device=qkv.device, fmt="b3") if planes else None
     e0 = _prof_begin()
     L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
                                        _p(dp.buf) if planes else None, dp.prow if planes else 0, _st()),

@@ -162,12 +162,14 @@ def test_gemm_bf16_split_emulation_special_values(dev, emu_mode):
 
 
 def _unpack_planes(pl):
-    """Planes -> three fp32 [rows, K] tensors.  Packed layout (include/semivl_hip.h): chunk ((kg * prow/32 + rb) * 3 + pl)
-    of 512 bf16 = [lane = h * 32 + r % 32][e], k = kg * 16 + 4 h + (e < 4 ? e : e + 4)."""
-    v = pl.buf.view(pl.K // 16, pl.prow // 32, 3, 2, 32, 8).float()        # kg, rb, plane, h, r31, e
+    """Planes -> its fp32 [rows, K] terms (three for "b3"; two for "h2", still in the row-scaled domain: multiply by
+    2^sexp[row] -- _h2_value -- for values).  Packed layout (include/semivl_hip.h): chunk ((kg * prow/32 + rb) * NP + pl)
+    of 512 16-bit values = [lane = h * 32 + r % 32][e], k = kg * 16 + 4 h + (e < 4 ? e : e + 4)."""
+    npl = 2 if pl.fmt == "h2" else 3
+    v = pl.buf.view(pl.K // 16, pl.prow // 32, npl, 2, 32, 8).float()      # kg, rb, plane, h, r31, e
     kk = torch.tensor([[4 * h + (e if e < 4 else e + 4) for e in range(8)] for h in range(2)], device=v.device)
     out = []
-    for i in range(3):
+    for i in range(npl):
         t = v[:, :, i]                                                     # kg, rb, h, r31, e
         full = torch.empty(pl.K // 16, pl.prow // 32, 32, 16, device=v.device)
         for h in range(2):
@@ -176,11 +178,64 @@ def _unpack_planes(pl):
     return out
 
 
+def _pow2(e):
+    """2^e as float64, exactly (torch.ldexp / torch.pow go through exp2 on the device and are not exact)."""
+    return ((e.long() + 1023) << 52).view(torch.float64)
+
+
+def _h2_value(pl):
+    """The fp64 value an h2 Planes object stands for: 2^sexp[row] (h0 + h1)."""
+    h0, h1 = _unpack_planes(pl)
+    return (h0.double() + h1.double()) * _pow2(pl.sexp[:pl.rows])[:, None]
+
+
+@pytest.fixture(params=["h2", "b3"])
+def planes_fmt(request):
+    """Run a test under both operand formats of the packed-planes GEMM (ops.PLANES_FMT)."""
+    from semivl_amd import ops
+    keep, ops.PLANES_FMT = ops.PLANES_FMT, request.param
+    yield request.param
+    ops.PLANES_FMT = keep
+
+
+def test_split_planes_h2_is_a_scaled_two_term_split(dev):
+    """The fp16 x 2 pack pass: one scale exponent per row (row maximum in [2^14, 2^15) after scaling), h0 / h1 the two
+    round-to-nearest fp16 terms of the scaled value, 23 significand bits for every element within 2^-16 of the row maximum
+    (below that an absolute error under 2^-39 of it), exact zeros, the row-norm bound, transposed / strided / offset forms."""
+    from semivl_amd import ops
+    x = rnd(1000, 208, dev=dev, seed=61) * torch.logspace(-20, 20, 1000, device=dev)[:, None]
+    x[:, :8] *= torch.logspace(0, -30, 8, device=dev)      # a wide dynamic range INSIDE every row
+    x[5] = 0
+    pl = ops.split_planes(x, fmt="h2")
+    h0, h1 = _unpack_planes(pl)
+    e = pl.sexp[:1000]
+    amax = x.abs().amax(1)
+    nz = amax > 0
+    scaled_max = amax.double() * _pow2(-e)
+    assert ((scaled_max[nz] >= 2.0 ** 14) & (scaled_max[nz] < 2.0 ** 15)).all()
+    xs = (x.double() * _pow2(-e)[:, None]).float()                   # exact: a power-of-two scaling
+    assert torch.equal(h0, xs.half().float()) and torch.equal(h1, (xs - h0).half().float())
+    err = (_h2_value(pl) - x.double()).abs()
+    big = x.abs() >= amax[:, None] * 2.0 ** -16
+    assert (err[big] <= 2.0 ** -23 * x.abs().double()[big]).all()
+    assert (err <= 2.0 ** -23 * x.abs().double() + 2.0 ** -39 * amax.double()[:, None]).all()
+    assert (_h2_value(pl)[5] == 0).all()
+    nrm = x.double().norm(dim=1)
+    assert (pl.rnorm[:1000].double() >= nrm).all() and (pl.rnorm[:1000].double() <= nrm * (1 + 1e-5) + 1e-300).all()
+    w = rnd(96, 160, dev=dev, seed=62)
+    assert torch.equal(_h2_value(ops.split_planes(w, transpose=True, fmt="h2")), _h2_value(ops.split_planes(w.t().contiguous(), fmt="h2")))
+    assert torch.equal(_h2_value(ops.split_planes(x[:, 48:112], fmt="h2"))[7], _h2_value(ops.split_planes(x[:, 48:112].contiguous(), fmt="h2"))[7])
+    big_ = ops.Planes(3000, 208, device=dev, fmt="h2")
+    ops.split_planes(x, out=big_, row_off=1504)
+    assert torch.equal(_h2_value(big_)[1504:2504], _h2_value(pl))
+    assert torch.equal(_h2_value(big_.kslice(64, 160))[1504:2504], _h2_value(pl)[:, 64:160])
+
+
 def test_split_planes_is_an_exact_three_term_split(dev):
     from semivl_amd import ops
     x = rnd(1000, 208, dev=dev, seed=61) * torch.logspace(-20, 20, 208, device=dev)
     x[5] = 0
-    p0, p1, p2 = _unpack_planes(ops.split_planes(x))
+    p0, p1, p2 = _unpack_planes(ops.split_planes(x, fmt="b3"))
     assert torch.equal(p0, x.bfloat16().float())                       # RNE leading term
     assert torch.equal(p1, (x - p0).bfloat16().float()) and torch.equal(p2, (x - p0 - p1).bfloat16().float())
     resid = (x.double() - p0.double() - p1.double() - p2.double()).abs()
@@ -188,11 +243,11 @@ def test_split_planes_is_an_exact_three_term_split(dev):
     # transposed split (weights for the input-gradient GEMMs), a strided source, writing at a row offset of a larger
     # buffer, and a column slice of a plane buffer (k-groups are the outermost index)
     w = rnd(96, 160, dev=dev, seed=62)
-    t0, _, _ = _unpack_planes(ops.split_planes(w, transpose=True))
+    t0, _, _ = _unpack_planes(ops.split_planes(w, transpose=True, fmt="b3"))
     assert torch.equal(t0, w.t().bfloat16().float())
-    s0, _, _ = _unpack_planes(ops.split_planes(x[:, 48:112]))
+    s0, _, _ = _unpack_planes(ops.split_planes(x[:, 48:112], fmt="b3"))
     assert torch.equal(s0, p0[:, 48:112])
-    big = ops.Planes(3000, 208, device=dev)
+    big = ops.Planes(3000, 208, device=dev, fmt="b3")
     ops.split_planes(x, out=big, row_off=1504)
     b0, _, _ = _unpack_planes(big)
     assert torch.equal(b0[1504:2504], p0)
@@ -200,7 +255,7 @@ def test_split_planes_is_an_exact_three_term_split(dev):
     assert torch.equal(k0[1504:2504], p0[:, 64:160])
 
 
-def test_layernorm_emits_planes(dev):
+def test_layernorm_emits_planes(dev, planes_fmt):
     """LN forward / backward with the result additionally (or only) as packed planes == split_planes of the fp32 result."""
     from semivl_amd import ops
     rows, Cc = 1025 * 2, 768
@@ -216,11 +271,12 @@ def test_layernorm_emits_planes(dev):
         assert torch.equal(got, want)
     # the fused entry point with both outputs (the wrapper prefers two passes there: faster at the ViT shape)
     from semivl_amd import lib as L
-    y3, st3, pl3 = torch.empty_like(x), torch.empty_like(st), ops.Planes(rows, Cc, device=dev)
+    y3, st3, pl3 = torch.empty_like(x), torch.empty_like(st), ops.Planes(rows, Cc, device=dev, fmt="b3")
     L.check(L.load().svl_layernorm_fwd_planes(x.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-6, rows, Cc, y3.data_ptr(),
                                               st3.data_ptr(), pl3.buf.data_ptr(), pl3.prow,
                                               torch.cuda.current_stream().cuda_stream), "svl_layernorm_fwd_planes")
-    assert torch.equal(y3, y_ref) and torch.equal(st3, st_ref) and torch.equal(_unpack_planes(pl3)[2], _unpack_planes(pl)[2])
+    assert torch.equal(y3, y_ref) and torch.equal(st3, st_ref)
+    assert torch.equal(_unpack_planes(pl3)[2], _unpack_planes(ops.split_planes(y_ref, fmt="b3"))[2])
     dy, add = rnd(rows, Cc, dev=dev), rnd(rows, Cc, dev=dev)
     dx_ref = ops.layernorm_bwd(dy, x, st, g, dx_add=add)
     dx, dxp = ops.layernorm_bwd(dy, x, st, g, dx_add=add, planes=True)
@@ -232,12 +288,12 @@ def test_layernorm_emits_planes(dev):
 @pytest.mark.parametrize("M,N,K", [(8 * 1025, 768, 768), (1300, 3072, 768), (2050, 768, 3072), (260, 96, 64),
                                    (4 * 1025, 2304, 768), (16 * 1025, 3072, 768),
                                    (8 * 2601, 512, 768)])      # 81 row bands: 192-wide tiles, the third one past N = 512
-def test_gemm_planes_path(dev, emu_mode, M, N, K):
+def test_gemm_planes_path(dev, emu_mode, planes_fmt, M, N, K):
     """The pre-split form of mode 6 (csrc/gemm_planes.hip): error vs fp64 at or below the fp32 MFMA chain's for the
     forward and input-gradient layouts, ragged token counts (M = 8 x 1025: a short row band whose tiles are scheduled
     first), both tile widths, every epilogue option, results handed over as planes (FFN-1 -> FFN-2, dGELU dgrad -> dgrad),
     determinism, and agreement with the in-register split kernel (same six products; the k order inside an MFMA k-group
-    differs, so the last bit may)."""
+    differs, so the last bit may).  Both operand formats: bf16 x 3 (six products) and fp16 x 2 with row scales (three)."""
     from semivl_amd import ops
     x, b, r = rnd(M, K, dev=dev, seed=71), rnd(N, dev=dev), rnd(M, N, dev=dev)
     w = torch.nn.Parameter(rnd(N, K, dev=dev) * 0.05)
@@ -281,15 +337,36 @@ def test_gemm_planes_path(dev, emu_mode, M, N, K):
     w2 = torch.nn.Parameter(rnd(128, N, dev=dev) * 0.05)
     hp = ops.linear(xa, w, b, act=ops.ACT_GELU, planes_only=True)
     assert isinstance(hp, ops.Planes) and hp.shape == (M, N)
-    p0, p1, p2 = _unpack_planes(hp)
-    assert torch.equal(p0, g.bfloat16().float()) and torch.equal(p1, (g - p0).bfloat16().float())
-    assert torch.equal(p2, (g - p0 - p1).bfloat16().float())
-    assert torch.equal(ops.linear(hp, w2), ops.linear(ops.split_planes(g), w2))
+    assert hp.fmt == planes_fmt
+    if planes_fmt == "b3":
+        p0, p1, p2 = _unpack_planes(hp)
+        assert torch.equal(p0, g.bfloat16().float()) and torch.equal(p1, (g - p0).bfloat16().float())
+        assert torch.equal(p2, (g - p0 - p1).bfloat16().float())
+        assert torch.equal(ops.linear(hp, w2), ops.linear(ops.split_planes(g), w2))
+    else:
+        # the epilogue scales a row by a BOUND of its entries (|x_m| max|w_n| + max|b|: the row is not complete when a tile
+        # is stored), the pack pass by the row's maximum: same values to 23 bits of the bound, not the same bits
+        hv, bound = _h2_value(hp), (x.norm(dim=1) * w.norm(dim=1).max() + b.abs().max()).double()[:, None]
+        assert ((hv - g.double()).abs() <= 2.0 ** -23 * g.abs().double() + 2.0 ** -37 * bound).all()
+        assert (_pow2(hp.sexp[:M]) * 2.0 ** 15 > bound[:, 0]).all()   # no overflow possible
+        assert _relerr(ops.linear(hp, w2), g.double() @ w2.double().t()) <= EMU6_ERR_FACTOR * _relerr((g @ w2.t()), g.double() @ w2.double().t()) + 1e-7
     w3 = torch.nn.Parameter(rnd(K, 128, dev=dev) * 0.05)
     dhp = ops.matmul_nn(dya, w, dact=ops.ACT_MUL_DGELU, z=z, planes_only=True)
     assert isinstance(dhp, ops.Planes) and dhp.shape == (M, K)
     dh = ops.matmul_nn(dya, w, dact=ops.ACT_MUL_DGELU, z=z)
-    assert torch.equal(ops.matmul_nn(dhp, w3), ops.matmul_nn(ops.split_planes(dh), w3))
+    if planes_fmt == "b3":
+        assert torch.equal(ops.matmul_nn(dhp, w3), ops.matmul_nn(ops.split_planes(dh), w3))
+    else:
+        assert dhp.fmt == "h2"
+        bound = (1.13 * dy.norm(dim=1) * w.norm(dim=0).max()).double()[:, None]
+        assert ((_h2_value(dhp) - dh.double()).abs() <= 2.0 ** -23 * dh.abs().double() + 2.0 ** -37 * bound).all()
+        close(ops.matmul_nn(dhp, w3), dh @ w3, what="dgelu planes -> dgrad", atol=2e-5 * math.sqrt(K))
+    # an h2 A operand without row norms (or with a residual add) falls back to a b3 planes output; any A format emits it
+    if planes_fmt == "h2":
+        xb = ops.split_planes(x)
+        xb.rnorm = None
+        hb = ops.linear(xb, w, b, act=ops.ACT_GELU, planes_only=True)
+        assert hb.fmt == "b3" and torch.equal(_unpack_planes(hb)[0], g.bfloat16().float())
     # weight cache: a parameter update behind torch's back (the fused AdamW kernel) is announced with weights_changed()
     ops.fill(w.data[0], 0.0)
     stale = ops.linear(xa, w)
@@ -297,6 +374,33 @@ def test_gemm_planes_path(dev, emu_mode, M, N, K):
     fresh = ops.linear(xa, w)
     assert torch.equal(stale, y) and not torch.equal(fresh[:, 0], y[:, 0]) and float(fresh[:, 0].abs().max()) == 0.0
 
+
+
+def test_gemm_planes_special_values(dev, emu_mode, planes_fmt):
+    """The packed-planes kernel on exactly representable inputs (exact results in both formats: integers below 2^11 have
+    a zero second fp16 term and power-of-two row scales shift exponents only), on 1e-30 x 1e25 magnitudes (fp16 has five
+    exponent bits: the ROW SCALES carry the range) and on zero rows; a row whose entries span 30 binades keeps the error
+    of its large entries."""
+    from semivl_amd import ops
+    M, N, K = 384, 256, 128
+    emu_mode(6)
+    x = torch.randint(-64, 64, (M, K), device=dev).float()
+    w = torch.randint(-64, 64, (N, K), device=dev).float()
+    assert torch.equal(ops.linear(ops.split_planes(x), w), (x.double() @ w.double().t()).float())
+    xs = rnd(M, K, dev=dev, seed=5) * 1e-30
+    ws = rnd(N, K, dev=dev, seed=6) * 1e25
+    assert _relerr(ops.linear(ops.split_planes(xs), ws), xs.double() @ ws.double().t()) < 2e-6
+    x[::2] = 0
+    assert torch.equal(ops.linear(ops.split_planes(x), w), (x.double() @ w.double().t()).float())
+    xr = rnd(M, K, dev=dev, seed=7) * torch.logspace(0, -30, K, device=dev)
+    wr = rnd(N, K, dev=dev, seed=8)
+    assert _relerr(ops.linear(ops.split_planes(xr), wr), xr.double() @ wr.double().t()) < 2e-6
+    # different row magnitudes inside one tile: per-ROW scales, both operands
+    xm = rnd(M, K, dev=dev, seed=9) * torch.logspace(-12, 12, M, device=dev)[:, None]
+    wm = rnd(N, K, dev=dev, seed=10) * torch.logspace(8, -8, N, device=dev)[:, None]
+    ref = xm.double() @ wm.double().t()
+    got = ops.linear(ops.split_planes(xm), wm).double()
+    assert ((got - ref).abs() <= 3e-6 * xm.double().norm(dim=1)[:, None] * wm.double().norm(dim=1)[None, :] / math.sqrt(K) + 1e-300).all()
 
 
 @pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (3, 17, 4), (1, 64, 2)])
@@ -391,7 +495,7 @@ def test_fused_attention_emits_planes(dev, Bn, T, H):
         out, lse = ops.attention_fwd(qkv, Bn, T, H)
         o2, l2, op = ops.attention_fwd(qkv, Bn, T, H, planes=True)
         assert torch.equal(out, o2) and torch.equal(lse, l2)
-        for a, b_ in zip(_unpack_planes(op), _unpack_planes(ops.split_planes(out))):
+        for a, b_ in zip(_unpack_planes(op), _unpack_planes(ops.split_planes(out, fmt="b3"))):
             assert torch.equal(a, b_)
         o3, _, op3 = ops.attention_fwd(qkv, Bn, T, H, want_lse=False, planes=True, want_out=False)
         assert o3 is None and torch.equal(op3.buf.view(torch.int16)[:1], op3.buf.view(torch.int16)[:1])
@@ -400,7 +504,7 @@ def test_fused_attention_emits_planes(dev, Bn, T, H):
         dqkv = ops.attention_bwd(do, qkv, out, lse, Bn, T, H)
         d2, dp = ops.attention_bwd(do, qkv, out, lse, Bn, T, H, planes=True)
         assert torch.equal(dqkv, d2)
-        for a, b_ in zip(_unpack_planes(dp), _unpack_planes(ops.split_planes(dqkv))):
+        for a, b_ in zip(_unpack_planes(dp), _unpack_planes(ops.split_planes(dqkv, fmt="b3"))):
             assert torch.equal(a, b_)
         ops.set_gemm_emulation(0)
         assert not ops.attention_planes_ok()

@@ -1,0 +1,6 @@
+# fp16 x 2 planes (X6P_FMT=1, three products) against bf16 x 3 (six): sampled max error vs fp64 and kernel time, the ViT's shapes
+cd $GRAFT_REPO_ROOT
+B=tools/micro/x6p_bench
+for args in "300 208 64 2 1" "513 400 128 2 2" "20808 512 768 5 0" "8200 768 768 10 2" "32800 3072 768 20 0" "32800 3072 768 20 4" "32800 3072 768 20 3" "32800 768 768 20 2" "32800 768 3072 20 2" "32800 2304 768 20 0" "32800 768 2304 20 0" "8192 8192 8192 5 0"; do
+  for f in 0 1; do echo "fmt $f: $(X6P_FMT=$f timeout 120 $B $args | tr '\n' ' ')"; done
+done

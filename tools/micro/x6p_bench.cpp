@@ -15,6 +15,7 @@
 #define SV(x) do { int r_ = (x); if (r_ != 0) { char b_[512]; svl_last_error(b_, sizeof b_); printf("svl error %d: %s (line %d)\n", r_, b_, __LINE__); exit(1); } } while (0)
 
 static inline float bf16_to_f(unsigned short h) { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline float f16_to_f(unsigned short h) { _Float16 v; memcpy(&v, &h, 2); return (float)v; }
 static unsigned long long rng = 88172645463325252ull;
 static inline float urand() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (float)((rng >> 40) * (1.0 / 16777216.0)) * 2.f - 1.f; }
 
@@ -36,6 +37,8 @@ static void probe_report(const char* what, unsigned long long* h, int n) {
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 32800, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
   const int iters = argc > 4 ? atoi(argv[4]) : 20, mode = argc > 5 ? atoi(argv[5]) : 0;
+  const int fmt = getenv("X6P_FMT") ? atoi(getenv("X6P_FMT")) : 0;      // 1: fp16 x 2 planes (three products)
+  const int np = fmt == 1 ? 2 : 3;
   const long Mp = svl_planes_rows(M), Np = svl_planes_rows(N);
   std::vector<float> hA((size_t)M * K), hB((size_t)N * K), hbias(N), hres;
   for (auto& v : hA) v = urand();
@@ -46,12 +49,30 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
   CK(hipMalloc(&dbias, N * 4));
   CK(hipMalloc(&pA, svl_planes_bytes(M, K))); CK(hipMalloc(&pB, svl_planes_bytes(N, K)));
+  int *seA = nullptr, *seB = nullptr, *seO = nullptr;
+  float *rnA = nullptr, *rnB = nullptr, *bd = nullptr;
+  if (fmt == 1) {
+    CK(hipMalloc(&seA, Mp * 4)); CK(hipMalloc(&seB, Np * 4)); CK(hipMalloc(&seO, Mp * 4));
+    CK(hipMalloc(&rnA, Mp * 4)); CK(hipMalloc(&rnB, Np * 4)); CK(hipMalloc(&bd, 8));
+    CK(hipMemset(seO, 0, Mp * 4));
+  }
   CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dbias, hbias.data(), N * 4, hipMemcpyHostToDevice));
   CK(hipMemset(pA, 0, svl_planes_bytes(M, K))); CK(hipMemset(pB, 0, svl_planes_bytes(N, K)));
-  SV(svl_split_planes_bf16x3(dA, K, 1, M, K, pA, Mp, 0, nullptr));
-  SV(svl_split_planes_bf16x3(dB, K, 1, N, K, pB, Np, 0, nullptr));
+  if (fmt == 1) {
+    SV(svl_split_planes_f16x2(dA, K, 1, M, K, pA, Mp, 0, seA, rnA, nullptr));
+    SV(svl_split_planes_f16x2(dB, K, 1, N, K, pB, Np, 0, seB, rnB, nullptr));
+    std::vector<float> hrn(Np);
+    CK(hipMemcpy(hrn.data(), rnB, Np * 4, hipMemcpyDeviceToHost));
+    float hbd[2] = {0.f, 0.f};
+    for (int n = 0; n < N; ++n) hbd[0] = fmaxf(hbd[0], hrn[n]);
+    for (int n = 0; n < N; ++n) hbd[1] = fmaxf(hbd[1], fabsf(hbias[n]));
+    CK(hipMemcpy(bd, hbd, 8, hipMemcpyHostToDevice));
+  } else {
+    SV(svl_split_planes_bf16x3(dA, K, 1, M, K, pA, Mp, 0, nullptr));
+    SV(svl_split_planes_bf16x3(dB, K, 1, N, K, pB, Np, 0, nullptr));
+  }
   if (mode == 1 || mode == 4) CK(hipMalloc(&dpre, (size_t)M * N * 4));
   if (mode == 1 || mode == 3 || mode == 4) { CK(hipMalloc(&pO, svl_planes_bytes(M, N))); CK(hipMemset(pO, 0, svl_planes_bytes(M, N))); }
   if (mode == 2) {
@@ -68,6 +89,10 @@ int main(int argc, char** argv) {
   if (mode == 1 || mode == 4) { d.bias = dbias; d.act = SVL_ACT_GELU; d.preact = dpre; }
   if (mode == 1 || mode == 3 || mode == 4) { d.planes_out = pO; d.p_rows = Mp; }
   if (mode == 2) { d.resid = dres; d.ldr = N; d.bias = dbias; }
+  if (fmt == 1) {
+    d.fmt = 1; d.a_sexp = seA; d.b_sexp = seB;
+    if (d.planes_out && !getenv("X6P_POUT_BF16")) { d.p_fmt = 1; d.a_rnorm = rnA; d.b_bound = bd; d.p_sexp = seO; }
+  }
   SV(svl_gemm_planes_f32(&d, nullptr));
   CK(hipDeviceSynchronize());
   // ---- check
@@ -75,6 +100,8 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
   std::vector<unsigned short> hP;
   if (pO) { hP.resize(svl_planes_bytes(M, N) / 2); CK(hipMemcpy(hP.data(), pO, hP.size() * 2, hipMemcpyDeviceToHost)); }
+  std::vector<int> hse;
+  if (pO && d.p_fmt == 1) { hse.resize(Mp); CK(hipMemcpy(hse.data(), seO, Mp * 4, hipMemcpyDeviceToHost)); }
   std::vector<float> hpre;
   if (dpre) { hpre.resize((size_t)M * N); CK(hipMemcpy(hpre.data(), dpre, hpre.size() * 4, hipMemcpyDeviceToHost)); }
   double worst = 0, worst_p = 0, worst_pre = 0, scale = 0;
@@ -101,6 +128,11 @@ int main(int argc, char** argv) {
       const long kg = n >> 4, rb = m >> 5;
       const int kk = (int)(n & 15), h = (kk >> 2) & 1, e = (kk & 3) + ((kk >> 3) << 2);
       double v = 0;
+      if (d.p_fmt == 1) {
+        for (int pl = 0; pl < 2; ++pl)
+          v += f16_to_f(hP[((kg * (Mp / 32) + rb) * 2 + pl) * 512 + (h * 32 + (m & 31)) * 8 + e]);
+        v = ldexp(v, hse[m]);
+      } else
       for (int pl = 0; pl < 3; ++pl)
         v += bf16_to_f(hP[((kg * (Mp / 32) + rb) * 3 + pl) * 512 + (h * 32 + (m & 31)) * 8 + e]);
       worst_p = fmax(worst_p, fabs(v - ref));
@@ -134,7 +166,8 @@ int main(int argc, char** argv) {
     probe_report("under the back-to-back GEMM launches", hpr, NP);
   }
   const double fl = 2.0 * M * N * K;
-  printf("  %.4f ms  %.1f TF fp32-eq  %.0f TF bf16 issued (%.3f of 2500)\n", ms, fl / ms * 1e-9, 6 * fl / ms * 1e-9,
-         6 * fl / ms * 1e-9 / 2500.0);
+  const int nprod = fmt == 1 ? 3 : 6;
+  printf("  %.4f ms  %.1f TF fp32-eq  %.0f TF %s issued (%.3f of 2500)\n", ms, fl / ms * 1e-9, nprod * fl / ms * 1e-9,
+         fmt == 1 ? "fp16" : "bf16", nprod * fl / ms * 1e-9 / 2500.0);
   return bad ? 2 : 0;
 }
