@@ -7,12 +7,35 @@ All tensor math is issued through libsemivl_hip.so (include/semivl_hip.h); there
 __version__ = "0.1.0"
 
 import os as _os
+import sys as _sys
 
-# Ranks of a multi-GPU job: one hardware queue per stream.  The HIP runtime maps a process's streams onto
-# GPU_MAX_HW_QUEUES (default 4) queues in creation order and serialises streams that share one; a rank owns main, second,
-# helper, communication streams and the communicator's own, so with 4 the bucketed gradient all-reduce can queue BEHIND
-# the backward kernels it is meant to overlap.  Read by the runtime when it initialises (first GPU call),
-# so it is set at import; an explicit setting wins.
-if int(_os.environ.get("WORLD_SIZE", "1")) > 1:
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL, tensor sharing)
+
+def multi_rank_defaults(force=False):
+    """Process-environment defaults of a rank of a multi-GPU job; called once at import, callable explicitly by a launcher
+    (`force=True`: also for WORLD_SIZE = 1, what `bench.py --as-multi` measures).
+
+    * GPU_MAX_HW_QUEUES=8 for WORLD_SIZE > 1: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES (default 4)
+      hardware queues in creation order and serialises streams that share one; a rank owns main, second, helper and
+      communication streams, so with 4 the bucketed gradient all-reduce can queue BEHIND the backward kernels it is meant to
+      overlap.
+    * HSA_ENABLE_IPC_MODE_LEGACY=0: MACHINE-SPECIFIC -- this pool's host driver only supports dmabuf IPC (RCCL and
+      cross-process tensor sharing fail with `hipIpcGetMemHandle: invalid argument` without it); harmless elsewhere.
+
+    Both are read by the runtime when it initialises (first GPU call): an explicit setting always wins (`setdefault`), and
+    a warning says so when the runtime is already up and the values set here can no longer take effect.  Returns the
+    variables this call set."""
+    changed = {}
+    if force or int(_os.environ.get("WORLD_SIZE", "1")) > 1:
+        if "GPU_MAX_HW_QUEUES" not in _os.environ:
+            _os.environ["GPU_MAX_HW_QUEUES"] = changed["GPU_MAX_HW_QUEUES"] = "8"
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in _os.environ:
+        _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = changed["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch = _sys.modules.get("torch")
+    if changed and torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        import warnings
+        warnings.warn(f"semivl_amd: {sorted(changed)} set after the HIP runtime initialised -- they take effect only in "
+                      f"processes started from here; export them before the first GPU call (or import semivl_amd first)")
+    return changed
+
+
+multi_rank_defaults()

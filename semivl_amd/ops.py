@@ -152,8 +152,19 @@ def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld
 # hardware queue (semivl_amd/__init__.py raises GPU_MAX_HW_QUEUES to 8 so that the communication stream does not share a
 # queue with the compute it overlaps) and weight-gradient GEMMs truly concurrent with the chain's GEMMs cost 20 ms per step
 # (DESIGN §9).  SVL_WGRAD_STREAM=1 / SVL_NO_WGRAD_STREAM=1 force either setting; cfg["wgrad_stream"] overrides per step.
-WGRAD_STREAM = (bool(os.environ.get("SVL_WGRAD_STREAM")) or int(os.environ.get("WORLD_SIZE", "1")) <= 1) \
-    and not os.environ.get("SVL_NO_WGRAD_STREAM")
+def _env_flag(name):
+    """An environment switch parsed as an integer (`NAME=0` is off, unlike bool("0"))."""
+    v = os.environ.get(name, "").strip()
+    if not v:
+        return False
+    try:
+        return int(v) != 0
+    except ValueError:
+        return v.lower() not in ("false", "no", "off")
+
+
+WGRAD_STREAM = (_env_flag("SVL_WGRAD_STREAM") or int(os.environ.get("WORLD_SIZE", "1")) <= 1) \
+    and not _env_flag("SVL_NO_WGRAD_STREAM")
 WGRAD_DEPTH = int(os.environ.get("SVL_WGRAD_DEPTH", "2"))
 _WG = {}
 _WG_KEEP = {}   # device index -> deque of (event on the side stream, tensors read before it, block number)

@@ -49,6 +49,25 @@ def confidence_weighted_loss(loss, conf_map, ignore_mask, cfg):
     raise ValueError(cfg["conf_mode"])
 
 
+def compute_mc_loss(pred, mask, ign, mcc_loss_reduce="mean_all", criterion_mc=None):
+    """semivl.py:52-58 (MaskCLIP guidance loss).  The reference reads `criterion_mc` / `mcc_loss_reduce` from module
+    globals set in main() (semivl.py:158-164); here they are arguments with the same meaning: reduce 'mean' ->
+    nn.CrossEntropyLoss(ignore_index=255), 'mean_valid' / 'mean_all' -> the per-pixel map (reduction='none') summed and
+    divided by the number of non-ignored pixels / by all pixels.  API-compatibility helper: an autograd-tracked scalar for
+    callers that write the loop body themselves; `semivl_train_step` uses the fused CE kernel instead."""
+    if criterion_mc is None:
+        criterion_mc = (torch.nn.CrossEntropyLoss(ignore_index=255) if mcc_loss_reduce == "mean" else
+                        torch.nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+    l_mc = criterion_mc(pred, mask)
+    if mcc_loss_reduce == "mean_valid":
+        l_mc = l_mc.sum() / (ign != 255).sum()
+    elif mcc_loss_reduce == "mean_all":
+        l_mc = l_mc.sum() / ign.numel()
+    elif mcc_loss_reduce != "mean":
+        raise ValueError(mcc_loss_reduce)
+    return l_mc
+
+
 def _cat2(a, b):
     """torch.cat((a, b)) along dim 0 with the library's copy kernel."""
     out = ops.empty(a.shape[0] + b.shape[0], *a.shape[1:], device=a.device)
@@ -87,6 +106,27 @@ LOSS_NAMES = ("loss", "loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "
 
 def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, reducer=None, fp_masks=None,
                       return_aux=False):
+    """One iteration of semivl.py:223-328 (see _semivl_train_step for the body).  Per-step overrides taken from `cfg`
+    (`wgrad_stream`, `overlap_streams`, `head_remat`, `head_chunk_class_images`) and the decode head's per-step memory
+    plan are undone when the step ends -- also when it raises -- so that a later grad-enabled decode outside a training
+    step (validation with gradients, a test, another batch size) never inherits a stale decision."""
+    head = getattr(model, "decode_head", None)
+    keep_wg = ops.WGRAD_STREAM
+    keep_head = {a_: getattr(head, a_) for a_ in ("remat", "chunk_class_images") if head is not None and hasattr(head, a_)}
+    try:
+        return _semivl_train_step(model, batch, iters, total_iters, cfg, optimizer, reducer, fp_masks, return_aux)
+    finally:
+        ops.WGRAD_STREAM = keep_wg
+        if head is not None:
+            head._bwd_ranges = None
+            head._remat_step = None
+            head._live_class_images = None
+            for a_, v_ in keep_head.items():
+                setattr(head, a_, v_)
+
+
+def _semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, reducer=None, fp_masks=None,
+                       return_aux=False):
     """One iteration of semivl.py:223-328 (method 'semivl', CELoss(ignore 255) / CELoss; conf_mode 'pixelwise' /
     'pixelavg' / 'pixelratio', train_utils.py:30-49; mcc_loss_reduce 'mean_all' / 'mean_valid' / 'mean', semivl.py:52-58).  `batch`: the 12 step tensors on the GPU.  No host syncs: the
     returned `losses` is a device float[8] (LOSS_NAMES order).
@@ -501,6 +541,14 @@ class GradAllReducer:
             backend = "nccl"          # the injected collective is stream-ordered like RCCL's
         self.overlap = (backend == "nccl") if overlap is None else bool(overlap)
         self._async = backend == "nccl"
+        # Where the collective's kernel runs.  ProcessGroupNCCL issues an `async_op=True` collective on a stream of ITS
+        # OWN (ordered after the caller's current stream), so the hardware queue that matters is one this class never
+        # sees.  Since torch 2.8 a blocking-style call (`async_op=False`) is enqueued on the CURRENT stream instead: issued
+        # inside `torch.cuda.stream(self._comm)` the RCCL kernel runs on the communication stream picked below -- the one
+        # whose queue was probed against the step's streams.  (`on_comm_stream=False`, or an older torch, keeps the
+        # async form + a stream-level wait.)
+        tv = tuple(int(x) for x in torch.__version__.split("+")[0].split(".")[:2])
+        self.on_comm_stream = tv >= (2, 8) and not os.environ.get("SVL_RCCL_ASYNC_OP")
         # stream -> hardware-queue map: the step's own streams are created FIRST (deterministic map, see
         # create_step_streams), then the communication stream, and the result is probed once and kept for the bench line
         self.queue_info = None
@@ -517,22 +565,28 @@ class GradAllReducer:
             names = ["main", "second"] + (["weight_gradient"] if len(step_streams) > 2 else [])
             tried, pick, shared = [], None, None
             for _ in range(6):
-                cand = torch.cuda.Stream()
+                cand = torch.cuda.Stream(optimizer.g.device)
                 sh_ = [n_ for n_, s_ in zip(names, step_streams) if ops.streams_share_queue(s_, cand)]
                 tried.append(cand)               # (kept alive: a destroyed stream's queue slot would be handed out again)
                 if pick is None or len(sh_) < len(shared):
                     pick, shared = cand, sh_
                 if not sh_:
                     break
-            self._probed_streams = tried
+            # (the unpicked candidates are kept only until the pick is made: a destroyed stream's queue slot is handed out
+            # again, which is fine once nothing else is created by this class)
+            self._probed_streams = [pick]
+            n_tried = len(tried)
+            del tried
             if self._async:
                 self._comm = pick
             self.queue_info = dict(gpu_max_hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                                    comm_stream_shares_queue=bool(shared), shares_queue_with=shared,
-                                   streams_probed=len(tried), weight_gradient_stream=bool(ops.WGRAD_STREAM),
+                                   streams_probed=n_tried, weight_gradient_stream=bool(ops.WGRAD_STREAM),
+                                   collective_runs_on=("the communication stream (async_op=False under torch >= 2.8)"
+                                                       if self.on_comm_stream else "ProcessGroupNCCL's internal stream"),
                                    comm_stream="dedicated" if self._async else "none (blocking backend; probed a stand-in)")
         elif self._async and on_gpu:
-            self._comm = torch.cuda.Stream()
+            self._comm = torch.cuda.Stream(optimizer.g.device)
         self._works, self._fired, self._complete = [], set(), [0] * len(self.buckets)
         self.early_fires = 0
         if self.world > 1 and groups:
@@ -567,12 +621,17 @@ class GradAllReducer:
                     e0.record(self._comm)
                 if self._collective is not None:
                     w = self._collective(g)
+                elif self.on_comm_stream:
+                    # enqueued on the current stream = self._comm (torch >= 2.8): no work object, nothing to wait for
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
+                    w = None
                 else:
                     w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                # ProcessGroupNCCL runs an async collective on its OWN stream, which only waits for the caller's; the
+                # (async form: ProcessGroupNCCL runs the collective on its OWN stream, which only waits for the caller's; the
                 # stream-level wait below orders the communication stream after the collective itself, so the events
-                # around it bracket its duration (not its enqueue) and joining `_comm` joins every collective
-                if w is not None:
+                # around it bracket its duration, not its enqueue, and joining `_comm` joins every collective.  Only for
+                # works whose wait() is stream-level: a blocking wait here would stall backward on the host.)
+                if w is not None and not os.environ.get("TORCH_NCCL_BLOCKING_WAIT"):
                     w.wait()
                 self._works.append(w)
                 if self.profile:

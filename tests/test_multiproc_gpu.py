@@ -170,6 +170,90 @@ def test_two_rank_step_different_shards_equals_accumulated_single_process(dev, n
     _check_two_ranks(dev, name, "gloo")
 
 
+def _rccl1_worker(port, name, q):
+    """ONE rank, backend 'nccl' (RCCL): the real ProcessGroupNCCL code path of GradAllReducer on a one-GPU box.  The
+    reducer is told `world=2` so that its multi-rank branch runs (communication stream picked against the step's
+    streams, buckets fired from inside backward, stream-ordered join); a one-rank all-reduce is the identity, so with
+    grad_scale reset to 1 the step must equal the reducer-less step bit for bit."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    # (the settings every rank of a multi-GPU run gets -- bench.py / semivl_amd.multi_rank_defaults: eight hardware queues,
+    # no weight-gradient stream; set before the HIP runtime initialises in this spawned process)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      GPU_MAX_HW_QUEUES="8", SVL_NO_WGRAD_STREAM="1")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from golden_util import build_hip, fixture_fp_masks, fixture_state, load_fixture
+    from semivl_amd.synthetic import exp40_cfg
+    from semivl_amd.train import FusedAdamW, GradAllReducer, semivl_train_step
+    z, c = load_fixture(name)
+    out = {}
+    for tag in ("plain", "rccl"):
+        hip = build_hip(c)
+        hip.load_state_dict(fixture_state(z, c, hip), strict=True)
+        hip.to(dev)
+        opt = FusedAdamW(hip, exp40_cfg()["optimizer"])
+        masks = [m.to(dev) for m in fixture_fp_masks(z, c)]
+        batch = {k: v.to(dev) for k, v in _shard(c, 0).items()}
+        red = None
+        if tag == "rccl":
+            red = GradAllReducer(opt, bucket_mb=0.05, overlap=True, world=2, profile=True)
+            opt.grad_scale = 1.0            # (the one-rank SUM is the identity)
+            seen = []
+            real = dist.all_reduce
+
+            def spy(t, *a, **kw):           # which stream is current when the collective is enqueued, and in which form
+                seen.append((torch.cuda.current_stream().cuda_stream, kw.get("async_op", False), t.numel()))
+                return real(t, *a, **kw)
+            dist.all_reduce = spy
+        try:
+            for it in range(2):
+                semivl_train_step(hip, batch, 3 + it, 50, dict(STEP_CFG), optimizer=opt, reducer=red, fp_masks=masks)
+        finally:
+            if tag == "rccl":
+                dist.all_reduce = real
+        torch.cuda.synchronize()
+        out[tag] = opt.p.cpu().numpy()
+        if red is not None:
+            out["report"] = red.timing_report()
+            out["seen"] = seen
+            out["comm"] = red._comm.cuda_stream
+            out["main"] = torch.cuda.current_stream().cuda_stream
+            out["on_comm"] = red.on_comm_stream
+            out["early"] = red.early_fires
+            out["nb"] = len(red.buckets)
+            out["backend"] = dist.get_backend()
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_runs_the_real_process_group_on_the_communication_stream(dev):
+    """The ProcessGroupNCCL branch of GradAllReducer on ONE GPU (a one-rank RCCL communicator): every bucket's
+    all-reduce is enqueued with the communication stream current and in the blocking-style form that torch >= 2.8 runs ON
+    that stream (not on the process group's internal one), buckets are launched from inside backward, the per-bucket HIP
+    events bracket real RCCL launches (> 0 ms), the picked stream shares a hardware queue with none of the step's streams,
+    and the step equals the reducer-less step bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    p = ctx.Process(target=_rccl1_worker, args=(port, "tiny", q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert out["backend"] == "nccl" and out["on_comm"], "torch >= 2.8 expected on this image"
+    assert np.array_equal(out["plain"], out["rccl"]), "identity all-reduce on the communication stream changed the step"
+    assert len(out["seen"]) == 2 * out["nb"] and out["nb"] >= 4
+    assert all(st == out["comm"] and st != out["main"] and not asy for st, asy, _ in out["seen"])
+    assert out["early"] >= out["nb"], "buckets must be launched from inside backward"
+    rep = out["report"]
+    assert rep and len(rep["buckets"]) == out["nb"] and all(b["ms"] > 0.0 for b in rep["buckets"]), rep
+    assert rep["queues"]["comm_stream_shares_queue"] is False and "communication stream" in rep["queues"]["collective_runs_on"], rep["queues"]
+    print("one-rank RCCL report:", rep)
+
+
 def test_two_rank_step_rccl(dev):
     """The same check over RCCL (backend 'nccl') with the collectives on the communication stream; needs two GPUs."""
     if torch.cuda.device_count() < 2:
