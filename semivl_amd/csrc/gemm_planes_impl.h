@@ -66,6 +66,7 @@ struct PlanesP {
   const float* b_bd;
   int* p_se;
   int p_np;                 // planes of the packed output: 3 (bf16 x 3) or 2 (fp16 x 2)
+  int epi_fast;             // 0: generic epilogue only (SVL_PLANES_NO_FAST_EPI=1, for A/B runs)
   int b_rb;                 // 32-row blocks the B operand's buffer holds
   int M, N, K;              // M valid rows from A's row block 0
   float* C;
@@ -81,7 +82,21 @@ struct PlanesP {
   int tiles_n, full_m, tail_rows;   // full_m = M / 256 row bands; tail_rows = M % 256
   int rcnt[8], fstart[8];   // per XCD x (blocks with id % 8 == x): ragged-band tiles it takes first, first full tile of its chunk
   int panel;                // column tiles per panel of the full-tile order (tile_of_block)
+#ifdef SVL_X6P_TIMING
+  unsigned long long* dbg;  // tools/micro/x6p_phases.hip: 8 stamps per block (100 MHz wall clock + shader cycles)
+#endif
 };
+#ifdef SVL_X6P_TIMING
+#define X6P_STAMP(slot)                                                                      \
+  do {                                                                                       \
+    if (p.dbg && lane == 0 && (wave & 3) == 0) {                                             \
+      p.dbg[((long)blockIdx.x * 2 + (wave >> 2)) * 8 + (slot)] = wall_clock64();            \
+      p.dbg[((long)blockIdx.x * 2 + (wave >> 2)) * 8 + 4 + (slot)] = clock64();             \
+    }                                                                                        \
+  } while (0)
+#else
+#define X6P_STAMP(slot) do {} while (0)
+#endif
 
 namespace {
 
@@ -379,6 +394,181 @@ __device__ __forceinline__ void x6p_epilogue(const PlanesP& p, f32x16 (&acc)[TM]
 }
 
 
+// ---- the same epilogue for launches whose pointers and leading dimensions allow 16-byte accesses (kernel variant EF = true;
+// every launch of the training step): masks instead of a scalar fallback at the matrix edges, and -- what matters -- NO
+// LOAD BEHIND A STORE.  vmcnt counts loads and stores alike on gfx950, so a bias / exponent / residual load
+// issued after the previous row block's stores made its s_waitcnt vmcnt(0) wait for those stores to reach memory: the generic
+// epilogue above ran the stores of a tile at ~8 B/clk/CU where a plain fill kernel does 47 (tools/micro/storebw.hip).  Here
+// everything that does not depend on the row block (B exponents, bias, A exponents, norm bounds) is read before the first
+// store, and the residual / saved pre-activation of row block i + 1 is requested before the stores of row block i.
+template <int NP, int TM, int TN, int EPI>
+__device__ __forceinline__ void x6p_epilogue_fast(const PlanesP& p, f32x16 (&acc)[TM][TN], int m0, int mvalid, int wm, int nw,
+                                                  char* wl, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  constexpr int WC = TN * 32, RS = WC * 4 + 16, LPR = WC / 4, NIT = 32 * LPR / 64;
+  const int mw = m0 + wm * TM * 32;                  // first row of this wave
+  const int rows_w = mvalid - wm * TM * 32;          // valid rows of this wave's block (may be <= 0 or > 32 TM)
+  // 0 / 1. B exponents and bias of the wave's columns are staged in LDS once (behind the transpose buffer) and read back per
+  // row block with ds_read_b128 -- no vmcnt involved; the A exponents / norm bounds of all row blocks are read up front
+  // (those arrays are as long as the padded plane buffers: rows past the edge read defined memory)
+  float* lb = reinterpret_cast<float*>(wl + 32 * RS);
+  int* le = reinterpret_cast<int*>(lb + WC);
+#pragma unroll
+  for (int c = lane; c < WC; c += 64) {
+    const bool ok = nw + c < p.N;
+    lb[c] = (p.bias && ok) ? p.bias[nw + c] : 0.f;
+    if constexpr (NP == 2) le[c] = (p.b_se && ok) ? p.b_se[nw + c] : 0;
+  }
+  int ea[TM];
+  static_for<0, TM>([&](auto I) { ea[decltype(I)::value] = (NP == 2 && p.a_se) ? p.a_se[mw + decltype(I)::value * 32 + l31] : 0; });
+  int eo[TM];
+  static_for<0, TM>([&](auto I) { eo[decltype(I)::value] = 0; });
+  if (p.P && p.p_np == 2) {
+    const float bd0 = p.b_bd[0], bd1 = p.b_bd[1];
+    static_for<0, TM>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      float bound = p.a_rn[mw + i * 32 + l31] * bd0 + bd1;
+      if constexpr (EPI == EPI_DGELU) bound *= 1.13f;
+      eo[i] = scale_exp_of(bound);
+    });
+  }
+  // residual / saved pre-activation of one row block: 16-byte loads, zero outside the matrix
+  auto resid4 = [&](int i, int j, int g) __attribute__((always_inline)) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    const int n = nw + 4 * hi + j * 32 + 8 * g;
+    if (i * 32 + l31 < rows_w && n < p.N) r = *reinterpret_cast<const f32x4*>(p.resid + (long)(mw + i * 32 + l31) * p.ldr + n);
+    return r;
+  };
+  // the wave's 32 x WC block (acc layout) -> dst rows through the LDS transpose, 16 B per lane, whole row segments per store
+  auto store_rows = [&](float* dst, const f32x16 (&o)[TN], int i, bool accumulate) __attribute__((always_inline)) {
+    static_for<0, TN>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      static_for<0, 4>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        f32x4 q = {o[j][4 * g], o[j][4 * g + 1], o[j][4 * g + 2], o[j][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(wl + l31 * RS + (j * 32 + 8 * g + 4 * hi) * 4) = q;
+      });
+    });
+    // 16 bytes per lane: linear index it * 64 + lane over the 32 x LPR quads of the block (LPR = 8 / 16 / 24 quads per row)
+    constexpr int HB = NIT > 4 ? 4 : NIT;              // read back and store in batches of four: 16 registers in flight
+    static_for<0, NIT / HB>([&](auto H) {
+      constexpr int h0 = decltype(H)::value * HB;
+      f32x4 q[HB];
+      float* d[HB];
+      bool ok[HB];
+#pragma unroll
+      for (int it = 0; it < HB; ++it) {
+        const int idx = (h0 + it) * 64 + lane, row = idx / LPR, c4 = (idx - row * LPR) * 4;
+        q[it] = *reinterpret_cast<const f32x4*>(wl + row * RS + c4 * 4);
+        d[it] = dst + (long)(mw + i * 32 + row) * p.ldc + nw + c4;
+        ok[it] = nw + c4 < p.N && i * 32 + row < rows_w;
+      }
+      if (accumulate) {
+#pragma unroll
+        for (int it = 0; it < HB; ++it)
+          if (ok[it]) q[it] += *reinterpret_cast<const f32x4*>(d[it]);
+      }
+#pragma unroll
+      for (int it = 0; it < HB; ++it)
+        if (ok[it]) *reinterpret_cast<f32x4*>(d[it]) = q[it];
+    });
+  };
+
+  constexpr bool RES = EPI != EPI_GELU;     // (GELU + residual add is served by the generic kernel: launch())
+  f32x4 rv[TN][4];
+  static_for<0, TN>([&](auto J) {
+    static_for<0, 4>([&](auto G) {
+      rv[decltype(J)::value][decltype(G)::value] = (RES && p.resid) ? resid4(0, decltype(J)::value, decltype(G)::value) : f32x4{0.f, 0.f, 0.f, 0.f};
+    });
+  });
+  static_for<0, TM>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if (i * 32 < rows_w) {       // (wave-uniform: row blocks past the edge of a ragged tile are skipped)
+      // (one straight-line block of four row blocks invites the scheduler to start all of them at once; the fences keep a
+      // row block's temporaries to itself)
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, TN>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        static_for<0, 4>([&](auto G) {
+          constexpr int g = decltype(G)::value;
+          const int c = j * 32 + 8 * g + 4 * hi;
+          if constexpr (NP == 2) {
+            const i32x4 eb = *reinterpret_cast<const i32x4*>(le + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = __builtin_amdgcn_ldexpf(acc[i][j][4 * g + e], ea[i] + eb[e]);
+          }
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(lb + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += b4[e];
+        });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      // 2. pre-activation copy
+      if (p.preact) store_rows(p.preact, acc[i], i, false);
+      __builtin_amdgcn_sched_barrier(0);
+      // 3. activation / residual / derivative product
+      static_for<0, TN>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        static_for<0, 4>([&](auto G) {
+          constexpr int g = decltype(G)::value;
+          const f32x4 r4 = RES ? rv[j][g] : f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (RES && i + 1 < TM) {   // the next row block's values are requested as soon as this block's are in
+            if (p.resid) rv[j][g] = resid4(i + 1, j, g);       // registers, i.e. BEFORE this row block's stores
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][4 * g + e];
+            const float r = r4[e];
+            if constexpr (EPI == EPI_GELU) v = gelu_erf(v) + r;
+            else if constexpr (EPI == EPI_DGELU) v *= gelu_erf_grad(r);
+            else {
+              if (p.act == SVL_ACT_RELU) v = fmaxf(v, 0.f);
+              if (p.act == SVL_ACT_MUL_DRELU) v = r > 0.f ? v : 0.f;
+              else v += r;
+            }
+            acc[i][j][4 * g + e] = v;
+          }
+          if constexpr (EPI == EPI_DGELU) __builtin_amdgcn_sched_barrier(0);   // (erf + exp temporaries of one 4-run at a time)
+        });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      // 4. outputs
+      if (p.C) store_rows(p.C, acc[i], i, p.accumulate != 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p.P) {
+        if (p.p_np == 2 && nw == 0 && hi == 0) p.p_se[mw + i * 32 + l31] = eo[i];
+        static_for<0, TN>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          static_for<0, 2>([&](auto G2) {
+            constexpr int g2 = decltype(G2)::value;
+            const int nb = nw + j * 32 + 16 * g2;
+            if (nb < p.N) {   // (wave-uniform; rows past the edge land in padding nobody reads)
+              float o8[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o8[e] = acc[i][j][8 * g2 + e];
+              if (p.p_np == 2) {
+                f16x8 h0, h1;
+                split2x8(o8, eo[i], h0, h1);
+                char* q = p.P + (long)(nb >> 4) * p.p_ks + (long)((mw + i * 32) >> 5) * (2 * CH) + lane * 16;
+                *reinterpret_cast<f16x8*>(q) = h0;
+                *reinterpret_cast<f16x8*>(q + CH) = h1;
+              } else {
+                bf16x8 h0, h1, h2;
+                split3x8(o8, h0, h1, h2);
+                char* q = p.P + (long)(nb >> 4) * p.p_ks + (long)((mw + i * 32) >> 5) * (3 * CH) + lane * 16;
+                *reinterpret_cast<bf16x8*>(q) = h0;
+                *reinterpret_cast<bf16x8*>(q + CH) = h1;
+                *reinterpret_cast<bf16x8*>(q + 2 * CH) = h2;
+              }
+            }
+          });
+        });
+      }
+    }
+  });
+}
+
+
 // cross products in issue order, smallest first: NP = 3: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0);  NP = 2: (1,0) (0,1) (0,0)
 template <int NP> constexpr int prod_a(int t) {
   return NP == 3 ? (t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0) : (t == 0 ? 1 : 0);
@@ -387,7 +577,7 @@ template <int NP> constexpr int prod_b(int t) {
   return NP == 3 ? (t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0) : (t == 1 ? 1 : 0);
 }
 
-template <int NP, int BN, int EPI>
+template <int NP, int BN, int EPI, bool EF>
 __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
   extern __shared__ __attribute__((aligned(1024))) char sm[];
   // wave grid WM x WN over the 256 x BN tile, 32x32 MFMA blocks per wave TM x TN:
@@ -399,12 +589,13 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
   constexpr int STAGE = NCH * CH;
   constexpr int CPW = (NCH + 7) / 8;                   // LDS-DMA instructions per wave and k-group (upper bound)
   constexpr bool EVEN = NCH % 8 == 0;                  // every wave issues CPW; else waves >= NCH % 8 issue CPW - 1
-  static_assert(NSTAGE * STAGE <= 160 * 1024 && 8 * 32 * (TN * 128 + 16) <= 160 * 1024, "LDS");
+  static_assert(NSTAGE * STAGE <= 160 * 1024 && 8 * (32 * (TN * 128 + 16) + TN * 32 * 8) <= 160 * 1024, "LDS");
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wm = wave / WN, wq = wave % WN;
 
+  X6P_STAMP(0);
   const TileRef tr = tile_of_block(p);
   const int m0 = tr.m0, n0 = tr.tn * BN, mvalid = tr.rows;
   const int nblk = (mvalid + 31) >> 5;                 // row blocks of A this tile needs
@@ -473,6 +664,7 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
     wait_vm<0>();
   }
   __builtin_amdgcn_s_barrier();                 // B_0: k-group 0 is in LDS for everybody
+  X6P_STAMP(1);
   if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
   __builtin_amdgcn_sched_barrier(0);
 
@@ -551,8 +743,18 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
   if (vb == TM) kloop(std::true_type{});
   else kloop(std::false_type{});
   if (grp == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two groups match: every LDS read is done
+  X6P_STAMP(2);
 
-  x6p_epilogue<NP, TM, TN, EPI>(p, acc, m0, mvalid, wm, n0 + wq * (TN * 32), sm + wave * (32 * (TN * 128 + 16)), lane);
+  // (ONE epilogue per kernel: with both behind a branch the accumulators are merged through copies and the argument
+  // struct ends up in scratch -- 400 bytes per lane)
+  const int nw = n0 + wq * (TN * 32);
+  char* wl = sm + wave * (32 * (TN * 128 + 16) + TN * 32 * 8);
+  if constexpr (EF) x6p_epilogue_fast<NP, TM, TN, EPI>(p, acc, m0, mvalid, wm, nw, wl, lane);
+  else x6p_epilogue<NP, TM, TN, EPI>(p, acc, m0, mvalid, wm, nw, wl, lane);
+#ifdef SVL_X6P_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stamp 3 = this wave's stores have left)
+#endif
+  X6P_STAMP(3);
 }
 
 
@@ -564,21 +766,21 @@ inline bool attr_needed(std::atomic<uint64_t>& mask) {
   return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
 }
 
-template <int NP, int BN, int EPI>
+template <int NP, int BN, int EPI, bool EF>
 int launch_kernel(const PlanesP& q, long blocks, hipStream_t st) {
   constexpr int TN_ = BN / 32 / (BN == 192 ? 2 : 4);
-  constexpr size_t stages = (size_t)NSTAGE * ((BM + BN) / 32 * NP) * CH, scratch = (size_t)8 * 32 * (TN_ * 128 + 16);
+  constexpr size_t stages = (size_t)NSTAGE * ((BM + BN) / 32 * NP) * CH, scratch = (size_t)8 * (32 * (TN_ * 128 + 16) + TN_ * 32 * 8);
   constexpr size_t lds = stages > scratch ? stages : scratch;     // (the epilogue's transpose buffers alias the stages)
   static std::atomic<uint64_t> mask{0};
   if (attr_needed(mask))
-    SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6p_kernel<NP, BN, EPI>),
+    SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6p_kernel<NP, BN, EPI, EF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((gemm_x6p_kernel<NP, BN, EPI>), dim3((unsigned)blocks), dim3(512), lds, st, q);
+  hipLaunchKernelGGL((gemm_x6p_kernel<NP, BN, EPI, EF>), dim3((unsigned)blocks), dim3(512), lds, st, q);
   SVL_LAUNCH_CHECK("svl_gemm_planes_f32");
   return SVL_OK;
 }
 
-template <int NP, int BN>
+template <int NP, int BN, bool EF>
 int launch_tile(PlanesP q, hipStream_t st) {
   q.tiles_n = (q.N + BN - 1) / BN;
   q.full_m = q.M / BM;
@@ -600,9 +802,9 @@ int launch_tile(PlanesP q, hipStream_t st) {
     q.fstart[x] = (int)fs;
     fs += blocks - rag;
   }
-  if (q.act == SVL_ACT_GELU) return launch_kernel<NP, BN, EPI_GELU>(q, total, st);
-  if (q.act == SVL_ACT_MUL_DGELU) return launch_kernel<NP, BN, EPI_DGELU>(q, total, st);
-  return launch_kernel<NP, BN, EPI_LIGHT>(q, total, st);
+  if (q.act == SVL_ACT_GELU) return launch_kernel<NP, BN, EPI_GELU, EF>(q, total, st);
+  if (q.act == SVL_ACT_MUL_DGELU) return launch_kernel<NP, BN, EPI_DGELU, EF>(q, total, st);
+  return launch_kernel<NP, BN, EPI_LIGHT, EF>(q, total, st);
 }
 
 // Tile width: 256 unless a narrower tile wastes less of the last round of the grid (256 CUs x 1 block; the ragged row
@@ -625,9 +827,15 @@ int launch(const PlanesP& q, hipStream_t st) {
       if (cost(128) < cost(bn)) bn = 128;
     }
   }
-  if (bn == 128) return launch_tile<NP, 128>(q, st);
-  if (bn == 192) return launch_tile<NP, 192>(q, st);
-  return launch_tile<NP, 256>(q, st);
+  // epilogue variant: 16-byte accesses throughout (every launch of the step) or the scalar-capable generic one, which
+  // exists for 128-wide tiles only (any shape can be tiled that way)
+  const bool al16 = ((reinterpret_cast<uintptr_t>(q.C) | reinterpret_cast<uintptr_t>(q.preact) | reinterpret_cast<uintptr_t>(q.resid)) & 15) == 0;
+  const bool ef = q.epi_fast && al16 && (q.N & 3) == 0 && (q.ldc & 3) == 0 && (!q.resid || (q.ldr & 3) == 0) &&
+                  !(q.act == SVL_ACT_GELU && q.resid);
+  if (!ef) return launch_tile<NP, 128, false>(q, st);
+  if (bn == 128) return launch_tile<NP, 128, true>(q, st);
+  if (bn == 192) return launch_tile<NP, 192, true>(q, st);
+  return launch_tile<NP, 256, true>(q, st);
 }
 
 }  // namespace
