@@ -63,13 +63,22 @@ GRAD_MAX_ERR = 6e-3           # the far ends of the chains); element-wise bound 
 # get their own bound; every other tensor keeps GRAD_REL_L2.
 SHARED_FAR_END = ("backbone.pos_embed", "backbone.layers.0.attn.attn.in_proj_weight", "backbone.layers.0.attn.attn.out_proj.weight",
                   "decode_head.skip_proj.1.0.weight")
-GRAD_REL_L2_SHARED = 1.2e-2
+GRAD_REL_L2_SHARED = 1.2e-2     # split-product modes only; the exact fp32 mode keeps GRAD_REL_L2 on these tensors too
+MCLIP_TIE = 1e-5                # MaskCLIP label ties: top-2 probability gap / distance to the threshold (round 4: 1e-4)
+# Ratchets (round-4 review): what this tree MEASURES on each full-size case -- (most label flips in one map, worst rel-L2 over
+# the ordinary tensors, worst rel-L2 over SHARED_FAR_END) -- asserted with 30 % headroom (+2 flips), so that a regression
+# inside the generous fixed bounds above still fails.  The kernels are deterministic: the numbers only move when the
+# arithmetic of a kernel changes, and then they are re-measured (the test prints `RATCHET measured`).
+RATCHET = {("pascal", 0): (21, 1.3e-3, 2.7e-3), ("pascal", 6): (14, 2.1e-3, 4.3e-3),
+           ("coco", 0): (1, 8.2e-4, 1.1e-3), ("coco", 6): (2, 4.8e-4, 7.4e-4),
+           ("ade", 0): (6, 1.4e-3, 2.8e-3), ("ade", 6): (5, 5.4e-4, 8.9e-4)}
 
 
-def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stack=(), after_bn=(), after_bn_tol=None):
+def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stack=(), after_bn=(), after_bn_tol=None,
+               ratchet=None):
     """Losses / logits within north_star's 1e-3 (logits in fact within LOGIT_ERR_BOUND); label maps bit-exact except at fp
     ties of the oracle, with a FIXED budget: a flip needs the oracle's top-2 logit gap to be below TIE_EPS (MaskCLIP
-    labels: top-2 probability gap or distance to the 0.9 threshold below 1e-4 -- its softmax runs at temperature 100);
+    labels: top-2 probability gap or distance to the 0.9 threshold below MCLIP_TIE -- its softmax runs at temperature 100);
     every parameter gradient against the oracle's: rel-L2 <= GRAD_REL_L2 and every element within GRAD_MAX_ERR of the
     tensor's scale.  `bn_stack`: parameter-name fragments of ReLU-on-BatchNorm stacks (3e-2: pre-activations within
     rounding of 0 flip, test_model_gpu.py::test_conv_encoder_matches_oracle); `after_bn`: tensors fed by such a stack's
@@ -101,13 +110,13 @@ def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stac
         t = logits.detach().topk(2, dim=1).values
         return t[:, 0] - t[:, 1]
     t2 = aux["mclip_top2"]
-    mtie = ((t2[:, 0] - t2[:, 1]) < 1e-4) | ((t2[:, 0] - cfg["mcc_conf_thresh"]).abs() < 1e-4)
+    mtie = ((t2[:, 0] - t2[:, 1]) < MCLIP_TIE) | ((t2[:, 0] - cfg["mcc_conf_thresh"]).abs() < MCLIP_TIE)
     ties = dict(mask_w=gap(aux["pred_w"]) <= TIE_EPS, mask_w_other=gap(aux["pred_w_other"]) <= TIE_EPS,
                 mclip=mtie[:B], mclip_other=mtie[B:])
     flips = {k: assert_labels(haux[k].cpu().numpy(), aux[k].numpy(), ties[k].numpy(), k)
              for k in ("mask_w", "mask_w_other", "mclip", "mclip_other")}
     for k, n in flips.items():
-        assert n <= 5e-4 * aux[k].numel(), (k, n)
+        assert n <= 5e-4 * aux[k].numel() and n <= int(ties[k].sum()), (k, n)   # (only tie pixels may flip: the tie budget)
     assert (haux["conf_w"].cpu() - aux["conf_w"]).abs().max().item() < 1e-4
     og = {n: p.grad for n, p in orc.named_parameters() if p.grad is not None}
     hg = {n: p.grad for n, p in hip.named_parameters() if p.grad is not None}
@@ -137,6 +146,14 @@ def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stac
     print(f"[gemm_mode {gemm_mode}] logit errs {errs}, label flips at ties {flips}; largest grad max-err / scale:",
           [(f"{v:.1e}", n) for v, n in table[-6:]], "; largest rel-L2:", [(f"{v:.1e}", n) for v, n in t2_[-10:]],
           "; head rel-L2:", [(f"{v:.1e}", n) for v, n in t2_ if ("up2" in n or "skip_proj" in n or "up1" in n)][-8:])
+    plain = [v for v, n in t2_ if n != "decode_head.head.bias" and not any(s_ in n for s_ in bn_stack) and
+             not any(s_ in n for s_ in after_bn) and n not in SHARED_FAR_END]
+    shared = [v for v, n in t2_ if n in SHARED_FAR_END]
+    meas = (max(flips.values()), max(plain), max(shared) if shared else 0.0)
+    print(f"RATCHET measured [gemm_mode {gemm_mode}]: flips {meas[0]}, rel-L2 {meas[1]:.2e}, shared far end {meas[2]:.2e}; asserted: {ratchet}")
+    if ratchet is not None:
+        assert meas[0] <= int(1.3 * ratchet[0]) + 2, ("label flips ratchet", meas, ratchet)
+        assert meas[1] <= 1.3 * ratchet[1] and meas[2] <= 1.3 * ratchet[2], ("gradient rel-L2 ratchet", meas, ratchet)
     for n in og:
         ref = og[n]
         err = (hg[n].cpu() - ref).abs().max().item()
@@ -149,7 +166,7 @@ def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stac
             assert rel2 < 3e-2 or ref.norm().item() < 1e-7, f"{n}: rel L2 {rel2}"
             continue
         tol2 = after_bn_tol if (after_bn_tol is not None and any(s_ in n for s_ in after_bn)) else GRAD_REL_L2
-        if n in SHARED_FAR_END:
+        if n in SHARED_FAR_END and gemm_mode != 0:
             tol2 = max(tol2, GRAD_REL_L2_SHARED)
         assert rel2 < tol2, f"{n}: grad rel L2 {rel2} (bound {tol2})"
         assert err < (GRAD_MAX_ERR if tol2 == GRAD_REL_L2 else 1.5 * tol2) * scale + 1e-8, f"{n}: grad max err {err} vs scale {scale}"
@@ -182,7 +199,7 @@ def fullsize_case():
 def test_fullsize_step_matches_oracle(dev, fullsize_case, gemm_mode):
     """gemm_mode 0: exact fp32 MFMA; 6: the ViT linears on the bf16 pipe (3-way split, 6 products) -- same tolerances."""
     cfg, hip, orc, batch, masks, loss, aux = fullsize_case
-    check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode)
+    check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode, ratchet=RATCHET[("pascal", gemm_mode)])
 
 
 def test_fullsize_gradient_error_against_fp64(dev):
@@ -242,9 +259,9 @@ def test_fullsize_step_large_class_counts(dev, nclass, dataset):
     batch = O.synthetic_batch(1, 512, nclass, seed=100 + nclass)
     masks = fp_masks_for((768, 768, 512), seed=nclass)
     loss, aux = oracle_step(orc, cfg, batch, masks, 0.0)
-    check_step(dev, cfg, hip, orc, batch, masks, loss, aux)
-    # the arithmetic bench.py measures by default (GEMMs, attention, tiled / ASPP convolutions as bf16 x 6 split products)
-    check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=6)
+    check_step(dev, cfg, hip, orc, batch, masks, loss, aux, ratchet=RATCHET[(dataset, 0)])
+    # the arithmetic bench.py measures by default (GEMMs, attention, tiled / ASPP convolutions as split products)
+    check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=6, ratchet=RATCHET[(dataset, 6)])
     hip.decode_head.chunk_class_images = 1344
 
 
@@ -282,6 +299,50 @@ def test_fullsize_cityscapes_recipe(dev):
                 assert (bh.cpu().float() - bo.float()).abs().max().item() < 1e-4 * max(1.0, bo.float().abs().max().item()), n
 
 
+@pytest.mark.parametrize("nclass,dataset,crop,B", [(21, "pascal", 512, 16), (81, "coco", 512, 16), (19, "cityscapes", 801, 8)])
+def test_forward_is_batch_invariant_at_baseline_batch(dev, nclass, dataset, crop, B):
+    """Oracle parity runs at B <= 2; BASELINE.json's configs run B = 16 (8 at 801^2) per GPU.  The bridge is a property of
+    the forward in the arithmetic bench.py measures (mode 6): every op is per sample, so
+      * the ViT encoder's features (planes GEMMs with per-row scales, fused attention, LayerNorm) of sample i from the
+        full-batch forward equal the two-sample forward's BIT FOR BIT -- a tile map, a split or a scale that depended on the
+        batch would show;
+      * the decoder's logits agree to rounding (measured 2.1e-6, asserted 1e-5 -- north_star's tolerance is 1e-3): its
+        kernel SELECTION depends on the row count (the short-K row stream serves launches of >= 32768 rows, split-K plans
+        follow the tile count), i.e. the same sums in another order, not another computation;
+      * MaskCLIP labels are identical, pseudo labels wherever the top-2 logit gap exceeds that rounding."""
+    from golden_util import seeded_state
+    from semivl_amd import ops
+    from semivl_amd.model.builder import build_model
+    from semivl_amd.synthetic import exp40_cfg, synthetic_batch
+    cfg = exp40_cfg(B, crop, nclass, dataset)
+    hip = build_model(cfg)
+    hip.load_state_dict(seeded_state([(k, tuple(v.shape)) for k, v in hip.state_dict().items()], 5150 + nclass), strict=True)
+    hip.to(dev).eval()
+    img = synthetic_batch(B, crop, nclass, seed=77, device=dev)["img_w"]
+    ops.set_gemm_emulation(6)
+    worst = 0.0
+    try:
+        with torch.no_grad():
+            full = hip(img)
+            lab = hip.forward_maskclip(img, 0.9)
+            feats, _ = hip.backbone.forward_tokens(hip.renormalize_img_for_clip(img), need_global=False)
+            for s0 in (0, B - 2):
+                sub = img[s0:s0 + 2].contiguous()
+                fsub, _ = hip.backbone.forward_tokens(hip.renormalize_img_for_clip(sub), need_global=False)
+                for fa, fb in zip(feats, fsub):
+                    assert torch.equal(fa[s0:s0 + 2], fb), f"encoder features of samples {s0}, {s0 + 1} depend on the batch ({dataset}, B = {B})"
+                part = hip(sub)
+                worst = max(worst, float((full[s0:s0 + 2] - part).abs().max()))
+                assert torch.equal(lab[s0:s0 + 2], hip.forward_maskclip(sub, 0.9))
+                t2 = part.topk(2, dim=1).values
+                clear = (t2[:, 0] - t2[:, 1]) > 1e-5
+                assert torch.equal(full[s0:s0 + 2].argmax(1)[clear], part.argmax(1)[clear])
+    finally:
+        ops.set_gemm_emulation(0)
+    print(f"[{dataset} B={B}] logits of the full batch vs two-sample forwards: max |diff| {worst:.2e}")
+    assert worst < 1e-5 and full.shape == (B, nclass, crop, crop) and torch.isfinite(full).all()
+
+
 def test_fullsize_ade150_head_forward(dev):
     """N = 150 classes (ADE config): eval forward of the full model vs the oracle (exercises the seq=150 attention,
     N=150 similarity GEMM and class-batched decoder at 150 class-images per image)."""
@@ -305,5 +366,5 @@ def test_fullsize_ade150_head_forward(dev):
         rm, top2 = orc.forward_maskclip(img, 0.9, True)
         hm = hip.forward_maskclip(img.to(dev), 0.9)
     assert (out.cpu() - ref).abs().max().item() < 1e-3
-    tie = ((top2[:, 0] - top2[:, 1]) < 1e-4) | ((top2[:, 0] - 0.9).abs() < 1e-4)
+    tie = ((top2[:, 0] - top2[:, 1]) < MCLIP_TIE) | ((top2[:, 0] - 0.9).abs() < MCLIP_TIE)
     assert_labels(hm.cpu().numpy(), rm.numpy(), tie.numpy(), "maskclip labels")

@@ -32,10 +32,10 @@ for f in sorted(glob.glob(R+"/gpurun_out/pmcx_*/**/*counter_collection.csv", rec
             if d==last: vals[c]=v
 a=os.environ.get("X6P_ARGS","32768 3072 768 3 0").split()
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-    sha=hashlib.sha256(open(R+"/semivl_amd/csrc/gemm_planes.hip","rb").read()).hexdigest()[:16]
+    sha=hashlib.sha256(open(R+"/semivl_amd/csrc/gemm_planes_impl.h","rb").read()).hexdigest()[:16]
     fb, wb = vals["FETCH_SIZE"]*1024*2, vals["WRITE_SIZE"]*1024
     clk = vals.get("GRBM_GUI_ACTIVE")
-    rec=dict(src_sha16=sha, M=int(a[0]), N=int(a[1]), K=int(a[2]), mode=int(a[4]), fetch_bytes=fb, write_bytes=wb, traffic_bytes=fb+wb,
+    rec=dict(src_sha16=sha, fmt=os.environ.get("X6P_FMT", "0"), M=int(a[0]), N=int(a[1]), K=int(a[2]), mode=int(a[4]), fetch_bytes=fb, write_bytes=wb, traffic_bytes=fb+wb,
              counters=vals,
              note="FETCH_SIZE (KB, doubled: gfx950 under-reads 16 B/lane loads by 2x, MI355X_MICROARCH.md) + WRITE_SIZE of the last "
                   "gemm_x6p_kernel launch of tools/micro/x6p_bench (mode %s: 1 = bias + GELU + pre-activation + planes out + fp32 C, 4 = the same without C -- FFN-1 as the training step launches it)" % a[4] + ", separate "
