@@ -466,6 +466,20 @@ int svl_attention_fwd(const float* qkv, int B, int T, int H, float* out, float* 
                       int64_t planes_rows, svl_stream_t stream);
 int svl_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int H,
                       float* dsum_ws, float* dqkv, void* dqkv_planes, int64_t planes_rows, svl_stream_t stream);
+/* The same two operations on fp16 x 2 PRE-PACKED operands (round 5; csrc/attn_h2.hip): a pack pass writes the (image, head)
+ * slices of q / k / v / dout as two fp16 planes with one power-of-two scale per slice, in the fragment layouts the MFMA
+ * kernels read (LDS-DMA, no operand split inside the loops); three products h1 b0 + a0 h1' + a0 b0 per term on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation replace the six of the bf16 x 3 form -- error vs fp64 at the level of the
+ * fp32 kernels' (tests/test_ops_gpu.py).  `ws` = caller-provided scratch of svl_attention_h2_ws_bytes(B, T, H, backward)
+ * bytes, 1 KiB aligned, private to the call's stream until the call's work has finished.  Results, argument meaning and the
+ * optional bf16 x 3 planes outputs as above (the planes outputs need no emulation mode here).  Match
+ * maskclip_vit.py:77-84,141 (q pre-scaled by 64^-0.5 -- exact --, fp32 softmax). */
+int64_t svl_attention_h2_ws_bytes(int B, int T, int H, int backward);
+int svl_attention_fwd_h2(const float* qkv, int B, int T, int H, float* out, float* lse, void* out_planes,
+                         int64_t planes_rows, void* ws, int64_t ws_bytes, svl_stream_t stream);
+int svl_attention_bwd_h2(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int H,
+                         float* dsum_ws, float* dqkv, void* dqkv_planes, int64_t planes_rows, void* ws, int64_t ws_bytes,
+                         svl_stream_t stream);
 
 /* Small-sequence multi-head attention for the SemanticTransformer (vlg_head.py:39-67; seq = num classes).
  * qkv rows: token (g, s) at row  (g / inner) * outer_stride + (g % inner) * inner_stride + s * seq_stride,

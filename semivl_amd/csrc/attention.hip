@@ -15,61 +15,10 @@
 // cls-token row, so up to 4 leftover rows are computed by the `*_rows_kernel`s (VALU, one block per row, helper
 // stream, concurrent with the MFMA grids), and an inner tile whose valid rows fit in 32 runs one 32-row half only.
 // qkv is the in-proj output [B*T, 3E] (q | k | v, heads contiguous 64-wide), out / dout are [B*T, E].
-#include "svl_common.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "attn_shared.h"
+#include "attn_h2.h"
 
 namespace {
-
-constexpr int D = 64;
-constexpr int LDP = D + 4;  // padded LDS row: 16-byte aligned rows, conflict-free for b128 (A-style) and b32 (B-style) reads
-constexpr float RESCALE_LOG2 = 8.f;
-constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
-
-// exp(x - m) as one fma + v_exp_f32: 2^(x * log2(e) - m2) with m2 = m * log2(e) rounded ONCE per row, so every
-// probability of a row (and the running rescale factor) refers to the same m2 and the rounding cancels in p / l.
-__device__ __forceinline__ float exp_sub2(float x, float m2) { return __builtin_amdgcn_exp2f(fmaf(x, LOG2E, -m2)); }
-
-struct AttnP {
-  const float* qkv;
-  float* out;
-  float* lse;
-  const float* dout;
-  const float* dsum;
-  float* dqkv;
-  int B, T, H;
-  long ld;  // 3E
-  long E;
-  float scale;
-  // optional packed bf16x3 planes of the result rows (operand format of csrc/gemm_planes.hip; null = not wanted): the
-  // attention output [B T, E] in the forward, dqkv [B T, 3E] in the backward (dQ by the dq kernel, dK | dV by the dkv kernel)
-  char* planes;
-  long planes_ks;   // bytes between k-groups = padded rows x 96
-  int interleaved;  // 1: row blocks of a z interleaved with its partial one (SVL_ATTN_INTERLEAVED, A/B aid); 0: partials last
-};
-
-__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
-
-// Block -> (row block of BQ rows, (image, head) z) for the x6 kernels' 1-D grids: the FULL row blocks first, row-block-major
-// inside a z (consecutive blocks share K / V in L2), the partial last row blocks of all z at the END of the grid -- they are
-// the cheap ones (2 of 8 waves active at T = 2602) and so fill the last round instead of standing in every 11th slot:
-// 2112 blocks on 256 CUs = 8.25 rounds of which the last quarter round used to cost a full one.
-__device__ __forceinline__ void attn_block(const AttnP& p, int BQ, int& rb, int& z) {
-  const int nfull = p.T / BQ, BH = p.B * p.H, lin = (int)blockIdx.x;
-  if (p.interleaved) {
-    const int nb = (p.T + BQ - 1) / BQ;
-    z = lin / nb;
-    rb = lin - z * nb;
-    return;
-  }
-  if (lin < nfull * BH) {
-    z = lin / nfull;
-    rb = lin - z * nfull;
-  } else {
-    z = lin - nfull * BH;
-    rb = nfull;
-  }
-}
 
 // Cooperative load of a [64 rows x 64 floats] tile (rows row0.. of one head slice) into registers: 4 float4 per thread.
 __device__ __forceinline__ void tile_gload(float4 (&rg)[4], const float* base, long ld, int row0, int T, int tid) {
@@ -480,47 +429,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
 // LDS rows are 64 bf16 (128 B, 8 sixteen-byte slots) with slot c of row r stored at c ^ ((r ^ (r >> 3)) & 7): the 16
 // lanes of every ds_read_b128 group and the 8 lanes of every ds_write_b128 group (row-major and transposed staging)
 // land on distinct slots -- conflict-free without padding, 8 KB per plane.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int XPL = 64 * 64;   // plane stride (elements)
 constexpr int XIMG = 3 * XPL;  // one [64 x 64] tile image (3 planes)
 
 __device__ __forceinline__ int xoff(int r, int c) { return r * 64 + (((c ^ r ^ (r >> 3)) & 7) << 3); }
 
-// 5.5 VALU per element: one v_cvt_pk_bf16_f32 per PAIR and plane (the packed word is the operand register as is), a
-// shift / an and to read the two bf16 back as floats, two subtractions.  (Written on pairs explicitly: the loops are
-// issue-bound and left to itself the compiler converts element by element.)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split3x8(const float (&v)[8], bf16x8 (&h)[3]) {
-  float x[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = v[j];
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    u32x4 w;
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp) {
-      const f32x2 pr = {x[2 * jp], x[2 * jp + 1]};
-      const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
-      w[jp] = u;
-      if (pl < 2) {
-        x[2 * jp] -= __builtin_bit_cast(float, u << 16);
-        x[2 * jp + 1] -= __builtin_bit_cast(float, u & 0xffff0000u);
-      }
-    }
-    h[pl] = __builtin_bit_cast(bf16x8, w);
-  }
-}
-// One lane's 8 values of row R -- columns 16 kg + 4 hi + {0..3, 8..11}, exactly the lane (hi, R % 32) of the packed-planes
-// chunk (k-group kg, row block R / 32) -- split and stored as three 16 B pieces (1 KiB apart: the chunk's planes).
-__device__ __forceinline__ void emit_planes8(char* planes, long ks, int kg, long R, int hi, const float (&x)[8]) {
-  bf16x8 h[3];
-  split3x8(x, h);
-  char* c = planes + (long)kg * ks + (R >> 5) * 3072 + (((long)hi << 5) + (R & 31)) * 16;
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8*>(c + pl * 1024) = h[pl];
-}
 // the same for ONE value (row kernels): column col of row R
 __device__ __forceinline__ void emit_planes1(char* planes, long ks, int col, long R, float x) {
   const int kg = col >> 4, j = col & 15, hh = (j >> 2) & 1, e = ((j >> 3) << 2) + (j & 3);
@@ -654,14 +567,6 @@ __device__ __forceinline__ void tr_sstore(__bf16* img, const float (&rg)[4096 / 
 // The loop is ISSUE-bound (a 32x32x16 MFMA occupies the pipe for 32 cycles = ~8 issue slots), so everything that is not
 // arithmetic is kept out of it: the ragged-key mask lives in a peeled copy of the last tile, the wave index is scalar
 // (addresses on the SALU), the row max is v_max3_f32.
-constexpr int FQ = 256;
-
-__device__ __forceinline__ float max3(float a, float b, float c) {   // (fmaxf would canonicalise every MFMA result first)
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-
 __global__ __launch_bounds__(512) void attn_fwd_x6_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) __bf16 sm[2 * 2 * XIMG];   // [buffer][K | Vt][plane][64 x 64]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -1406,5 +1311,82 @@ extern "C" int svl_attention_bwd(const float* qkv, const float* out, const float
   if (x6) hipLaunchKernelGGL(attn_bwd_dq_x6_kernel, dim3(nb * B * H), dim3(512), 0, st, p);
   else hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nb, B * H), dim3(256), 0, st, p);
   SVL_LAUNCH_CHECK("svl_attention_bwd/dq");
+  return r > 0 ? svl_join(st) : SVL_OK;
+}
+
+// ---- fp16 x 2 path (attn_h2.hip): operands pre-packed into a caller-provided workspace, three products per term
+namespace {
+int check_planes_h2(const void* planes, int64_t planes_rows, int B, int T, const char* who) {
+  if (!planes) return SVL_OK;
+  SVL_CHECK_ARG(planes_rows % 256 == 0 && planes_rows >= (int64_t)B * T && ((uintptr_t)planes & 15) == 0,
+                "%s: planes_rows must be a multiple of 256 covering B x T rows, planes 16-byte aligned", who);
+  return SVL_OK;
+}
+}  // namespace
+
+extern "C" int64_t svl_attention_h2_ws_bytes(int B, int T, int H, int backward) {
+  if (B <= 0 || T <= 0 || H <= 0) return 0;
+  return svl_attn_h2::ws_bytes(B, T, H, backward);
+}
+
+extern "C" int svl_attention_fwd_h2(const float* qkv, int B, int T, int H, float* out, float* lse, void* out_planes,
+                                    int64_t planes_rows, void* ws, int64_t ws_bytes, svl_stream_t stream) {
+  int rc = check(qkv, B, T, H, "svl_attention_fwd_h2");
+  if (rc) return rc;
+  SVL_CHECK_ARG(out || out_planes, "svl_attention_fwd_h2: out missing");
+  rc = check_planes_h2(out_planes, planes_rows, B, T, "svl_attention_fwd_h2");
+  if (rc) return rc;
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.planes = (char*)out_planes; p.planes_ks = planes_rows * 96;
+  static const int interleaved_f = getenv("SVL_ATTN_INTERLEAVED") ? 1 : 0;
+  p.interleaved = interleaved_f;
+  p.qkv = qkv; p.out = out; p.lse = lse; p.B = B; p.T = T; p.H = H; p.E = (long)H * D; p.ld = 3 * p.E; p.scale = 0.125f;
+  hipStream_t st = (hipStream_t)stream;
+  int nb = 0;
+  const int r = rows_split(T, &nb, FQ);
+  if (r > 0) {   // the leftover rows: fp32 VALU kernels on the helper stream, straight from qkv
+    hipStream_t aux = nullptr;
+    rc = svl_fork(st, &aux);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_fwd_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * FQ);
+    SVL_LAUNCH_CHECK("svl_attention_fwd_h2/rows");
+  }
+  rc = svl_attn_h2::fwd(p, nb, ws, ws_bytes, st);
+  if (rc) return rc;
+  return r > 0 ? svl_join(st) : SVL_OK;
+}
+
+extern "C" int svl_attention_bwd_h2(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T,
+                                    int H, float* dsum_ws, float* dqkv, void* dq_planes, int64_t planes_rows, void* ws,
+                                    int64_t ws_bytes, svl_stream_t stream) {
+  int rc = check(qkv, B, T, H, "svl_attention_bwd_h2");
+  if (rc) return rc;
+  SVL_CHECK_ARG(out && dout && lse && dsum_ws && dqkv, "svl_attention_bwd_h2: null args");
+  rc = check_planes_h2(dq_planes, planes_rows, B, T, "svl_attention_bwd_h2");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.planes = (char*)dq_planes; p.planes_ks = planes_rows * 96;
+  static const int interleaved_b = getenv("SVL_ATTN_INTERLEAVED") ? 1 : 0;
+  p.interleaved = interleaved_b;
+  p.qkv = qkv; p.dout = dout; p.lse = const_cast<float*>(lse); p.dsum = dsum_ws; p.dqkv = dqkv;
+  p.B = B; p.T = T; p.H = H; p.E = (long)H * D; p.ld = 3 * p.E; p.scale = 0.125f;
+  rc = svl_attn_h2::bwd_prepare(p, out, dsum_ws, ws, ws_bytes, st);
+  if (rc) return rc;
+  int nb = 0;
+  const int r = rows_split(T, &nb, FQ);
+  if (r > 0) {  // after D = rowsum(dO * O) (both need it), concurrent with the MFMA grids
+    hipStream_t aux = nullptr;
+    rc = svl_fork(st, &aux);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * FQ);
+    SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dkv_rows");
+    hipLaunchKernelGGL(attn_bwd_dq_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * FQ);
+    SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dq_rows");
+  }
+  rc = svl_attn_h2::bwd_main(p, nb, ws, st);
+  if (rc) return rc;
   return r > 0 ? svl_join(st) : SVL_OK;
 }

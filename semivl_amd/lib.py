@@ -146,6 +146,9 @@ SIGNATURES = {
     "svl_aug_gaussian_blur_u8": (_I, [_P, _I, _I, _F, _P, _P, _P]),
     "svl_attention_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P]),
     "svl_attention_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P]),
+    "svl_attention_h2_ws_bytes": (_L, [_I, _I, _I, _I]),
+    "svl_attention_fwd_h2": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P]),
+    "svl_attention_bwd_h2": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P]),
     "svl_conv_cout1_fwd": (_I, [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "svl_conv_cout1_wgrad_blocks": (_I, [_I, _I, _I]),
     "svl_conv_cout1_wgrad": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -797,6 +797,25 @@ def attention_planes_ok():
             and not os.environ.get("SVL_ATTN_NO_PLANES"))
 
 
+# fp16 x 2 attention kernels on pre-packed operands (csrc/attn_h2.hip; round 5) serve emulation mode 6 by default;
+# SVL_ATTN_FMT=b3 keeps the bf16 x 6 kernels (A/B runs), SVL_ATTN_NO_EMU=1 the exact fp32 ones.
+ATTN_FMT = os.environ.get("SVL_ATTN_FMT", "h2")
+assert ATTN_FMT in ("h2", "b3")
+
+
+def attention_h2():
+    return get_gemm_emulation() == 6 and ATTN_FMT == "h2" and not os.environ.get("SVL_ATTN_NO_EMU")
+
+
+def _attn_ws(Bn, T, H, backward, dev):
+    n = L.load().svl_attention_h2_ws_bytes(Bn, T, H, 1 if backward else 0)
+    return torch.empty(n + 1024, dtype=torch.uint8, device=dev), n
+
+
+def _ws_ptr(ws):
+    return (ws.data_ptr() + 1023) // 1024 * 1024
+
+
 def attention_fwd(qkv, Bn, T, H, want_lse=True, planes=False, want_out=True):
     """Flash-style fused attention: qkv [Bn*T, 3E] -> (out [Bn*T, E] or None, lse [Bn*H*T] or None[, out as Planes]).
     planes=True (attention_planes_ok()) additionally returns the output as packed planes, written by the kernel's own
@@ -806,8 +825,13 @@ def attention_fwd(qkv, Bn, T, H, want_lse=True, planes=False, want_out=True):
     lse = empty(Bn * H * T, device=qkv.device) if want_lse else None
     op = Planes(Bn * T, E, device=qkv.device, fmt="b3") if planes else None
     e0 = _prof_begin()
-    L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if planes else None,
-                                       op.prow if planes else 0, _st()), "svl_attention_fwd")
+    if attention_h2():
+        ws, n = _attn_ws(Bn, T, H, False, qkv.device)
+        L.check(L.load().svl_attention_fwd_h2(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if planes else None,
+                                              op.prow if planes else 0, _ws_ptr(ws), n, _st()), "svl_attention_fwd_h2")
+    else:
+        L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if planes else None,
+                                           op.prow if planes else 0, _st()), "svl_attention_fwd")
     _prof_end(_attn_family(), e0, 4.0 * Bn * H * T * T * 64, ("fwd", Bn, T, H))
     return (out, lse, op) if planes else (out, lse)
 
@@ -819,9 +843,15 @@ def attention_bwd(dout, qkv, out, lse, Bn, T, H, planes=False):
     E = H * 64
     dp = Planes(Bn * T, 3 * E, device=qkv.device, fmt="b3") if planes else None
     e0 = _prof_begin()
-    L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
-                                       _p(dp.buf) if planes else None, dp.prow if planes else 0, _st()),
-            "svl_attention_bwd")
+    if attention_h2():
+        wsb, n = _attn_ws(Bn, T, H, True, qkv.device)
+        L.check(L.load().svl_attention_bwd_h2(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
+                                              _p(dp.buf) if planes else None, dp.prow if planes else 0, _ws_ptr(wsb), n,
+                                              _st()), "svl_attention_bwd_h2")
+    else:
+        L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
+                                           _p(dp.buf) if planes else None, dp.prow if planes else 0, _st()),
+                "svl_attention_bwd")
     _prof_end(_attn_family(), e0, 14.0 * Bn * H * T * T * 64, ("bwd", Bn, T, H))
     return (dqkv, dp) if planes else dqkv
 

@@ -419,10 +419,34 @@ def test_vit_attention(dev, Bn, T, H):
     close(dqkv, gref, atol=5e-5, what="attn bwd")
 
 
+class _attn_path:
+    """Selects the fused-attention kernel family for a test: "f32" exact fp32 MFMA kernels (mode 0), "b3" bf16 x 6 and
+    "h2" fp16 x 2 on pre-packed operands (both emulation mode 6; ops.ATTN_FMT picks between them)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        from semivl_amd import ops
+        self.old = ops.ATTN_FMT
+        if self.path != "f32":
+            ops.ATTN_FMT = self.path
+            ops.set_gemm_emulation(6)
+            assert ops.attention_h2() == (self.path == "h2")
+
+    def __exit__(self, *exc):
+        from semivl_amd import ops
+        ops.ATTN_FMT = self.old
+        ops.set_gemm_emulation(0)
+
+
+@pytest.mark.parametrize("path", ["f32", "h2", "b3"])
 @pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 17, 4), (1, 64, 1), (2, 129, 3), (1, 128, 2),
-                                    (2, 130, 2), (1, 260, 3), (1, 133, 2), (1, 161, 1), (1, 97, 2)])
-def test_fused_attention(dev, Bn, T, H):
-    """Flash-style kernel vs explicit softmax(q k^T / 8) v and its autograd; ragged T, spiky logits (forces rescales)."""
+                                    (2, 130, 2), (1, 260, 3), (1, 133, 2), (1, 161, 1), (1, 97, 2), (1, 256, 1), (2, 257, 2),
+                                    (1, 516, 2), (1, 81, 3)])
+def test_fused_attention(dev, Bn, T, H, path):
+    """Flash-style kernels (all three families) vs explicit softmax(q k^T / 8) v and its autograd in fp64; ragged T (whole
+    blocks, leftover rows on the VALU kernels, partial blocks), spiky logits (forces rescales); deterministic."""
     from semivl_amd import ops
     D, E = 64, 64 * H
     qkv = rnd(Bn * T, 3 * E, dev=dev, seed=50)
@@ -433,23 +457,31 @@ def test_fused_attention(dev, Bn, T, H):
     q, k, v = [t.reshape(Bn, T, H, D).transpose(1, 2) for t in qkv.view(Bn, T, 3 * E).split(E, dim=2)]
     sc = (q.double() * D ** -0.5) @ k.double().transpose(-1, -2)
     ref = (sc.softmax(-1) @ v.double()).transpose(1, 2).reshape(Bn * T, E)
-    out, lse = ops.attention_fwd(qkv.detach(), Bn, T, H)
-    close(out, ref.float(), atol=3e-5, what="flash fwd")
-    close(lse.view(Bn, H, T), torch.logsumexp(sc, -1).float(), atol=2e-5, what="lse")
     do = rnd(Bn * T, E, dev=dev)
     (g,) = torch.autograd.grad(ref, qkv, do.double())
-    dqkv = ops.attention_bwd(do, qkv.detach(), out, lse, Bn, T, H)
-    close(dqkv[:, 2 * E:], g[:, 2 * E:].float(), atol=1e-4, what="flash dV")
-    close(dqkv[:, E:2 * E], g[:, E:2 * E].float(), atol=1e-4, what="flash dK")
-    close(dqkv[:, :E], g[:, :E].float(), atol=1e-4, what="flash dQ")
-    o2, _ = ops.attention_fwd(qkv.detach(), Bn, T, H)
-    assert torch.equal(out, o2) and torch.equal(dqkv, ops.attention_bwd(do, qkv.detach(), out, lse, Bn, T, H))
+    with _attn_path(path):
+        out, lse = ops.attention_fwd(qkv.detach(), Bn, T, H)
+        close(out, ref.float(), atol=3e-5, what="flash fwd")
+        close(lse.view(Bn, H, T), torch.logsumexp(sc, -1).float(), atol=2e-5, what="lse")
+        dqkv = ops.attention_bwd(do, qkv.detach(), out, lse, Bn, T, H)
+        close(dqkv[:, 2 * E:], g[:, 2 * E:].float(), atol=1e-4, what="flash dV")
+        close(dqkv[:, E:2 * E], g[:, E:2 * E].float(), atol=1e-4, what="flash dK")
+        close(dqkv[:, :E], g[:, :E].float(), atol=1e-4, what="flash dQ")
+        o2, _ = ops.attention_fwd(qkv.detach(), Bn, T, H)
+        assert torch.equal(out, o2) and torch.equal(dqkv, ops.attention_bwd(do, qkv.detach(), out, lse, Bn, T, H))
 
 
+@pytest.mark.parametrize("fmt", ["h2", "b3"])
 @pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 17, 4), (2, 129, 3), (1, 161, 1), (1, 97, 2)])
-def test_fused_attention_split_emulation(dev, Bn, T, H):
+def test_fused_attention_split_emulation(dev, Bn, T, H, fmt):
     """svl_set_gemm_emulation(6) covers the attention products: the error vs fp64 stays at the level of the exact fp32
-    kernels' (bound: EMU6_ERR_FACTOR x theirs + 1e-6), on the same ragged / spiky cases, and the result is deterministic."""
+    kernels', on the same ragged / spiky cases, and the result is deterministic.
+    bf16 x 6 ("b3"): largest error <= EMU6_ERR_FACTOR x the fp32 kernels' + 1e-6, as since round 2.
+    fp16 x 2 ("h2", round 5): the error LEVEL -- its root mean square over the tensor -- <= EMU6_ERR_FACTOR x the fp32 kernels'
+    (+ 1e-7), and the largest error <= 2 x theirs + 1e-6.  On these cases (|logit| up to ~220) every implementation's largest
+    error is one rounding of a logit / of the saved fp32 LSE (half an ulp of 200 = 7.6e-6, times |dO| |V|): a single draw
+    whose ratio between two correct implementations scatters over 0.4 ... 1.6 (tools/dbg_attn_err.py: both families, both
+    directions), so the single-sample maximum is held to 2 x and the stable statistic carries the 1.2."""
     from semivl_amd import ops
     D, E = 64, 64 * H
     qkv = rnd(Bn * T, 3 * E, dev=dev, seed=51)
@@ -460,28 +492,34 @@ def test_fused_attention_split_emulation(dev, Bn, T, H):
     qd = qkv.double().requires_grad_(True)
     q, k, v = [t.reshape(Bn, T, H, D).transpose(1, 2) for t in qd.view(Bn, T, 3 * E).split(E, dim=2)]
     sc = (q * D ** -0.5) @ k.transpose(-1, -2)
-    ref = (sc.softmax(-1) @ v).transpose(1, 2).reshape(Bn * T, E)
-    (g,) = torch.autograd.grad(ref, qd, do.double())
-    res = {}
-    try:
-        for mode in (0, 6):
-            ops.set_gemm_emulation(mode)
+    ref = (sc.softmax(-1) @ v).transpose(1, 2).reshape(Bn * T, E).detach()
+    (g,) = torch.autograd.grad((sc.softmax(-1) @ v).transpose(1, 2).reshape(Bn * T, E), qd, do.double())
+    lse_ref = torch.logsumexp(sc, -1).detach()
+    res, rms = {}, {}
+    for mode in (0, 6):
+        with _attn_path("f32" if mode == 0 else fmt):
             out, lse = ops.attention_fwd(qkv, Bn, T, H)
             dqkv = ops.attention_bwd(do, qkv, out, lse, Bn, T, H)
-            res[mode] = (float((out.double() - ref).abs().max()), float((dqkv.double() - g).abs().max()),
-                         float((lse.view(Bn, H, T).double() - torch.logsumexp(sc, -1)).abs().max()))
+            errs = (out.double() - ref, dqkv.double() - g, lse.view(Bn, H, T).double() - lse_ref)
+            res[mode] = tuple(float(e.abs().max()) for e in errs)
+            rms[mode] = tuple(float(e.pow(2).mean().sqrt()) for e in errs)
             o2, l2 = ops.attention_fwd(qkv, Bn, T, H)
             assert torch.equal(out, o2) and torch.equal(lse, l2)
             assert torch.equal(dqkv, ops.attention_bwd(do, qkv, out, lse, Bn, T, H))
-    finally:
-        ops.set_gemm_emulation(0)
-    lse_ulp = 1.2e-7 * float(torch.logsumexp(sc, -1).abs().max())     # LSE itself is O(100) on the spiky rows
-    for e0, e6, what, slack in zip(res[0], res[6], ("out", "dqkv", "lse"), (1e-6, 1e-6, 2 * lse_ulp)):
-        assert e6 <= EMU6_ERR_FACTOR * e0 + slack, (what, e0, e6)
+    lse_ulp = 1.2e-7 * float(lse_ref.abs().max())     # LSE itself is O(100) on the spiky rows
+    print(f"ATTN_GATE {fmt} B{Bn} T{T} H{H}: max ratio " + " ".join(f"{b / max(a, 1e-30):.2f}" for a, b in zip(res[0], res[6])) +
+          " rms ratio " + " ".join(f"{b / max(a, 1e-30):.2f}" for a, b in zip(rms[0], rms[6])))
+    for i, (what, slack) in enumerate((("out", 1e-6), ("dqkv", 1e-6), ("lse", 2 * lse_ulp))):
+        if fmt == "b3":
+            assert res[6][i] <= EMU6_ERR_FACTOR * res[0][i] + slack, (what, res[0][i], res[6][i])
+        else:
+            assert rms[6][i] <= EMU6_ERR_FACTOR * rms[0][i] + 0.1 * slack, (what, "rms", rms[0][i], rms[6][i])
+            assert res[6][i] <= 2.0 * res[0][i] + slack, (what, "max", res[0][i], res[6][i])
 
 
+@pytest.mark.parametrize("fmt", ["h2", "b3"])
 @pytest.mark.parametrize("Bn,T,H", [(2, 1025, 12), (1, 2602, 2), (3, 260, 4), (2, 129, 3)])
-def test_fused_attention_emits_planes(dev, Bn, T, H):
+def test_fused_attention_emits_planes(dev, Bn, T, H, fmt):
     """The bf16x6 attention kernels' planes outputs (out-projection / in_proj input-gradient A operands written by the
     epilogues, leftover-row kernels included) == split_planes of their own fp32 results, bit for bit; the fp32 results are
     unchanged by asking for planes; out may be dropped in gradient-free passes; exact mode refuses."""
@@ -489,9 +527,11 @@ def test_fused_attention_emits_planes(dev, Bn, T, H):
     E = 64 * H
     qkv = rnd(Bn * T, 3 * E, dev=dev, seed=52)
     do = rnd(Bn * T, E, dev=dev)
+    old_fmt = ops.ATTN_FMT
     try:
+        ops.ATTN_FMT = fmt
         ops.set_gemm_emulation(6)
-        assert ops.attention_planes_ok()
+        assert ops.attention_planes_ok() and ops.attention_h2() == (fmt == "h2")
         out, lse = ops.attention_fwd(qkv, Bn, T, H)
         o2, l2, op = ops.attention_fwd(qkv, Bn, T, H, planes=True)
         assert torch.equal(out, o2) and torch.equal(lse, l2)
@@ -511,6 +551,7 @@ def test_fused_attention_emits_planes(dev, Bn, T, H):
         with pytest.raises(RuntimeError):
             ops.attention_fwd(qkv, Bn, T, H, planes=True)
     finally:
+        ops.ATTN_FMT = old_fmt
         ops.set_gemm_emulation(0)
 
 
