@@ -5,8 +5,8 @@
 // v_mfma_f32_32x32x16_f16.  Replaces nn.MultiheadAttention's bmm / softmax / bmm (maskclip_vit.py:77-84,141 via mmcv).
 //
 // Operands.  A pack pass (attn_pack_kernel, one block per (image, head) z and tensor) writes, per z, the head's
-// [T x 64] slice of Q / K / V / dO with ONE scale exponent e per (z, tensor) -- max |x| 2^-e in [2^14, 2^15): every element
-// within 2^-18 of the slice's largest keeps 22 significand bits, smaller ones an absolute error below 2^-40 of it -- in the
+// [T x 64] slice of Q / K / V / dO with ONE scale exponent e per (z, tensor) -- max |x| 2^-e in [2^11, 2^15): every element
+// within 2^-15 of the slice's largest keeps 22 significand bits, smaller ones an absolute error below 2^-37 of it -- in the
 // two fragment layouts the kernels read (1 KiB chunks = the register image of one MFMA operand, lane = hh 32 + row % 32,
 // 8 halfs per lane; Tp = T rounded up to 64, rows past T are zeros):
 //   row-major  "rm":  chunk (rb, kg, pl) at ((rb 4 + kg) 2 + pl) KiB: rows 32 rb + r, d = 16 kg + 4 hh + {0..3, 8..11}
@@ -95,17 +95,25 @@ __device__ __forceinline__ f32x16 mfma_h(const f16x8& a, const f16x8& b, const f
   c0 = mfma_h(a0[0], b0[0], c0);      \
   c1 = mfma_h(a1[0], b1[0], c1);
 
-// x = h0 + h1 (|x| < 2^15): pairs converted with one packed instruction each way
+// x = h0 + h1 (|x| < 2^16).  MIX: four VALU per pair -- v_cvt_pk_f16_f32, the residuals x - h0 by v_fma_mix_f32 (reads the
+// fp16 halves in place), v_cvt_pk_f16_f32; else five (conversion back + one packed subtract).
+template <bool MIX>
 __device__ __forceinline__ void split2x8(const float (&x)[8], f16x8 (&h)[2]) {
   u32x4 w0, w1;
 #pragma unroll
   for (int jp = 0; jp < 4; ++jp) {
     const f32x2 pr = {x[2 * jp], x[2 * jp + 1]};
-    const f16x2 a = __builtin_convertvector(pr, f16x2);
-    const f32x2 r = pr - __builtin_convertvector(a, f32x2);
-    const f16x2 b = __builtin_convertvector(r, f16x2);
-    w0[jp] = __builtin_bit_cast(unsigned, a);
-    w1[jp] = __builtin_bit_cast(unsigned, b);
+    const f16x2 ah = __builtin_convertvector(pr, f16x2);
+    const unsigned a = __builtin_bit_cast(unsigned, ah);
+    f32x2 r;
+    if constexpr (MIX) {
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(a), "v"(pr[0]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(a), "v"(pr[1]));
+    } else {
+      r = pr - __builtin_convertvector(ah, f32x2);
+    }
+    w0[jp] = a;
+    w1[jp] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
   }
   h[0] = __builtin_bit_cast(f16x8, w0);
   h[1] = __builtin_bit_cast(f16x8, w1);
@@ -133,84 +141,96 @@ struct PackP {
   int B, T, H, Tp;
 };
 
+// ONE pass over the slice in the common case: the exponent is taken from the first 64 rows' largest |x| with 2^3 of headroom
+// (every element up to 8 x that keeps clear of fp16's range; the 2^-18 window of full precision shrinks to 2^-15 of the
+// slice's largest), the true maximum is tracked while packing, and only a slice that outgrows the headroom is packed again
+// with its exact exponent (deterministic: the exponent is a function of the data).  64 rows per trip through LDS.
 __global__ __launch_bounds__(256) void attn_pack_kernel(const PackP p) {
-  __shared__ __attribute__((aligned(16))) float tile[32 * LDP];
+  __shared__ __attribute__((aligned(16))) float tile[64 * LDP];
   __shared__ float red[4];
   const int tid = threadIdx.x, z = blockIdx.x, w = p.which[blockIdx.y];
   const int b = z / p.H, h = z - b * p.H;
   const long ld = p.ld[w];
   const float* src = p.src[w] + (long)b * p.T * ld + h * D;
   const int r16 = tid >> 4, c4 = (tid & 15) << 2;
-  // pass 1: largest |x| and largest row sum of squares of the slice
-  float mx = 0.f, nr = 0.f;
-  for (int r0 = 0; r0 < p.T; r0 += 64) {
-    float4 v[4];
+  const int nrb = p.Tp >> 5;
+  char* rm = p.rm[w] ? p.rm[w] + (long)z * nrb * 8192 : nullptr;
+  char* tr = p.tr[w] ? p.tr[w] + (long)z * p.Tp * 256 : nullptr;
+  const int lane = tid & 63, cq = tid >> 6, hh = lane >> 5, r = lane & 31;
+  auto rows = [&](int r0, float4 (&v)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 16 * i + r16;
       v[i] = row < p.T ? *reinterpret_cast<const float4*>(src + (long)row * ld + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  auto amax4 = [](const float4& a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); };
+  auto exp_of = [](float mx) {   // mx = f 2^E, f in [0.5, 1): mx 2^-e = f 2^15
+    const int e = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - 15 : 0;
+    return e < -100 ? -100 : (e > 100 ? 100 : e);
+  };
+  float4 v[4];
+  rows(0, v);
+  float m0 = fmaxf(fmaxf(amax4(v[0]), amax4(v[1])), fmaxf(amax4(v[2]), amax4(v[3])));
+  m0 = block_max_256(m0, red);
+  int e = exp_of(m0) + 3;
+  float mx = 0.f, nr = 0.f;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (attempt) rows(0, v);
+    mx = 0.f;
+    nr = 0.f;
+    for (int r0 = 0; r0 < p.Tp; r0 += 64) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
-      float ss = v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+      for (int i = 0; i < 4; ++i) {
+        mx = fmaxf(mx, amax4(v[i]));
+        float ss = v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-      nr = fmaxf(nr, ss);
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        nr = fmaxf(nr, ss);
+        *reinterpret_cast<float4*>(&tile[(16 * i + r16) * LDP + c4]) =
+            make_float4(__builtin_amdgcn_ldexpf(v[i].x, -e), __builtin_amdgcn_ldexpf(v[i].y, -e),
+                        __builtin_amdgcn_ldexpf(v[i].z, -e), __builtin_amdgcn_ldexpf(v[i].w, -e));
+      }
+      if (r0 + 64 < p.Tp) rows(r0 + 64, v);
+      __syncthreads();
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int rb = (r0 >> 5) + half;
+        const float* th = tile + half * 32 * LDP;
+        if (rm) {   // chunk (rb, kg = cq): lane (hh, r) = row r, d = 16 kg + 4 hh + {0..3, 8..11}
+          const float* t = th + r * LDP + 16 * cq + 4 * hh;
+          const float4 u = *reinterpret_cast<const float4*>(t), q = *reinterpret_cast<const float4*>(t + 8);
+          const float x[8] = {u.x, u.y, u.z, u.w, q.x, q.y, q.z, q.w};
+          f16x8 hp[2];
+          split2x8<true>(x, hp);
+          char* c = rm + (long)((rb * 4 + cq) * 2) * 1024 + lane * 16;
+          *reinterpret_cast<f16x8*>(c) = hp[0];
+          *reinterpret_cast<f16x8*>(c + 1024) = hp[1];
+        }
+        if (tr) {   // chunk (kgt = 2 rb + (cq >> 1), rbd = cq & 1): lane (hh, r) = d 32 rbd + r, tokens 16 kgl + 4 hh + {0..3, 8..11}
+          const int kgl = cq >> 1, rbd = cq & 1;
+          const float* t = th + (16 * kgl + 4 * hh) * LDP + 32 * rbd + r;
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = t[((j & 3) + 8 * (j >> 2)) * LDP];
+          f16x8 hp[2];
+          split2x8<true>(x, hp);
+          char* c = tr + (long)(((2 * rb + kgl) * 2 + rbd) * 2) * 1024 + lane * 16;
+          *reinterpret_cast<f16x8*>(c) = hp[0];
+          *reinterpret_cast<f16x8*>(c + 1024) = hp[1];
+        }
+      }
+      __syncthreads();
     }
+    mx = block_max_256(mx, red);
+    const int ex = exp_of(mx);
+    if (ex <= e && ex >= e - 3) break;   // the headroom held: mx 2^-e in [2^11, 2^15)
+    e = ex;                              // (rare) the slice outgrew it (or its first rows were zeros): once more, exact exponent
   }
-  mx = block_max_256(mx, red);
   nr = block_max_256(nr, red);
-  int e = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - 15 : 0;     // mx = f 2^E, f in [0.5, 1): mx 2^-e = f 2^15
-  e = e < -100 ? -100 : (e > 100 ? 100 : e);
   if (tid == 0) {
     p.exps[z * 4 + w] = e;
     p.nrm[z * 4 + w] = sqrtf(nr);
-  }
-  // pass 2 (the slice comes from L2 / Infinity Cache now): 32 rows at a time through LDS into both layouts
-  const int nrb = p.Tp >> 5;
-  char* rm = p.rm[w] ? p.rm[w] + (long)z * nrb * 8192 : nullptr;
-  char* tr = p.tr[w] ? p.tr[w] + (long)z * p.Tp * 256 : nullptr;
-  const int lane = tid & 63, cq = tid >> 6, hh = lane >> 5, r = lane & 31;
-  auto rows = [&](int rb, float4& v0, float4& v1) {
-    const int ra = rb * 32 + r16, rbw = ra + 16;
-    v0 = ra < p.T ? *reinterpret_cast<const float4*>(src + (long)ra * ld + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v1 = rbw < p.T ? *reinterpret_cast<const float4*>(src + (long)rbw * ld + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
-  float4 v0, v1;
-  rows(0, v0, v1);
-  for (int rb = 0; rb < nrb; ++rb) {
-    *reinterpret_cast<float4*>(&tile[r16 * LDP + c4]) =
-        make_float4(__builtin_amdgcn_ldexpf(v0.x, -e), __builtin_amdgcn_ldexpf(v0.y, -e), __builtin_amdgcn_ldexpf(v0.z, -e),
-                    __builtin_amdgcn_ldexpf(v0.w, -e));
-    *reinterpret_cast<float4*>(&tile[(16 + r16) * LDP + c4]) =
-        make_float4(__builtin_amdgcn_ldexpf(v1.x, -e), __builtin_amdgcn_ldexpf(v1.y, -e), __builtin_amdgcn_ldexpf(v1.z, -e),
-                    __builtin_amdgcn_ldexpf(v1.w, -e));
-    if (rb + 1 < nrb) rows(rb + 1, v0, v1);
-    __syncthreads();
-    if (rm) {   // chunk (rb, kg = cq): lane (hh, r) = row r, d = 16 kg + 4 hh + {0..3, 8..11}
-      const float* t = tile + r * LDP + 16 * cq + 4 * hh;
-      const float4 u = *reinterpret_cast<const float4*>(t), q = *reinterpret_cast<const float4*>(t + 8);
-      const float x[8] = {u.x, u.y, u.z, u.w, q.x, q.y, q.z, q.w};
-      f16x8 hp[2];
-      split2x8(x, hp);
-      char* c = rm + (long)((rb * 4 + cq) * 2) * 1024 + lane * 16;
-      *reinterpret_cast<f16x8*>(c) = hp[0];
-      *reinterpret_cast<f16x8*>(c + 1024) = hp[1];
-    }
-    if (tr) {   // chunk (kgt = 2 rb + (cq >> 1), rbd = cq & 1): lane (hh, r) = d 32 rbd + r, tokens 16 kgl + 4 hh + {0..3, 8..11}
-      const int kgl = cq >> 1, rbd = cq & 1;
-      const float* t = tile + (16 * kgl + 4 * hh) * LDP + 32 * rbd + r;
-      float x[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = t[((j & 3) + 8 * (j >> 2)) * LDP];
-      f16x8 hp[2];
-      split2x8(x, hp);
-      char* c = tr + (long)(((2 * rb + kgl) * 2 + rbd) * 2) * 1024 + lane * 16;
-      *reinterpret_cast<f16x8*>(c) = hp[0];
-      *reinterpret_cast<f16x8*>(c + 1024) = hp[1];
-    }
-    __syncthreads();
   }
 }
 
@@ -248,7 +268,9 @@ __global__ __launch_bounds__(256) void attn_ld_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------ forward
 constexpr int STG_F = 32 * 1024;   // K rm (16 chunks) | V tr (16 chunks) of one 64-key tile
 
+template <int V>
 __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H2W w) {
+  constexpr bool MIX = (V & 1) != 0;
   extern __shared__ __attribute__((aligned(1024))) char sm[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -295,10 +317,22 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
   wait_vm<6>();                        // K of tile 0 (this wave's part) has landed
   interval_barrier();
 
+  const bool short_last = p.T - (nkt - 1) * 64 <= 32;          // keys 32..63 of the last tile do not exist
   auto phase1 = [&](int kt) __attribute__((always_inline)) {   // S^T = K Q^T: 24 MFMAs, 16 fragment reads
     const char* Ks = sm + (kt % 3) * STG_F + lane16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    if (kt == nkt - 1 && short_last) {
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        f16x8 a0[2], bq[2] = {qf[0][kg], qf[1][kg]};
+        frag2(a0, Ks + (kg * 2) * 1024);
+        s0 = mfma_h(a0[1], bq[0], s0);
+        s0 = mfma_h(a0[0], bq[1], s0);
+        s0 = mfma_h(a0[0], bq[0], s0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       f16x8 a0[2], a1[2], bq[2] = {qf[0][kg], qf[1][kg]};
@@ -335,8 +369,10 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
       m2s = mnew;
     }
     float sum0 = 0.f, sum1 = 0.f;
+    const int ntp = (kt == nkt - 1 && short_last) ? 2 : 4;     // (s1 is -inf there: its probabilities are zeros)
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
+      if (tp >= ntp) break;
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -344,7 +380,7 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
         if (j & 1) sum1 += x[j]; else sum0 += x[j];
       }
       f16x8 pb[2], a0[2], a1[2];
-      split2x8(x, pb);
+      split2x8<MIX>(x, pb);
       frag2(a0, Vt + ((tp * 2) * 2) * 1024);
       frag2(a1, Vt + ((tp * 2 + 1) * 2) * 1024);
       H2_PAIR(o0, a0, o1, a1, pb)
@@ -352,16 +388,31 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
     l += sum0 + sum1;
   };
 
-  const int nint = 2 * nkt + 1;
-  for (int n = 0; n < nint; ++n) {
-    issue_part((n >> 1) + 2, n & 1, ((n >> 1) + 2) % 3);
-    const int k = n - off;
-    if (wave_active && k >= 0 && k < 2 * nkt) {
-      if (k & 1) phase2(k >> 1);
-      else phase1(k >> 1);
-    }
-    wait_vm<6>();                      // the part issued three intervals ago has landed: it is read from the next interval on
+  if constexpr ((V & 2) != 0) {        // A/B variant: all waves in lockstep, one barrier per tile
+    wait_vm<4>();
     interval_barrier();
+    for (int kt = 0; kt < nkt; ++kt) {
+      issue_part(kt + 2, 0, (kt + 2) % 3);
+      issue_part(kt + 2, 1, (kt + 2) % 3);
+      if (wave_active) {
+        phase1(kt);
+        phase2(kt);
+      }
+      wait_vm<4>();
+      interval_barrier();
+    }
+  } else {
+    const int nint = 2 * nkt + 1;
+    for (int n = 0; n < nint; ++n) {
+      issue_part((n >> 1) + 2, n & 1, ((n >> 1) + 2) % 3);
+      const int k = n - off;
+      if (wave_active && k >= 0 && k < 2 * nkt) {
+        if (k & 1) phase2(k >> 1);
+        else phase1(k >> 1);
+      }
+      wait_vm<6>();                    // the part issued three intervals ago has landed: it is read from the next interval on
+      interval_barrier();
+    }
   }
   wait_vm<0>();
   if (wave_active && qi < p.T) {
@@ -399,7 +450,9 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
 // ------------------------------------------------------------------------------------------------ backward: dQ
 constexpr int STG_Q = 48 * 1024;   // K rm | V rm | K tr of one 64-key tile
 
+template <int V>
 __global__ __launch_bounds__(512) void attn_dq_h2_kernel(const AttnP p, const H2W w) {
+  constexpr bool MIX = (V & 1) != 0;
   extern __shared__ __attribute__((aligned(1024))) char sm[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -480,7 +533,7 @@ __global__ __launch_bounds__(512) void attn_dq_h2_kernel(const AttnP p, const H2
             for (int j = 0; j < 8; ++j)
               x[j] = __builtin_amdgcn_exp2f(fmaf(sa[8 * t + j], c, a_i)) * fmaf(dp[8 * t + j], cdp, -d_i);
             f16x8 pb[2], a0[2], a1[2];
-            split2x8(x, pb);
+            split2x8<MIX>(x, pb);
             frag2(a0, Kt + (((2 * jt + t) * 2) * 2) * 1024);
             frag2(a1, Kt + (((2 * jt + t) * 2 + 1) * 2) * 1024);
             H2_PAIR(dq0, a0, dq1, a1, pb)
@@ -516,7 +569,9 @@ __global__ __launch_bounds__(512) void attn_dq_h2_kernel(const AttnP p, const H2
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 constexpr int STG_K = 33 * 1024;   // Q rm | dO rm | Q tr | dO tr (8 chunks each) | the 32 queries' (a, d') pairs (+ over-read)
 
+template <int V>
 __global__ __launch_bounds__(512) void attn_dkv_h2_kernel(const AttnP p, const H2W w) {
+  constexpr bool MIX = (V & 1) != 0;
   extern __shared__ __attribute__((aligned(1024))) char sm[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -525,7 +580,7 @@ __global__ __launch_bounds__(512) void attn_dkv_h2_kernel(const AttnP p, const H
   const int b = z / p.H, h = z - b * p.H;
   const int k0 = rb_ * FQ + wave * 32;
   const bool wave_active = k0 < p.T;
-  const int nqt = w.Tp >> 5;
+  const int nqt = (p.T + 31) >> 5;          // 32-query tiles that hold a query (the operand sets are padded to 64)
   const long rmz = (long)(w.Tp >> 5) * 8192, trz = (long)w.Tp * 256;
   const char* src4[4] = {w.q_rm + z * rmz, w.do_rm + z * rmz, w.q_tr + z * trz, w.do_tr + z * trz};
   const char* ldsrc = reinterpret_cast<const char*>(w.ld + (long)z * w.Tp * 2);
@@ -603,8 +658,8 @@ __global__ __launch_bounds__(512) void attn_dkv_h2_kernel(const AttnP p, const H
           }
         }
         f16x8 pa[2], sa2[2], o0[2], o1[2], q0f[2], q1f[2];
-        split2x8(xp, pa);
-        split2x8(xs, sa2);
+        split2x8<MIX>(xp, pa);
+        split2x8<MIX>(xs, sa2);
         frag2(o0, Ot + ((t * 2) * 2) * 1024);
         frag2(o1, Ot + ((t * 2 + 1) * 2) * 1024);
         H2_2(dv0, pa, o0, dv1, pa, o1)
@@ -688,6 +743,10 @@ bool attr_once(std::atomic<uint64_t>& mask) {
   const uint64_t bit = 1ull << (dev & 63);
   return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
 }
+int variant() {   // SVL_ATTN_H2_VARIANT: bit 0 = v_fma_mix split, bit 1 = forward without the half-tile skew (A/B runs)
+  static const int v = getenv("SVL_ATTN_H2_VARIANT") ? atoi(getenv("SVL_ATTN_H2_VARIANT")) & 3 : 3;
+  return v;
+}
 template <typename K>
 int set_lds(K kernel, std::atomic<uint64_t>& mask, int bytes) {
   if (attr_once(mask))
@@ -751,10 +810,16 @@ int fwd(const AttnP& p, int nb, void* ws_, long wsb, hipStream_t st) {
   hipLaunchKernelGGL(attn_pack_kernel, dim3(p.B * p.H, 3), dim3(256), 0, st, q);
   SVL_LAUNCH_CHECK("svl_attention_fwd_h2/pack");
   if (nb > 0) {
-    static std::atomic<uint64_t> mask{0};
-    rc = set_lds(attn_fwd_h2_kernel, mask, 3 * STG_F);
-    if (rc) return rc;
-    hipLaunchKernelGGL(attn_fwd_h2_kernel, dim3(nb * p.B * p.H), dim3(512), 3 * STG_F, st, p, w);
+    static std::atomic<uint64_t> mask[4];
+    const dim3 grid(nb * p.B * p.H);
+#define SVL_LAUNCH_V(KERN, LDS)                                                    \
+    switch (variant()) {                                                            \
+      case 0: rc = set_lds(KERN<0>, mask[0], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<0>, grid, dim3(512), LDS, st, p, w); break; \
+      case 1: rc = set_lds(KERN<1>, mask[1], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<1>, grid, dim3(512), LDS, st, p, w); break; \
+      case 2: rc = set_lds(KERN<2>, mask[2], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<2>, grid, dim3(512), LDS, st, p, w); break; \
+      default: rc = set_lds(KERN<3>, mask[3], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<3>, grid, dim3(512), LDS, st, p, w); break; \
+    }
+    SVL_LAUNCH_V(attn_fwd_h2_kernel, 3 * STG_F)
     SVL_LAUNCH_CHECK("svl_attention_fwd_h2");
   }
   return SVL_OK;
@@ -798,15 +863,18 @@ int bwd_main(const AttnP& p, int nb, void* ws_, hipStream_t st) {
   if (nb <= 0) return SVL_OK;
   const Layout l = layout(p.B, p.T, p.H, 1);
   const H2W w = views(l, static_cast<char*>(ws_), 1);
-  static std::atomic<uint64_t> mk{0}, mq{0};
-  int rc = set_lds(attn_dkv_h2_kernel, mk, 3 * STG_K);
-  if (rc) return rc;
-  rc = set_lds(attn_dq_h2_kernel, mq, 3 * STG_Q);
-  if (rc) return rc;
-  hipLaunchKernelGGL(attn_dkv_h2_kernel, dim3(nb * p.B * p.H), dim3(512), 3 * STG_K, st, p, w);
-  SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dkv");
-  hipLaunchKernelGGL(attn_dq_h2_kernel, dim3(nb * p.B * p.H), dim3(512), 3 * STG_Q, st, p, w);
-  SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dq");
+  int rc = SVL_OK;
+  const dim3 grid(nb * p.B * p.H);
+  {
+    static std::atomic<uint64_t> mask[4];
+    SVL_LAUNCH_V(attn_dkv_h2_kernel, 3 * STG_K)
+    SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dkv");
+  }
+  {
+    static std::atomic<uint64_t> mask[4];
+    SVL_LAUNCH_V(attn_dq_h2_kernel, 3 * STG_Q)
+    SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dq");
+  }
   return SVL_OK;
 }
 

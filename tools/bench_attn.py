@@ -2,7 +2,7 @@
 Usage: python tools/bench_attn.py [B T H]"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from semivl_amd import ops
 
 

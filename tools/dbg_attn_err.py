@@ -1,7 +1,7 @@
 """Per-output error of the fused attention against fp64 on the spiky test case (tests/test_ops_gpu.py::test_fused_attention_split_emulation)."""
 import os, sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from semivl_amd import ops
 
 
