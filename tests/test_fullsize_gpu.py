@@ -69,9 +69,12 @@ MCLIP_TIE = 1e-5                # MaskCLIP label ties: top-2 probability gap / d
 # the ordinary tensors, worst rel-L2 over SHARED_FAR_END) -- asserted with 30 % headroom (+2 flips), so that a regression
 # inside the generous fixed bounds above still fails.  The kernels are deterministic: the numbers only move when the
 # arithmetic of a kernel changes, and then they are re-measured (the test prints `RATCHET measured`).
-RATCHET = {("pascal", 0): (21, 1.3e-3, 2.7e-3), ("pascal", 6): (14, 2.1e-3, 4.3e-3),
-           ("coco", 0): (1, 8.2e-4, 1.1e-3), ("coco", 6): (2, 4.8e-4, 7.4e-4),
-           ("ade", 0): (6, 1.4e-3, 2.8e-3), ("ade", 6): (5, 5.4e-4, 8.9e-4)}
+# Mode 6 re-measured when the fused attention moved to fp16 x 2 operands (round 5, csrc/attn_h2.hip; the exact-mode rows did
+# not move): pascal (14, 2.1e-3, 4.3e-3) -> (13, 2.0e-3, 4.2e-3), coco (2, 4.8e-4, 7.4e-4) -> (3, 3.0e-4, 6.7e-4),
+# ade (5, 5.4e-4, 8.9e-4) -> (6, 6.4e-4, 1.27e-3) -- on coco / ade still less than half of the exact fp32 mode's distance.
+RATCHET = {("pascal", 0): (21, 1.3e-3, 2.7e-3), ("pascal", 6): (13, 2.1e-3, 4.3e-3),
+           ("coco", 0): (1, 8.2e-4, 1.1e-3), ("coco", 6): (3, 3.1e-4, 6.8e-4),
+           ("ade", 0): (6, 1.4e-3, 2.8e-3), ("ade", 6): (6, 6.5e-4, 1.3e-3)}
 
 
 def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stack=(), after_bn=(), after_bn_tol=None,
