@@ -803,6 +803,9 @@ ATTN_FMT = os.environ.get("SVL_ATTN_FMT", "h2")
 assert ATTN_FMT in ("h2", "b3")
 
 
+ATTN_OUT_REPACK = not os.environ.get("SVL_ATTN_NO_REPACK")     # A/B: keep the kernels' own bf16 x 3 planes outputs
+
+
 def attention_h2():
     return get_gemm_emulation() == 6 and ATTN_FMT == "h2" and not os.environ.get("SVL_ATTN_NO_EMU")
 
@@ -821,14 +824,21 @@ def attention_fwd(qkv, Bn, T, H, want_lse=True, planes=False, want_out=True):
     planes=True (attention_planes_ok()) additionally returns the output as packed planes, written by the kernel's own
     epilogue; want_out=False then skips the fp32 copy (gradient-free passes)."""
     E = H * 64
-    out = empty(Bn * T, E, device=qkv.device) if (want_out or not planes) else None
+    # h2 consumers (PLANES_FMT): the fp32 result is packed by the generic pass -- 38 us at [32800, 768], less than what the
+    # out-projection saves on fp16 x 2 operands (three products instead of the six of the kernels' own bf16 x 3 planes)
+    repack = planes and attention_h2() and PLANES_FMT == "h2" and ATTN_OUT_REPACK
+    out = empty(Bn * T, E, device=qkv.device) if (want_out or not planes or repack) else None
     lse = empty(Bn * H * T, device=qkv.device) if want_lse else None
-    op = Planes(Bn * T, E, device=qkv.device, fmt="b3") if planes else None
+    op = Planes(Bn * T, E, device=qkv.device, fmt="b3") if (planes and not repack) else None
     e0 = _prof_begin()
     if attention_h2():
         ws, n = _attn_ws(Bn, T, H, False, qkv.device)
-        L.check(L.load().svl_attention_fwd_h2(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if planes else None,
-                                              op.prow if planes else 0, _ws_ptr(ws), n, _st()), "svl_attention_fwd_h2")
+        L.check(L.load().svl_attention_fwd_h2(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if op is not None else None,
+                                              op.prow if op is not None else 0, _ws_ptr(ws), n, _st()), "svl_attention_fwd_h2")
+        if repack:
+            op = split_planes(out)
+            if not want_out:
+                out = None
     else:
         L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if planes else None,
                                            op.prow if planes else 0, _st()), "svl_attention_fwd")
@@ -841,13 +851,16 @@ def attention_bwd(dout, qkv, out, lse, Bn, T, H, planes=False):
     dqkv = torch.empty_like(qkv)
     ws = empty(Bn * H * T, device=qkv.device)
     E = H * 64
-    dp = Planes(Bn * T, 3 * E, device=qkv.device, fmt="b3") if planes else None
+    repack = planes and attention_h2() and PLANES_FMT == "h2" and ATTN_OUT_REPACK
+    dp = Planes(Bn * T, 3 * E, device=qkv.device, fmt="b3") if (planes and not repack) else None
     e0 = _prof_begin()
     if attention_h2():
         wsb, n = _attn_ws(Bn, T, H, True, qkv.device)
         L.check(L.load().svl_attention_bwd_h2(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
-                                              _p(dp.buf) if planes else None, dp.prow if planes else 0, _ws_ptr(wsb), n,
-                                              _st()), "svl_attention_bwd_h2")
+                                              _p(dp.buf) if dp is not None else None, dp.prow if dp is not None else 0,
+                                              _ws_ptr(wsb), n, _st()), "svl_attention_bwd_h2")
+        if repack:
+            dp = split_planes(dqkv)
     else:
         L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
                                            _p(dp.buf) if planes else None, dp.prow if planes else 0, _st()),

@@ -527,11 +527,25 @@ def test_fused_attention_emits_planes(dev, Bn, T, H, fmt):
     E = 64 * H
     qkv = rnd(Bn * T, 3 * E, dev=dev, seed=52)
     do = rnd(Bn * T, E, dev=dev)
-    old_fmt = ops.ATTN_FMT
+    old_fmt, old_rp = ops.ATTN_FMT, ops.ATTN_OUT_REPACK
     try:
         ops.ATTN_FMT = fmt
         ops.set_gemm_emulation(6)
         assert ops.attention_planes_ok() and ops.attention_h2() == (fmt == "h2")
+        if fmt == "h2" and ops.PLANES_FMT == "h2":
+            # default wiring of the h2 family: the fp32 results repacked as fp16 x 2 planes (what their consumers' GEMMs take)
+            out, lse = ops.attention_fwd(qkv, Bn, T, H)
+            o2, l2, op = ops.attention_fwd(qkv, Bn, T, H, planes=True)
+            assert op.fmt == "h2" and torch.equal(out, o2) and torch.equal(lse, l2)
+            assert (_h2_value(op) - out.double()).abs().max() <= 2.0 ** -21 * float(out.abs().max())
+            o3, _, op3 = ops.attention_fwd(qkv, Bn, T, H, want_lse=False, planes=True, want_out=False)
+            assert o3 is None and torch.equal(op3.sexp[:op.rows], op.sexp[:op.rows])
+            for a, b_ in zip(_unpack_planes(op3), _unpack_planes(op)):
+                assert torch.equal(a, b_)
+            d2, dp = ops.attention_bwd(do, qkv, out, lse, Bn, T, H, planes=True)
+            assert dp.fmt == "h2" and torch.equal(d2, ops.attention_bwd(do, qkv, out, lse, Bn, T, H))
+            assert (_h2_value(dp) - d2.double()).abs().max() <= 2.0 ** -21 * float(d2.abs().max())
+        ops.ATTN_OUT_REPACK = False      # the kernels' own bf16 x 3 planes outputs
         out, lse = ops.attention_fwd(qkv, Bn, T, H)
         o2, l2, op = ops.attention_fwd(qkv, Bn, T, H, planes=True)
         assert torch.equal(out, o2) and torch.equal(lse, l2)
@@ -551,7 +565,7 @@ def test_fused_attention_emits_planes(dev, Bn, T, H, fmt):
         with pytest.raises(RuntimeError):
             ops.attention_fwd(qkv, Bn, T, H, planes=True)
     finally:
-        ops.ATTN_FMT = old_fmt
+        ops.ATTN_FMT, ops.ATTN_OUT_REPACK = old_fmt, old_rp
         ops.set_gemm_emulation(0)
 
 
