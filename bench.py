@@ -287,9 +287,11 @@ def main():
                steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 2), higher_is_better=True, scaling="weak",
                vs_baseline=None,
                dtype="f32" if a.gemm_arith == "f32" else
-               f"f32 (fp32 in/out/accumulate everywhere; large dense GEMMs as {a.gemm_arith} split products on the bf16 MFMA pipe, "
-               f"error vs fp64 at the level of the plain fp32 MFMA chain's (tests: <= 1.2x, measured 0.85-1.15x): the dense GEMMs, the fused ViT attention, the >= 32-channel "
-               f"convolutions' forward / input gradient and the tiled 3x3 weight gradient; the remaining MFMA kernels on the fp32 pipe)",
+               f"f32 (fp32 in / out / accumulate everywhere; the MFMA products as split 16-bit terms with fp32 accumulation, error vs "
+               f"fp64 at the level of the plain fp32 MFMA chain's (tests/test_ops_gpu.py): the ViT's linears and fused attention on "
+               f"fp16 x 2 operands with power-of-two scales (3 products per fp32 MAC: svl_gemm_planes_f32 fmt 1, "
+               f"svl_attention_*_h2), the decoder's >= 32-channel convolutions' forward / input gradient, weight gradients and "
+               f"narrow GEMMs on bf16 x 3 terms (6 products: --gemm-arith {a.gemm_arith}); the remaining MFMA kernels on the fp32 pipe)",
                data="synthetic",
                config=dict(workload=f"SemiVL step, {dataset} N={a.nclass}, {cfg['model'].replace('mmseg.', '')}, {a.crop}x{a.crop}, "
                                     f"bs={a.batch}/GPU labeled + {a.batch}/GPU unlabeled" +
@@ -350,7 +352,7 @@ def main():
                                              note="SURVEY §8(d)'s per-step figure: 19 decoder forward-equivalents per image "
                                                   "pair, of which the step (like the reference's useful work) executes 14"),
                                kernel="all MFMA launches of one step: gemm_kernel / conv kernels + attn_{fwd,bwd}_kernel "
-                                      "(v_mfma_f32_32x32x2_f32)" + (" + gemm_bf16x_kernel / attn_*_x6_kernel (v_mfma_f32_32x32x16_bf16, 6 products)"
+                                      "(v_mfma_f32_32x32x2_f32)" + (" + gemm_bf16x_kernel (v_mfma_f32_32x32x16_bf16, 6 products) / gemm_x6p_kernel<2> + attn_*_h2_kernel (v_mfma_f32_32x32x16_f16, 3 products)"
                                                                        if gx else ""), launches=len(g),
                                kernel_time_ms=round(t_gemm * 1e3, 2),
                                executed_tflops=round(issued / t_gemm / 1e12, 2),
@@ -361,8 +363,9 @@ def main():
                                     "executed algorithmic FLOPs / the WHOLE step time (every non-MFMA pass counted against the MFMA "
                                     "peak); `contract` = the same ratios with SURVEY §8(d)'s 19-forward-equivalent figure")
         def nprod_of(tag_):
-            """16-bit products a launch issues per fp32 MAC: 3 on fp16 x 2 planes, else the mode's 6 (3 in bf16x3 mode)."""
-            return 3 if (tag_ and tag_[0] == "planes_h2") or a.gemm_arith == "bf16x3" else 6
+            """16-bit products a launch issues per fp32 MAC: 3 on fp16 x 2 operands (packed-planes GEMM, fused attention on
+            pre-packed operands), else the mode's 6 (3 in bf16x3 mode)."""
+            return 3 if (tag_ and tag_[0] in ("planes_h2", "fwd_h2", "bwd_h2")) or a.gemm_arith == "bf16x3" else 6
 
         if gx:   # the split-emulation GEMM family against ITS pipe: 16-bit dense peak vs the products actually issued
             nprod = 6 if a.gemm_arith == "bf16x6" else 3
@@ -371,7 +374,8 @@ def main():
             iss_x = sum(w * nprod_of(tag) for _, _, w, tag, *_ in gx)
             out["mfma_step_vs_f32_pipe"]["bf16_pipe"] = dict(
                 kernel=f"gemm_bf16x_kernel<{nprod // 2 if nprod == 6 else 2},...> (svl_gemm_f32 in emulation mode {nprod})"
-                       + (" + attn_{fwd,bwd_dq,bwd_dkv}_x6_kernel" if prof.get("attention_bf16x") else ""),
+                       + (" + gemm_x6p_kernel<2, ...> (fp16 x 2 planes) + attn_{fwd,dq,dkv}_h2_kernel (fp16 x 2 pre-packed operands)"
+                          if prof.get("attention_bf16x") else ""),
                 launches=len(gx), kernel_time_ms=round(t_x * 1e3, 2), achieved=round(f_x / t_x / 1e12, 2),
                 issued_16bit_tflops=round(iss_x / t_x / 1e12, 1), peak=PEAK_BF16_MFMA_TF, unit="TFLOP/s",
                 frac=round(iss_x / t_x / 1e12 / PEAK_BF16_MFMA_TF, 4),
@@ -460,7 +464,10 @@ def main():
                     "gemm_bf16x": "svl_gemm_f32 / svl_gemm_planes_f32 / tiled 3x3 in the split arithmetic (gemm_bf16x_kernel, "
                                   "gemm_x6p_kernel, conv3x3_*_bf16x_kernel: v_mfma_f32_32x32x16_bf16)",
                     "attention": "svl_attention_* (attn_*_kernel, fp32 MFMA)",
-                    "attention_bf16x": "svl_attention_* (attn_*_x6_kernel, v_mfma_f32_32x32x16_bf16)"}[fam]
+                    "attention_bf16x": "svl_attention_*_h2 (attn_{fwd,dq,dkv}_h2_kernel on fp16 x 2 pre-packed operands, "
+                                       "v_mfma_f32_32x32x16_f16; pack pass included in the launch's duration)"
+                                       if tag[0] in ("fwd_h2", "bwd_h2") else
+                                       "svl_attention_* (attn_*_x6_kernel, v_mfma_f32_32x32x16_bf16)"}[fam]
             out["roofline"] = dict(
                 bound="mfma", achieved=round(d_tf, 1), peak=round(peak, 1),
                 unit="TFLOP/s (fp32-equivalent)" if on_bf16 else "TFLOP/s", frac=round(d_tf / peak, 4), traffic=None,

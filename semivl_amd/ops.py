@@ -842,7 +842,7 @@ def attention_fwd(qkv, Bn, T, H, want_lse=True, planes=False, want_out=True):
     else:
         L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if planes else None,
                                            op.prow if planes else 0, _st()), "svl_attention_fwd")
-    _prof_end(_attn_family(), e0, 4.0 * Bn * H * T * T * 64, ("fwd", Bn, T, H))
+    _prof_end(_attn_family(), e0, 4.0 * Bn * H * T * T * 64, ("fwd_h2" if attention_h2() else "fwd", Bn, T, H))
     return (out, lse, op) if planes else (out, lse)
 
 
@@ -865,7 +865,7 @@ def attention_bwd(dout, qkv, out, lse, Bn, T, H, planes=False):
         L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
                                            _p(dp.buf) if planes else None, dp.prow if planes else 0, _st()),
                 "svl_attention_bwd")
-    _prof_end(_attn_family(), e0, 14.0 * Bn * H * T * T * 64, ("bwd", Bn, T, H))
+    _prof_end(_attn_family(), e0, 14.0 * Bn * H * T * T * 64, ("bwd_h2" if attention_h2() else "bwd", Bn, T, H))
     return (dqkv, dp) if planes else dqkv
 
 
