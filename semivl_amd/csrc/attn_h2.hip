@@ -352,11 +352,14 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
         if (key + 32 >= p.T) s1[r] = -INFINITY;
       }
     }
-    float mloc = max3(s0[0], s1[0], s0[1]);
-    mloc = max3(mloc, s1[1], s0[2]);
+    // two independent v_max3 chains (half the dependent depth)
+    float ma = max3(s0[0], s0[1], s0[2]), mb = max3(s1[0], s1[1], s1[2]);
 #pragma unroll
-    for (int r = 2; r < 15; ++r) mloc = max3(mloc, s1[r], s0[r + 1]);
-    mloc = fmaxf(mloc, s1[15]);
+    for (int r = 3; r < 15; r += 2) {
+      ma = max3(ma, s0[r], s0[r + 1]);
+      mb = max3(mb, s1[r], s1[r + 1]);
+    }
+    float mloc = max3(ma, mb, fmaxf(s0[15], s1[15]));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mloc2 = mloc * c;
     const bool raise = mloc2 > m2s + (7.f + RESCALE_LOG2);   // lazy rescale (attention.hip::attn_fwd_kernel)
