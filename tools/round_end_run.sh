@@ -1,9 +1,9 @@
-# End-of-round evidence run on the 1-GPU box (profiles/README.md):  gpurun -- 'TAG=r4_x bash tools/round_end_run.sh'
+# End-of-round evidence run on the 1-GPU box (profiles/README.md):  gpurun -- 'TAG=r5_x bash tools/round_end_run.sh'
 cd $GRAFT_REPO_ROOT
-T=${TAG:-r4}
+T=${TAG:-r5}
 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -25 > gpurun_out/${T}_pytest.log
 # PMC records of the dominant launches (quoted by bench.py as roofline.traffic / roofline_hbm.traffic)
-bash tools/pmc_x6p.sh 32800 3072 768 4 > gpurun_out/${T}_pmc_x6p_ffn1.txt 2>&1   # mode 4 = FFN-1 as the step launches it (no fp32 C)
+X6P_FMT=1 bash tools/pmc_x6p.sh 32800 3072 768 4 > gpurun_out/${T}_pmc_x6p_ffn1.txt 2>&1   # mode 4 = FFN-1 as the step launches it (no fp32 C); fmt 1 = fp16 x 2 planes
 bash tools/pmc_ce.sh > gpurun_out/${T}_pmc_ce.txt 2>&1
 SVL_GEMM_EMU=0 bash tools/pmc_traffic.sh tools/one_gemm.py gemm_kernel > gpurun_out/${T}_pmc_gemm_f32.txt 2>&1
 mkdir -p profiles && cp gpurun_out/pmc_x6p_traffic.json gpurun_out/pmc_ce_traffic.json gpurun_out/pmc_gemm_traffic.json profiles/ 2>/dev/null
@@ -16,7 +16,7 @@ for m in bf16x6 f32; do
   cd $GRAFT_REPO_ROOT; DB=$(find gpurun_out/prof_$m -name "*.db" | head -1)
   python tools/rocpd_stats.py $DB > gpurun_out/${T}_kernel_stats_bs16_$m.csv
   python tools/rocpd_attrib.py $DB 0.34 1.0 > gpurun_out/${T}_attrib_$m.txt
-  if [ $m = bf16x6 ]; then python tools/rocpd_dispatches.py $DB gemm_x6p_kernelILi256ELi1E 1548 > gpurun_out/${T}_dominant_dispatches.csv; fi
+  if [ $m = bf16x6 ]; then python tools/rocpd_dispatches.py $DB gemm_x6p_kernelILi2ELi256ELi1E 1548 > gpurun_out/${T}_dominant_dispatches.csv; fi
   rm -rf gpurun_out/prof_$m
 done
 # the N > 1 code path on this one-GPU box: two ranks over gloo (blocking all-reduce) -- the `allreduce` object with the
