@@ -42,7 +42,7 @@ typedef enum svl_status {
   SVL_ERR_UNSUPPORTED = -3
 } svl_status;
 
-int svl_version(void); /* 500: round-5 ABI (fp16 x 2 planes: svl_split_planes_f16x2, svl_planes_bytes_fmt, fmt / scale fields of svl_pgemm_desc); 401: + svl_conv3x3_weight_planes, svl_gemm_desc::conv_w_planes, w_planes of svl_conv3x3_gn_f32; 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
+int svl_version(void); /* 501: + svl_attention_{fwd,bwd}_h2, svl_attention_h2_ws_bytes (fused attention on fp16 x 2 pre-packed operands); 500: round-5 ABI (fp16 x 2 planes: svl_split_planes_f16x2, svl_planes_bytes_fmt, fmt / scale fields of svl_pgemm_desc); 401: + svl_conv3x3_weight_planes, svl_gemm_desc::conv_w_planes, w_planes of svl_conv3x3_gn_f32; 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
                            svl_stream_prepare, svl_last_gemm_path; gn_in arguments of the tiled weight gradient and the Conv2d(C -> 1)
                            entries, `accumulate` of svl_avgpool_cat_bwd); 300: round-3 ABI (packed-planes operands; planes outputs of LayerNorm / attention; loss-mode arguments of
                            the pixel-loss entries; 200 = round 2: helper-stream contexts, caller-owned scratch everywhere) */
