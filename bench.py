@@ -214,6 +214,21 @@ def pmc_traffic_record(batch, name="pmc_gemm_traffic.json", src="gemm.hip"):
     return None, f"no PMC record for this kernel source (profiles/{name} absent or from another {src})"
 
 
+def rocprof_dispatch_record(batch, src="gemm_planes_impl.h"):
+    """Per-dispatch durations of the dominant launch as rocprofv3 --kernel-trace timed them inside the step of the same
+    command (profiles/dominant_dispatches.json, written by tools/round_end_run.sh from the committed per-dispatch rows):
+    used only when it was measured on the SAME kernel source."""
+    import hashlib
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "dominant_dispatches.json")))
+        sha = hashlib.sha256(open(os.path.join(ROOT, "semivl_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+        if rec.get("src_sha16") == sha and rec.get("M") == 32 * 1025 * batch // 16:
+            return rec
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -514,6 +529,13 @@ def main():
                 opb = 4 if h2 else 6        # bytes per operand element
                 traffic, tnote = (pmc_traffic_record(a.batch, "pmc_x6p_traffic.json", "gemm_planes_impl.h") if planes
                                   else (None, "no PMC record for this kernel"))
+                rr = rocprof_dispatch_record(a.batch) if planes else None
+                rocprof_in_step = None if rr is None else dict(
+                    mean_ms=round(rr["mean_us"] * 1e-3, 4), min_ms=round(rr["min_us"] * 1e-3, 4), dispatches=rr["n"],
+                    frac=round(fl_ / (rr["mean_us"] * 1e-6) / 1e12 / peak, 4), source=rr.get("source"),
+                    note="the same launches as rocprofv3 --kernel-trace timed them inside the overlapped step (kernel begin -> "
+                         "end); `avg_ms` brackets the launch with HIP events on its stream, which also contain the time the "
+                         "dispatch waits for CUs another stream's kernel holds -- the event figure is the larger one")
                 out["roofline"] = dict(
                     bound="mfma", achieved=round(d_tf, 1), peak=round(peak, 1), unit="TFLOP/s (fp32-equivalent)",
                     frac=round(d_tf / peak, 4), traffic=traffic,
@@ -528,7 +550,7 @@ def main():
                     flops_per_launch=fl_, mfma_issued_tflops=round(d_tf * nprod, 1),
                     frac_of_16bit_dense_peak=round(d_tf * nprod / PEAK_BF16_MFMA_TF, 4),
                     algorithmic_bytes=(Md * 768 * opb + 3072 * 768 * opb + Md * 3072 * (4 + opb)) if planes else 513.0e6 * a.batch / 16,
-                    traffic_note=tnote, clock_mhz=clock,
+                    traffic_note=tnote, clock_mhz=clock, rocprof_in_step=rocprof_in_step,
                     frac_solo_at_sustained_clock=(round(fl_ / (solo_ms * 1e-3) / 1e12 / peak * PEAK_CLOCK_MHZ / clock["under_dominant_kernel"], 4)
                                                   if clock and clock["under_dominant_kernel"] else None),
                     note=f"achieved = 2MNK / mean launch duration INSIDE the timed step (HIP events on the launch stream, the "

@@ -365,6 +365,12 @@ int svl_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
  * LN1 -> qkv and LN2 -> FFN-1 of every ViT block (maskclip_vit.py:120-144). */
 int svl_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
                              float* y, float* stats, void* planes, int64_t planes_rows, svl_stream_t stream);
+/* The same with the result as fp16 x 2 planes (svl_pgemm_desc.fmt = 1): sexp [planes_rows] receives the rows' scale exponents,
+ * rnorm [planes_rows] (optional) upper bounds of their L2 norms; the planes are bit-identical to svl_split_planes_f16x2 over
+ * the fp32 result (which `y`, optional here, still receives). */
+int svl_layernorm_fwd_planes_f16x2(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,
+                                   float* y, float* stats, void* planes, int64_t planes_rows, int32_t* sexp, float* rnorm,
+                                   svl_stream_t stream);
 /* dx = LN backward (+ dx_add if non-NULL, fused residual-grad add). If dgamma_part != NULL also writes
  * per-block partial sums dgamma_part/dbeta_part [nparts, C] (nparts = svl_layernorm_bwd_parts(rows)). */
 int svl_layernorm_bwd_parts(int64_t rows);

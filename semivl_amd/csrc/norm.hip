@@ -65,12 +65,56 @@ __device__ __forceinline__ void ln_emit_planes(const float* __restrict__ src, lo
   }
 }
 
+// The same for the fp16 x 2 operand format (csrc/gemm_planes_impl.h, NP = 2): two planes per chunk, x 2^-e[row] = h0 + h1
+// with the row exponents of the block in LDS (found by the row loop from the row's largest |y|, exactly as the generic pack
+// pass svl_split_planes_f16x2 finds them: the planes are bit-identical to that pass over the fp32 result).
+__device__ __forceinline__ void ln_emit_planes_h2(const float* __restrict__ src, long r0, long rows, int C,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* st /* LDS [32][2] */, const int* se /* LDS [32] */,
+                                                  char* __restrict__ planes, long p_ks) {
+  typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
+  const int t = threadIdx.x, r31 = t & 31, h = (t >> 5) & 1, kg0 = t >> 6;
+  const long r = r0 + r31;
+  const int nkg = C >> 4;
+  const float mean = st[2 * r31], rstd = st[2 * r31 + 1];
+  const int e = se[r31];
+  for (int kg = kg0; kg < nkg; kg += 4) {
+    float v[8];
+    const int k = kg * 16 + 4 * h;
+    if (r < rows) {
+      const float4 f0 = *reinterpret_cast<const float4*>(src + r * C + k), f1 = *reinterpret_cast<const float4*>(src + r * C + k + 8);
+      v[0] = f0.x; v[1] = f0.y; v[2] = f0.z; v[3] = f0.w; v[4] = f1.x; v[5] = f1.y; v[6] = f1.z; v[7] = f1.w;
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + k), g1 = *reinterpret_cast<const float4*>(gamma + k + 8);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + k), b1 = *reinterpret_cast<const float4*>(beta + k + 8);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (v[q] - mean) * rstd * gg[q] + bb[q];     // (the row loop's expression, bit for bit)
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    }
+    f16x8_ h0, h1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float u = __builtin_amdgcn_ldexpf(v[q], -e);
+      h0[q] = (_Float16)u;
+      h1[q] = (_Float16)(u - (float)h0[q]);
+    }
+    char* q_ = planes + (long)kg * p_ks + (r >> 5) * 2048 + (h * 32 + (int)(r & 31)) * 16;
+    *reinterpret_cast<f16x8_*>(q_) = h0;
+    *reinterpret_cast<f16x8_*>(q_ + 1024) = h1;
+  }
+}
+
 // rows_per_block = 4 (planes == null: one row per wave and pass) or 32 (planes: a whole row block, then ln_emit_planes)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, long rows, int C,
                                                             float* __restrict__ y, float* __restrict__ stats,
-                                                            char* __restrict__ planes, long p_ks) {
+                                                            char* __restrict__ planes, long p_ks, int* __restrict__ sexp,
+                                                            float* __restrict__ rnorm) {
   __shared__ float st_s[64];
+  __shared__ int se_s[32];
+  const bool h2 = sexp != nullptr;   // fp16 x 2 planes: the row loop also finds each row's largest |y| and its norm
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C4 = C >> 2;
   const int rpb = planes ? 32 : 4;
@@ -91,7 +135,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       }
       const float var = wave_sum(q) / C;
       const float rstd = 1.0f / sqrtf(var + eps);
-      if (y) {
+      float amax = 0.f, sq = 0.f;
+      if (y || h2) {
         float4* yr = reinterpret_cast<float4*>(y + r * C);
         for (int i = lane; i < C4; i += 64) {
           const float4 v = xr[i];
@@ -102,18 +147,34 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
           o.y = (v.y - mean) * rstd * g.y + b.y;
           o.z = (v.z - mean) * rstd * g.z + b.z;
           o.w = (v.w - mean) * rstd * g.w + b.w;
-          yr[i] = o;
+          if (y) yr[i] = o;
+          if (h2) {
+            amax = fmaxf(fmaxf(amax, fabsf(o.x)), fmaxf(fabsf(o.y), fmaxf(fabsf(o.z), fabsf(o.w))));
+            sq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+          }
+        }
+        if (h2) {
+          amax = wave_max(amax);
+          sq = wave_sum(sq);
         }
       }
       if (lane == 0) {
         stats[2 * r] = mean;
         stats[2 * r + 1] = rstd;
         if (planes) { st_s[2 * (r - r0)] = mean; st_s[2 * (r - r0) + 1] = rstd; }
+        if (h2) {
+          int e = amax > 0.f ? __builtin_amdgcn_frexp_expf(amax) - 15 : -15;    // (= scale_exp_of, csrc/gemm_planes_impl.h)
+          e = e < -100 ? -100 : (e > 100 ? 100 : e);
+          se_s[r - r0] = e;
+          sexp[r] = e;
+          if (rnorm) rnorm[r] = sqrtf(sq) * (1.f + 2e-5f);      // (an upper bound: fp32 sum of C squares, rounded up)
+        }
       }
     }
     if (planes) {
       __syncthreads();
-      ln_emit_planes(x, r0, rows, C, gamma, beta, st_s, planes, p_ks);
+      if (h2) ln_emit_planes_h2(x, r0, rows, C, gamma, beta, st_s, se_s, planes, p_ks);
+      else ln_emit_planes(x, r0, rows, C, gamma, beta, st_s, planes, p_ks);
       __syncthreads();
     }
   }
@@ -671,8 +732,21 @@ extern "C" int svl_layernorm_fwd_planes(const float* x, const float* gamma, cons
   const long rpb = planes ? 32 : 4;
   const int grid = (int)((rows + rpb - 1) / rpb > 4096 * 4 ? 4096 * 4 : (rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
-                     (long)rows, C, y, stats, (char*)planes, (long)planes_rows * 96);
+                     (long)rows, C, y, stats, (char*)planes, (long)planes_rows * 96, (int*)nullptr, (float*)nullptr);
   SVL_LAUNCH_CHECK("svl_layernorm_fwd");
+  return SVL_OK;
+}
+extern "C" int svl_layernorm_fwd_planes_f16x2(const float* x, const float* gamma, const float* beta, float eps, int64_t rows,
+                                              int C, float* y, float* stats, void* planes, int64_t planes_rows, int32_t* sexp,
+                                              float* rnorm, svl_stream_t stream) {
+  SVL_CHECK_ARG(x && gamma && beta && planes && sexp && stats && rows > 0 && C > 0 && C % 16 == 0 && planes_rows >= rows &&
+                    planes_rows % 256 == 0,
+                "svl_layernorm_fwd_planes_f16x2: bad args (C %% 16 == 0, planes_rows (%% 256 == 0) >= rows, sexp required)");
+  const long nb = (rows + 31) / 32;
+  const int grid = (int)(nb > 4096 * 4 ? 4096 * 4 : nb);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
+                     (long)rows, C, y, stats, (char*)planes, (long)planes_rows * 64, sexp, rnorm);
+  SVL_LAUNCH_CHECK("svl_layernorm_fwd_planes_f16x2");
   return SVL_OK;
 }
 extern "C" int svl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int64_t rows, int C,

@@ -108,6 +108,7 @@ SIGNATURES = {
     "svl_iou_hist_i64": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "svl_layernorm_fwd": (_I, [_P, _P, _P, _F, _L, _I, _P, _P, _P]),
     "svl_layernorm_fwd_planes": (_I, [_P, _P, _P, _F, _L, _I, _P, _P, _P, _L, _P]),
+    "svl_layernorm_fwd_planes_f16x2": (_I, [_P, _P, _P, _F, _L, _I, _P, _P, _P, _L, _P, _P, _P]),
     "svl_layernorm_bwd_parts": (_I, [_L]),
     "svl_layernorm_bwd": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P]),
     "svl_softmax_rows_fwd": (_I, [_P, _L, _I, _L, _F, _P]),

@@ -658,6 +658,9 @@ def chanmask(x, mask, scale, rows_per_img, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ normalisation
+LN_FUSED_H2 = not os.environ.get("SVL_LN_NO_FUSED_H2")      # A/B: LayerNorm -> fp16 x 2 planes in one kernel (planes-only calls)
+
+
 def layernorm_fwd(x, gamma, beta, eps, planes=False, want_y=True):
     """y = LN(x), stats.  planes=True additionally returns the result as packed Planes (the next GEMM's A operand);
     want_y=False then skips the fp32 copy (returns None for it)."""
@@ -668,6 +671,13 @@ def layernorm_fwd(x, gamma, beta, eps, planes=False, want_y=True):
         L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),
                 "svl_layernorm_fwd")
         return y, stats
+    if PLANES_FMT == "h2" and not want_y and LN_FUSED_H2:    # planes only: one kernel (row statistics, exponents, planes)
+        pl = Planes(rows, Cc, device=x.device, fmt="h2")
+        pl.rnorm = torch.empty(pl.prow, dtype=torch.float32, device=x.device)
+        L.check(L.load().svl_layernorm_fwd_planes_f16x2(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, None, _p(stats),
+                                                        _p(pl.buf), pl.prow, _p(pl.sexp), _p(pl.rnorm), _st()),
+                "svl_layernorm_fwd_planes_f16x2")
+        return None, stats, pl
     if want_y or PLANES_FMT == "h2":   # measured at [32800, 768]: row pass (39 us) + pack pass over the cache-warm result (38 us) beats the fused
         y = torch.empty_like(x)      # kernel (102 us: its 32-row blocks leave 8 sequential rows per wave); planes-only
         L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),

@@ -6,7 +6,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = "r4_w"        # the end-of-round evidence run (tools/round_end_run.sh)
+TAG = "r5_e"        # the end-of-round evidence run (tools/round_end_run.sh)
 
 
 def _line(name):
@@ -29,22 +29,33 @@ def test_default_line_contract_and_arithmetic():
     r = d["roofline"]
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_ms"] * 1e-3) / 1e12) < 0.5          # TF = FLOP / s
-    assert abs(r["flops_per_launch"] - 2.0 * 32800 * 3072 * 768) < 1 and abs(r["peak"] - 2500.0 / 6) < 0.1
-    assert r["traffic"] is not None and r["traffic"] > r["algorithmic_bytes"] > 1.0e9
+    # round 5: fp16 x 2 planes, three products per fp32 MAC
+    assert abs(r["flops_per_launch"] - 2.0 * 32800 * 3072 * 768) < 1 and abs(r["peak"] - 2500.0 / 3) < 0.1
+    assert "gemm_x6p_kernel<2, 256, EPI_GELU>" in r["kernel"]
+    # algorithmic bytes: A, B planes (4 B / element) read once, pre-activation (4 B) + result planes (4 B) written once
+    assert abs(r["algorithmic_bytes"] - (32800 * 768 * 4 + 3072 * 768 * 4 + 32800 * 3072 * 8)) < 1
+    assert r["traffic"] is not None and r["algorithmic_bytes"] < r["traffic"] < 1.6 * r["algorithmic_bytes"]
     assert 1000 < r["clock_mhz"]["under_dominant_kernel"] < 2400
-    assert abs(r["frac_at_sustained_clock"] - r["frac"] * 2400.0 / r["clock_mhz"]["under_dominant_kernel"]) < 2e-3
-    # (a) the same launches inside the overlapped step: never faster than solo, and the fraction follows from the time
-    assert r["avg_ms_in_step"] >= 0.97 * r["avg_ms"]
-    assert abs(r["frac_in_step"] - r["flops_per_launch"] / (r["avg_ms_in_step"] * 1e-3) / 1e12 / r["peak"]) < 2e-3
+    # (a) `frac` is the in-step figure (what `value` contains); the solo duration beside it is never slower
+    assert r["avg_ms"] >= 0.97 * r["avg_ms_solo"]
+    assert abs(r["frac_solo"] - r["flops_per_launch"] / (r["avg_ms_solo"] * 1e-3) / 1e12 / r["peak"]) < 2e-3
+    assert abs(r["frac_solo_at_sustained_clock"] - r["frac_solo"] * 2400.0 / r["clock_mhz"]["under_dominant_kernel"]) < 2e-3
+    if "rocprof_in_step" in r and r["rocprof_in_step"]:
+        q = r["rocprof_in_step"]
+        assert abs(q["frac"] - r["flops_per_launch"] / (q["mean_ms"] * 1e-3) / 1e12 / r["peak"]) < 2e-3
+        assert q["min_ms"] <= q["mean_ms"] <= 1.05 * r["avg_ms"]        # (events also hold the dispatch's wait for CUs)
     h = d["roofline_hbm"]
     assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 2e-3 and h["traffic"] is not None
     assert abs(h["frac_real_traffic"] - h["traffic"] / (h["avg_ms"] * 1e-3) / 1e9 / h["peak"]) < 2e-3
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"].startswith("protocol: 1 warm-up")
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"].startswith("protocol: 3 warm-up + 5 timed")
+    assert c["runs"][0]["threads"] == c["cores"] == c["physical_cores"] and c["best_thread_count"]["images_per_s"] >= c["value"]
     x = d["cross_mode_same_weights"]
     assert x["max_abs_diff"] < 1e-3 and len(x["losses_bf16x6"]) == 8
-    # 40 dominant launches of ~0.77 ms are a small part of the step, and the step holds them
+    # 40 dominant launches of ~0.5 - 0.8 ms are a small part of the step, and the step holds them
     assert r["launches"] * r["avg_ms"] < 0.2 * d["ms_per_step"]
+    v = d["roofline_vit_encoder"]      # products per fp32 MAC of the encoder's launches: between 3 (fp16 x 2) and 6 (bf16 x 3)
+    assert 3.0 <= v["products_per_fp32_mac"] < 4.0 and abs(v["peak"] - 2500.0 / v["products_per_fp32_mac"]) < 3.0
     # (c) executed FLOPs are the primary figure: ViT 2866.6 GF x B + decoder 1322.0 GF x 14/19 x B; the contract's beside it
     m = d["mfma_step_vs_f32_pipe"]
     assert abs(m["algorithmic_gflop_per_step"] - (2866.6 + 1322.0 * 14 / 19) * 16) < 1.0
@@ -59,21 +70,25 @@ def test_default_line_contract_and_arithmetic():
 
 
 def test_dominant_kernel_duration_agrees_with_rocprof_rows():
-    """roofline.avg_ms (HIP events inside bench.py, streams back to back) against the per-dispatch rows of the same kernel
-    and grid size in the rocprofv3 kernel trace of the same command (streams overlapped: the fastest dispatches are the
-    solo ones, the MEAN is what roofline.avg_ms_in_step measures with its own events)."""
+    """roofline.avg_ms_solo (HIP events inside bench.py, streams back to back) and roofline.avg_ms (the same brackets inside the
+    overlapped step) against the per-dispatch rows of the same kernel and grid size in the rocprofv3 kernel trace of the same
+    command.  The fastest dispatches are the solo ones.  The trace's MEAN is kernel begin -> end inside the overlapped step;
+    the event bracket additionally holds the time a dispatch waits for CUs that another stream's kernel occupies, so it is
+    the larger of the two (measured: 0.78 vs 0.63 ms) -- both are in the line (`avg_ms`, `rocprof_in_step.mean_ms`)."""
     r = _line(f"{TAG}_bench_default.json")["roofline"]
     rows = [row for row in csv.reader(open(os.path.join(P, f"{TAG}_dominant_dispatches.csv"))) if row and row[0][0].isdigit()]
     dur = sorted(float(row[1]) for row in rows)
     assert len(dur) >= 100 and all(int(row[2]) == 1548 for row in rows)
     solo = dur[len(dur) // 4]                      # lower quartile: launches that did not share the chip
-    assert abs(solo - r["avg_ms"] * 1e3) < 0.08 * r["avg_ms"] * 1e3, (solo, r["avg_ms"])
+    assert abs(solo - r["avg_ms_solo"] * 1e3) < 0.08 * r["avg_ms_solo"] * 1e3, (solo, r["avg_ms_solo"])
     mean = sum(dur) / len(dur)
-    assert abs(mean - r["avg_ms_in_step"] * 1e3) < 0.25 * mean, (mean, r["avg_ms_in_step"])
+    assert 0.70 * r["avg_ms"] * 1e3 < mean < 1.05 * r["avg_ms"] * 1e3, (mean, r["avg_ms"])
+    rec = json.load(open(os.path.join(P, "dominant_dispatches.json")))
+    assert rec["workgroups"] == 1548 and rec["n"] >= 100 and rec["min_us"] <= rec["mean_us"]
 
 
 def test_other_config_lines():
-    floors = dict(cityscapes=20.0, ade=22.0, coco=36.0, exact_f32=45.0)
+    floors = dict(cityscapes=27.0, ade=25.0, coco=40.0, exact_f32=45.0)
     for name, lo in floors.items():
         d = _line(f"{TAG}_bench_{name}.json")
         assert d["value"] > lo and d["n_gpus"] == 1
@@ -88,11 +103,11 @@ def test_other_config_lines():
         assert str(tuple(top["mode_MNKb"])).replace("'", "") in r["kernel"].replace("'", ""), (top, r["kernel"])
         assert abs(r["avg_ms"] * r["launches"] - top["ms"]) < 0.02 * top["ms"] + 0.01
         assert abs(r["share_of_mfma_time"] - top["ms"] / m["kernel_time_ms"]) < 5e-3
-        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3 and r["peak"] in (157.3, round(2500.0 / 6, 1))
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3 and r["peak"] in (157.3, round(2500.0 / 6, 1), round(2500.0 / 3, 1))
         assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_ms"] * 1e-3) / 1e12) < 0.5
 
 
-def test_kernel_summaries_show_the_round_4_claims():
+def test_kernel_summaries_show_the_round_4_and_5_claims():
     """`profiles/<TAG>_ade_kernel_stats.csv` (rocprofv3 kernel trace of the ADE step): the fp32-pipe GEMM instantiations the
     round-3 review listed are gone from the top of the table, the class sequences run on the fused attention kernels and the
     fused GroupNorm path is what executes."""
@@ -104,6 +119,8 @@ def test_kernel_summaries_show_the_round_4_claims():
         return sum(v[2] for k, v in rows.items() if frag in k)
     assert pct("gemm_kernelILi128ELi128ELi2ELi2ELi1ELi2ELi16") < 1.0      # im2col weight gradients on the fp32 pipe (7.6 % in round 3)
     assert pct("conv3x3_wgrad_tiled_kernelILi1ELi32") < 1.0                # the 32 -> 32 fp32 tiled weight gradient (2.5 %)
-    assert pct("seqattn_") < 0.2 and pct("attn_fwd_x6") > 1.0               # class sequences on the MFMA attention kernels
+    assert pct("seqattn_") < 0.2 and pct("attn_fwd_h2") > 1.0               # class sequences on the MFMA attention kernels
+    assert pct("attn_fwd_x6") + pct("attn_bwd_d") == 0.0 and pct("attn_dkv_h2") > 0.5            # round 5: the fp16 x 2 attention family, not the x 6 one
+    assert pct("gemm_x6p_kernelILi2E") > 3.0 * pct("gemm_x6p_kernelILi3E")  # the ViT linears on fp16 x 2 planes
     assert pct("gemm_bf16x_kernelILi3ELi1ELi2") > 1.0                       # im2col^T weight gradients on the split pipe
     assert pct("conv_cout1_tiled") > 0.1 and pct("groupnorm_apply") < 1.6   # head conv normalises its input (2.6 % in round 3)

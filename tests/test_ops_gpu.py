@@ -269,6 +269,12 @@ def test_layernorm_emits_planes(dev, planes_fmt):
     assert y_none is None
     for got, want in zip(_unpack_planes(pl2), _unpack_planes(pl)):
         assert torch.equal(got, want)
+    if pl2.fmt == "h2":     # (round 5) the fused kernel finds the row scales itself: the pack pass's, and a norm BOUND
+        assert torch.equal(pl2.sexp[:rows], pl.sexp[:rows])
+        nrm = y_ref.double().norm(dim=1)
+        assert (pl2.rnorm[:rows].double() >= nrm).all() and (pl2.rnorm[:rows].double() <= nrm * (1 + 1e-4)).all()
+        w = rnd(96, Cc, dev=dev, seed=64)
+        assert torch.equal(ops.linear(pl2, w), ops.linear(pl, w))
     # the fused entry point with both outputs (the wrapper prefers two passes there: faster at the ViT shape)
     from semivl_amd import lib as L
     y3, st3, pl3 = torch.empty_like(x), torch.empty_like(st), ops.Planes(rows, Cc, device=dev, fmt="b3")

@@ -7,18 +7,21 @@ X6P_FMT=1 bash tools/pmc_x6p.sh 32800 3072 768 4 > gpurun_out/${T}_pmc_x6p_ffn1.
 bash tools/pmc_ce.sh > gpurun_out/${T}_pmc_ce.txt 2>&1
 SVL_GEMM_EMU=0 bash tools/pmc_traffic.sh tools/one_gemm.py gemm_kernel > gpurun_out/${T}_pmc_gemm_f32.txt 2>&1
 mkdir -p profiles && cp gpurun_out/pmc_x6p_traffic.json gpurun_out/pmc_ce_traffic.json gpurun_out/pmc_gemm_traffic.json profiles/ 2>/dev/null
-python bench.py --steps 10 --warmup 3 > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
-for c in cityscapes ade coco; do python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-throughput-mode > gpurun_out/${T}_bench_$c.json 2>/dev/null; done
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-throughput-mode --gemm-arith f32 > gpurun_out/${T}_bench_exact_f32.json 2>/dev/null
 # kernel-trace summaries (both arithmetics) + wall-time attribution + per-dispatch rows of the dominant kernel
 for m in bf16x6 f32; do
   cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$m -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode --no-profile --gemm-arith $m > $GRAFT_REPO_ROOT/gpurun_out/${T}_bench_under_rocprof_$m.json 2>/dev/null
   cd $GRAFT_REPO_ROOT; DB=$(find gpurun_out/prof_$m -name "*.db" | head -1)
   python tools/rocpd_stats.py $DB > gpurun_out/${T}_kernel_stats_bs16_$m.csv
   python tools/rocpd_attrib.py $DB 0.34 1.0 > gpurun_out/${T}_attrib_$m.txt
-  if [ $m = bf16x6 ]; then python tools/rocpd_dispatches.py $DB gemm_x6p_kernelILi2ELi256ELi1E 1548 > gpurun_out/${T}_dominant_dispatches.csv; fi
+  if [ $m = bf16x6 ]; then
+    python tools/rocpd_dispatches.py $DB gemm_x6p_kernelILi2ELi256ELi1E 1548 > gpurun_out/${T}_dominant_dispatches.csv
+    python tools/dispatch_record.py gpurun_out/${T}_dominant_dispatches.csv ${T} > gpurun_out/dominant_dispatches.json && cp gpurun_out/dominant_dispatches.json profiles/
+  fi
   rm -rf gpurun_out/prof_$m
 done
+python bench.py --steps 10 --warmup 3 > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
+for c in cityscapes ade coco; do python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-throughput-mode > gpurun_out/${T}_bench_$c.json 2>/dev/null; done
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-throughput-mode --gemm-arith f32 > gpurun_out/${T}_bench_exact_f32.json 2>/dev/null
 # the N > 1 code path on this one-GPU box: two ranks over gloo (blocking all-reduce) -- the `allreduce` object with the
 # stream -> hardware-queue probe of the reducer
 SVL_DIST_BACKEND=gloo python bench.py --gpus 2 --batch 4 --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode --no-profile > gpurun_out/${T}_bench_gloo2.json 2> gpurun_out/${T}_bench_gloo2.err
