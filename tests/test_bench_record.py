@@ -120,7 +120,7 @@ def test_kernel_summaries_show_the_round_4_and_5_claims():
     assert pct("gemm_kernelILi128ELi128ELi2ELi2ELi1ELi2ELi16") < 1.0      # im2col weight gradients on the fp32 pipe (7.6 % in round 3)
     assert pct("conv3x3_wgrad_tiled_kernelILi1ELi32") < 1.0                # the 32 -> 32 fp32 tiled weight gradient (2.5 %)
     assert pct("seqattn_") < 0.2 and pct("attn_fwd_h2") > 1.0               # class sequences on the MFMA attention kernels
-    assert pct("attn_fwd_x6") + pct("attn_bwd_d") == 0.0 and pct("attn_dkv_h2") > 0.5            # round 5: the fp16 x 2 attention family, not the x 6 one
+    assert pct("attn_fwd_x6") + pct("attn_bwd_dq_x6") + pct("attn_bwd_dkv_x6") == 0.0 and pct("attn_dkv_h2") > 0.5            # round 5: the fp16 x 2 attention family, not the x 6 one
     assert pct("gemm_x6p_kernelILi2E") > 3.0 * pct("gemm_x6p_kernelILi3E")  # the ViT linears on fp16 x 2 planes
     assert pct("gemm_bf16x_kernelILi3ELi1ELi2") > 1.0                       # im2col^T weight gradients on the split pipe
     assert pct("conv_cout1_tiled") > 0.1 and pct("groupnorm_apply") < 1.6   # head conv normalises its input (2.6 % in round 3)
