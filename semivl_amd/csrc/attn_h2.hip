@@ -318,11 +318,14 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
   interval_barrier();
 
   const bool short_last = p.T - (nkt - 1) * 64 <= 32;          // keys 32..63 of the last tile do not exist
-  auto phase1 = [&](int kt) __attribute__((always_inline)) {   // S^T = K Q^T: 24 MFMAs, 16 fragment reads
+  // (LAST is a compile-time flag: the key mask and the short-tile forms live in the peeled last tile only -- with a runtime
+  // test the compiler if-converts the mask into 31 v_cndmask + 30 v_cmp per tile of EVERY tile)
+  auto phase1 = [&](int kt, auto last_c) __attribute__((always_inline)) {   // S^T = K Q^T: 24 MFMAs, 16 fragment reads
+    constexpr bool LAST = decltype(last_c)::value;
     const char* Ks = sm + (kt % 3) * STG_F + lane16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-    if (kt == nkt - 1 && short_last) {
+    if (LAST && short_last) {
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
         f16x8 a0[2], bq[2] = {qf[0][kg], qf[1][kg]};
@@ -341,9 +344,10 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
       H2_PAIR(s0, a0, s1, a1, bq)
     }
   };
-  auto phase2 = [&](int kt) __attribute__((always_inline)) {   // softmax, O^T += V^T P^T
+  auto phase2 = [&](int kt, auto last_c) __attribute__((always_inline)) {   // softmax, O^T += V^T P^T
+    constexpr bool LAST = decltype(last_c)::value;
     const char* Vt = sm + (kt % 3) * STG_F + 16384 + lane16;
-    if (kt == nkt - 1) {   // keys past T (zero rows) are masked
+    if (LAST) {   // keys past T (zero rows) are masked
       const int j0 = kt * 64;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -352,14 +356,23 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
         if (key + 32 >= p.T) s1[r] = -INFINITY;
       }
     }
-    // two independent v_max3 chains (half the dependent depth)
-    float ma = max3(s0[0], s0[1], s0[2]), mb = max3(s1[0], s1[1], s1[2]);
+    // The v_max3_f32 below are inline asm: the compiler's hazard recognizer does not see them as VALU reads of the MFMA
+    // results just issued by phase 1 (gfx950 has no interlock there: 11 wait states after an 8-pass MFMA, 19 after a 16-pass
+    // one).  Found when the key mask -- compiler-visible VALU on the same registers, which carried the wait states by
+    // accident -- moved into a peeled last tile: rows whose maximum jumps then read stale accumulators and overflowed fp16.
+    // Two independent maximum chains (half the dependent depth), written with fmaxf so that the COMPILER sees VALU reads of
+    // the MFMA results phase 1 has just issued and places the wait states gfx950 requires there (no interlock: 11 after an
+    // 8-pass MFMA).  The inline-asm v_max3_f32 of attention.hip (fine there: a barrier lies between) read STALE accumulators
+    // here as soon as nothing else touched them first -- found when the key mask, which had carried the wait states by
+    // accident, moved into the peeled last tile: rows whose maximum jumps missed their rescale and overflowed fp16.
+    auto max3c = [](float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); };
+    float ma = max3c(s0[0], s0[1], s0[2]), mb = max3c(s1[0], s1[1], s1[2]);
 #pragma unroll
     for (int r = 3; r < 15; r += 2) {
-      ma = max3(ma, s0[r], s0[r + 1]);
-      mb = max3(mb, s1[r], s1[r + 1]);
+      ma = max3c(ma, s0[r], s0[r + 1]);
+      mb = max3c(mb, s1[r], s1[r + 1]);
     }
-    float mloc = max3(ma, mb, fmaxf(s0[15], s1[15]));
+    float mloc = max3c(ma, mb, fmaxf(s0[15], s1[15]));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mloc2 = mloc * c;
     const bool raise = mloc2 > m2s + (7.f + RESCALE_LOG2);   // lazy rescale (attention.hip::attn_fwd_kernel)
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
       m2s = mnew;
     }
     float sum0 = 0.f, sum1 = 0.f;
-    const int ntp = (kt == nkt - 1 && short_last) ? 2 : 4;     // (s1 is -inf there: its probabilities are zeros)
+    const int ntp = (LAST && short_last) ? 2 : 4;     // (s1 is -inf there: its probabilities are zeros)
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
       if (tp >= ntp) break;
@@ -394,24 +407,34 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
   if constexpr ((V & 2) != 0) {        // A/B variant: all waves in lockstep, one barrier per tile
     wait_vm<4>();
     interval_barrier();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = 0; kt < nkt - 1; ++kt) {
       issue_part(kt + 2, 0, (kt + 2) % 3);
       issue_part(kt + 2, 1, (kt + 2) % 3);
       if (wave_active) {
-        phase1(kt);
-        phase2(kt);
+        phase1(kt, std::false_type{});
+        phase2(kt, std::false_type{});
       }
       wait_vm<4>();
       interval_barrier();
     }
+    if (wave_active) {     // the peeled last tile (landed: waited for at the end of the previous trip / in the prologue)
+      phase1(nkt - 1, std::true_type{});
+      phase2(nkt - 1, std::true_type{});
+    }
+    interval_barrier();
   } else {
     const int nint = 2 * nkt + 1;
     for (int n = 0; n < nint; ++n) {
       issue_part((n >> 1) + 2, n & 1, ((n >> 1) + 2) % 3);
       const int k = n - off;
       if (wave_active && k >= 0 && k < 2 * nkt) {
-        if (k & 1) phase2(k >> 1);
-        else phase1(k >> 1);
+        if ((k >> 1) == nkt - 1) {
+          if (k & 1) phase2(k >> 1, std::true_type{});
+          else phase1(k >> 1, std::true_type{});
+        } else {
+          if (k & 1) phase2(k >> 1, std::false_type{});
+          else phase1(k >> 1, std::false_type{});
+        }
       }
       wait_vm<6>();                    // the part issued three intervals ago has landed: it is read from the next interval on
       interval_barrier();
@@ -504,13 +527,12 @@ __global__ __launch_bounds__(512) void attn_dq_h2_kernel(const AttnP p, const H2
   issue_tile(1, 1);
   wait_vm<6>();
   interval_barrier();
-  for (int kt = 0; kt < nkt; ++kt) {
-    issue_tile(kt + 2, (kt + 2) % 3);
-    if (wave_active) {
+  auto tile = [&](int kt, auto last_c) __attribute__((always_inline)) {
+    constexpr bool last = decltype(last_c)::value;      // (compile-time: the key mask lives in the peeled last tile only)
+    {
       const char* Ks = sm + (kt % 3) * STG_Q + lane16;
       const char* Vs = Ks + 16384;
       const char* Kt = Ks + 32768;
-      const bool last = kt == nkt - 1;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         if (!last || jt == 0 || p.T - kt * 64 > 32) {   // keys 32..63 of a short last tile do not exist
@@ -544,9 +566,14 @@ __global__ __launch_bounds__(512) void attn_dq_h2_kernel(const AttnP p, const H2
         }
       }
     }
+  };
+  for (int kt = 0; kt < nkt - 1; ++kt) {
+    issue_tile(kt + 2, (kt + 2) % 3);
+    if (wave_active) tile(kt, std::false_type{});
     wait_vm<6>();                      // tile kt + 1 (issued one tile ago) has landed
     interval_barrier();
   }
+  if (wave_active) tile(nkt - 1, std::true_type{});
   wait_vm<0>();
   if (wave_active && qi < p.T) {
     const float f = __builtin_amdgcn_ldexpf(1.f, gs - 14 + ek - 3);   // dQ = scale sum dS K = 2^(g - 14 + ek - 3) sum dS' K'
