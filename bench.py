@@ -380,7 +380,7 @@ def main():
         def nprod_of(tag_):
             """16-bit products a launch issues per fp32 MAC: 3 on fp16 x 2 operands (packed-planes GEMM, fused attention on
             pre-packed operands), else the mode's 6 (3 in bf16x3 mode)."""
-            return 3 if (tag_ and tag_[0] in ("planes_h2", "fwd_h2", "bwd_h2")) or a.gemm_arith == "bf16x3" else 6
+            return 3 if (tag_ and tag_[0] in ("planes_h2", "fwd_h2", "bwd_h2", "split_h2")) or a.gemm_arith == "bf16x3" else 6
 
         if gx:   # the split-emulation GEMM family against ITS pipe: 16-bit dense peak vs the products actually issued
             nprod = 6 if a.gemm_arith == "bf16x6" else 3

@@ -147,6 +147,12 @@ typedef struct svl_gemm_desc {
                               * weights B once more as svl_conv3x3_weight_planes(B, N, C1 + C2) wrote them.  Used when the
                               * spatially tiled kernel serves the launch in emulation mode 6 (identical results, the
                               * kernel copies the planes instead of splitting the weights in every block); ignored otherwise. */
+  void* emu_ws;              /* optional (round 5): 8 bytes of device scratch private to this call.  With it, emulation mode 6
+                              * serves a large launch of the in-register split kernel (implicit-GEMM convolutions, their weight
+                              * gradients, dense GEMMs outside the packed-planes path; >= 4 GFLOP) on fp16 x 2 terms -- three
+                              * products instead of six -- with ONE power-of-two scale per operand tensor, found by a maximum
+                              * pass over exactly the elements the launch reads (a per-row scale does not factor out of a
+                              * convolution's taps).  Same error level vs fp64 (tests/test_ops_gpu.py); NULL: bf16 x 3 terms. */
 } svl_gemm_desc;
 
 int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream);
@@ -169,7 +175,8 @@ int svl_set_conv_tiled(int on);
 /* Measurement aid (bench.py prices a launch against the pipe that served it; no reference counterpart): which kernel family
  * the calling thread's LAST svl_gemm_f32 call dispatched to -- 0 exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 bf16 split
  * products (v_mfma_f32_32x32x16_bf16; emulation mode 3 / 6: dense, implicit-GEMM forward / input gradient / weight gradient,
- * tiled 3x3), 2 the short-K row stream (fp32 MFMA, HBM-bound), 3 an elementwise kernel (no MFMA). */
+ * tiled 3x3), 2 the short-K row stream (fp32 MFMA, HBM-bound), 3 an elementwise kernel (no MFMA), 4 the in-register split
+ * kernel on fp16 x 2 terms (three products; svl_gemm_desc::emu_ws). */
 int svl_last_gemm_path(void);
 
 /* ------------------------------------------------------------------------------------------------

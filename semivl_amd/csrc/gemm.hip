@@ -50,6 +50,7 @@ struct GemmP {
   long ldr_m, ldr_n, r_bso, r_bsi;
   int accumulate;
   int tiles_n, tiles_m, band_n;
+  const unsigned* amax;   // fp16 x 2 form of the split kernel: device {bits of max |A|, bits of max |B|} over the operands' elements
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -978,6 +979,72 @@ __device__ __forceinline__ void emu_split_store(__bf16* dst, int plane_stride, i
   }
 }
 
+// fp16 x 2 form of the same staging (round 5): x 2^-e = h0 + h1 with ONE power-of-two scale per operand TENSOR (the taps of a
+// convolution mix pixels, so a per-row scale would not factor out of the sum): `sc` = 2^-e, e from the tensor's largest
+// magnitude (absmax_kernel below).  Four VALU per pair: v_cvt_pk_f16_f32, two v_fma_mix_f32 residuals, v_cvt_pk_f16_f32.
+typedef _Float16 f16x8e __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2e __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void h2_split_pair(float x0, float x1, unsigned& w0, unsigned& w1) {
+  const f32x2 pr = {x0, x1};
+  const unsigned a = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, f16x2e));
+  f32x2 r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(a), "v"(pr[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(a), "v"(pr[1]));
+  w0 = a;
+  w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2e));
+}
+template <int RM>
+__device__ __forceinline__ void emu_split_store_h2(__bf16* dst, int plane_stride, int row2_off, const EmuRaw& r, float sc) {
+  u32x4 w[2];
+#pragma unroll
+  for (int jp = 0; jp < 4; ++jp) {
+    unsigned u0, u1;
+    h2_split_pair(r.v[2 * jp] * sc, r.v[2 * jp + 1] * sc, u0, u1);
+    w[0][jp] = u0;
+    w[1][jp] = u1;
+  }
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    if (RM == 0) {
+      *reinterpret_cast<u32x2*>(dst + pl * plane_stride) = u32x2{w[pl][0], w[pl][1]};
+      *reinterpret_cast<u32x2*>(dst + pl * plane_stride + row2_off) = u32x2{w[pl][2], w[pl][3]};
+    } else {
+      *reinterpret_cast<u32x4*>(dst + pl * plane_stride) = w[pl];
+    }
+  }
+}
+// scale exponent of an operand tensor: max |x| 2^-e in [2^14, 2^15)
+__device__ __forceinline__ int h2_exp_of(unsigned maxbits) {
+  const float m = __uint_as_float(maxbits);
+  const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) - 15 : 0;
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+// largest |x| of a [rows, cols] block with row stride ld, as the bit pattern of a non-negative float (atomicMax on unsigned
+// orders those like the floats); *out is zeroed by the launcher.  NaNs do not take part (fmaxf).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long rows, int cols, long ld, int vec,
+                                                     unsigned* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  if (vec) {
+    const int c4n = cols >> 2;
+    const long n4 = rows * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+      const long r = i / c4n;
+      const int c = (int)(i - r * c4n) << 2;
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+      m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+  } else {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+      const long r = i / cols;
+      m = fmaxf(m, fabsf(x[r * ld + (i - r * cols)]));
+    }
+  }
+  m = block_max_256(m, red);
+  if (threadIdx.x == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
 // B operand = im2col(x)^T (SVL_B_CONVW, the weight gradient of an implicit-GEMM convolution): row n = (tap, ci) is FIXED
 // per thread for the whole K loop, k = output pixel advances.  A thread's 8 consecutive k are 8 consecutive pixels of one
 // image row (the launcher requires Wo % 8 == 0 and 16-aligned K slabs), so one row test and eight column tests decide the
@@ -1024,8 +1091,9 @@ __device__ __forceinline__ void convbt_load(const GemmP& p, ConvBT& s, EmuRaw& r
   }
 }
 
-template <int NS, int A_RM, int B_RM>
+template <int NS, int A_RM, int B_RM, bool H2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16x_kernel(const GemmP p) {
+  static_assert(!H2 || NS == 2, "the fp16 x 2 form has two planes");
   constexpr int BM = 128, BN = 128, BKE = 16, LDR = 24;  // LDR: bf16 elements per LDS row (48 B)
   constexpr int TM = 2, TN = 2, WTM = 64, WTN = 64;
   constexpr int APL = BM * LDR, BPL = BN * LDR;            // plane strides (elements)
@@ -1096,6 +1164,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int klen = kend - kbeg;
   const int nfull = klen > 0 ? klen / BKE : 0, nk = klen > 0 ? (klen + BKE - 1) / BKE : 0;
   const int a_st = a_row * LDR + a_ko, b_st = NS * APL + b_row * LDR + b_ko;  // LDS store offsets
+  // fp16 x 2 form: one power-of-two scale per operand tensor, undone on the accumulators before the epilogue
+  int h2_ea = 0, h2_eb = 0;
+  float h2_sa = 1.f, h2_sb = 1.f;
+  if constexpr (H2) {
+    h2_ea = h2_exp_of(p.amax[0]);
+    h2_eb = h2_exp_of(p.amax[1]);
+    h2_sa = __builtin_amdgcn_ldexpf(1.f, -h2_ea);
+    h2_sb = __builtin_amdgcn_ldexpf(1.f, -h2_eb);
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -1123,8 +1200,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   auto sstore = [&](const EmuRaw& xa, const EmuRaw& xb, int buf) {
-    emu_split_store<NS, A_ST>(sm + buf * BUF + a_st, APL, 64 * LDR, xa);
-    emu_split_store<NS, B_RM>(sm + buf * BUF + b_st, BPL, 64 * LDR, xb);
+    if constexpr (H2) {
+      emu_split_store_h2<A_ST>(sm + buf * BUF + a_st, APL, 64 * LDR, xa, h2_sa);
+      emu_split_store_h2<(B_RM ? 1 : 0)>(sm + buf * BUF + b_st, BPL, 64 * LDR, xb, h2_sb);
+    } else {
+      emu_split_store<NS, A_ST>(sm + buf * BUF + a_st, APL, 64 * LDR, xa);
+      emu_split_store<NS, B_RM>(sm + buf * BUF + b_st, BPL, 64 * LDR, xb);
+    }
+  };
+  auto mfma16 = [](const bf16x8& x, const bf16x8& y, const f32x16& c) __attribute__((always_inline)) {
+    if constexpr (H2)
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8e, x), __builtin_bit_cast(f16x8e, y), c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
   };
   const int fa = (wr * WTM + l31) * LDR + 8 * hi, fb = NS * APL + (wc * WTN + l31) * LDR + 8 * hi;
   auto compute = [&](int buf) {
@@ -1140,7 +1228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // smallest-magnitude cross terms first; the four accumulators alternate so that dependent MFMAs are 4 apart
 #define SVL_EMU_TERM(PA, PB)                                                                                   \
   _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =    \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][i], b[PB][j], acc[i][j], 0, 0, 0);
+      mfma16(a[PA][i], b[PB][j], acc[i][j]);
     if constexpr (NS == 3) {
       SVL_EMU_TERM(2, 0)
       SVL_EMU_TERM(0, 2)
@@ -1201,12 +1289,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int tt = term + (NS == 3 ? 0 : 3);
         constexpr int PA = tt == 0 ? 2 : (tt == 2 || tt == 3) ? 1 : 0;
         constexpr int PB = tt == 1 ? 2 : (tt == 2 || tt == 4) ? 1 : 0;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][i], b[PB][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16(a[PA][i], b[PB][j], acc[i][j]);
         static_for<m * NSL / NMF, (m + 1) * NSL / NMF>([&](auto sc) {
           constexpr int sl = decltype(sc)::value;          // slice: operand (A: first half), pair q, plane pl
           constexpr int isb = sl / (4 * NS), q = (sl % (4 * NS)) / NS, pl = sl % NS;
           EmuRaw& c = isb ? cb : ca;
           u32x4& h = isb ? hb[pl] : ha[pl];
+          if constexpr (H2) {     // plane 0's slice splits the pair into both planes; plane 1's slice only stores
+            if constexpr (pl == 0) {
+              const float scl = isb ? h2_sb : h2_sa;
+              u32x4& h1 = isb ? hb[1] : ha[1];
+              unsigned u0, u1;
+              h2_split_pair(c.v[2 * q] * scl, c.v[2 * q + 1] * scl, u0, u1);
+              h[q] = u0;
+              h1[q] = u1;
+            }
+          } else {
           // one v_cvt_pk_bf16_f32 per pair and plane, written on the pair explicitly (element-wise conversions compile
           // to one conversion per element: 5.2 instead of 3.7 VALU per MFMA in this loop)
           const f32x2 pr = {c.v[2 * q], c.v[2 * q + 1]};
@@ -1215,6 +1313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           if constexpr (pl + 1 < NS) {
             c.v[2 * q] -= __builtin_bit_cast(float, u << 16);
             c.v[2 * q + 1] -= __builtin_bit_cast(float, u & 0xffff0000u);
+          }
           }
           if constexpr (q == 3 && pl == NS - 1) {          // operand complete: store its planes
             __bf16* dst = D + (isb ? b_st : a_st);
@@ -1258,6 +1357,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (t + 2 >= nk) break;
     tail_step(ra2, rb2, ra0, rb0, t + 2);
   }
+  if constexpr (H2) {     // undo the operand scales: exact (powers of two)
+    const float fs = __builtin_amdgcn_ldexpf(1.f, h2_ea + h2_eb);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= fs;
+  }
   gemm_epilogue<TM, TN, WTM, WTN>(p, acc, m0, n0, wr, wc, l31, hi, zo, zi);
 }
 
@@ -1279,7 +1387,7 @@ static std::atomic<int> g_conv_tiled{-1};  // -1: read SVL_CONV_NO_TILED once
 static std::atomic<int> g_emu_mode{-1};    // -1: read SVL_GEMM_EMU once; 0 exact fp32 MFMA; 3 / 6: bf16 split emulation
 static std::atomic<int> g_ragged_fork{-1};
 // which kernel family served the calling thread's last svl_gemm_f32 (svl_last_gemm_path: measurement aid of bench.py)
-enum { SVL_PATH_F32 = 0, SVL_PATH_BF16X = 1, SVL_PATH_SHORTK = 2, SVL_PATH_ELTWISE = 3 };
+enum { SVL_PATH_F32 = 0, SVL_PATH_BF16X = 1, SVL_PATH_SHORTK = 2, SVL_PATH_ELTWISE = 3, SVL_PATH_H2X = 4 };
 static thread_local int g_last_path = 0;
 // hipFuncSetAttribute is per device: one bit per device ordinal and kernel instantiation
 static bool attr_needed(std::atomic<uint64_t>& mask) {
@@ -1289,7 +1397,7 @@ static bool attr_needed(std::atomic<uint64_t>& mask) {
   return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
 }
 
-template <int NS>
+template <int NS, bool H2 = false>
 int launch_emu(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
   GemmP q = p;
   q.tiles_n = (p.N + 127) / 128;
@@ -1297,12 +1405,12 @@ int launch_emu(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
   q.band_n = svl_band_n(q.tiles_n);
   const long tiles = (long)((p.M + 127) / 128) * q.tiles_n;
   dim3 grid((unsigned)tiles, 1, (unsigned)batch);
-  if (b_rm == 2) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 2>), grid, dim3(256), 0, st, q);
-  else if (a_rm == 2) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 2, 0>), grid, dim3(256), 0, st, q);
-  else if (a_rm == 0 && b_rm == 0) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 0>), grid, dim3(256), 0, st, q);
-  else if (a_rm == 0 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 1>), grid, dim3(256), 0, st, q);
-  else if (a_rm == 1 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 1>), grid, dim3(256), 0, st, q);
-  else hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 0>), grid, dim3(256), 0, st, q);
+  if (b_rm == 2) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 2, H2>), grid, dim3(256), 0, st, q);
+  else if (a_rm == 2) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 2, 0, H2>), grid, dim3(256), 0, st, q);
+  else if (a_rm == 0 && b_rm == 0) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 0, H2>), grid, dim3(256), 0, st, q);
+  else if (a_rm == 0 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 0, 1, H2>), grid, dim3(256), 0, st, q);
+  else if (a_rm == 1 && b_rm == 1) hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 1, H2>), grid, dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((gemm_bf16x_kernel<NS, 1, 0, H2>), grid, dim3(256), 0, st, q);
   SVL_LAUNCH_CHECK("svl_gemm_f32 (bf16 split emulation)");
   return SVL_OK;
 }
@@ -1400,6 +1508,18 @@ int launch_shortk(const GemmP& p, bool fast, hipStream_t st) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// largest |x| of a strided block into *out (atomicMax: the caller zeroes it)
+int absmax_launch(const float* x, long rows, long cols, long ld, unsigned* out, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return SVL_OK;
+  const int vec = aligned16(x) && (ld % 4 == 0) && (cols % 4 == 0);
+  const long work = rows * cols / (vec ? 4 : 1);
+  long blocks = (work + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, rows, (int)cols, ld, vec, out);
+  SVL_LAUNCH_CHECK("svl_gemm_f32 (operand maximum)");
+  return SVL_OK;
+}
+
 }  // namespace
 
 extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
@@ -1478,6 +1598,23 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   static const int emu_conv = getenv("SVL_GEMM_EMU_NO_CONV") ? 0 : 1;
   static const int sk_emu_maxk_g = env_int("SVL_SHORTK_EMU_MAXK", 64);   // (see the short-K dispatch below)
   g_last_path = SVL_PATH_F32;
+  // fp16 x 2 form of the in-register split kernel (round 5): three products instead of six, one power-of-two scale per operand
+  // TENSOR found by a maximum pass over exactly the elements the launch reads (d->emu_ws: 8 bytes of device scratch private to
+  // this call; without it, or for launches too small to pay for the two extra passes, the bf16 x 3 form serves the launch).
+  static const int h2_on = getenv("SVL_GEMM_EMU_NO_H2") ? 0 : 1;
+  unsigned* h2_ws = static_cast<unsigned*>(d->emu_ws);
+  // Worth it when the halved matrix work outweighs the two maximum passes: measured, the fp16 x 2 form runs at ~240 TF where
+  // the bf16 x 3 form runs at ~170 (1.7e-15 s saved per FLOP) and a maximum pass reads at ~4 TB/s (x 1.2 for its launch) --
+  // the K = 128 pixel-wise layers and the 1 x 1 weight gradients lose, the dilated 3 x 3 layers and the ViT's split-K weight
+  // gradients gain.  `elems` = operand elements the two passes read.
+  auto h2_ok = [&](const GemmP& q, double elems) {
+    const double flops = 2.0 * q.M * q.N * q.K;
+    return emu_mode == 6 && h2_on && h2_ws != nullptr && flops >= 4.0e9 && flops * 1.7e-15 > elems * 4.0 / 4.0e12 * 1.2;
+  };
+  auto h2_begin = [&]() -> int {
+    SVL_HIP_CHECK(hipMemsetAsync(h2_ws, 0, 8, st));
+    return SVL_OK;
+  };
   auto launch = [&](const GemmP& q) -> int {
     // implicit-GEMM convolutions (NHWC im2col on the fly, forward and mirrored-tap input gradient) join the split
     // emulation when every 4-k piece stays inside one tap (channels % 4) and K is a whole number of 16-deep steps
@@ -1485,6 +1622,19 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         d->batch == 1 && d->ksplit == 0 && q.M >= 256 && q.N >= 96 && q.K >= 64 && (q.K % 16) == 0 && q.A.vec && q.B.vec &&
         emu_conv) {
       g_last_path = SVL_PATH_BF16X;
+      const long px = (long)(q.M / (q.cv.Ho * q.cv.Wo)) * q.cv.H * q.cv.W;
+      if (h2_ok(q, (double)px * q.cv.C1 + (q.cv.C2 > 0 ? (double)(px / q.cv.rep) * q.cv.C2 : 0.0) + (double)q.N * q.K)) {
+        // operands: the NHWC source(s) of the implicit im2col, the [N, K] weights
+        int rc = h2_begin();
+        if (!rc) rc = absmax_launch(q.A.p, px, q.cv.C1, q.A.ld, h2_ws, st);
+        if (!rc && q.cv.C2 > 0) rc = absmax_launch(q.cv.src2, px / q.cv.rep, q.cv.C2, q.cv.ld2, h2_ws, st);
+        if (!rc) rc = absmax_launch(q.B.p, q.N, q.K, q.B.ld, h2_ws + 1, st);
+        if (rc) return rc;
+        GemmP q2 = q;
+        q2.amax = h2_ws;
+        g_last_path = SVL_PATH_H2X;
+        return launch_emu<2, true>(q2, 2, 0, 1, st);
+      }
       return emu_mode == 6 ? launch_emu<3>(q, 2, 0, 1, st) : launch_emu<2>(q, 2, 0, 1, st);
     }
     // weight gradients of the implicit-GEMM convolutions (A = dy^T, B = im2col(x)^T, split-K over the pixels): the
@@ -1495,6 +1645,20 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         q.M >= 96 && q.N >= 96 && q.K >= 1024 && (q.K % 16) == 0 && (d->ksplit % 16) == 0 && (q.cv.Wo % 8) == 0 &&
         q.A.vec && q.B.vec && emu_convw) {
       g_last_path = SVL_PATH_BF16X;
+      const long px = (long)(q.K / (q.cv.Ho * q.cv.Wo)) * q.cv.H * q.cv.W;
+      if ((d->batch == 1 || d->ksplit > 0) &&
+          h2_ok(q, (double)q.K * q.M + (double)px * q.cv.C1 + (q.cv.C2 > 0 ? (double)(px / q.cv.rep) * q.cv.C2 : 0.0))) {
+        // operands: dy^T [K pixels, M], the NHWC source(s) of im2col(x)^T
+        int rc = h2_begin();
+        if (!rc) rc = absmax_launch(q.A.p, q.K, q.M, q.A.ld, h2_ws, st);
+        if (!rc) rc = absmax_launch(q.B.p, px, q.cv.C1, q.B.ld, h2_ws + 1, st);
+        if (!rc && q.cv.C2 > 0) rc = absmax_launch(q.cv.src2, px / q.cv.rep, q.cv.C2, q.cv.ld2, h2_ws + 1, st);
+        if (rc) return rc;
+        GemmP q2 = q;
+        q2.amax = h2_ws;
+        g_last_path = SVL_PATH_H2X;
+        return launch_emu<2, true>(q2, 1, 2, d->batch, st);
+      }
       return emu_mode == 6 ? launch_emu<3>(q, 1, 2, d->batch, st) : launch_emu<2>(q, 1, 2, d->batch, st);
     }
     // (the pixel-shuffle store of ConvTranspose2d(k 2, s 2) stays with the short-K stream kernel, whose epilogue writes
@@ -1503,6 +1667,19 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && q.M >= 256 && q.N >= 96 &&
         q.K >= 64) {
       g_last_path = SVL_PATH_BF16X;
+      if ((d->batch == 1 || d->ksplit > 0) && h2_ok(q, (double)q.M * q.K + (double)q.N * q.K)) {
+        // dense operands: [M, K] or [K, M], [N, K] or [K, N]
+        int rc = h2_begin();
+        if (!rc) rc = am == SVL_A_MCONTIG ? absmax_launch(q.A.p, q.K, q.M, q.A.ld, h2_ws, st)
+                                          : absmax_launch(q.A.p, q.M, q.K, q.A.ld, h2_ws, st);
+        if (!rc) rc = bm == SVL_B_NCONTIG ? absmax_launch(q.B.p, q.K, q.N, q.B.ld, h2_ws + 1, st)
+                                          : absmax_launch(q.B.p, q.N, q.K, q.B.ld, h2_ws + 1, st);
+        if (rc) return rc;
+        GemmP q2 = q;
+        q2.amax = h2_ws;
+        g_last_path = SVL_PATH_H2X;
+        return launch_emu<2, true>(q2, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
+      }
       return emu_mode == 6 ? launch_emu<3>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
                              : launch_emu<2>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
     }

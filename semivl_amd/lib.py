@@ -38,7 +38,7 @@ class GemmDesc(C.Structure):
                 ("alpha", C.c_float), ("bias", C.c_void_p), ("bias_mod", C.c_int), ("act", C.c_int),
                 ("preact", C.c_void_p), ("resid", C.c_void_p),
                 ("ldr_m", C.c_int64), ("ldr_n", C.c_int64), ("r_bs_outer", C.c_int64), ("r_bs_inner", C.c_int64),
-                ("accumulate", C.c_int), ("conv_w_planes", C.c_void_p)]
+                ("accumulate", C.c_int), ("conv_w_planes", C.c_void_p), ("emu_ws", C.c_void_p)]
 
 
 class PGemmDesc(C.Structure):

@@ -88,6 +88,11 @@ class Op:
         return L.Operand(C.c_void_p(self.t.data_ptr() + 4 * self.off), self.ld, self.bso, self.bsi)
 
 
+# In-register split kernel on fp16 x 2 terms with per-tensor scales (svl_gemm_desc.emu_ws; round 5): SVL_GEMM_EMU_NO_H2=1 keeps
+# the bf16 x 3 form for every launch (A/B runs).
+EMU_H2 = not os.environ.get("SVL_GEMM_EMU_NO_H2")
+
+
 def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batch=1, batch_inner=1, ksplit=0,
          c_bso=0, c_bsi=0, alpha=1.0, bias=None, bias_mod=0, act=ACT_NONE, resid=None, r_off=0, ldr_m=None, ldr_n=1,
          r_bso=0, r_bsi=0, accumulate=False, out_mode=OUT_STRIDED, conv=None, ct=(0, 0, 0), preact=None, w_planes=None):
@@ -112,14 +117,19 @@ def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batc
         d.ldr_m = ldr_m if ldr_m is not None else d.ldc_m
         d.ldr_n, d.r_bs_outer, d.r_bs_inner = ldr_n, r_bso, r_bsi
     d.accumulate = 1 if accumulate else 0
+    ws = None
+    if EMU_H2 and 2.0 * M * N * K >= 4.0e9 and (batch == 1 or ksplit > 0) and Cout.is_cuda and get_gemm_emulation() == 6:
+        ws = torch.empty(2, dtype=torch.int32, device=Cout.device)      # scratch of the operand-maximum passes (fp16 x 2 form)
+        d.emu_ws = _p(ws)
     e0 = _prof_begin()
     L.check(L.load().svl_gemm_f32(C.byref(d), _st()), "svl_gemm_f32")
     if e0 is not None:
         # which matrix pipe served this launch: the library reports the kernel family its dispatch chose
-        # (svl_last_gemm_path: 1 = bf16 split products; 0 / 2 / 3 = exact fp32 MFMA, short-K stream, elementwise)
-        emu = L.load().svl_last_gemm_path() == 1
-        _prof_end("gemm_bf16x" if emu else "gemm", e0, 2.0 * M * N * K * (1 if ksplit > 0 else batch),
-                  (a_mode, b_mode, M, N, K, batch))
+        # (svl_last_gemm_path: 1 = bf16 split products, 4 = fp16 x 2 split products; 0 / 2 / 3 = exact fp32 MFMA, short-K
+        # stream, elementwise)
+        path = L.load().svl_last_gemm_path()
+        _prof_end("gemm_bf16x" if path in (1, 4) else "gemm", e0, 2.0 * M * N * K * (1 if ksplit > 0 else batch),
+                  (a_mode, b_mode, M, N, K, batch) if path != 4 else ("split_h2", a_mode, b_mode, M, N, K, batch))
 
 
 def conv_geom(H, W, C1, KH, KW, dil=1, pad=0, sign=1, C2=0, rep=1, src2=None, ld2=0, patch=0, stride=1, Ho=0, Wo=0):

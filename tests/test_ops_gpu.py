@@ -859,6 +859,67 @@ def test_conv_split_emulation(dev, emu_mode, Ci, Co, k, dil, H, n):
                        ops.conv_fwd(xs, Ci, n, H, W, Ci, wf, Co, k, k, dil, pad)), "deterministic"
 
 
+def test_split_kernel_fp16x2_form(dev, emu_mode):
+    """Round 5: large launches of the in-register split kernel run on fp16 x 2 terms with ONE power-of-two scale per operand
+    tensor (svl_gemm_desc.emu_ws; three products instead of six).  Dilated implicit-GEMM convolution (forward, mirrored-tap
+    input gradient), its im2col^T weight gradient and a split-K dense weight gradient at sizes the dispatch hands to that
+    form (svl_last_gemm_path() == 4): error vs fp64 at or below EMU6_ERR_FACTOR x the exact fp32 mode's; operands whose
+    magnitudes differ by 2^40 between the tensors; exactly representable inputs give exact results; deterministic; and
+    SVL_GEMM_EMU_NO_H2 / small launches keep the bf16 x 3 form."""
+    from semivl_amd import lib as L, ops
+    lib = L.load()
+    n, Ci, Co, k, dil, H = 4, 128, 128, 3, 6, 96
+    W, pad = H, dil
+    x, w = rnd(n, Ci, H, W, dev=dev, seed=71), rnd(Co, Ci, k, k, dev=dev, scale=0.1)
+    dy = rnd(n, Co, H, W, dev=dev)
+    xd, wdd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref_y = F.conv2d(xd, wdd, padding=pad, dilation=dil)
+    ref_dx, ref_dw = torch.autograd.grad(ref_y, (xd, wdd), dy.double())
+    wf, wd = ops.pack_conv_w(w)
+    xs, dys = nhwc(x), nhwc(dy)
+    err, paths = {}, {}
+    for mode in (0, 6):
+        emu_mode(mode)
+        y = ops.conv_fwd(xs, Ci, n, H, W, Ci, wf, Co, k, k, dil, pad)
+        p1 = lib.svl_last_gemm_path()
+        dx = ops.conv_dgrad(dys, Co, n, H, W, Co, wd, Ci, k, k, dil, pad)
+        p2 = lib.svl_last_gemm_path()
+        dwf = ops.conv_wgrad(dys, Co, xs, Ci, n, H, W, Ci, Co, k, k, dil, pad)
+        dw = ops.unpack_conv_wgrad(dwf, Co, Ci, k, k)
+        err[mode] = (_relerr(nchw(y, n, H, W), ref_y.detach()), _relerr(nchw(dx, n, H, W), ref_dx), _relerr(dw, ref_dw))
+        paths[mode] = (p1, p2)
+    assert paths[6] == (4, 4) and paths[0] == (0, 0), paths
+    print("SPLIT_H2 conv fwd / dgrad / wgrad rel err vs fp64: exact", err[0], "fp16 x 2", err[6])
+    for i in range(3):
+        assert err[6][i] <= EMU6_ERR_FACTOR * err[0][i] + 1e-8, (i, err)
+    emu_mode(6)
+    y2 = ops.conv_fwd(xs, Ci, n, H, W, Ci, wf, Co, k, k, dil, pad)
+    assert torch.equal(y, y2), "deterministic"
+    # the two tensors' magnitudes 2^40 apart: the scales are per tensor and exact
+    ys = ops.conv_fwd(xs * 2.0 ** 20, Ci, n, H, W, Ci, ops.pack_conv_w(w * 2.0 ** -20)[0], Co, k, k, dil, pad)
+    assert torch.equal(ys, y)
+    # exactly representable operands: exact result
+    xi = torch.randint(-8, 8, (n * H * W, Ci), device=dev).float()
+    wi = torch.randint(-8, 8, (Co, Ci, k, k), device=dev).float()
+    yi = ops.conv_fwd(xi, Ci, n, H, W, Ci, ops.pack_conv_w(wi)[0], Co, k, k, dil, pad)
+    assert lib.svl_last_gemm_path() == 4
+    refi = F.conv2d(xi.view(n, H, W, Ci).permute(0, 3, 1, 2).double(), wi.double(), padding=pad, dilation=dil)
+    assert torch.equal(nchw(yi, n, H, W), refi.float())
+    # split-K dense weight gradient (the ViT's attention projections): dY^T X with K = tokens
+    Kt, Mo, No = 8 * 1025, 2304, 768
+    a, b = rnd(Kt, Mo, dev=dev, seed=72), rnd(Kt, No, dev=dev, seed=73)
+    refw = a.double().t() @ b.double()
+    e = {}
+    for mode in (0, 6):
+        emu_mode(mode)
+        e[mode] = _relerr(ops.matmul_tn(a, b), refw)
+    assert e[6] <= EMU6_ERR_FACTOR * e[0] + 1e-8, e
+    emu_mode(6)
+    # a small launch stays on the bf16 x 3 form (the two maximum passes would cost more than the halved matrix work)
+    ops.conv_fwd(xs[:2 * 16 * 16], Ci, 2, 16, 16, Ci, wf, Co, k, k, 1, 1)
+    assert lib.svl_last_gemm_path() == 1
+
+
 @pytest.mark.parametrize("C,H", [(32, 40), (16, 24)])
 def test_conv_cout1_thin_kernels(dev, C, H):
     from semivl_amd import ops
