@@ -1667,7 +1667,11 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && q.M >= 256 && q.N >= 96 &&
         q.K >= 64) {
       g_last_path = SVL_PATH_BF16X;
-      if ((d->batch == 1 || d->ksplit > 0) && h2_ok(q, (double)q.M * q.K + (double)q.N * q.K)) {
+      // (dense launches: opt-in, SVL_GEMM_EMU_H2_DENSE=1.  The ViT's split-K weight gradients gain 17 % (in_proj) and lose
+      //  9 % (out_proj: the two maximum passes), 2 ms of the step together; the full-size fp64 comparison of the in_proj
+      //  gradient of block 10 moved from 0.9e-3 to 1.02e-3 against its 1.016e-3 bound, so they stay on bf16 x 3)
+      static const int h2_dense = getenv("SVL_GEMM_EMU_H2_DENSE") ? 1 : 0;
+      if (h2_dense && (d->batch == 1 || d->ksplit > 0) && h2_ok(q, (double)q.M * q.K + (double)q.N * q.K)) {
         // dense operands: [M, K] or [K, M], [N, K] or [K, N]
         int rc = h2_begin();
         if (!rc) rc = am == SVL_A_MCONTIG ? absmax_launch(q.A.p, q.K, q.M, q.A.ld, h2_ws, st)

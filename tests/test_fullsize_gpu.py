@@ -225,30 +225,43 @@ def test_fullsize_gradient_error_against_fp64(dev):
     g32 = {n: p.grad.clone() for n, p in orc.named_parameters() if p.grad is not None}
     orc64 = copy.deepcopy(orc).double()
     b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
-    oracle_step(orc64, cfg, b64, [m.double() for m in masks], 0.0)
-    g64 = {n: p.grad for n, p in orc64.named_parameters() if p.grad is not None}
+    _, aux64 = oracle_step(orc64, cfg, b64, [m.double() for m in masks], 0.0)
+    g64 = {n: p.grad.clone() for n, p in orc64.named_parameters() if p.grad is not None}
     rel = lambda a, b: ((a.double() - b).norm() / (b.norm() + 1e-30)).item()
     own = {n: rel(g32[n], g64[n]) for n in g32}
+    within = lambda e_, o_: e_ <= 3e-3 and e_ <= 4 * (o_ + 1e-4)
+    maps = ("mask_w", "mask_w_other", "mclip", "mclip_other")
     rows = []
     for mode in (0, 6):
         for p_ in hip.parameters():
             p_.grad = None
         ops.set_gemm_emulation(mode)
         try:
-            semivl_train_step(hip, {k: v.to(dev) for k, v in batch.items()}, 100, 1000, cfg, fp_masks=[m.to(dev) for m in masks])
+            _, haux = semivl_train_step(hip, {k: v.to(dev) for k, v in batch.items()}, 100, 1000, cfg,
+                                        fp_masks=[m.to(dev) for m in masks], return_aux=True)
         finally:
             ops.set_gemm_emulation(0)
-        for n, p_ in hip.named_parameters():
-            if p_.grad is None or n == "decode_head.head.bias":
-                continue
-            e = rel(p_.grad.cpu(), g64[n])
-            rows.append((e / (own[n] + 1e-4), mode, n, e, own[n]))
+        hg = {n: p_.grad.cpu() for n, p_ in hip.named_parameters() if p_.grad is not None and n != "decode_head.head.bias"}
+        mine = [(rel(g, g64[n]) / (own[n] + 1e-4), mode, n, rel(g, g64[n]), own[n]) for n, g in hg.items()]
+        # Pseudo-label ties, as in check_step: ONE target that flips against the float64 run moves every gradient tensor of
+        # this random-init step by ~1e-3 of its norm, and WHICH near-ties flip changes with any change of a kernel's rounding
+        # (round 5: the decoder's fp16 x 2 convolutions and the fp16 x 2 attention, each inside the bounds alone, together
+        # flipped one more and put all of the ViT's tensors at 4.1 - 4.2 x).  When a bound is exceeded and label maps differ,
+        # the float64 step is repeated with the PRODUCT's label maps and the gradients are compared under the same decisions.
+        flips = {k: int((haux[k].cpu() != aux64[k]).sum()) for k in maps}
+        if sum(flips.values()) > 0 and not all(within(e_, o_) for _, _, _, e_, o_ in mine):
+            assert sum(flips.values()) <= 5e-4 * aux64["mask_w"].numel(), flips       # (a handful of near-ties, not a drift)
+            oracle_step(orc64, cfg, b64, [m.double() for m in masks], 0.0, label_override={k: haux[k].cpu() for k in maps})
+            g64o = {n: p.grad for n, p in orc64.named_parameters() if p.grad is not None}
+            mine = [(rel(g, g64o[n]) / (own[n] + 1e-4), mode, n, rel(g, g64o[n]), own[n]) for n, g in hg.items()]
+            print(f"[gemm_mode {mode}] float64 gradients recomputed under the product's tie decisions ({flips})")
+        rows += mine
     top = sorted(((v, n) for n, v in own.items() if n != "decode_head.head.bias"))[-4:]
     rows.sort()
     print("fp32 oracle vs fp64 (rel-L2), largest:", [(f"{v:.1e}", n) for v, n in top], "; product vs fp64, worst ratios to the oracle's own error:",
           [(f"{r_:.1f}x", m_, n_, f"{e_:.1e}", f"{o_:.1e}") for r_, m_, n_, e_, o_ in rows[-14:]])
     for r_, m_, n_, e_, o_ in rows:
-        assert e_ <= 3e-3 and e_ <= 4 * (o_ + 1e-4), f"mode {m_} {n_}: {e_:.2e} vs the fp32 oracle's own {o_:.2e}"
+        assert within(e_, o_), f"mode {m_} {n_}: {e_:.2e} vs the fp32 oracle's own {o_:.2e}"
 
 
 @pytest.mark.parametrize("nclass,dataset", [(81, "coco"), (150, "ade")])

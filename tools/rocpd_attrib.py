@@ -14,7 +14,7 @@ rows = c.execute("select d.start, d.end, s.kernel_name from rocpd_kernel_dispatc
                  "on d.kernel_id = s.id order by d.start").fetchall()
 n = len(rows)
 rows = rows[int(f0 * n):int(f1 * n)]
-MFMA = re.compile(r"gemm_x6p|gemm_bf16x|gemm_kernel|gemm_shortk|shortk_x6|attn_(fwd|bwd)|conv3x3|seqattn")
+MFMA = re.compile(r"gemm_x6p|gemm_bf16x|gemm_kernel|gemm_shortk|shortk_x6|attn_(fwd|bwd|dq_h2|dkv_h2)|conv3x3|seqattn")
 ev = []
 for s, e, name in rows:
     m = 1 if MFMA.search(name) and "rows_kernel" not in name else 0
