@@ -42,7 +42,7 @@ typedef enum svl_status {
   SVL_ERR_UNSUPPORTED = -3
 } svl_status;
 
-int svl_version(void); /* 501: + svl_attention_{fwd,bwd}_h2, svl_attention_h2_ws_bytes (fused attention on fp16 x 2 pre-packed operands); 500: round-5 ABI (fp16 x 2 planes: svl_split_planes_f16x2, svl_planes_bytes_fmt, fmt / scale fields of svl_pgemm_desc); 401: + svl_conv3x3_weight_planes, svl_gemm_desc::conv_w_planes, w_planes of svl_conv3x3_gn_f32; 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
+int svl_version(void); /* 502: + svl_ce_up_fused_f32, svl_softmax_max_up_f32, svl_ce_up_num_blocks (pixel losses on head-resolution logits); 501: + svl_attention_{fwd,bwd}_h2, svl_attention_h2_ws_bytes (fused attention on fp16 x 2 pre-packed operands); 500: round-5 ABI (fp16 x 2 planes: svl_split_planes_f16x2, svl_planes_bytes_fmt, fmt / scale fields of svl_pgemm_desc); 401: + svl_conv3x3_weight_planes, svl_gemm_desc::conv_w_planes, w_planes of svl_conv3x3_gn_f32; 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
                            svl_stream_prepare, svl_last_gemm_path; gn_in arguments of the tiled weight gradient and the Conv2d(C -> 1)
                            entries, `accumulate` of svl_avgpool_cat_bwd); 300: round-3 ABI (packed-planes operands; planes outputs of LayerNorm / attention; loss-mode arguments of
                            the pixel-loss entries; 200 = round 2: helper-stream contexts, caller-owned scratch everywhere) */
@@ -310,6 +310,37 @@ typedef struct svl_ce_desc {
 int64_t svl_ce_num_blocks(int B, int N, int64_t HW); /* -1 if N is unsupported (N > 256) */
 int svl_ce_fused_f32(const svl_ce_desc* d, svl_stream_t stream);
 int svl_ce_finalize(const float* partials, int64_t nblocks, double* sums /* [4] device */, svl_stream_t stream);
+
+/* Round 5: the same two pixel-loss entry points on logits that exist ONLY at the head's resolution.  The reference
+ * resizes the head's [B, N, h, w] map to the crop (vlg_head.py:247, builder.py:93-97: bilinear, align_corners as
+ * configured) and runs semivl.py:232,252 / 267-323 on the [B, N, H, W] result; here the resize (ATen upsample_bilinear2d
+ * index math) is evaluated inside the kernels and the gradient is returned at the LOW resolution -- what
+ * F.interpolate's backward would hand to the head.  Full-resolution logits / dlogits are never written.
+ * Geometry: upsampling only (H >= h, W >= w), ratio <= 4.5 with at most 40 resized rows / columns per 8 head-resolution cells, N <= 160; svl_ce_up_num_blocks < 0 when unsupported
+ * (callers then resize with svl_bilinear_planes_fwd and use svl_ce_fused_f32).  Maps (target, conf, ign, mc_target) are
+ * full resolution [B, H, W]; partials: [svl_ce_up_num_blocks][4], reduced by svl_ce_finalize.  Deterministic. */
+typedef struct svl_ce_up_desc {
+  const float* logits;   /* [B, N, h, w] */
+  int B, N;
+  int h, w, H, W;
+  int align_corners;
+  const int64_t* target; /* [B, H, W] */
+  int use_ignore_t;
+  const float* conf;     /* [B, H, W] or NULL */
+  const int64_t* ign;    /* [B, H, W] or NULL */
+  float conf_thresh;
+  int all_pixels;
+  const int64_t* mc_target; /* [B, H, W] or NULL */
+  float* partials;
+  float* dlogits;        /* [B, N, h, w] or NULL: d(loss)/d(logits) at the head's resolution */
+  const float* gscale;   /* [2] device scalars, required when dlogits != NULL */
+  const float* img_weight; /* [B] device or NULL */
+} svl_ce_up_desc;
+int64_t svl_ce_up_num_blocks(int B, int N, int h, int w, int H, int W, int align_corners);
+int svl_ce_up_fused_f32(const svl_ce_up_desc* d, svl_stream_t stream);
+/* conf / label [B, H, W] = softmax(dim 1).max(dim 1) of the resized logits (semivl.py:232,252); first maximum wins. */
+int svl_softmax_max_up_f32(const float* logits, int B, int N, int h, int w, int H, int W, int align_corners, float* conf,
+                           int64_t* label, svl_stream_t stream);
 
 /* Loss assembly without host syncs (semivl.py:267-323).
  * counts: int64[4] device = #valid of {mask_x != 255, ignore_mask_mixed1, ignore_mask_mixed2, ignore_mask} != 255.

@@ -58,6 +58,14 @@ class CeDesc(C.Structure):
                 ("dlogits", C.c_void_p), ("gscale", C.c_void_p), ("img_weight", C.c_void_p)]
 
 
+class CeUpDesc(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("B", C.c_int), ("N", C.c_int), ("h", C.c_int), ("w", C.c_int), ("H", C.c_int),
+                ("W", C.c_int), ("align_corners", C.c_int), ("target", C.c_void_p), ("use_ignore_t", C.c_int),
+                ("conf", C.c_void_p), ("ign", C.c_void_p), ("conf_thresh", C.c_float), ("all_pixels", C.c_int),
+                ("mc_target", C.c_void_p), ("partials", C.c_void_p), ("dlogits", C.c_void_p), ("gscale", C.c_void_p),
+                ("img_weight", C.c_void_p)]
+
+
 class SeqAttnDesc(C.Structure):
     _fields_ = [("groups", C.c_int), ("inner", C.c_int), ("seq", C.c_int), ("heads", C.c_int),
                 ("outer_stride", C.c_int64), ("inner_stride", C.c_int64), ("seq_stride", C.c_int64),
@@ -89,6 +97,9 @@ SIGNATURES = {
     "svl_ce_num_blocks": (_L, [_I, _I, _L]),
     "svl_ce_fused_f32": (_I, [C.POINTER(CeDesc), _P]),
     "svl_ce_finalize": (_I, [_P, _L, _P, _P]),
+    "svl_ce_up_num_blocks": (_L, [_I, _I, _I, _I, _I, _I, _I]),
+    "svl_ce_up_fused_f32": (_I, [C.POINTER(CeUpDesc), _P]),
+    "svl_softmax_max_up_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "svl_semivl_gscale": (_I, [_P, _D, _F, _P, _P, _P, _P]),
     "svl_semivl_loss": (_I, [_P, _D, _F, _P, _P, _P, _P]),
     "svl_conf_ratio_f32": (_I, [_P, _P, _I, _L, _F, _P, _P, _P]),

@@ -198,12 +198,23 @@ class VLM(nn.Module):
         return self.decode_head.forward(x, force_output_pred_masks=True)["pred_masks"]
 
     # -- forward_wrapper (builder.py:56-102) ---------------------------------------------------------------------
+    def head_res_size(self, in_size):
+        """(h, w) of the decode head's own logit map for an input of `in_size`, when forward(head_res=True) would return
+        it un-resized (the input is the training crop: ONE resize separates it from the loss), else None."""
+        S_ = self.decode_head.image_size
+        if tuple(in_size) != (S_, S_):
+            return None
+        ps = self.backbone.patch_size
+        return (4 * ((in_size[0] + ps - 1) // ps), 4 * ((in_size[1] + ps - 1) // ps))
+
     def forward(self, img, gt=None, need_fp=False, only_fp=False, forward_mode="default", fp_masks=None,
-                split_fp=True, fp_range=None):
+                split_fp=True, fp_range=None, head_res=False):
         """Logits [b, N, H, W] at input resolution; with need_fp a 2-tuple (plain, feature-perturbed) halves.
         `fp_masks` (list of three {0,1} tensors [b, C_i]) injects the F.dropout2d channel masks for parity tests;
         `split_fp=False` returns the un-chunked [2b, ...] tensor; `fp_range=(s0, s1)` (with split_fp=False) perturbs
-        and decodes only samples [s0, s1): output [b + s1 - s0, ...]."""
+        and decodes only samples [s0, s1): output [b + s1 - s0, ...].  `head_res=True` (training crops only, see
+        head_res_size): the logits are returned at the head's resolution [b, N, 4 hp, 4 wp] and the caller evaluates the
+        resize of vlg_head.py:247 / builder.py:93-97 inside its loss kernels (ops.ce_up_fused / ops.softmax_max_up)."""
         if forward_mode == "maskclip_trust":    # builder.py:57-58 calls a method the reference never defines
             raise AttributeError("'VLM' object has no attribute 'train_maskclip_trust'")
         if forward_mode != "default":
@@ -242,9 +253,10 @@ class VLM(nn.Module):
         # the head resizes its 4x map to (img_size, img_size) (vlg_head.py:247), forward_wrapper then resizes to the input
         # size (builder.py:93-97): one and the same interpolation when the input IS img_size (every training crop), two
         # chained ones for evaluation windows of another shape (supervised.py:104-133)
+        at_head = head_res and self.head_res_size(in_size) is not None
         out = self.decode_head.forward_tokens(feats, self.text_feat_f32(img.device), (hp, wp), masks, self.fp_rate,
-                                              out_size=(S_, S_), fp_range=fp_range if need_fp else None,
-                                              skip0_hw=skip0_hw)
+                                              out_size=(4 * hp, 4 * wp) if at_head else (S_, S_),
+                                              fp_range=fp_range if need_fp else None, skip0_hw=skip0_hw)
         if in_size != (S_, S_):
             out = _PlanesResizeFn.apply(out, in_size, self.align_corners)
         if need_fp and split_fp:

@@ -91,11 +91,21 @@ class Op:
 # In-register split kernel on fp16 x 2 terms with per-tensor scales (svl_gemm_desc.emu_ws; round 5): SVL_GEMM_EMU_NO_H2=1 keeps
 # the bf16 x 3 form for every launch (A/B runs).
 EMU_H2 = not os.environ.get("SVL_GEMM_EMU_NO_H2")
+EMU_H2_WGRAD = not os.environ.get("SVL_GEMM_EMU_H2_NO_WGRAD")     # (split-K launches: the weight gradients)
+EMU_H2_FWD = not os.environ.get("SVL_GEMM_EMU_H2_NO_FWD")         # (forward / input-gradient launches)
+EMU_H2_DGRAD = not os.environ.get("SVL_GEMM_EMU_H2_NO_DGRAD")     # (conv_dgrad launches: the decoder's input gradients)
+# conv_fwd launches (the dilated ASPP convolutions' forward): OFF by default since the end of round 5.  With the fp16 x 2
+# attention AND these launches on the fp16 x 2 form, tests/test_fullsize_gpu.py::test_fullsize_gradient_error_against_fp64
+# left its bound (seven pseudo-label ties decided the other way, and under the product's decisions the ViT's gradients
+# still 4.0 - 4.4 x the fp32 oracle's own distance from float64, bound 4 x; either feature alone: <= 3.7 x, no flips).
+# The input / weight gradients keep the form (same test: green).  SVL_GEMM_EMU_H2_CONVFWD=1 turns it back on (A/B).
+EMU_H2_CONVFWD = bool(int(os.environ.get("SVL_GEMM_EMU_H2_CONVFWD", "0")))
 
 
 def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batch=1, batch_inner=1, ksplit=0,
          c_bso=0, c_bsi=0, alpha=1.0, bias=None, bias_mod=0, act=ACT_NONE, resid=None, r_off=0, ldr_m=None, ldr_n=1,
-         r_bso=0, r_bsi=0, accumulate=False, out_mode=OUT_STRIDED, conv=None, ct=(0, 0, 0), preact=None, w_planes=None):
+         r_bso=0, r_bsi=0, accumulate=False, out_mode=OUT_STRIDED, conv=None, ct=(0, 0, 0), preact=None, w_planes=None,
+         emu_h2=True):
     d = L.GemmDesc()
     d.conv_w_planes = _p(w_planes)
     d.a_mode, d.b_mode, d.M, d.N, d.K = a_mode, b_mode, M, N, K
@@ -118,7 +128,8 @@ def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batc
         d.ldr_n, d.r_bs_outer, d.r_bs_inner = ldr_n, r_bso, r_bsi
     d.accumulate = 1 if accumulate else 0
     ws = None
-    if EMU_H2 and 2.0 * M * N * K >= 4.0e9 and (batch == 1 or ksplit > 0) and Cout.is_cuda and get_gemm_emulation() == 6:
+    if (EMU_H2 and emu_h2 and (EMU_H2_WGRAD if ksplit > 0 else EMU_H2_FWD) and 2.0 * M * N * K >= 4.0e9 and (batch == 1 or ksplit > 0)
+            and Cout.is_cuda and get_gemm_emulation() == 6):
         ws = torch.empty(2, dtype=torch.int32, device=Cout.device)      # scratch of the operand-maximum passes (fp16 x 2 form)
         d.emu_ws = _p(ws)
     e0 = _prof_begin()
@@ -750,6 +761,7 @@ def groupnorm_fwd(x, ldx, gamma, beta, eps, imgs, HW, Cc, G, relu, y, ldy):
 
 
 CONV_GN_FUSED = not os.environ.get("SVL_NO_CONV_GN_FUSED")
+UP_LOSS = not os.environ.get("SVL_NO_UP_LOSS")      # A/B: the logits' resize evaluated inside the pixel-loss kernels (train.py)
 GN_DEFER = not os.environ.get("SVL_NO_GN_DEFER")     # GroupNorm + ReLU applied by the consuming convolution (model/vlg_head.py)
 
 
@@ -1047,7 +1059,7 @@ def conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, KH, KW, dil, pad, bias=None, act=AC
         ldo = Co
     g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
     gemm(A_CONV, B_KC, M, Co, K, Op(x, ldx), Op(wf, K), out, ldc_m=ldo, bias=bias, act=act, conv=g, resid=resid,
-         ldr_m=ldr, w_planes=w_planes_of(wf) if (KH, dil, pad, stride) == (3, 1, 1, 1) else None)
+         ldr_m=ldr, w_planes=w_planes_of(wf) if (KH, dil, pad, stride) == (3, 1, 1, 1) else None, emu_h2=EMU_H2_CONVFWD)
     return out
 
 
@@ -1060,7 +1072,7 @@ def conv_dgrad(dy, lddy, imgs, H, W, Co, wd, Ci, KH, KW, dil, pad, out=None, ldo
         ldo = Ci
     g = conv_geom(H, W, Co, KH, KW, dil, pad, -1)
     gemm(A_CONV, B_KC, M, Ci, K, Op(dy, lddy), Op(wd, K), out, ldc_m=ldo, conv=g, accumulate=accumulate,
-         w_planes=w_planes_of(wd) if (KH, dil, pad) == (3, 1, 1) else None)
+         w_planes=w_planes_of(wd) if (KH, dil, pad) == (3, 1, 1) else None, emu_h2=EMU_H2_DGRAD)
     return out
 
 
@@ -1294,6 +1306,47 @@ def ce_fused(logits, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0,
     L.check(lib.svl_ce_fused_f32(C.byref(d), _st()), "svl_ce_fused_f32")
     # algorithmic bytes: fwd (4N+20) + bwd (8N+20) B/px when dlogits is produced, else fwd only
     _prof_end("ce_fused", e0, float(Bn * HW) * ((12 * N + 40) if dlogits is not None else (4 * N + 20)), (Bn, N, HW))
+    if sums_out is None:
+        sums_out = empty(4, dtype=torch.float64, device=logits.device)
+    L.check(lib.svl_ce_finalize(_p(partials), nblk, _p(sums_out), _st()), "svl_ce_finalize")
+    return sums_out
+
+
+def ce_up_ok(Bn, N, h, w, H, W, align):
+    """Whether the pixel-loss kernels can evaluate the resize [h, w] -> [H, W] themselves (svl_ce_up_num_blocks)."""
+    return L.load().svl_ce_up_num_blocks(int(Bn), int(N), int(h), int(w), int(H), int(W), 1 if align else 0) > 0
+
+
+def softmax_max_up(logits, H, W, align):
+    """softmax(dim 1).max(dim 1) of bilinear(logits [B, N, h, w] -> [H, W]) without writing the resized tensor."""
+    Bn, N, h, w = logits.shape
+    conf = empty(Bn, H, W, device=logits.device)
+    label = empty(Bn, H, W, dtype=torch.int64, device=logits.device)
+    e0 = _prof_begin()
+    L.check(L.load().svl_softmax_max_up_f32(_p(logits), Bn, N, h, w, H, W, 1 if align else 0, _p(conf), _p(label), _st()),
+            "svl_softmax_max_up_f32")
+    _prof_end("softmax_max_up", e0, float(Bn) * (4.0 * N * h * w + 12.0 * H * W), (Bn, N, h * w, H * W))
+    return conf, label
+
+
+def ce_up_fused(logits, H, W, align, target, use_ignore_t, conf=None, ign=None, conf_thresh=0.0, mc=None, dlogits=None,
+                gscale=None, sums_out=None, all_pixels=False, img_weight=None):
+    """ce_fused on bilinear(logits [B, N, h, w] -> [H, W]) with the resize evaluated inside the kernel; `dlogits`
+    [B, N, h, w] receives d(loss)/d(logits) at the LOW resolution.  Returns sums (double[4] device)."""
+    Bn, N, h, w = logits.shape
+    lib = L.load()
+    nblk = lib.svl_ce_up_num_blocks(Bn, N, h, w, H, W, 1 if align else 0)
+    if nblk <= 0:
+        raise RuntimeError(f"svl_ce_up_fused: unsupported geometry N={N} {h}x{w} -> {H}x{W}")
+    partials = empty(nblk, 4, device=logits.device)
+    d = L.CeUpDesc(_p(logits), Bn, N, h, w, H, W, 1 if align else 0, _p(target), 1 if use_ignore_t else 0, _p(conf),
+                   _p(ign), float(conf_thresh), 1 if all_pixels else 0, _p(mc), _p(partials), _p(dlogits), _p(gscale),
+                   _p(img_weight))
+    e0 = _prof_begin()
+    L.check(lib.svl_ce_up_fused_f32(C.byref(d), _st()), "svl_ce_up_fused_f32")
+    # bytes the kernel moves: low-resolution logits in (+ gradient out) and 28 B of maps per full-resolution pixel
+    _prof_end("ce_up_fused", e0, float(Bn) * ((8.0 if dlogits is not None else 4.0) * N * h * w + 28.0 * H * W),
+              (Bn, N, h * w, H * W))
     if sums_out is None:
         sums_out = empty(4, dtype=torch.float64, device=logits.device)
     L.check(lib.svl_ce_finalize(_p(partials), nblk, _p(sums_out), _st()), "svl_ce_finalize")

@@ -179,12 +179,34 @@ def _semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, re
             side = _SIDE[dev] = torch.cuda.Stream(dev)
     main = torch.cuda.current_stream(dev) if img_x.is_cuda else None
     pl_side = side if getattr(model, "conv_encoder", None) is None else None
+    # The logits stay at the head's resolution (round 5): the bilinear resize to the crop (vlg_head.py:247, builder.py:93-97)
+    # is evaluated inside the softmax-max / cross-entropy kernels and the gradient comes back at the head's resolution --
+    # the [B, N, H, W] tensors and the two resize passes do not exist.  `up` = (H, W, align_corners) or None (models without
+    # the option, geometries the kernels do not take, cfg / SVL_NO_UP_LOSS: the resized tensors as before).
+    up = None
+    if img_x.is_cuda and cfg.get("fuse_upsample_loss", ops.UP_LOSS) and hasattr(model, "head_res_size"):
+        hs = model.head_res_size(tuple(img_x.shape[2:]))
+        if hs is not None and ops.ce_up_ok(B, model.num_classes, hs[0], hs[1], img_x.shape[2], img_x.shape[3],
+                                           model.align_corners):
+            up = (int(img_x.shape[2]), int(img_x.shape[3]), bool(model.align_corners))
+    fwd_kw = dict(head_res=True) if up is not None else {}
+
+    def smax(pred):
+        return ops.softmax_max_up(pred, *up) if up is not None else ops.softmax_max(pred)
+
+    def full_res(pred):
+        """(return_aux only) the resized logits the fused kernels never write"""
+        if up is None:
+            return pred
+        pred = pred.contiguous()
+        return ops.bilinear_planes_fwd(pred, pred.shape[2], pred.shape[3], up[2], up[0], up[1])
+
     model.eval()
     if side is not None:
         side.wait_stream(main)
     with torch.no_grad(), (torch.cuda.stream(pl_side) if pl_side is not None else contextlib.nullcontext()):
-        pred_w_other = model(b["img_w_other"])
-        conf_w_other, mask_w_other = ops.softmax_max(pred_w_other)
+        pred_w_other = model(b["img_w_other"], **fwd_kw)
+        conf_w_other, mask_w_other = smax(pred_w_other)
         if not return_aux:
             del pred_w_other
     with torch.no_grad(), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
@@ -217,11 +239,11 @@ def _semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, re
         frac = cfg.get("act_mem_fraction", 0.70)
         head.act_limit_bytes = (None if frac is None or not img_x.is_cuda else
                                 int(frac * torch.cuda.get_device_properties(dev).total_memory))
-    preds4 = model(_cat2(img_w, img_x), need_fp=True, fp_masks=fp_masks, split_fp=False, fp_range=(0, B))
-    preds_s = model(_cat2(img_s1, img_s2))                                                 # [s1, s2]
+    preds4 = model(_cat2(img_w, img_x), need_fp=True, fp_masks=fp_masks, split_fp=False, fp_range=(0, B), **fwd_kw)
+    preds_s = model(_cat2(img_s1, img_s2), **fwd_kw)                                       # [s1, s2]
     pred_w, pred_x, pred_w_fp = preds4[:B], preds4[B:2 * B], preds4[2 * B:]
     pred_s1, pred_s2 = preds_s[:B], preds_s[B:]
-    conf_w, mask_w = ops.softmax_max(pred_w.detach())
+    conf_w, mask_w = smax(pred_w.detach())
     if side is not None:        # join: the label maps of the side stream are consumed from here on
         main.wait_stream(side)
         for t_ in ((conf_w_other, mask_w_other, mclip_all) if pl_side is not None else (mclip_all,)):
@@ -259,13 +281,18 @@ def _semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, re
     dls = torch.empty_like(preds_s)
     ops.fill(dl4[:B], 0.0)  # pred_w is detached (semivl.py:251)
     sums = ops.empty(4, 4, dtype=torch.float64, device=dev)
-    ops.ce_fused(pred_x.detach(), mask_x, True, dlogits=dl4[B:2 * B], gscale=gscale[0], sums_out=sums[0])
-    ops.ce_fused(pred_s1.detach(), mw1, False, conf=cw1, ign=ig1, conf_thresh=thr, mc=mc1, dlogits=dls[:B],
-                 gscale=gscale[1], sums_out=sums[1], all_pixels=whole_map, img_weight=ratios[0])
-    ops.ce_fused(pred_s2.detach(), mw2, False, conf=cw2, ign=ig2, conf_thresh=thr, mc=mc2, dlogits=dls[B:],
-                 gscale=gscale[2], sums_out=sums[2], all_pixels=whole_map, img_weight=ratios[1])
-    ops.ce_fused(pred_w_fp.detach(), mask_w, False, conf=conf_w, ign=ign, conf_thresh=thr, mc=mclip,
-                 dlogits=dl4[2 * B:], gscale=gscale[3], sums_out=sums[3], all_pixels=whole_map, img_weight=ratios[2])
+    def ce(pred, *a_, **kw):
+        if up is not None:
+            return ops.ce_up_fused(pred, up[0], up[1], up[2], *a_, **kw)
+        return ops.ce_fused(pred, *a_, **kw)
+
+    ce(pred_x.detach(), mask_x, True, dlogits=dl4[B:2 * B], gscale=gscale[0], sums_out=sums[0])
+    ce(pred_s1.detach(), mw1, False, conf=cw1, ign=ig1, conf_thresh=thr, mc=mc1, dlogits=dls[:B],
+       gscale=gscale[1], sums_out=sums[1], all_pixels=whole_map, img_weight=ratios[0])
+    ce(pred_s2.detach(), mw2, False, conf=cw2, ign=ig2, conf_thresh=thr, mc=mc2, dlogits=dls[B:],
+       gscale=gscale[2], sums_out=sums[2], all_pixels=whole_map, img_weight=ratios[1])
+    ce(pred_w_fp.detach(), mask_w, False, conf=conf_w, ign=ign, conf_thresh=thr, mc=mclip,
+       dlogits=dl4[2 * B:], gscale=gscale[3], sums_out=sums[3], all_pixels=whole_map, img_weight=ratios[2])
     losses = ops.empty(8, device=dev)
     ops.semivl_loss(sums, numel_u, lam, losses, factors, mc_counts)
     # backward (+ all-reduce) + optimizer
@@ -289,8 +316,8 @@ def _semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, re
                           warmup_ratio=cfg.get("warmup_ratio", 1e-6))
     if return_aux:
         aux = dict(mask_w=mask_w, mask_w_other=mask_w_other, mclip=mclip, mclip_other=mclip_other, conf_w=conf_w,
-                   pred_x=pred_x.detach(), pred_s1=pred_s1.detach(), pred_w=pred_w.detach(),
-                   pred_w_other=pred_w_other, dl4=dl4, dls=dls)
+                   pred_x=full_res(pred_x.detach()), pred_s1=full_res(pred_s1.detach()), pred_w=full_res(pred_w.detach()),
+                   pred_w_other=full_res(pred_w_other), dl4=dl4, dls=dls, upsample_in_loss=up is not None)
         return losses, aux
     return losses
 

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_field_order():
     import semivl_amd.lib as L
     src = open(os.path.join(ROOT, "include", "semivl_hip.h")).read()
-    for cname, cls in (("svl_gemm_desc", L.GemmDesc), ("svl_conv_geom", L.ConvGeom), ("svl_ce_desc", L.CeDesc),
+    for cname, cls in (("svl_gemm_desc", L.GemmDesc), ("svl_conv_geom", L.ConvGeom), ("svl_ce_desc", L.CeDesc), ("svl_ce_up_desc", L.CeUpDesc),
                        ("svl_seqattn_desc", L.SeqAttnDesc), ("svl_operand", L.Operand), ("svl_pgemm_desc", L.PGemmDesc)):
         body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)

@@ -96,7 +96,9 @@ def test_train_step_matches_reference_fixture(dev, name):
         assert abs(g.norm().item() - ref[0]) < tol * ref[0] + floor, f"grad norm of {k}: {g.norm().item()} vs {ref[0]}"
         if ("grad/" + k) in z.files:
             full = z["grad/" + k]
-            e = np.abs(g.cpu().numpy() - full).max() / max(np.abs(full).max(), 1e-5)
+            # (head.bias: sum(softmax - onehot) = 0 exactly; what is compared is rounding noise -- 1e-7 when the probabilities
+            #  come from exp(x - lse) as in the resize-fused loss kernel, 3e-9 from e / sum(e): an absolute bound there)
+            e = np.abs(g.cpu().numpy() - full).max() / max(np.abs(full).max(), 1e-3 if k == "decode_head.head.bias" else 1e-5)
             assert e < 5e-3, f"grad of {k}: rel max err {e}"
     print(f"[{name}] worst grad-norm rel err {worst:.2e}")
 
