@@ -46,3 +46,20 @@ def test_struct_layouts_match_header_field_order():
             names = re.sub(r"^(const\s+)?[A-Za-z_0-9]+\s*\*?\s*", "", decl, count=1)
             fields += [re.sub(r"[\s\*]", "", n) for n in names.split(",")]
         assert fields == [f[0] for f in cls._fields_], (cname, fields, [f[0] for f in cls._fields_])
+
+
+def test_resize_fused_loss_geometry_query_is_host_only():
+    """svl_ce_up_num_blocks runs the kernels' own tile functions on the host (no GPU): the training geometries are taken,
+    reductions / ratios above 4.5 / class counts whose staged tile would not fit are refused (callers then resize)."""
+    import semivl_amd.lib as L
+    lib = L.load()
+    q = lambda B, N, h, w, H, W, a: lib.svl_ce_up_num_blocks(B, N, h, w, H, W, a)
+    for align in (0, 1):
+        assert q(16, 21, 128, 128, 512, 512, align) == 16 * 16 * 16          # VOC / COCO / ADE crops
+        assert q(8, 19, 204, 204, 801, 801, align) == 8 * 26 * 26            # Cityscapes 801^2 (51 patches per side)
+        assert q(2, 5, 8, 8, 32, 32, align) == 2                             # the fixtures' 32^2 crops
+        assert q(1, 150, 24, 40, 96, 160, align) == 3 * 5
+        assert q(2, 21, 64, 64, 512, 512, align) == -1                       # ratio 8
+        assert q(2, 21, 128, 128, 64, 64, align) == -1                       # a reduction
+        assert q(2, 161, 128, 128, 512, 512, align) == -1                    # N x 11 x 11 floats + the pixel state > 160 KB
+        assert q(0, 21, 128, 128, 512, 512, align) == -1

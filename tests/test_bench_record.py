@@ -6,7 +6,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = "r5_e"        # the end-of-round evidence run (tools/round_end_run.sh)
+TAG = "r5_h"        # the end-of-round evidence run (tools/round_end_run.sh)
 
 
 def _line(name):
@@ -47,6 +47,14 @@ def test_default_line_contract_and_arithmetic():
     h = d["roofline_hbm"]
     assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 2e-3 and h["traffic"] is not None
     assert abs(h["frac_real_traffic"] - h["traffic"] / (h["avg_ms"] * 1e-3) / 1e9 / h["peak"]) < 2e-3
+    # end of round 5: the step's cross entropy runs on head-resolution logits -- the HBM-bound kernel above is measured
+    # standalone on the step's shape, the kernel the step launches is recorded beside it
+    k = h["step_kernel"]
+    assert h["in_step"] is False and "ce_up_kernel" in k["kernel"] and k["launches"] == 4
+    assert abs(k["bytes_moved"] - 16 * (8 * 21 * 128 * 128 + 28 * 512 * 512)) < 1           # low-res logits in + gradient out + maps
+    assert abs(k["bytes_not_moved"] - 16 * 512 * 512 * ((8 * 21 + 28) + 8 * 21 * (1 + 1 / 16))) < 1
+    assert abs(k["achieved_gbs"] - k["bytes_moved"] / (k["avg_ms"] * 1e-3) / 1e9) < 1.0 and k["frac_of_hbm_peak"] < 0.1
+    assert d["phase_ms"]["pixel_loss"] < 4 * k["avg_ms"] + 2 * k["softmax_max_up_ms"] + 0.3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"].startswith("protocol: 3 warm-up + 5 timed")
     assert c["runs"][0]["threads"] == c["cores"] == c["physical_cores"] and c["best_thread_count"]["images_per_s"] >= c["value"]
@@ -124,3 +132,6 @@ def test_kernel_summaries_show_the_round_4_and_5_claims():
     assert pct("gemm_x6p_kernelILi2E") > 3.0 * pct("gemm_x6p_kernelILi3E")  # the ViT linears on fp16 x 2 planes
     assert pct("gemm_bf16x_kernelILi3ELi1ELi2") > 1.0                       # im2col^T weight gradients on the split pipe
     assert pct("conv_cout1_tiled") > 0.1 and pct("groupnorm_apply") < 1.6   # head conv normalises its input (2.6 % in round 3)
+    # end of round 5: the logits' resize passes and the HBM-bound loss pass are gone from the step; their work is in ce_up_kernel
+    assert pct("bilinear_planes_fwd") == 0.0 and pct("bilinear_planes_bwd") == 0.0 and pct("ce_fused_kernel") == 0.0
+    assert pct("softmax_max_kernel") == 0.0 and 0.0 < pct("ce_up_kernel") < 1.5 and pct("softmax_max_up_kernel") > 0.0
