@@ -11,6 +11,7 @@
 // Replaces the same reference lines as gemm_planes.hip (F.linear and its input gradient on the ViT blocks,
 // maskclip_vit.py:94-100,110-118,141-142).
 #include "gemm_planes_impl.h"
+#include <stdlib.h>
 
 int svl_planes_launch_h2(const PlanesP& p, hipStream_t st) { return launch<2>(p, st); }
 
@@ -19,6 +20,9 @@ namespace {
 // One block per 32-row block.  Phase 1: the rows' largest magnitude and squared norm (double: 1e25-sized rows must not
 // overflow the sum) -> scale exponent and norm bound.  Phase 2: thread = (row, k-group, lane half) as in the bf16 x 3 pack
 // pass, the rows re-read from L2 (a 32 x 768 fp32 block is 96 KiB).
+// gridDim.y > 1 (few row blocks: the 768- / 2304-row weight matrices are 24 / 72 blocks on 256 CUs and took 70 us per
+// call, 62 calls per training step): every y-slice repeats phase 1 (the exponent needs the whole row; the re-reads are L2
+// hits) and writes its share of the k-groups -- the planes are bit-identical to the one-slice launch.
 __global__ __launch_bounds__(256) void pack_planes_h2_kernel(const float* __restrict__ x, long ld, long ks, long rows, int K,
                                                              char* __restrict__ planes, long p_ks, long row_off,
                                                              int* __restrict__ sexp, float* __restrict__ rnorm) {
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(256) void pack_planes_h2_kernel(const float* __rest
   }
   __syncthreads();
   const int nkg = K >> 4;
-  for (int idx = tid; idx < nkg * 64; idx += 256) {
+  const int kg_lo = (int)((long)nkg * blockIdx.y / gridDim.y), kg_hi = (int)((long)nkg * (blockIdx.y + 1) / gridDim.y);
+  for (int idx = kg_lo * 64 + tid; idx < kg_hi * 64; idx += 256) {
     const int r31 = idx & 31, h = (idx >> 5) & 1, kg = idx >> 6;
     const long r = rb * 32 + r31;
     float v[8];
@@ -119,7 +124,15 @@ extern "C" int svl_split_planes_f16x2(const float* x, int64_t ld, int64_t k_stri
                     row_off >= 0 && (planes_rows & 255) == 0 && (row_off & 31) == 0,
                 "svl_split_planes_f16x2: bad args (K %% 16, planes_rows %% 256, row_off %% 32 must be 0; sexp required)");
   const long blocks = (rows + 31) / 32;
-  hipLaunchKernelGGL(pack_planes_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ld,
+  int ysplit = 1;
+  static const bool no_ysplit = getenv("SVL_PACK_NO_YSPLIT") != nullptr;      // (A/B switch)
+  if (blocks < 256 && !no_ysplit) {
+    ysplit = (int)(512 / blocks);
+    if (ysplit > 8) ysplit = 8;
+    if (ysplit > (K >> 6)) ysplit = K >> 6;      // at least four k-groups per slice
+    if (ysplit < 1) ysplit = 1;
+  }
+  hipLaunchKernelGGL(pack_planes_h2_kernel, dim3((unsigned)blocks, (unsigned)ysplit), dim3(256), 0, (hipStream_t)stream, x, (long)ld,
                      (long)k_stride, (long)rows, K, (char*)planes, (long)planes_rows * 64, (long)row_off, sexp, rnorm);
   SVL_LAUNCH_CHECK("svl_split_planes_f16x2");
   return SVL_OK;

@@ -229,6 +229,13 @@ def test_split_planes_h2_is_a_scaled_two_term_split(dev):
     ops.split_planes(x, out=big_, row_off=1504)
     assert torch.equal(_h2_value(big_)[1504:2504], _h2_value(pl))
     assert torch.equal(_h2_value(big_.kslice(64, 160))[1504:2504], _h2_value(pl)[:, 64:160])
+    # the weight matrices of the ViT (few row blocks: the launch splits the k-groups over gridDim.y, the planes must not depend on it)
+    for rows_, K_, tr_ in ((768, 768, False), (768, 3072, False), (2304, 768, False), (768, 2304, True), (3072, 768, True)):
+        w_ = rnd(K_, rows_, dev=dev, seed=63).t() if tr_ else rnd(rows_, K_, dev=dev, seed=63)
+        pw = ops.split_planes(w_.t().contiguous(), transpose=True, fmt="h2") if tr_ else ops.split_planes(w_, fmt="h2")
+        a0, a1 = _unpack_planes(pw)
+        ws = (w_.double() * _pow2(-pw.sexp[:rows_])[:, None]).float()
+        assert torch.equal(a0[:rows_], ws.half().float()) and torch.equal(a1[:rows_], (ws - a0[:rows_]).half().float()), (rows_, K_, tr_)
 
 
 def test_split_planes_is_an_exact_three_term_split(dev):
