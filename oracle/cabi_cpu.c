@@ -11,6 +11,9 @@
  *   svl_ce_fused_f32 (+finalize, semivl_gscale / semivl_loss, conf_avg_factor, conf_ratio_f32)
  *                            CE(ignore 255) / CE(none) * confidence weight / mc CE  semivl.py:52-58,267-323,
  *                                                                                   utils/train_utils.py:30-49
+ *   svl_ce_up_fused_f32, svl_softmax_max_up_f32 (+ svl_ce_up_num_blocks)
+ *                            the same on logits at the head's resolution: F.interpolate(bilinear) -> loss -> its backward
+ *                                                                                   vlg_head.py:247, builder.py:93-97
  *   svl_maskclip_labels      upsample -> softmax(100 x) -> max -> threshold         model/vlm.py:100-109
  *   svl_concept_max_f32      per-class max over concept channels                    model/text_embeddings.py:188-193
  *   svl_iou_hist_i64         intersectionAndUnion                                   third_party/unimatch/util/utils.py:91-103
@@ -19,6 +22,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../include/semivl_hip.h"
@@ -148,6 +152,133 @@ int svl_ce_fused_f32(const svl_ce_desc* d, svl_stream_t s) {
   }
   return SVL_OK;
 }
+/* ---- the same two pixel-loss entry points on logits at the head's resolution (include/semivl_hip.h, round 5): the plain
+ * restatement of  F.interpolate(logits, (H, W), mode='bilinear', align_corners)  (vlg_head.py:247, builder.py:93-97; ATen
+ * upsample_bilinear2d: area_pixel_compute_source_index + guard_index_and_lambda)  followed by semivl.py:232,252 /
+ * semivl.py:267-323, and of autograd's scatter of the resized gradient back onto the [h, w] grid.  No tiling: one partial
+ * per image; every upsampling geometry of ratio <= 4.5 is taken (the HIP kernels additionally bound a tile's region). */
+static void src_index_a(int dst, float scale, int in, int align, int* i0, int* i1, float* l0, float* l1) {
+  float s = align ? scale * dst : scale * (dst + 0.5f) - 0.5f;
+  if (!align && s < 0.f) s = 0.f;
+  *i0 = (int)s < in - 1 ? (int)s : in - 1;
+  *i1 = *i0 + 1 < in - 1 ? *i0 + 1 : in - 1;
+  *l1 = fminf(fmaxf(s - *i0, 0.f), 1.f);
+  *l0 = 1.f - *l1;
+}
+static float up_scale(int in, int out, int align) {
+  if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+static int up_ok(int N, int h, int w, int H, int W, int align) {
+  return N > 0 && N <= 160 && h >= 2 && w >= 2 && H >= h && W >= w && up_scale(h, H, align) >= 2.f / 9.f &&
+         up_scale(w, W, align) >= 2.f / 9.f;
+}
+int64_t svl_ce_up_num_blocks(int B, int N, int h, int w, int H, int W, int align) {
+  return (B > 0 && up_ok(N, h, w, H, W, align)) ? B : -1;
+}
+/* the N resized logits of pixel (oy, ox) of image `x` [N, h, w] */
+static void up_pixel(const float* x, int N, int h, int w, int y0, int y1, float ly0, float ly1, int x0, int x1, float lx0,
+                     float lx1, float* v) {
+  for (int c = 0; c < N; ++c) {
+    const float* t = x + (int64_t)c * h * w;
+    v[c] = ly0 * (lx0 * t[y0 * w + x0] + lx1 * t[y0 * w + x1]) + ly1 * (lx0 * t[y1 * w + x0] + lx1 * t[y1 * w + x1]);
+  }
+}
+int svl_softmax_max_up_f32(const float* logits, int B, int N, int h, int w, int H, int W, int align, float* conf,
+                           int64_t* label, svl_stream_t s) {
+  (void)s;
+  CHECK(logits && conf && label && B > 0, "svl_softmax_max_up_f32: bad args");
+  CHECK(up_ok(N, h, w, H, W, align), "svl_softmax_max_up_f32: unsupported geometry");
+  const float sh = up_scale(h, H, align), sw = up_scale(w, W, align);
+  float v[160];
+  for (int b = 0; b < B; ++b)
+    for (int oy = 0; oy < H; ++oy)
+      for (int ox = 0; ox < W; ++ox) {
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index_a(oy, sh, h, align, &y0, &y1, &ly0, &ly1);
+        src_index_a(ox, sw, w, align, &x0, &x1, &lx0, &lx1);
+        up_pixel(logits + (int64_t)b * N * h * w, N, h, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1, v);
+        float m = v[0];
+        int idx = 0;
+        for (int c = 1; c < N; ++c)
+          if (v[c] > m) { m = v[c]; idx = c; }           /* first maximum wins (torch.max) */
+        float sum = 0.f;
+        for (int c = 0; c < N; ++c) sum += expf(v[c] - m);
+        conf[((int64_t)b * H + oy) * W + ox] = 1.f / sum;
+        label[((int64_t)b * H + oy) * W + ox] = idx;
+      }
+  return SVL_OK;
+}
+int svl_ce_up_fused_f32(const svl_ce_up_desc* d, svl_stream_t s) {
+  (void)s;
+  CHECK(d && d->logits && d->target && d->partials, "svl_ce_up_fused_f32: null args");
+  CHECK(d->B > 0 && up_ok(d->N, d->h, d->w, d->H, d->W, d->align_corners), "svl_ce_up_fused_f32: unsupported geometry");
+  CHECK((d->conf == NULL) == (d->ign == NULL), "svl_ce_up_fused_f32: conf and ign go together");
+  CHECK(d->dlogits == NULL || d->gscale != NULL, "svl_ce_up_fused_f32: gscale required with dlogits");
+  const int N = d->N, h = d->h, w = d->w, H = d->H, W = d->W, al = d->align_corners;
+  const float sh = up_scale(h, H, al), sw = up_scale(w, W, al);
+  float v[160];
+  double* acc = d->dlogits ? (double*)malloc(sizeof(double) * (size_t)N * h * w) : NULL;
+  CHECK(!d->dlogits || acc, "svl_ce_up_fused_f32: out of memory");
+  for (int b = 0; b < d->B; ++b) {
+    double st = 0, sm = 0, sc = 0, nv = 0;
+    const float* x = d->logits + (int64_t)b * N * h * w;
+    if (acc) memset(acc, 0, sizeof(double) * (size_t)N * h * w);
+    for (int oy = 0; oy < H; ++oy)
+      for (int ox = 0; ox < W; ++ox) {
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index_a(oy, sh, h, al, &y0, &y1, &ly0, &ly1);
+        src_index_a(ox, sw, w, al, &x0, &x1, &lx0, &lx1);
+        up_pixel(x, N, h, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1, v);
+        const int64_t o = ((int64_t)b * H + oy) * W + ox;
+        float m = -INFINITY;
+        for (int c = 0; c < N; ++c) m = fmaxf(m, v[c]);
+        float sum = 0.f;
+        for (int c = 0; c < N; ++c) sum += expf(v[c] - m);
+        const float lse = m + logf(sum);
+        const int64_t t = d->target[o];
+        const int t_ok = !(d->use_ignore_t && t == 255);
+        float wt = 1.f;
+        int valid = t_ok;
+        if (d->conf) {
+          const int vv = d->ign[o] != 255;
+          const float cf = d->conf[o];
+          wt = d->all_pixels ? 1.f : ((cf >= d->conf_thresh && vv) ? 1.f : 0.f);
+          if (d->img_weight) wt *= d->img_weight[b];
+          valid = vv;
+          if (vv) sc += cf;
+        }
+        nv += valid;
+        int ti = -1, mi = -1;
+        if (t_ok) { ti = (int)t; st += wt * (lse - v[ti]); }
+        if (d->mc_target && d->mc_target[o] != 255) { mi = (int)d->mc_target[o]; sm += lse - v[mi]; }
+        if (acc) {
+          const float gt = t_ok ? d->gscale[0] * wt : 0.f, gm = mi >= 0 ? d->gscale[1] : 0.f;
+          for (int c = 0; c < N; ++c) {
+            double g = (double)(gt + gm) * (double)(expf(v[c] - m) / sum);
+            if (c == ti) g -= gt;
+            if (c == mi) g -= gm;
+            double* a = acc + (int64_t)c * h * w;           /* F.interpolate's backward: the four taps of the pixel */
+            a[y0 * w + x0] += (double)(ly0 * lx0) * g;
+            a[y0 * w + x1] += (double)(ly0 * lx1) * g;
+            a[y1 * w + x0] += (double)(ly1 * lx0) * g;
+            a[y1 * w + x1] += (double)(ly1 * lx1) * g;
+          }
+        }
+      }
+    if (acc) {
+      float* dl = d->dlogits + (int64_t)b * N * h * w;
+      for (int64_t i = 0; i < (int64_t)N * h * w; ++i) dl[i] = (float)acc[i];
+    }
+    float* pp = d->partials + 4 * b;
+    pp[0] = (float)st; pp[1] = (float)sm; pp[2] = (float)sc; pp[3] = (float)nv;
+  }
+  free(acc);
+  return SVL_OK;
+}
+
 int svl_ce_finalize(const float* partials, int64_t nblocks, double* sums, svl_stream_t s) {
   (void)s;
   CHECK(partials && sums && nblocks > 0, "svl_ce_finalize: bad args");

@@ -201,6 +201,76 @@ def test_cpu_maskclip_labels_iou_hist_adamw():
         assert np.abs(p - ref_p.detach().numpy()).max() < 1e-6
 
 
+def _up_case(N, h, w, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    B = 2
+    lg = (torch.randn(B, N, h, w, generator=g) * 2).contiguous()
+    lab = torch.randint(0, N, (B, H, W), generator=g)
+    conf = torch.rand(B, H, W, generator=g)
+    ign = torch.zeros(B, H, W, dtype=torch.int64)
+    ign[:, -3:] = 255
+    mc = torch.randint(0, N, (B, H, W), generator=g)
+    mc[torch.rand(B, H, W, generator=g) < 0.5] = 255
+    return lg, lab, conf, ign, mc
+
+
+@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("N,h,w,H,W", [(5, 8, 8, 32, 32), (7, 13, 20, 50, 79), (21, 16, 16, 64, 64), (3, 9, 9, 9, 9)])
+def test_cpu_resize_fused_losses_match_interpolate_and_autograd(N, h, w, H, W, align):
+    """svl_softmax_max_up_f32 / svl_ce_up_fused_f32 of the CPU backend (the plain-C restatement of F.interpolate -> loss ->
+    its backward) against PyTorch itself: vlg_head.py:247 / builder.py:93-97 + semivl.py:232,252,267-323."""
+    lib = K.load()
+    lg, lab, conf, ign, mc = _up_case(N, h, w, H, W, seed=41)
+    B = lg.shape[0]
+    assert lib.svl_ce_up_num_blocks(B, N, h, w, H, W, int(align)) == B
+    up = F.interpolate(lg, size=(H, W), mode="bilinear", align_corners=align)
+    cf, lb = np.zeros((B, H, W), np.float32), np.zeros((B, H, W), np.int64)
+    K.check(lib.svl_softmax_max_up_f32(K.ptr(lg.numpy()), B, N, h, w, H, W, int(align), K.ptr(cf), K.ptr(lb), None))
+    rc, rl = up.softmax(1).max(1)
+    top2 = up.topk(2, dim=1).values
+    tie = ((top2[:, 0] - top2[:, 1]) < 1e-5).numpy()
+    assert np.array_equal(lb[~tie], rl.numpy()[~tie]) and np.abs(cf - rc.numpy()).max() < 5e-6
+    lgr = lg.clone().requires_grad_(True)
+    upr = F.interpolate(lgr, size=(H, W), mode="bilinear", align_corners=align)
+    valid = ign != 255
+    lu = (F.cross_entropy(upr, lab, reduction="none") * ((conf >= 0.7) & valid)).sum() / valid.sum().item()
+    lm = F.cross_entropy(upr, mc, ignore_index=255, reduction="none").sum() / ign.numel()
+    (g,) = torch.autograd.grad(0.125 * lu + 0.03 * lm, lgr)
+    gs = np.array([0.125 / valid.sum().item(), 0.03 / ign.numel()], np.float32)
+    sums, dl = K.ce_up_fused(lg.numpy(), H, W, align, lab.numpy(), False, conf.numpy(), ign.numpy(), 0.7, mc.numpy(), gs)
+    assert abs(sums[0] / sums[3] - lu.item()) < 1e-5 and abs(sums[1] / ign.numel() - lm.item()) < 1e-5
+    assert sums[3] == valid.sum().item() and abs(sums[2] - (conf * valid).sum().item()) < 1e-2
+    assert np.abs(dl - g.numpy()).max() < 2e-9 + 2e-4 * np.abs(g.numpy()).max()
+    # geometries the entry points refuse (callers resize and use svl_ce_fused_f32)
+    assert lib.svl_ce_up_num_blocks(B, N, 8, 8, 64, 64, int(align)) == -1 and lib.svl_ce_up_num_blocks(B, N, 16, 16, 8, 8, 0) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("align", [False, True])
+def test_hip_resize_fused_losses_agree_with_the_cpu_backend(dev, align):
+    """The HIP kernels (tiled, gather-form backward) against the plain-C restatement (per-pixel scatter) of the same entry
+    points: labels identical off ties, sums / confidences / head-resolution gradients to rounding."""
+    from semivl_amd import ops
+    lib = K.load()
+    for (N, h, w, H, W) in ((21, 32, 32, 128, 128), (19, 26, 20, 101, 79), (150, 8, 8, 32, 32)):
+        lg, lab, conf, ign, mc = _up_case(N, h, w, H, W, seed=43)
+        B = lg.shape[0]
+        cf, lb = np.zeros((B, H, W), np.float32), np.zeros((B, H, W), np.int64)
+        K.check(lib.svl_softmax_max_up_f32(K.ptr(lg.numpy()), B, N, h, w, H, W, int(align), K.ptr(cf), K.ptr(lb), None))
+        gcf, glb = ops.softmax_max_up(lg.to(dev), H, W, align)
+        up = F.interpolate(lg, size=(H, W), mode="bilinear", align_corners=align)
+        top2 = up.topk(2, dim=1).values
+        tie = ((top2[:, 0] - top2[:, 1]) < 1e-5).numpy()
+        assert np.array_equal(glb.cpu().numpy()[~tie], lb[~tie]) and np.abs(gcf.cpu().numpy() - cf).max() < 5e-6
+        gs = torch.tensor([0.37, 0.11])
+        sums, dl = K.ce_up_fused(lg.numpy(), H, W, align, lab.numpy(), False, conf.numpy(), ign.numpy(), 0.6, mc.numpy(), gs.numpy())
+        gdl = torch.empty_like(lg, device=dev)
+        gsums = ops.ce_up_fused(lg.to(dev), H, W, align, lab.to(dev), False, conf=conf.to(dev), ign=ign.to(dev), conf_thresh=0.6,
+                                mc=mc.to(dev), dlogits=gdl, gscale=gs.to(dev))
+        assert np.abs(gsums.cpu().numpy() - sums).max() < 1e-3 * max(1.0, np.abs(sums).max()) and gsums[3].item() == sums[3]
+        assert np.abs(gdl.cpu().numpy() - dl).max() < 1e-5 * max(1.0, np.abs(dl).max())
+
+
 @pytest.mark.gpu
 def test_hip_library_agrees_with_cpu_backend_on_the_same_inputs(dev):
     """Two implementations of the same entry points (HIP kernels vs plain C): integer outputs identical, fp32 outputs to
