@@ -280,7 +280,7 @@ class VLGHead(nn.Module):
         self.load_text_embedding = None
         # memory plan (see _chunk_plan / _head_forward): class-images per chunk, allocated-bytes ceiling above which a
         # chunk's activations are not kept but recomputed in backward (None: keep everything), live sample ranges
-        self.chunk_class_images = 1344
+        self.chunk_class_images = int(_os.environ.get("SVL_HEAD_CHUNK", "1344"))
         self.act_limit_bytes = None
         self.remat = None              # None: decide per step from the activation budget (_remat_decision)
         self._bwd_ranges = None
