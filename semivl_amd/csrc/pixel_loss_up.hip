@@ -14,6 +14,7 @@
 // by each block that needs them instead of being exchanged through atomics.
 #include "svl_common.h"
 #include <atomic>
+#include <stdlib.h>
 
 namespace {
 
@@ -22,7 +23,6 @@ constexpr int LR = TC + 3;       // staged cells per edge: one halo cell on eith
                                  // so that a pixel's second column tap is ALWAYS the next staged cell (one ds_read2_b32 per row)
 constexpr int CSTR = LR * LR;    // class stride of the staged tile
 constexpr int RMAX = 40;         // full-resolution rows / columns a block evaluates (checked per tile on the host)
-constexpr int PSTR = RMAX * RMAX;
 constexpr int CG = 8;            // classes per gradient round
 constexpr int NT = 512;          // threads of the cross-entropy kernel (CG x TC x TC)
 constexpr int MAXF = 10;         // full-resolution columns in one cell's footprint
@@ -45,6 +45,7 @@ struct UpP {
   float* conf_out;       // softmax-max mode
   int64_t* label_out;
   int ncy, ncx;
+  int pstr;             // stride of the per-pixel LDS arrays: >= the largest region (rows x columns) of any block
 };
 
 __device__ __host__ inline float up_scale(int in, int out, bool align) {
@@ -100,9 +101,13 @@ struct Taps {
 __device__ __forceinline__ float up_interp(const float* __restrict__ t, const Taps& k) {
   return k.ly0 * (k.lx0 * t[k.o00] + k.lx1 * t[k.o00 + 1]) + k.ly1 * (k.lx0 * t[k.o10] + k.lx1 * t[k.o10 + 1]);
 }
+// The cross-entropy kernel works in BASE 2: the staged logits are multiplied by log2(e) once (the resize is linear), so every
+// exponential of the two class loops is ONE v_exp_f32 instead of the ~12 instructions of expf (the compiler then unrolls the
+// class loops by four on packed fp32 math); log-sum-exp and the loss terms are scaled back by ln 2 once per pixel.
+constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
 // one branch-free step of the online softmax (one exponential per class; m = -inf at the start gives s = 1)
 __device__ __forceinline__ void up_online(float x, float& m, float& s) {
-  const float d = x - m, e = expf(-fabsf(d));
+  const float d = x - m, e = __builtin_amdgcn_exp2f(-fabsf(d));
   s = d > 0.f ? fmaf(s, e, 1.f) : s + e;
   m = fmaxf(m, x);
 }
@@ -172,13 +177,15 @@ __global__ __launch_bounds__(NT) void ce_up_kernel(const UpP p) {
   __shared__ float rl0[RMAX], rl1[RMAX], cl0[RMAX], cl1[RMAX];
   __shared__ int cr_lo[TC], cr_hi[TC], cc_lo[TC], cc_hi[TC];
   __shared__ float red[NT / 64][4];
+  // (the pixel arrays are strided by the launch's largest region, not by RMAX^2: 72 KB in all at N = 21 and 128 -> 512, two
+  //  blocks per CU -- the kernel waits on LDS round trips more than on anything else, profiles/r5_h_pmc_sq_ce_up.txt)
+  const int PS = p.pstr;
   float* tile = smem;                       // [N][CSTR]
-  float* st_lse = smem + p.N * CSTR;        // per evaluated pixel: log-sum-exp, g_t + g_m, g_t, g_m, (target | guidance << 16)
-  float* st_gs = st_lse + PSTR;
-  float* st_gt = st_gs + PSTR;
-  float* st_gm = st_gt + PSTR;
-  int* st_ix = reinterpret_cast<int*>(st_gm + PSTR);
-  float* dbuf = st_gm + 2 * PSTR;           // [CG][PSTR]: d(loss)/d(resized logit) of one class round
+  float* st_lse = smem + p.N * CSTR;        // per evaluated pixel: log-sum-exp, g_t, g_m, (target | guidance << 16)
+  float* st_gt = st_lse + PS;
+  float* st_gm = st_gt + PS;
+  int* st_ix = reinterpret_cast<int*>(st_gm + PS);
+  float* dbuf = st_gm + 2 * PS;             // [CG][PS]: d(loss)/d(resized logit) of one class round
 
   const int tid = threadIdx.x;
   const int per = p.ncy * p.ncx;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(NT) void ce_up_kernel(const UpP p) {
       const float* g = p.logits + (long)b * p.N * p.h * p.w + (long)imin_(s0y + cr, p.h - 1) * p.w + imin_(s0x + cc, p.w - 1);
       float* d = tile + cr * LR + cc;
       const long hw = (long)p.h * p.w;
-      for (int c = cl; c < p.N; c += NT / 128) d[c * CSTR] = g[c * hw];
+      for (int c = cl; c < p.N; c += NT / 128) d[c * CSTR] = g[c * hw] * LOG2E;
     }
   }
   __syncthreads();
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(NT) void ce_up_kernel(const UpP p) {
     for (int c = 0; c < p.N; ++c) {
       up_online(up_interp(tile + c * CSTR, k), m, s);
     }
-    const float lse = m + logf(s);
+    const float lse = m + log2f(s);                 // (base 2, like the staged logits)
     const bool t_ok = !(p.use_ignore_t && t == 255);
     const int ti = t_ok ? (int)t : -1;
     const int mi = (p.mc && mm != 255) ? (int)mm : -1;
@@ -262,14 +269,13 @@ __global__ __launch_bounds__(NT) void ce_up_kernel(const UpP p) {
       const float xt = (ti >= 0 && ti < p.N) ? up_interp(tile + ti * CSTR, k) : 0.f;
       const float xm = (mi >= 0 && mi < p.N) ? up_interp(tile + mi * CSTR, k) : 0.f;
       n_v += valid ? 1.f : 0.f;
-      s_t += t_ok ? w * (lse - xt) : 0.f;
-      s_m += mi >= 0 ? lse - xm : 0.f;
+      s_t += t_ok ? w * (LN2 * (lse - xt)) : 0.f;
+      s_m += mi >= 0 ? LN2 * (lse - xm) : 0.f;
       s_c += sc;
     }
     const float gt = t_ok ? g0 * w : 0.f;
     const float gm = mi >= 0 ? g1 : 0.f;
     st_lse[px] = lse;
-    st_gs[px] = gt + gm;
     st_gt[px] = gt;
     st_gm[px] = gm;
     st_ix[px] = (int)((unsigned)(ti & 0xffff) | ((unsigned)mi << 16));
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(NT) void ce_up_kernel(const UpP p) {
       k.o00 = (y0 - s0y) * LR + (x0 - s0x);
       k.o10 = (ry1[r] - s0y) * LR + (x0 - s0x);
       k.ly0 = rl0[r]; k.ly1 = rl1[r]; k.lx0 = cl0[q]; k.lx1 = cl1[q];
-      const float lse = st_lse[px], gs = st_gs[px], gt = st_gt[px], gm = st_gm[px];
+      const float lse = st_lse[px], gt = st_gt[px], gm = st_gm[px], gs = gt + gm;
       const int ix = st_ix[px];
       const int ti = (int)(short)(ix & 0xffff), mi = ix >> 16;
 #pragma unroll
@@ -329,16 +335,16 @@ __global__ __launch_bounds__(NT) void ce_up_kernel(const UpP p) {
         const int c = cg0 + j;
         float d = 0.f;
         if (c < p.N && gs != 0.f) {
-          d = gs * expf(up_interp(tile + c * CSTR, k) - lse);
+          d = gs * __builtin_amdgcn_exp2f(up_interp(tile + c * CSTR, k) - lse);
           if (c == ti) d -= gt;
           if (c == mi) d -= gm;
         }
-        dbuf[j * PSTR + px] = d;
+        dbuf[j * PS + px] = d;
       }
     }
     __syncthreads();
     if (cell_ok && cg0 + bj < p.N) {
-      const float* dj = dbuf + bj * PSTR;
+      const float* dj = dbuf + bj * PS;
       float acc = 0.f;
       for (int r = rlo; r <= rhi; ++r) {
         const float wy = (ry0[r] == yl ? rl0[r] : 0.f) + (ry1[r] == yl ? rl1[r] : 0.f);
@@ -354,23 +360,26 @@ __global__ __launch_bounds__(NT) void ce_up_kernel(const UpP p) {
   }
 }
 
-inline bool up_axis_ok(int in, int out, bool align) {
+inline bool up_axis_ok(int in, int out, bool align, int* max_region = nullptr) {
   if (in < 2 || out < in) return false;
   const float sc = up_scale(in, out, align);
   if (!(sc >= MIN_SCALE)) return false;
+  int mx = 0;
   for (int t = 0; t * TC < in; ++t) {
     int c0, c1, s0, ns, r0, nr;
     up_axis<true>(t, in, out, sc, align, c0, c1, s0, ns, r0, nr);
     if (nr > RMAX || ns + 1 > LR) return false;
+    mx = nr > mx ? nr : mx;
     up_axis<false>(t, in, out, sc, align, c0, c1, s0, ns, r0, nr);
     if (nr > RMAX || ns + 1 > LR) return false;
   }
+  if (max_region) *max_region = mx;
   return true;
 }
 inline bool up_ok(int N, int h, int w, int H, int W, int align) {
   return N > 0 && N <= 160 && up_axis_ok(h, H, align != 0) && up_axis_ok(w, W, align != 0);
 }
-inline size_t ce_up_lds(int N) { return ((size_t)N * CSTR + (size_t)(5 + CG) * PSTR) * sizeof(float); }
+inline size_t ce_up_lds(int N, int pstr) { return ((size_t)N * CSTR + (size_t)(4 + CG) * pstr) * sizeof(float); }
 
 // hipFuncSetAttribute is per device: one bit per device ordinal
 bool attr_needed(std::atomic<uint64_t>& mask) {
@@ -423,11 +432,20 @@ extern "C" int svl_ce_up_fused_f32(const svl_ce_up_desc* d, svl_stream_t stream)
   p.mc = d->mc_target; p.partials = d->partials; p.dlogits = d->dlogits; p.gscale = d->gscale;
   p.img_weight = d->img_weight;
   p.ncy = (d->h + TC - 1) / TC; p.ncx = (d->w + TC - 1) / TC;
+  int my = 0, mx = 0;
+  (void)up_axis_ok(d->h, d->H, p.align != 0, &my);
+  (void)up_axis_ok(d->w, d->W, p.align != 0, &mx);
+  p.pstr = ((my * mx + 31) / 32) * 32;
+  {
+    static const char* force = getenv("SVL_CE_UP_PSTR");      // (A/B: "max" = RMAX^2 for every launch)
+    if (force && force[0] == 'm') p.pstr = RMAX * RMAX;
+  }
   static std::atomic<uint64_t> mask{0};
   if (attr_needed(mask))
     SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ce_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       158 * 1024));
-  hipLaunchKernelGGL(ce_up_kernel, dim3((unsigned)((long)d->B * p.ncy * p.ncx)), dim3(NT), ce_up_lds(d->N), (hipStream_t)stream, p);
+  hipLaunchKernelGGL(ce_up_kernel, dim3((unsigned)((long)d->B * p.ncy * p.ncx)), dim3(NT), ce_up_lds(d->N, p.pstr),
+                     (hipStream_t)stream, p);
   SVL_LAUNCH_CHECK("svl_ce_up_fused_f32");
   return SVL_OK;
 }
