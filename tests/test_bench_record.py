@@ -6,7 +6,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = "r5_l"        # the end-of-round evidence run (tools/round_end_run.sh)
+TAG = "r5_m"        # the end-of-round evidence run (tools/round_end_run.sh)
 
 
 def _line(name):
