@@ -5,6 +5,7 @@ python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -25 > gpurun_out/${T}
 # PMC records of the dominant launches (quoted by bench.py as roofline.traffic / roofline_hbm.traffic)
 X6P_FMT=1 bash tools/pmc_x6p.sh 32800 3072 768 4 > gpurun_out/${T}_pmc_x6p_ffn1.txt 2>&1   # mode 4 = FFN-1 as the step launches it (no fp32 C); fmt 1 = fp16 x 2 planes
 bash tools/pmc_ce.sh > gpurun_out/${T}_pmc_ce.txt 2>&1
+bash tools/pmc_sq.sh tools/one_ce_up.py ce_up_kernel > gpurun_out/${T}_pmc_sq_ce_up.txt 2>&1   # SQ counters of the kernel the step launches for its pixel losses
 SVL_GEMM_EMU=0 bash tools/pmc_traffic.sh tools/one_gemm.py gemm_kernel > gpurun_out/${T}_pmc_gemm_f32.txt 2>&1
 mkdir -p profiles && cp gpurun_out/pmc_x6p_traffic.json gpurun_out/pmc_ce_traffic.json gpurun_out/pmc_gemm_traffic.json profiles/ 2>/dev/null
 # kernel-trace summaries (both arithmetics) + wall-time attribution + per-dispatch rows of the dominant kernel
