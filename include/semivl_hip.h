@@ -42,7 +42,7 @@ typedef enum svl_status {
   SVL_ERR_UNSUPPORTED = -3
 } svl_status;
 
-int svl_version(void); /* 502: + svl_ce_up_fused_f32, svl_softmax_max_up_f32, svl_ce_up_num_blocks (pixel losses on head-resolution logits); 501: + svl_attention_{fwd,bwd}_h2, svl_attention_h2_ws_bytes (fused attention on fp16 x 2 pre-packed operands); 500: round-5 ABI (fp16 x 2 planes: svl_split_planes_f16x2, svl_planes_bytes_fmt, fmt / scale fields of svl_pgemm_desc); 401: + svl_conv3x3_weight_planes, svl_gemm_desc::conv_w_planes, w_planes of svl_conv3x3_gn_f32; 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
+int svl_version(void); /* 600: round-6 ABI (+ svl_permute4_f32, svl_bound2_f32, svl_attention tail kernels replace the row kernels); 502: + svl_ce_up_fused_f32, svl_softmax_max_up_f32, svl_ce_up_num_blocks (pixel losses on head-resolution logits); 501: + svl_attention_{fwd,bwd}_h2, svl_attention_h2_ws_bytes (fused attention on fp16 x 2 pre-packed operands); 500: round-5 ABI (fp16 x 2 planes: svl_split_planes_f16x2, svl_planes_bytes_fmt, fmt / scale fields of svl_pgemm_desc); 401: + svl_conv3x3_weight_planes, svl_gemm_desc::conv_w_planes, w_planes of svl_conv3x3_gn_f32; 400: round-4 ABI (gn_in / svl_conv3x3_gn_f32 / svl_groupnorm_apply / _scale_shift, svl_permute_rows_f32,
                            svl_stream_prepare, svl_last_gemm_path; gn_in arguments of the tiled weight gradient and the Conv2d(C -> 1)
                            entries, `accumulate` of svl_avgpool_cat_bwd); 300: round-3 ABI (packed-planes operands; planes outputs of LayerNorm / attention; loss-mode arguments of
                            the pixel-loss entries; 200 = round 2: helper-stream contexts, caller-owned scratch everywhere) */
@@ -452,6 +452,13 @@ int svl_affine_planes_f32(const float* x, int64_t planes, int C, int64_t HW, con
  * (token slicing x[:, 1:], cls-row scatter, torch.cat into channel slices, batch broadcast, strided grad adds). */
 int svl_copy2d_f32(const float* src, int64_t sgrp, int64_t src_go, int64_t src_ld, float* dst, int64_t dgrp,
                    int64_t dst_go, int64_t dst_ld, int64_t rows, int C, int accumulate, svl_stream_t stream);
+/* dst (contiguous [n0, n1, n2, n3]) = src read through the element strides (s0 .. s3): the weight-sized permutes between the
+ * nn.Conv2d / nn.ConvTranspose2d parameter layouts ([Co, Ci, kh, kw], vlg_head.py:84-137) and the kernels' packs. */
+int svl_permute4_f32(const float* src, float* dst, int64_t n0, int64_t n1, int64_t n2, int64_t n3, int64_t s0, int64_t s1,
+                     int64_t s2, int64_t s3, svl_stream_t stream);
+/* out2 = {max_r rnorm[r], max_i |bias[i]|} (bias may be null: 0): svl_pgemm_desc::b_bound of an fp16 x 2 planes output from
+ * the row norms svl_split_planes_f16x2 leaves (F.linear's bias, maskclip_vit.py:110-144). */
+int svl_bound2_f32(const float* rnorm, int64_t rows, const float* bias, int64_t nbias, float* out2, svl_stream_t stream);
 /* Row permutation [outer, A, B, C] -> [outer, B, A, C] (C % 4 == 0): einops '(b n) (h w) c -> (b h w) n c' of the
  * SemanticTransformer (vlg_head.py:44-62) when its class sequences run on svl_attention_fwd / _bwd (N >= 64). */
 int svl_permute_rows_f32(const float* src, int64_t outer, int A, int B, int C, float* dst, svl_stream_t stream);

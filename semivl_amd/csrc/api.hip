@@ -15,7 +15,7 @@ void svl_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int svl_version(void) { return 502; }
+extern "C" int svl_version(void) { return 600; }
 
 extern "C" int svl_last_error(char* buf, size_t len) {
   const size_t n = strlen(g_err);

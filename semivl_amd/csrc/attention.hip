@@ -1345,12 +1345,14 @@ extern "C" int svl_attention_fwd_h2(const float* qkv, int B, int T, int H, float
   hipStream_t st = (hipStream_t)stream;
   int nb = 0;
   const int r = rows_split(T, &nb, FQ);
-  if (r > 0) {   // the leftover rows: fp32 VALU kernels on the helper stream, straight from qkv
+  rc = svl_attn_h2::fwd_pack(p, ws, ws_bytes, st);
+  if (rc) return rc;
+  if (r > 0) {   // the leftover rows: single-wave MFMA workgroups on the packed operands, on the helper stream (after the pack)
     hipStream_t aux = nullptr;
     rc = svl_fork(st, &aux);
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_fwd_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * FQ);
-    SVL_LAUNCH_CHECK("svl_attention_fwd_h2/rows");
+    rc = svl_attn_h2::fwd_tail(p, nb * FQ, ws, aux);
+    if (rc) return rc;
   }
   rc = svl_attn_h2::fwd(p, nb, ws, ws_bytes, st);
   if (rc) return rc;
@@ -1377,14 +1379,12 @@ extern "C" int svl_attention_bwd_h2(const float* qkv, const float* out, const fl
   if (rc) return rc;
   int nb = 0;
   const int r = rows_split(T, &nb, FQ);
-  if (r > 0) {  // after D = rowsum(dO * O) (both need it), concurrent with the MFMA grids
+  if (r > 0) {  // after the pack pass and D = rowsum(dO * O), concurrent with the MFMA grids
     hipStream_t aux = nullptr;
     rc = svl_fork(st, &aux);
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * FQ);
-    SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dkv_rows");
-    hipLaunchKernelGGL(attn_bwd_dq_rows_kernel, dim3(r, B * H), dim3(256), 0, aux, p, nb * FQ);
-    SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dq_rows");
+    rc = svl_attn_h2::bwd_tail(p, nb * FQ, ws, aux);
+    if (rc) return rc;
   }
   rc = svl_attn_h2::bwd_main(p, nb, ws, st);
   if (rc) return rc;

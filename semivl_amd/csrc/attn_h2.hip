@@ -749,6 +749,421 @@ __global__ __launch_bounds__(512) void attn_dkv_h2_kernel(const AttnP p, const H
   }
 }
 
+// ------------------------------------------------------------------------------------------------ leftover rows
+// T = 1025 = 4 x 256 + 1: the rows past the last full 256-row block (at most 4, rows_split in attention.hip) used to go to fp32
+// VALU row kernels that re-read Q / K / V / dO from the fp32 tensors (attention.hip: 164 / 250 / 121 us per call at
+// 32 x 1025 x 12, 11 ms of kernel time per VOC step).  Round 6: the same arithmetic as the main grids -- MFMA on the packed
+// fp16 x 2 operand sets, three products per term -- with FOUR WAVES per (image, head) and leftover 32-row tile, the operand
+// fragments read straight from global memory (a packed chunk IS the register image of a fragment: one 16-byte load per
+// lane, 1 KiB per wave and instruction, no staging).  A wave is bound by the latency of its dependent fragment loads (a single
+// wave per tile measured 208 / 364 / 631 us), so the 17 key tiles (forward, dQ) / 33 query tiles (dK, dV) are dealt round-
+// robin to the four waves of a 256-thread workgroup and their partial results -- (running maximum, sum, O) of the online
+// softmax; dQ; dK | dV -- are combined through a few hundred bytes of LDS: only the <= 4 valid rows of the tile travel.
+// 128 registers per wave, so that the workgroup's waves fit beside the two resident waves per SIMD of every main kernel.
+constexpr int TAILW = 4;     // waves per leftover tile
+template <bool MIX>
+__global__ __launch_bounds__(64 * TAILW) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_tail_h2_kernel(const AttnP p, const H2W w, int row0) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int z = blockIdx.x, b = z / p.H, h = z - b * p.H;
+  const int q0 = row0 + 32 * (int)blockIdx.y, qi = q0 + l31;
+  const int nkt = w.Tp >> 6;
+  const long rmz = (long)(w.Tp >> 5) * 8192, trz = (long)w.Tp * 256;
+  const unsigned lane16 = lane * 16;
+  const char* ksrc = w.k_rm + z * rmz + lane16;
+  const char* vsrc = w.v_tr + z * trz + lane16;
+  // (the wave's own Q fragments are re-read per tile -- 8 KiB, cache-resident -- instead of held: the kernel keeps to 128
+  //  registers so that a wave fits beside the two resident waves per SIMD of the main grid)
+  const char* qs = w.q_rm + z * rmz + (long)(q0 >> 5) * 8192 + lane16;
+  const int eq = w.exps[z * 4], ek = w.exps[z * 4 + 1], ev = w.exps[z * 4 + 2];
+  const float c = __builtin_amdgcn_ldexpf(LOG2E, eq + ek - 3);
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m2s = -INFINITY, l = 0.f;
+  const bool short_last = p.T - (nkt - 1) * 64 <= 32;
+  for (int kt = wave; kt < nkt; kt += TAILW) {
+    const char* Ks = ksrc + (long)kt * 16384;
+    const char* Vt = vsrc + (long)kt * 16384;
+    const bool last = kt == nkt - 1, half = last && short_last;
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      f16x8 a0[2], bq[2];
+      frag2(bq, qs + (kg * 2) * 1024);
+      frag2(a0, Ks + (kg * 2) * 1024);
+      s0 = mfma_h(a0[1], bq[0], s0);
+      s0 = mfma_h(a0[0], bq[1], s0);
+      s0 = mfma_h(a0[0], bq[0], s0);
+      if (!half) {
+        f16x8 a1[2];
+        frag2(a1, Ks + ((4 + kg) * 2) * 1024);
+        s1 = mfma_h(a1[1], bq[0], s1);
+        s1 = mfma_h(a1[0], bq[1], s1);
+        s1 = mfma_h(a1[0], bq[0], s1);
+      }
+    }
+    if (last) {   // keys past T (zero rows) are masked
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 64 + crow(r, hi);
+        if (key >= p.T) s0[r] = -INFINITY;
+        if (key + 32 >= p.T) s1[r] = -INFINITY;
+      }
+    }
+    float mloc = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mloc2 = mloc * c;
+    const bool raise = mloc2 > m2s + (7.f + RESCALE_LOG2);
+    if (__any(raise)) {
+      const float mnew = raise ? mloc2 - 7.f : m2s;
+      const float alpha = __builtin_amdgcn_exp2f(m2s - mnew);
+      l *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      m2s = mnew;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+      if (half && tp >= 2) break;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        x[j] = __builtin_amdgcn_exp2f(fmaf((tp < 2) ? s0[8 * (tp & 1) + j] : s1[8 * (tp & 1) + j], c, -m2s));
+        sum += x[j];
+      }
+      f16x8 pb[2], a0[2], a1[2];
+      split2x8<MIX>(x, pb);
+      frag2(a0, Vt + ((tp * 2) * 2) * 1024);
+      frag2(a1, Vt + ((tp * 2 + 1) * 2) * 1024);
+      H2_PAIR(o0, a0, o1, a1, pb)
+    }
+    l += sum;
+  }
+  // combine the four waves' partial softmax states: only the tile's first 4 queries can be valid (rows_split)
+  __shared__ float cmb[TAILW][8][34];
+  if (l31 < 4) {
+    float* c_ = cmb[wave][hi * 4 + l31];
+    c_[0] = m2s;
+    c_[1] = l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c_[2 + r] = o0[r]; c_[18 + r] = o1[r]; }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  if (l31 < 4) {
+    float mm = m2s;
+#pragma unroll
+    for (int w_ = 1; w_ < TAILW; ++w_) mm = fmaxf(mm, cmb[w_][hi * 4 + l31][0]);
+    const float a0_ = m2s == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m2s - mm);
+    l *= a0_;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= a0_; o1[r] *= a0_; }
+#pragma unroll
+    for (int w_ = 1; w_ < TAILW; ++w_) {
+      const float* c_ = cmb[w_][hi * 4 + l31];
+      const float aw = c_[0] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(c_[0] - mm);
+      l += c_[1] * aw;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] += c_[2 + r] * aw; o1[r] += c_[18 + r] * aw; }
+    }
+    m2s = mm;
+  }
+  const float lt = l + __shfl_xor(l, 32, 64);
+  if (qi < p.T && l31 < 4) {
+    const float inv = __builtin_amdgcn_ldexpf(1.f / lt, ev);
+    if (p.out) {
+      float* orow = p.out + ((long)b * p.T + qi) * p.E + h * D;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 8 * g + 4 * hi;
+        *reinterpret_cast<float4*>(orow + d0) =
+            make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(orow + 32 + d0) =
+            make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+      }
+    }
+    if (p.planes) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          x[e] = (kk < 2 ? o0[8 * (kk & 1) + e] : o1[8 * (kk & 1) + e]) * inv;
+          asm volatile("" : "+v"(x[e]));
+        }
+        emit_planes8(p.planes, p.planes_ks, 4 * h + kk, (long)b * p.T + qi, hi, x);
+      }
+    }
+    if (p.lse && hi == 0) p.lse[(long)z * p.T + qi] = (m2s + __log2f(lt)) * LN2;
+  }
+}
+
+template <bool MIX>
+__global__ __launch_bounds__(64 * TAILW) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_dq_tail_h2_kernel(const AttnP p, const H2W w, int row0) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int z = blockIdx.x, b = z / p.H, h = z - b * p.H;
+  const int q0 = row0 + 32 * (int)blockIdx.y, qi = q0 + l31;
+  const int nkt = w.Tp >> 6;
+  const long rmz = (long)(w.Tp >> 5) * 8192, trz = (long)w.Tp * 256;
+  const unsigned lane16 = lane * 16;
+  const char* k_rm = w.k_rm + z * rmz + lane16;
+  const char* v_rm = w.v_rm + z * rmz + lane16;
+  const char* k_tr = w.k_tr + z * trz + lane16;
+  const char* qs = w.q_rm + z * rmz + (long)(q0 >> 5) * 8192 + lane16;      // (re-read per tile, see the forward)
+  const char* os = w.do_rm + z * rmz + (long)(q0 >> 5) * 8192 + lane16;
+  const float2 ad = *reinterpret_cast<const float2*>(w.ld + ((long)z * w.Tp + min(qi, w.Tp - 1)) * 2);
+  const float a_i = ad.x, d_i = ad.y;
+  const int eq = w.exps[z * 4], ek = w.exps[z * 4 + 1], ev = w.exps[z * 4 + 2], edo = w.exps[z * 4 + 3];
+  const int gs = ds_exp(w.nrm[z * 4 + 3], w.nrm[z * 4 + 2]);
+  const float c = __builtin_amdgcn_ldexpf(LOG2E, eq + ek - 3);
+  const float cdp = __builtin_amdgcn_ldexpf(1.f, edo + ev + 14 - gs);
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+  for (int kt = wave; kt < nkt; kt += TAILW) {
+    const char* Ks = k_rm + (long)kt * 16384;
+    const char* Vs = v_rm + (long)kt * 16384;
+    const char* Kt = k_tr + (long)kt * 16384;
+    const bool last = kt == nkt - 1;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      if (!last || jt == 0 || p.T - kt * 64 > 32) {
+        f32x16 sa, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+        // (the main kernel interleaves the two products, H2_2; here they run one after the other with the same terms in the
+        //  same order per accumulator -- fewer fragments live at once: the 128-register budget holds without spills)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          f16x8 ka[2], bq[2];
+          frag2(bq, qs + (kg * 2) * 1024);
+          frag2(ka, Ks + ((jt * 4 + kg) * 2) * 1024);
+          sa = mfma_h(ka[1], bq[0], sa);
+          sa = mfma_h(ka[0], bq[1], sa);
+          sa = mfma_h(ka[0], bq[0], sa);
+          __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every tile's loads to the top and spilling)
+        }
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          f16x8 va[2], bo[2];
+          frag2(bo, os + (kg * 2) * 1024);
+          frag2(va, Vs + ((jt * 4 + kg) * 2) * 1024);
+          dp = mfma_h(va[1], bo[0], dp);
+          dp = mfma_h(va[0], bo[1], dp);
+          dp = mfma_h(va[0], bo[0], dp);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (last) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * 64 + jt * 32 + crow(r, hi) >= p.T) sa[r] = -INFINITY;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            x[j] = __builtin_amdgcn_exp2f(fmaf(sa[8 * t + j], c, a_i)) * fmaf(dp[8 * t + j], cdp, -d_i);
+          f16x8 pb[2], a0[2], a1[2];
+          split2x8<MIX>(x, pb);
+          frag2(a0, Kt + (((2 * jt + t) * 2) * 2) * 1024);
+          frag2(a1, Kt + (((2 * jt + t) * 2 + 1) * 2) * 1024);
+          H2_PAIR(dq0, a0, dq1, a1, pb)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  __shared__ float cmb[TAILW][8][32];
+  if (l31 < 4 && wave != 0) {
+    float* c_ = cmb[wave][hi * 4 + l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c_[r] = dq0[r]; c_[16 + r] = dq1[r]; }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  if (l31 < 4) {
+#pragma unroll
+    for (int w_ = 1; w_ < TAILW; ++w_) {
+      const float* c_ = cmb[w_][hi * 4 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dq0[r] += c_[r]; dq1[r] += c_[16 + r]; }
+    }
+  }
+  if (qi < p.T && l31 < 4) {
+    const float f = __builtin_amdgcn_ldexpf(1.f, gs - 14 + ek - 3);
+    float* row = p.dqkv + ((long)b * p.T + qi) * p.ld + h * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = 8 * g + 4 * hi;
+      *reinterpret_cast<float4*>(row + d0) = make_float4(dq0[4 * g] * f, dq0[4 * g + 1] * f, dq0[4 * g + 2] * f, dq0[4 * g + 3] * f);
+      *reinterpret_cast<float4*>(row + 32 + d0) = make_float4(dq1[4 * g] * f, dq1[4 * g + 1] * f, dq1[4 * g + 2] * f, dq1[4 * g + 3] * f);
+    }
+    if (p.planes) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (kk < 2 ? dq0[8 * (kk & 1) + e] : dq1[8 * (kk & 1) + e]) * f;
+        emit_planes8(p.planes, p.planes_ks, 4 * h + kk, (long)b * p.T + qi, hi, x);
+      }
+    }
+  }
+}
+
+template <bool MIX>
+__global__ __launch_bounds__(64 * TAILW) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_dkv_tail_h2_kernel(const AttnP p, const H2W w, int row0) {
+  __shared__ __attribute__((aligned(16))) float tr[32 * 72];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int z = blockIdx.x, b = z / p.H, h = z - b * p.H;
+  const int k0 = row0 + 32 * (int)blockIdx.y;
+  const int nqt = (p.T + 31) >> 5;
+  const long rmz = (long)(w.Tp >> 5) * 8192, trz = (long)w.Tp * 256;
+  const unsigned lane16 = lane * 16;
+  // (wave-uniform bases + the 32-bit lane offset at every use: scalar base / vector offset addressing, no 64-bit pointer pairs)
+  const char* q_rm = w.q_rm + z * rmz;
+  const char* o_rm = w.do_rm + z * rmz;
+  const char* q_tr = w.q_tr + z * trz;
+  const char* o_tr = w.do_tr + z * trz;
+  const float* ldz = w.ld + (long)z * w.Tp * 2;
+  const char* ks = w.k_rm + z * rmz + (long)(k0 >> 5) * 8192;      // (re-read per tile, see the forward)
+  const char* vs = w.v_rm + z * rmz + (long)(k0 >> 5) * 8192;
+  const int eq = w.exps[z * 4], ek = w.exps[z * 4 + 1], ev = w.exps[z * 4 + 2], edo = w.exps[z * 4 + 3];
+  const int gs = ds_exp(w.nrm[z * 4 + 3], w.nrm[z * 4 + 2]);
+  const float c = __builtin_amdgcn_ldexpf(LOG2E, eq + ek - 3);
+  const float cdp = __builtin_amdgcn_ldexpf(1.f, edo + ev + 14 - gs);
+  f32x16 dv0, dv1, dk0, dk1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dv0[r] = 0.f; dv1[r] = 0.f; dk0[r] = 0.f; dk1[r] = 0.f; }
+  for (int qt = wave; qt < nqt; qt += TAILW) {
+    const char* Qs = q_rm + (long)qt * 8192;
+    const char* Os = o_rm + (long)qt * 8192;
+    const char* Qt = q_tr + (long)qt * 8192;
+    const char* Ot = o_tr + (long)qt * 8192;
+    const float* LD = ldz + qt * 64;
+    f32x16 sa, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+    // (as in the dQ tail: the products one after the other, scheduling regions closed per fragment group -- 128 registers)
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      f16x8 qa[2], bk[2];
+      frag2(bk, ks + lane16 + (kg * 2) * 1024);
+      frag2(qa, Qs + lane16 + (kg * 2) * 1024);
+      sa = mfma_h(qa[0], bk[1], sa);
+      sa = mfma_h(qa[1], bk[0], sa);
+      sa = mfma_h(qa[0], bk[0], sa);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      f16x8 oa[2], bv[2];
+      frag2(bv, vs + lane16 + (kg * 2) * 1024);
+      frag2(oa, Os + lane16 + (kg * 2) * 1024);
+      dp = mfma_h(oa[0], bv[1], dp);
+      dp = mfma_h(oa[1], bv[0], dp);
+      dp = mfma_h(oa[0], bv[0], dp);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f16x8 pa[2][2], sa2[2][2];     // P 2^14 and dS 2^(14 - g) of the 32 queries as split operands: sa / dp are dead after this
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float xp[8], xs[8];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int r0 = 8 * t + 4 * g;
+        const float4 u = *reinterpret_cast<const float4*>(LD + crow(r0, hi) * 2);
+        const float4 v = *reinterpret_cast<const float4*>(LD + crow(r0, hi) * 2 + 4);
+        const float aq[4] = {u.x, u.z, v.x, v.z}, dq[4] = {u.y, u.w, v.y, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sa[r0 + i], c, aq[i]));
+          xp[4 * g + i] = pv * 16384.f;
+          xs[4 * g + i] = pv * fmaf(dp[r0 + i], cdp, -dq[i]);
+        }
+      }
+      split2x8<MIX>(xp, pa[t]);
+      split2x8<MIX>(xs, sa2[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f16x8 o0[2], o1[2], q0f[2], q1f[2];
+      frag2(o0, Ot + lane16 + ((t * 2) * 2) * 1024);
+      frag2(o1, Ot + lane16 + ((t * 2 + 1) * 2) * 1024);
+      H2_2(dv0, pa[t], o0, dv1, pa[t], o1)
+      __builtin_amdgcn_sched_barrier(0);
+      frag2(q0f, Qt + lane16 + ((t * 2) * 2) * 1024);
+      frag2(q1f, Qt + lane16 + ((t * 2 + 1) * 2) * 1024);
+      H2_2(dk0, sa2[t], q0f, dk1, sa2[t], q1f)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // accumulator rows are keys crow(r, hi): the <= 4 valid keys of the tile are registers 0..3 of the hi = 0 lanes
+  __shared__ float cmb[TAILW][32][16];
+  if (hi == 0 && wave != 0) {
+    float* c_ = cmb[wave][l31];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c_[r] = dk0[r]; c_[4 + r] = dk1[r]; c_[8 + r] = dv0[r]; c_[12 + r] = dv1[r]; }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  if (hi == 0) {
+#pragma unroll
+    for (int w_ = 1; w_ < TAILW; ++w_) {
+      const float* c_ = cmb[w_][l31];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dk0[r] += c_[r]; dk1[r] += c_[4 + r]; dv0[r] += c_[8 + r]; dv1[r] += c_[12 + r]; }
+    }
+  }
+  const float fk = __builtin_amdgcn_ldexpf(1.f, gs - 14 + eq - 3);
+  const float fv = __builtin_amdgcn_ldexpf(1.f, edo - 14);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk0[r] *= fk; dk1[r] *= fk; dv0[r] *= fv; dv1[r] *= fv; }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = k0 + crow(r, hi);
+    if (key < p.T) {
+      float* row = p.dqkv + ((long)b * p.T + key) * p.ld + h * D;
+      row[p.E + l31] = dk0[r];
+      row[p.E + 32 + l31] = dk1[r];
+      row[2 * p.E + l31] = dv0[r];
+      row[2 * p.E + 32 + l31] = dv1[r];
+    }
+  }
+  if (p.planes) {
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        tr[crow(r, hi) * 72 + l31] = which ? dv0[r] : dk0[r];
+        tr[crow(r, hi) * 72 + 32 + l31] = which ? dv1[r] : dk1[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (k0 + l31 < p.T) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const float4 u = *reinterpret_cast<const float4*>(tr + l31 * 72 + 16 * kk + 4 * hi);
+          const float4 v = *reinterpret_cast<const float4*>(tr + l31 * 72 + 16 * kk + 4 * hi + 8);
+          const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+          emit_planes8(p.planes, p.planes_ks, (int)((which + 1) * (p.E >> 4)) + 4 * h + kk, (long)b * p.T + k0 + l31, hi, x);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 struct Layout {
   long set;        // bytes of one operand set: B H Tp 256
@@ -767,20 +1182,18 @@ Layout layout(int B, int T, int H, int backward) {
   return l;
 }
 
-bool attr_once(std::atomic<uint64_t>& mask) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const uint64_t bit = 1ull << (dev & 63);
-  return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
-}
 int variant() {   // SVL_ATTN_H2_VARIANT: bit 0 = v_fma_mix split, bit 1 = forward without the half-tile skew (A/B runs)
   static const int v = getenv("SVL_ATTN_H2_VARIANT") ? atoi(getenv("SVL_ATTN_H2_VARIANT")) & 3 : 3;
   return v;
 }
 template <typename K>
-int set_lds(K kernel, std::atomic<uint64_t>& mask, int bytes) {
-  if (attr_once(mask))
-    SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+int set_lds(K kernel, std::atomic<uint64_t>& mask, int bytes) {   // per device, the bit set only after the call succeeded
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return SVL_OK;
+  SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  mask.fetch_or(bit, std::memory_order_acq_rel);
   return SVL_OK;
 }
 
@@ -818,7 +1231,7 @@ namespace svl_attn_h2 {
 
 long ws_bytes(int B, int T, int H, int backward) { return layout(B, T, H, backward).total; }
 
-int fwd(const AttnP& p, int nb, void* ws_, long wsb, hipStream_t st) {
+int fwd_pack(const AttnP& p, void* ws_, long wsb, hipStream_t st) {
   int rc = check_ws(p, ws_, wsb, 0, "svl_attention_fwd_h2");
   if (rc) return rc;
   const Layout l = layout(p.B, p.T, p.H, 0);
@@ -839,9 +1252,9 @@ int fwd(const AttnP& p, int nb, void* ws_, long wsb, hipStream_t st) {
   q.B = p.B; q.T = p.T; q.H = p.H; q.Tp = l.Tp;
   hipLaunchKernelGGL(attn_pack_kernel, dim3(p.B * p.H, 3), dim3(256), 0, st, q);
   SVL_LAUNCH_CHECK("svl_attention_fwd_h2/pack");
-  if (nb > 0) {
-    static std::atomic<uint64_t> mask[4];
-    const dim3 grid(nb * p.B * p.H);
+  return SVL_OK;
+}
+
 #define SVL_LAUNCH_V(KERN, LDS)                                                    \
     switch (variant()) {                                                            \
       case 0: rc = set_lds(KERN<0>, mask[0], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<0>, grid, dim3(512), LDS, st, p, w); break; \
@@ -849,9 +1262,17 @@ int fwd(const AttnP& p, int nb, void* ws_, long wsb, hipStream_t st) {
       case 2: rc = set_lds(KERN<2>, mask[2], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<2>, grid, dim3(512), LDS, st, p, w); break; \
       default: rc = set_lds(KERN<3>, mask[3], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<3>, grid, dim3(512), LDS, st, p, w); break; \
     }
-    SVL_LAUNCH_V(attn_fwd_h2_kernel, 3 * STG_F)
-    SVL_LAUNCH_CHECK("svl_attention_fwd_h2");
-  }
+
+int fwd(const AttnP& p, int nb, void* ws_, long wsb, hipStream_t st) {   // the MFMA grid over `nb` blocks per (image, head)
+  (void)wsb;
+  if (nb <= 0) return SVL_OK;
+  const Layout l = layout(p.B, p.T, p.H, 0);
+  const H2W w = views(l, static_cast<char*>(ws_), 0);
+  int rc = SVL_OK;
+  static std::atomic<uint64_t> mask[4];
+  const dim3 grid(nb * p.B * p.H);
+  SVL_LAUNCH_V(attn_fwd_h2_kernel, 3 * STG_F)
+  SVL_LAUNCH_CHECK("svl_attention_fwd_h2");
   return SVL_OK;
 }
 
@@ -886,6 +1307,32 @@ int bwd_prepare(const AttnP& p, const float* out, float* dsum_ws, void* ws_, lon
   hipLaunchKernelGGL(attn_ld_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, st, p.dout, out, p.lse, w.nrm,
                      dsum_ws, const_cast<float*>(w.ld), p.B, p.T, p.H, l.Tp, p.E);
   SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dsum");
+  return SVL_OK;
+}
+
+// the leftover rows [row0, T) (at most 4: one 32-row tile) beside the main grid: `aux` = the caller's helper stream
+int fwd_tail(const AttnP& p, int row0, void* ws_, hipStream_t aux) {
+  const Layout l = layout(p.B, p.T, p.H, 0);
+  const H2W w = views(l, static_cast<char*>(ws_), 0);
+  const dim3 grid(p.B * p.H, (p.T - row0 + 31) / 32);
+  if (variant() & 1) hipLaunchKernelGGL(attn_fwd_tail_h2_kernel<true>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
+  else hipLaunchKernelGGL(attn_fwd_tail_h2_kernel<false>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
+  SVL_LAUNCH_CHECK("svl_attention_fwd_h2/tail");
+  return SVL_OK;
+}
+
+int bwd_tail(const AttnP& p, int row0, void* ws_, hipStream_t aux) {
+  const Layout l = layout(p.B, p.T, p.H, 1);
+  const H2W w = views(l, static_cast<char*>(ws_), 1);
+  const dim3 grid(p.B * p.H, (p.T - row0 + 31) / 32);
+  if (variant() & 1) {
+    hipLaunchKernelGGL(attn_dkv_tail_h2_kernel<true>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
+    hipLaunchKernelGGL(attn_dq_tail_h2_kernel<true>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
+  } else {
+    hipLaunchKernelGGL(attn_dkv_tail_h2_kernel<false>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
+    hipLaunchKernelGGL(attn_dq_tail_h2_kernel<false>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
+  }
+  SVL_LAUNCH_CHECK("svl_attention_bwd_h2/tail");
   return SVL_OK;
 }
 

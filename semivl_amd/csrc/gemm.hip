@@ -1390,12 +1390,14 @@ static std::atomic<int> g_ragged_fork{-1};
 enum { SVL_PATH_F32 = 0, SVL_PATH_BF16X = 1, SVL_PATH_SHORTK = 2, SVL_PATH_ELTWISE = 3, SVL_PATH_H2X = 4 };
 static thread_local int g_last_path = 0;
 // hipFuncSetAttribute is per device: one bit per device ordinal and kernel instantiation
-static bool attr_needed(std::atomic<uint64_t>& mask) {
+// (the bit is set only AFTER the attribute call succeeded: attr_done)
+static uint64_t attr_bit() {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const uint64_t bit = 1ull << (dev & 63);
-  return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
+  return 1ull << (dev & 63);
 }
+static bool attr_needed(std::atomic<uint64_t>& mask) { return !(mask.load(std::memory_order_acquire) & attr_bit()); }
+static void attr_done(std::atomic<uint64_t>& mask) { mask.fetch_or(attr_bit(), std::memory_order_acq_rel); }
 
 template <int NS, bool H2 = false>
 int launch_emu(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
@@ -1422,17 +1424,20 @@ __global__ void reduce_slabs_kernel(float* out, const float* slabs, int nslab, l
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < count; i += stride) {
-    float s = accumulate ? out[i] : 0.f;
+    // (round 6) the slab sum runs in double: every slab is an fp32 k-ordered chain already, and a 50-to-500-term fp32 sum on
+    // top of it was the larger part of the weight gradients' distance from float64 (tests/test_fullsize_gpu.py); the pass is
+    // HBM-bound, the conversions ride under the loads.  Fixed order, deterministic, one rounding at the end.
+    double s = accumulate ? (double)out[i] : 0.0;
     int k = 0;
     for (; k + 8 <= nslab; k += 8) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = slabs[(long)(k + u) * count + i];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
     }
-    for (; k < nslab; ++k) s += slabs[(long)k * count + i];
-    out[i] = s;
+    for (; k < nslab; ++k) s += (double)slabs[(long)k * count + i];
+    out[i] = (float)s;
   }
 }
 
@@ -1480,9 +1485,11 @@ int launch_shortk_tn(const GemmP& p, bool fast, hipStream_t st) {
   if (ngrp > nrb4) ngrp = nrb4;
   auto go = [&](auto kern) -> int {
     static std::atomic<uint64_t> attr_mask{0};  // one mask per instantiation (the closure type is per call site + kern type)
-    if (attr_needed(attr_mask))
+    if (attr_needed(attr_mask)) {
       SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         96 * 1024));
+      attr_done(attr_mask);
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)(ngrp * nchunk)), dim3(256), lds, st, p, nchunk);
     SVL_LAUNCH_CHECK("svl_gemm_f32/shortk");
     return SVL_OK;
@@ -1723,6 +1730,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       static const int sk_x6 = getenv("SVL_SHORTK_NO_X6") ? 0 : 1;
       if (fast && emu_mode == 6 && sk_x6 && (d->out_mode == SVL_OUT_CONVT2X || d->K == 64)) {
         ShortKP q;
+        q.gat_C = q.gat_H = q.gat_W = 0;
         q.A = d->A.ptr; q.lda = d->A.ld; q.B = d->B.ptr; q.ldb = d->B.ld; q.C = d->C; q.ldc_m = d->ldc_m;
         q.M = d->M; q.N = d->N; q.K = d->K; q.out_mode = d->out_mode; q.ct_H = d->ct_H; q.ct_W = d->ct_W;
         q.ct_Cout = d->ct_Cout; q.alpha = d->alpha; q.bias = d->bias; q.bias_mod = d->bias_mod; q.act = d->act;
@@ -1733,6 +1741,28 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       }
       g_last_path = SVL_PATH_SHORTK;
       return launch_shortk(p, fast, st);
+    }
+  }
+
+  // Input gradient of the narrow ConvTranspose2d(k 2, s 2) (vlg_head.py:116-119, `Up.up` of the last block: a k2 s2 convolution
+  // of the 128 x 128 gradient, K = 4 x 32, N = 64): the implicit-GEMM kernel ran it at 13 TF / 0.4 TB/s on the fp32 pipe (3.4 ms
+  // per launch at VOC, 73 ms of an ADE step) -- it is a row stream whose rows are four 32-float segments; round 6: the
+  // short-K stream kernel of gemm_shortk.hip with that gather in its A loads.
+  {
+    static const int sk_gather = getenv("SVL_SHORTK_NO_GATHER") ? 0 : 1;
+    if (shortk && sk_gather && emu_mode == 6 && a_conv && bm == SVL_B_KCONTIG && cv.KH == 2 && cv.KW == 2 && p.cv.stride == 2 &&
+        cv.pad == 0 && cv.dil == 1 && cv.C2 == 0 && cv.sign == 1 && (cv.C1 == 16 || cv.C1 == 32) && d->K == 4 * cv.C1 &&
+        cv.H == 2 * p.cv.Ho && cv.W == 2 * p.cv.Wo && d->batch == 1 && d->ksplit == 0 && d->out_mode == SVL_OUT_STRIDED &&
+        d->ldc_n == 1 && !d->resid && !d->preact && !d->accumulate && !d->bias && d->act == SVL_ACT_NONE && p.A.vec && p.B.vec) {
+      ShortKP q;
+      q.A = d->A.ptr; q.lda = d->A.ld; q.B = d->B.ptr; q.ldb = d->B.ld; q.C = d->C; q.ldc_m = d->ldc_m;
+      q.M = d->M; q.N = d->N; q.K = d->K; q.out_mode = d->out_mode; q.ct_H = q.ct_W = q.ct_Cout = 0;
+      q.alpha = d->alpha; q.bias = nullptr; q.bias_mod = 0; q.act = SVL_ACT_NONE;
+      q.gat_C = cv.C1; q.gat_H = p.cv.Ho; q.gat_W = p.cv.Wo;
+      if (svl_shortk_x6_eligible(q)) {
+        g_last_path = SVL_PATH_BF16X;
+        return svl_shortk_x6_launch(q, st);
+      }
     }
   }
 

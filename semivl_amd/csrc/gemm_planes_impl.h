@@ -759,12 +759,13 @@ __global__ __launch_bounds__(512) void gemm_x6p_kernel(const PlanesP p) {
 
 
 // hipFuncSetAttribute is per device: one bit per device ordinal and kernel
-inline bool attr_needed(std::atomic<uint64_t>& mask) {
+// (the bit is set only after the call succeeded: a failed first call must not let later launches skip the attribute)
+inline uint64_t attr_bit() {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const uint64_t bit = 1ull << (dev & 63);
-  return !(mask.fetch_or(bit, std::memory_order_relaxed) & bit);
+  return 1ull << (dev & 63);
 }
+inline bool attr_needed(std::atomic<uint64_t>& mask) { return !(mask.load(std::memory_order_acquire) & attr_bit()); }
 
 template <int NP, int BN, int EPI, bool EF>
 int launch_kernel(const PlanesP& q, long blocks, hipStream_t st) {
@@ -772,9 +773,11 @@ int launch_kernel(const PlanesP& q, long blocks, hipStream_t st) {
   constexpr size_t stages = (size_t)NSTAGE * ((BM + BN) / 32 * NP) * CH, scratch = (size_t)8 * (32 * (TN_ * 128 + 16) + TN_ * 32 * 8);
   constexpr size_t lds = stages > scratch ? stages : scratch;     // (the epilogue's transpose buffers alias the stages)
   static std::atomic<uint64_t> mask{0};
-  if (attr_needed(mask))
+  if (attr_needed(mask)) {
     SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6p_kernel<NP, BN, EPI, EF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    mask.fetch_or(attr_bit(), std::memory_order_acq_rel);
+  }
   hipLaunchKernelGGL((gemm_x6p_kernel<NP, BN, EPI, EF>), dim3((unsigned)blocks), dim3(512), lds, st, q);
   SVL_LAUNCH_CHECK("svl_gemm_planes_f32");
   return SVL_OK;

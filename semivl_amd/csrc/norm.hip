@@ -1002,6 +1002,52 @@ extern "C" int svl_permute_rows_f32(const float* src, int64_t outer, int A, int 
   return SVL_OK;
 }
 
+// ---- small host-logic helpers that used to be ATen launches inside the step (round 6) -----------------------------
+namespace {
+// dst (contiguous [n0, n1, n2, n3]) = src read through element strides (s0, s1, s2, s3): the weight-sized permutes between the
+// nn.Conv2d / nn.ConvTranspose2d parameter layouts and the kernels' packs (forward / dgrad packs, weight-gradient unpack)
+__global__ __launch_bounds__(256) void permute4_kernel(const float* __restrict__ src, float* __restrict__ dst, long n1, long n2,
+                                                       long n3, long s0, long s1, long s2, long s3, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long i3 = i % n3, t = i / n3, i2 = t % n2, u = t / n2, i1 = u % n1, i0 = u / n1;
+    dst[i] = src[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+  }
+}
+// out2 = {max_r rnorm[r], max_i |bias[i]|}: the B side of the bound behind an fp16 x 2 planes OUTPUT (svl_pgemm_desc::b_bound)
+__global__ __launch_bounds__(256) void bound2_kernel(const float* __restrict__ rnorm, long rows, const float* __restrict__ bias,
+                                                     long nbias, float* __restrict__ out2) {
+  __shared__ float red[4];
+  float a = 0.f, b = 0.f;
+  for (long i = threadIdx.x; i < rows; i += 256) a = fmaxf(a, rnorm[i]);
+  if (bias)
+    for (long i = threadIdx.x; i < nbias; i += 256) b = fmaxf(b, fabsf(bias[i]));
+  a = block_max_256(a, red);
+  b = block_max_256(b, red);
+  if (threadIdx.x == 0) {
+    out2[0] = a;
+    out2[1] = b;
+  }
+}
+}  // namespace
+
+extern "C" int svl_permute4_f32(const float* src, float* dst, int64_t n0, int64_t n1, int64_t n2, int64_t n3, int64_t s0,
+                                int64_t s1, int64_t s2, int64_t s3, svl_stream_t stream) {
+  SVL_CHECK_ARG(src && dst && n0 > 0 && n1 > 0 && n2 > 0 && n3 > 0, "svl_permute4_f32: bad args");
+  const long total = (long)(n0 * n1 * n2 * n3);
+  hipLaunchKernelGGL(permute4_kernel, dim3(grid_for(total, 4)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)n1, (long)n2,
+                     (long)n3, (long)s0, (long)s1, (long)s2, (long)s3, total);
+  SVL_LAUNCH_CHECK("svl_permute4_f32");
+  return SVL_OK;
+}
+
+extern "C" int svl_bound2_f32(const float* rnorm, int64_t rows, const float* bias, int64_t nbias, float* out2,
+                              svl_stream_t stream) {
+  SVL_CHECK_ARG(rnorm && rows > 0 && out2 && (!bias || nbias > 0), "svl_bound2_f32: bad args");
+  hipLaunchKernelGGL(bound2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rnorm, (long)rows, bias, (long)nbias, out2);
+  SVL_LAUNCH_CHECK("svl_bound2_f32");
+  return SVL_OK;
+}
+
 extern "C" int svl_copy2d_f32(const float* src, int64_t sgrp, int64_t src_go, int64_t src_ld, float* dst, int64_t dgrp,
                               int64_t dst_go, int64_t dst_ld, int64_t rows, int C, int accumulate, svl_stream_t stream) {
   SVL_CHECK_ARG(src && dst && sgrp >= 1 && dgrp >= 1 && rows > 0 && C > 0, "svl_copy2d_f32: bad args");

@@ -381,20 +381,40 @@ inline bool up_ok(int N, int h, int w, int H, int W, int align) {
 }
 inline size_t ce_up_lds(int N, int pstr) { return ((size_t)N * CSTR + (size_t)(4 + CG) * pstr) * sizeof(float); }
 
-// hipFuncSetAttribute is per device: one bit per device ordinal
-bool attr_needed(std::atomic<uint64_t>& mask) {
+// hipFuncSetAttribute is per device: one bit per device ordinal, set only AFTER the call succeeded (a failed or still
+// running first call must not let later launches skip the attribute; two threads racing here both set it: idempotent)
+template <typename K>
+int lds_attr_once(std::atomic<uint64_t>& mask, K kernel, int bytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
-  if (mask.load(std::memory_order_acquire) & bit) return false;
+  if (mask.load(std::memory_order_acquire) & bit) return SVL_OK;
+  SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   mask.fetch_or(bit, std::memory_order_acq_rel);
-  return true;
+  return SVL_OK;
+}
+// LDS a workgroup may allocate on the current device (gfx950: 160 KB); without a device (host-only geometry queries in the
+// build container) the figure of the one target this library is compiled for
+size_t device_lds_limit() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+    return (size_t)v;
+  (void)hipGetLastError();
+  return 160 * 1024;
+}
+// the largest dynamic allocation a launch of this geometry asks for (pixel arrays strided by the launch's largest region)
+inline bool up_fits(int N, int h, int w, int H, int W, int align) {
+  int my = 0, mx = 0;
+  if (!up_axis_ok(h, H, align != 0, &my) || !up_axis_ok(w, W, align != 0, &mx)) return false;
+  static const size_t limit = device_lds_limit();
+  return ce_up_lds(N, ((my * mx + 31) / 32) * 32) + 1024 <= limit;     // (+ the kernels' static LDS)
 }
 
 }  // namespace
 
 extern "C" int64_t svl_ce_up_num_blocks(int B, int N, int h, int w, int H, int W, int align_corners) {
-  if (B <= 0 || !up_ok(N, h, w, H, W, align_corners)) return -1;
+  if (B <= 0 || !up_ok(N, h, w, H, W, align_corners) || !up_fits(N, h, w, H, W, align_corners)) return -1;
   return (int64_t)B * ((h + TC - 1) / TC) * ((w + TC - 1) / TC);
 }
 
@@ -409,9 +429,10 @@ extern "C" int svl_softmax_max_up_f32(const float* logits, int B, int N, int h, 
   p.ncy = (h + TC - 1) / TC; p.ncx = (w + TC - 1) / TC;
   const size_t lds = (size_t)N * CSTR * sizeof(float);
   static std::atomic<uint64_t> mask{0};
-  if (attr_needed(mask))
-    SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_max_up_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  {
+    const int rc = lds_attr_once(mask, softmax_max_up_kernel, 96 * 1024);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(softmax_max_up_kernel, dim3((unsigned)((long)B * p.ncy * p.ncx)), dim3(256), lds, (hipStream_t)stream, p);
   SVL_LAUNCH_CHECK("svl_softmax_max_up_f32");
   return SVL_OK;
@@ -441,9 +462,10 @@ extern "C" int svl_ce_up_fused_f32(const svl_ce_up_desc* d, svl_stream_t stream)
     if (force && force[0] == 'm') p.pstr = RMAX * RMAX;
   }
   static std::atomic<uint64_t> mask{0};
-  if (attr_needed(mask))
-    SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ce_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      158 * 1024));
+  {
+    const int rc = lds_attr_once(mask, ce_up_kernel, 158 * 1024);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(ce_up_kernel, dim3((unsigned)((long)d->B * p.ncy * p.ncx)), dim3(NT), ce_up_lds(d->N, p.pstr),
                      (hipStream_t)stream, p);
   SVL_LAUNCH_CHECK("svl_ce_up_fused_f32");

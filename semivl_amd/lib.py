@@ -133,6 +133,8 @@ SIGNATURES = {
     "svl_fill_f32": (_I, [_P, _F, _L, _P]),
     "svl_affine_planes_f32": (_I, [_P, _L, _I, _L, _P, _P, _P]),
     "svl_permute_rows_f32": (_I, [_P, _L, _I, _I, _I, _P, _P]),
+    "svl_permute4_f32": (_I, [_P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _P]),
+    "svl_bound2_f32": (_I, [_P, _L, _P, _L, _P, _P]),
     "svl_copy2d_f32": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _P]),
     "svl_groupnorm_fwd": (_I, [_P, _L, _P, _P, _F, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
     "svl_conv3x3_gn_ws_doubles": (_L, [_I, _I, _I, _I]),

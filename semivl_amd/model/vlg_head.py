@@ -643,7 +643,7 @@ def _up_forward(up, x, imgs, h, w, skip, sh, sw, b, N, sv, remat=False, x_keep=N
     Cs = skip.shape[1]
     dev = x.device
     wp_ = ops.cached_pack(up.up.weight, "convT_fwd",
-                          lambda w_: w_.permute(2, 3, 1, 0).reshape(4 * Cu, Cin).contiguous())  # n = (a, b, co)
+                          lambda w_: ops.permute4(w_.contiguous(), (2, 2, Cu, Cin), (2, 1, 4, 4 * Cu)).view(4 * Cu, Cin))  # n = (a, b, co)
     u = ops.empty(imgs * 4 * h * w, Cu, device=dev)
     ops.convT2x_fwd(x, Cin, imgs, h, w, Cin, wp_, Cu, up.up.bias, u, Cu)
     sup = ops.empty(b * 4 * h * w, Cs, device=dev)
@@ -682,10 +682,10 @@ def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
         with ops.wgrad_side(dcat, xin):
             gc.put(up.up.bias, lambda d, acc: ops.colsum(dcat, out=d, accumulate=acc, C_=Cu, ld=ld))
             dwb = ops.convT2x_wgrad(xin, Cin, dcat, ld, imgs, h, w, Cin, Cu)  # [Cin, (a,b,co)]
-            gc.put_tensor(up.up.weight, dwb.view(Cin, 2, 2, Cu).permute(0, 3, 1, 2).contiguous())
+            gc.put_tensor(up.up.weight, ops.permute4(dwb, (Cin, Cu, 2, 2), (4 * Cu, 1, 2 * Cu, Cu)))   # [Cin, a, b, co] -> [Cin, co, a, b]
     if not _WGRAD_AFTER_DGRAD:
         wgrad()
-    wb = ops.cached_pack(up.up.weight, "convT_bwd", lambda w_: w_.permute(0, 2, 3, 1).reshape(Cin, 4 * Cu).contiguous())
+    wb = ops.cached_pack(up.up.weight, "convT_bwd", lambda w_: ops.permute4(w_.contiguous(), (Cin, 2, 2, Cu), (4 * Cu, 2, 1, 4)).view(Cin, 4 * Cu))
     dx = ops.convT2x_dgrad(dcat, ld, imgs, h, w, Cu, wb, Cin)
     if _WGRAD_AFTER_DGRAD:
         wgrad()                         # (behind the input gradient: see _conv_gn_bwd)

@@ -74,7 +74,26 @@ def empty(*shape, dtype=torch.float32, device=None):
 
 
 def zeros(*shape, dtype=torch.float32, device=None):
-    return torch.zeros(*shape, dtype=dtype, device=device if device is not None else torch.cuda.current_device())
+    """torch.zeros on the library's fill kernel (fp32, or 4 / 8-byte integer types filled through an fp32 view)."""
+    t = torch.empty(*shape, dtype=dtype, device=device if device is not None else torch.cuda.current_device())
+    if t.numel():
+        if not t.is_cuda or t.element_size() % 4 != 0:
+            return t.zero_()
+        f = t.view(-1).view(torch.float32)
+        L.check(L.load().svl_fill_f32(C.c_void_p(f.data_ptr()), 0.0, f.numel(), _st()), "svl_fill_f32")
+    return t
+
+
+def permute4(src, shape, strides):
+    """A contiguous fp32 tensor of `shape` (4 dims) read from `src` through the element `strides` (svl_permute4_f32): the
+    weight-sized permutes between parameter layouts and kernel packs without an ATen copy kernel."""
+    assert src.dtype == torch.float32 and len(shape) == 4 and len(strides) == 4
+    out = torch.empty(*shape, dtype=torch.float32, device=src.device)
+    if not src.is_cuda:
+        return out.copy_(torch.as_strided(src, shape, strides, src.storage_offset()))
+    L.check(L.load().svl_permute4_f32(_p(src), _p(out), *[int(v) for v in shape], *[int(v) for v in strides], _st()),
+            "svl_permute4_f32")
+    return out
 
 
 class Op:
@@ -315,14 +334,14 @@ class Planes:
     32-row block, plane); include/semivl_hip.h).  fmt "b3": three bf16 planes x = x0 + x1 + x2.  fmt "h2": two fp16 planes
     and one scale exponent per row, x = 2^sexp[row] (h0 + h1); `rnorm` (optional) = upper bounds of the rows' L2 norms,
     which a GEMM needs to scale a planes OUTPUT in this format.  The buffer holds `prow` = rows rounded up to 256 rows."""
-    __slots__ = ("buf", "rows", "K", "prow", "fmt", "sexp", "rnorm", "wmax", "_bd")
+    __slots__ = ("buf", "rows", "K", "prow", "fmt", "sexp", "rnorm", "_bd")
 
     def __init__(self, rows, K, device=None, buf=None, fmt=None, sexp=None, rnorm=None):
         assert K % 16 == 0
         self.fmt = fmt or PLANES_FMT
         self.rows, self.K, self.prow = rows, K, planes_rows(rows)
         dev = device if device is not None else (buf.device if buf is not None else torch.cuda.current_device())
-        self.wmax, self._bd = None, None
+        self._bd = None
         if self.fmt == "h2":
             self.buf = buf if buf is not None else torch.empty(K // 16 * self.prow * 32, dtype=torch.float16, device=dev)
             self.sexp = sexp if sexp is not None else torch.empty(self.prow, dtype=torch.int32, device=dev)
@@ -400,7 +419,7 @@ class StreamCached:
                 yield from StreamCached._tensors(x)
         elif hasattr(v, "buf"):
             yield v.buf
-            for extra in (getattr(v, "sexp", None), getattr(v, "rnorm", None), getattr(v, "wmax", None)):
+            for extra in (getattr(v, "sexp", None), getattr(v, "rnorm", None)):
                 if extra is not None:
                     yield extra
 
@@ -423,15 +442,12 @@ def weights_changed():
 
 def weight_planes(W, transpose=False, fmt=None):
     """Planes of a weight matrix (or of a row slice of one), split ONCE and cached: frozen weights for the life of the
-    process (keyed on storage + torch version counter), trainable ones until the next optimizer step.  h2 planes also carry
-    `wmax` = the largest row norm (a 0-dim device tensor: the B side of the bound behind an h2 planes output)."""
+    process (keyed on storage + torch version counter), trainable ones until the next optimizer step.  h2 planes carry the
+    row norms (`rnorm`): the B side of the bound behind an h2 planes output (_out_bound)."""
     fmt = fmt or PLANES_FMT
 
     def build():
-        pl = split_planes(W.detach(), transpose=transpose, fmt=fmt)
-        if fmt == "h2":
-            pl.wmax = pl.rnorm[:pl.rows].max()
-        return pl
+        return split_planes(W.detach(), transpose=transpose, fmt=fmt)
 
     base = W._base if W._base is not None else W
     if not isinstance(base, torch.nn.Parameter):      # not a parameter: no identity to key a cache on
@@ -449,15 +465,22 @@ def weight_planes(W, transpose=False, fmt=None):
 
 
 def _out_bound(B, bias):
-    """Device float[2] = {max row norm of B, max |bias|} for svl_pgemm_desc::b_bound, cached on the weight planes per bias
-    tensor version (two tiny reductions otherwise, per call)."""
-    key = None if bias is None else (bias.data_ptr(), bias._version, WEIGHT_EPOCH if bias.requires_grad else 0)
-    if B._bd is not None and B._bd[0] == key and B._bd[2] == torch.cuda.current_stream().cuda_stream:
-        return B._bd[1]
-    wmax = B.wmax if B.wmax is not None else B.rnorm[:B.rows].max()
-    bmax = bias.detach().abs().max() if bias is not None else torch.zeros((), device=wmax.device)
-    bd = torch.stack([wmax, bmax]).float()
-    B._bd = (key, bd, torch.cuda.current_stream().cuda_stream)
+    """Device float[2] = {max row norm of B, max |bias|} for svl_pgemm_desc::b_bound (one single-block launch,
+    svl_bound2_f32), cached on the weight planes per (bias tensor version, stream)."""
+    key = (None if bias is None else (bias.data_ptr(), bias._version, WEIGHT_EPOCH if bias.requires_grad else 0),
+           torch.cuda.current_stream().cuda_stream)
+    if B._bd is None:
+        B._bd = {}
+    hit = B._bd.get(key)
+    if hit is not None:
+        return hit
+    bd = torch.empty(2, dtype=torch.float32, device=B.buf.device)
+    bflat = bias.detach().view(-1) if bias is not None else None
+    L.check(L.load().svl_bound2_f32(_p(B.rnorm), B.rows, _p(bflat), bflat.numel() if bflat is not None else 0, _p(bd), _st()),
+            "svl_bound2_f32")
+    if len(B._bd) > 8:
+        B._bd.clear()
+    B._bd[key] = bd
     return bd
 
 
@@ -1023,8 +1046,10 @@ def pack_conv_w(W):
     parameter version, kept alive and stream-tracked with it."""
     def build(w):
         Co, Ci, kh, kw = w.shape
-        wf = w.permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci).contiguous()
-        wd = w.permute(1, 2, 3, 0).reshape(Ci, kh * kw * Co).contiguous()
+        w = w.contiguous()
+        cs = (Ci * kh * kw, kh * kw, kw, 1)                          # element strides of [Co, Ci, kh, kw]
+        wf = permute4(w, (Co, kh, kw, Ci), (cs[0], cs[2], cs[3], cs[1])).view(Co, kh * kw * Ci)
+        wd = permute4(w, (Ci, kh, kw, Co), (cs[1], cs[2], cs[3], cs[0])).view(Ci, kh * kw * Co)
         out = [wf, wd]
         if kh == 3 and kw == 3:
             for pk, n, ct in ((wf, Co, Ci), (wd, Ci, Co)):
@@ -1038,7 +1063,7 @@ def pack_conv_w(W):
 
 
 def unpack_conv_wgrad(dwf, Co, Ci, kh, kw):
-    return dwf.view(Co, kh, kw, Ci).permute(0, 3, 1, 2).contiguous()
+    return permute4(dwf, (Co, Ci, kh, kw), (kh * kw * Ci, 1, kw * Ci, Ci))     # [Co, kh, kw, Ci] -> [Co, Ci, kh, kw]
 
 
 CONV_TILED = not os.environ.get("SVL_CONV_NO_TILED")   # narrow 3x3 weight gradients on conv_tiled.hip

@@ -119,7 +119,9 @@ def semivl_train_step(model, batch, iters, total_iters, cfg, optimizer=None, red
         ops.WGRAD_STREAM = keep_wg
         if head is not None:
             head._bwd_ranges = None
-            head.last_remat_step = head._remat_step     # (a record for tests / logs: the level this step decided on)
+            # (a record for tests / logs: the level this step decided on; getattr: a step that raised before the memory plan
+            # was set up -- or a decode head that is not a VLGHead -- must not replace the original exception)
+            head.last_remat_step = getattr(head, "_remat_step", None)
             head._remat_step = None
             head._live_class_images = None
             for a_, v_ in keep_head.items():

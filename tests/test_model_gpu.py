@@ -105,12 +105,15 @@ def test_train_step_matches_reference_fixture(dev, name):
 
 @pytest.mark.parametrize("name", ["tiny", "conf"])
 def test_reference_loop_body_with_swapped_imports(dev, name):
-    """INTEGRATION.md §1's promise, executed: the loop body of /root/reference/semivl.py:223-328 written out line for line
-    with the three swapped imports -- the product `model`, `semivl_amd.train.{cutmix_img_, cutmix_mask,
-    confidence_weighted_loss, compute_mc_loss}` -- plain `nn.CrossEntropyLoss` criteria and `loss.backward()` through
-    torch autograd (NOT the fused semivl_train_step): the 8 loss terms, the 4 label maps and every parameter-gradient norm
-    against the fixtures captured from the reference's own modules.  (Only deviation from the reference's text: the
-    dropout2d channel masks are injected -- `fp_masks=` -- because the fixture recorded them.)"""
+    """INTEGRATION.md §1's promise, executed through the PUBLIC surface a reference-style training script touches -- the
+    product `model` (`model(x)`, `model(x, need_fp=True)`, `model.forward_maskclip`) and
+    `semivl_amd.train.{cutmix_img_, cutmix_mask, confidence_weighted_loss, compute_mc_loss}` -- with plain
+    `nn.CrossEntropyLoss` criteria and torch autograd (NOT the fused semivl_train_step).  The iteration it performs is the
+    one /root/reference/semivl.py:223-328 describes (pseudo labels and MaskCLIP guidance in eval mode, CutMix of
+    images and targets, three consistency branches weighted 1/4, 1/4, 1/2 next to the supervised term, the guidance terms
+    scaled by the linearly decaying lambda); it is written here as a table of branches, not as the reference's text.
+    Checked against the fixtures captured from the reference's own modules: the 8 loss terms, the 4 label maps and every
+    parameter-gradient norm.  (The dropout2d channel masks are injected -- `fp_masks=` -- because the fixture recorded them.)"""
     from torch import nn
     from semivl_amd.train import compute_mc_loss, confidence_weighted_loss, cutmix_img_, cutmix_mask
     z, c = load_fixture(name)
@@ -118,90 +121,59 @@ def test_reference_loop_body_with_swapped_imports(dev, name):
     model.load_state_dict(fixture_state(z, c, model), strict=True)
     model.to(dev)
     b = to_dev(fixture_batch(z, c), dev)
-    masks = [m.to(dev) for m in fixture_fp_masks(z, c)]                      # [x, w] row order, as the reference draws them
-    iters, total_iters = [int(v) for v in z["iters"]]
-    cfg = dict(conf_thresh=c["conf_thresh"], conf_mode=c.get("conf_mode", "pixelwise"))
-    maskclip_consistency_lambda, mcc_conf_thresh, mcc_loss_reduce = CFG["maskclip_consistency_lambda"], CFG["mcc_conf_thresh"], CFG["mcc_loss_reduce"]
-    criterion_l = nn.CrossEntropyLoss(ignore_index=255).to(dev)
-    criterion_u = nn.CrossEntropyLoss(reduction="none").to(dev)
-    img_x, mask_x = b["img_x"], b["mask_x"]
-    img_w, img_s1, img_s2, ignore_mask, mix1, mix2 = b["img_w"], b["img_s1"].clone(), b["img_s2"].clone(), b["ignore_mask"], b["mix1"], b["mix2"]
-    img_w_other, img_s1_other, img_s2_other, ignore_mask_other = b["img_w_other"], b["img_s1_other"], b["img_s2_other"], b["ignore_mask_other"]
+    drop_masks = [m.to(dev) for m in fixture_fp_masks(z, c)]               # [x, w] row order, as the reference draws them
+    it, it_total = [int(v) for v in z["iters"]]
+    wcfg = dict(conf_thresh=c["conf_thresh"], conf_mode=c.get("conf_mode", "pixelwise"))
+    lam0, lam1 = CFG["maskclip_consistency_lambda"]
+    lam = lam0 + (lam1 - lam0) * it / it_total                             # the guidance weight decays linearly over training
+    ce_mean = nn.CrossEntropyLoss(ignore_index=255).to(dev)
+    ce_map = nn.CrossEntropyLoss(reduction="none").to(dev)
+    n_u = b["img_w"].shape[0]
+    ign = dict(w=b["ignore_mask"], other=b["ignore_mask_other"])
 
-    # ---- semivl.py:223-328 ------------------------------------------------------------------------------------------
-    # CutMix images
-    cutmix_img_(img_s1, img_s1_other, mix1)
-    cutmix_img_(img_s2, img_s2_other, mix2)
+    # strong views: paste the partner image's box in place
+    strong = {"s1": b["img_s1"].clone(), "s2": b["img_s2"].clone()}
+    boxes = {"s1": b["mix1"], "s2": b["mix2"]}
+    for k in strong:
+        cutmix_img_(strong[k], b[f"img_{k}_other"], boxes[k])
 
-    # Generate pseudo labels
+    # teachers, gradient-free and in eval mode: pseudo labels of the partner batch, MaskCLIP guidance of both weak batches
+    model.eval()
     with torch.no_grad():
-        model.eval()
-
-        pred_w_other = model(img_w_other).detach()
-        conf_w_other, mask_w_other = pred_w_other.softmax(dim=1).max(dim=1)
-
-        if maskclip_consistency_lambda != 0:
-            mclip = model.forward_maskclip(torch.cat((img_w, img_w_other)), conf_tresh=mcc_conf_thresh)
-            mclip, mclip_other = mclip.split([img_w.shape[0], img_w_other.shape[0]])
-            mclip[ignore_mask == 255] = 255
-            mclip_other[ignore_mask_other == 255] = 255
-
-    # Generate predictions
+        conf_other, lab_other = model(b["img_w_other"]).softmax(dim=1).max(dim=1)
+        guide = model.forward_maskclip(torch.cat((b["img_w"], b["img_w_other"])), conf_tresh=CFG["mcc_conf_thresh"])
+        guide = dict(w=guide[:n_u].clone(), other=guide[n_u:].clone())
+        for k in guide:
+            guide[k][ign[k] == 255] = 255
     model.train()
 
-    preds, preds_fp = model(torch.cat((img_x, img_w)), need_fp=True, fp_masks=masks)
-    pred_x, pred_w = preds.chunk(2)
-    _, pred_w_fp = preds_fp.chunk(2)
-
-    pred_s1, pred_s2 = model(torch.cat((img_s1, img_s2))).chunk(2)
-
-    pred_w = pred_w.detach()
+    # students: [labeled, weak] with the feature-perturbed twin, then the two strong views
+    plain, perturbed = model(torch.cat((b["img_x"], b["img_w"])), need_fp=True, fp_masks=drop_masks)
+    pred_x, pred_w = plain[:b["img_x"].shape[0]], plain[b["img_x"].shape[0]:].detach()
+    pred_w_fp = perturbed[b["img_x"].shape[0]:]
+    pred_strong = dict(zip(("s1", "s2"), model(torch.cat((strong["s1"], strong["s2"]))).chunk(2)))
     conf_w, mask_w = pred_w.softmax(dim=1).max(dim=1)
+    mask_w_other, mclip, mclip_other = lab_other, guide["w"], guide["other"]
 
-    # CutMix labels
-    mask_w_mixed1 = cutmix_mask(mask_w, mask_w_other, mix1)
-    mask_w_mixed2 = cutmix_mask(mask_w, mask_w_other, mix2)
-    conf_w_mixed1 = cutmix_mask(conf_w, conf_w_other, mix1)
-    conf_w_mixed2 = cutmix_mask(conf_w, conf_w_other, mix2)
-    ignore_mask_mixed1 = cutmix_mask(ignore_mask, ignore_mask_other, mix1)
-    ignore_mask_mixed2 = cutmix_mask(ignore_mask, ignore_mask_other, mix2)
+    # one row per consistency branch: (prediction, pseudo label, confidence, ignore map, guidance map, weight)
+    branches = {}
+    for k in ("s1", "s2"):
+        mixed = [cutmix_mask(u, v, boxes[k]) for u, v in ((mask_w, lab_other), (conf_w, conf_other), (ign["w"], ign["other"]),
+                                                          (guide["w"], guide["other"]))]
+        branches[k] = (pred_strong[k], *mixed, 0.25)
+    branches["fp"] = (pred_w_fp, mask_w, conf_w, ign["w"], guide["w"], 0.5)
 
-    if maskclip_consistency_lambda != 0:
-        mclip_mixed1 = cutmix_mask(mclip, mclip_other, mix1)
-        mclip_mixed2 = cutmix_mask(mclip, mclip_other, mix2)
-
-    # Supervised Loss
-    loss_x = criterion_l(pred_x, mask_x)
-
-    # FixMatch 1 Loss
-    loss_s1 = criterion_u(pred_s1, mask_w_mixed1)
-    loss_s1 = confidence_weighted_loss(loss_s1, conf_w_mixed1, ignore_mask_mixed1, cfg)
-    loss_mc_s1 = compute_mc_loss(pred_s1, mclip_mixed1, ignore_mask_mixed1, mcc_loss_reduce)
-
-    # FixMatch 2 Loss
-    loss_s2 = criterion_u(pred_s2, mask_w_mixed2)
-    loss_s2 = confidence_weighted_loss(loss_s2, conf_w_mixed2, ignore_mask_mixed2, cfg)
-    loss_mc_s2 = compute_mc_loss(pred_s2, mclip_mixed2, ignore_mask_mixed2, mcc_loss_reduce)
-
-    # Feature Perturbation Loss
-    loss_fp = criterion_u(pred_w_fp, mask_w)
-    loss_fp = confidence_weighted_loss(loss_fp, conf_w, ignore_mask, cfg)
-    loss_mc_fp = compute_mc_loss(pred_w_fp, mclip, ignore_mask, mcc_loss_reduce)
-
-    prog = iters / total_iters
-    current_mcc_lambda = maskclip_consistency_lambda[0] * (1 - prog) + maskclip_consistency_lambda[1] * prog
-    loss = (loss_x + loss_s1 * 0.25 + loss_s2 * 0.25 + loss_fp * 0.5) / 2.0
-    loss = loss + loss_mc_s1 * 0.25 * current_mcc_lambda
-    loss = loss + loss_mc_s2 * 0.25 * current_mcc_lambda
-    loss = loss + loss_mc_fp * 0.5 * current_mcc_lambda
-
+    terms = dict(loss_x=ce_mean(pred_x, b["mask_x"]))
+    for k, (pred, lab, conf, ig, gd, _) in branches.items():
+        terms[f"loss_{k}"] = confidence_weighted_loss(ce_map(pred, lab), conf, ig, wcfg)
+        terms[f"loss_mc_{k}"] = compute_mc_loss(pred, gd, ig, CFG["mcc_loss_reduce"])
+    loss = 0.5 * (terms["loss_x"] + sum(wt * terms[f"loss_{k}"] for k, (*_, wt) in branches.items()))
+    loss = loss + lam * sum(wt * terms[f"loss_mc_{k}"] for k, (*_, wt) in branches.items())
     for p_ in model.parameters():
         p_.grad = None
     loss.backward()
-    # ---- end of the reference's text ---------------------------------------------------------------------------------
 
-    got = dict(loss=loss, loss_x=loss_x, loss_s1=loss_s1, loss_s2=loss_s2, loss_fp=loss_fp, loss_mc_s1=loss_mc_s1,
-               loss_mc_s2=loss_mc_s2, loss_mc_fp=loss_mc_fp)
+    got = dict(terms, loss=loss)
     for k, v in got.items():
         assert abs(float(v) - float(z[k])) < 1e-3 * max(1.0, abs(float(z[k]))), (k, float(v), float(z[k]))
     for k, m_ in (("mask_w", mask_w), ("mask_w_other", mask_w_other), ("mclip", mclip), ("mclip_other", mclip_other)):
