@@ -763,6 +763,14 @@ def main():
                                            note="python bench.py --gpus 1 --as-multi: what every rank of `--gpus N` runs with; "
                                                 "divide a multi-GPU `value` by N x THIS for scaling efficiency of the "
                                                 "communication alone")
+            # kept for the N > 1 runs the driver starts next on this node: they print their efficiency against it themselves
+            try:
+                import socket
+                json.dump(dict(host=socket.gethostname(), batch=a.batch, crop=a.crop, nclass=a.nclass, gemm_arith=a.gemm_arith,
+                               value=child["value"], ms_per_step=child["ms_per_step"], default_line_value=round(ips, 3)),
+                          open(os.path.join(ROOT, ".bench_n1_anchor.json"), "w"))
+            except OSError:
+                pass
         except Exception as e:
             out["n1_same_settings"] = dict(value=None, note=f"child run failed: {type(e).__name__}: {e}")
     if world > 1:      # the communication side of the last timed step, so that a scaling curve explains itself
@@ -771,6 +779,22 @@ def main():
         if rank == 0 and rep is not None:
             out["allreduce"] = dict(rep, payload_mb=round(opt.g.numel() * 4 / 2 ** 20, 1), backend=dist.get_backend(),
                                     world=world)
+        if rank == 0:
+            # efficiency against the N = 1 anchor with THESE settings (8 hardware queues, no weight-gradient stream), left by
+            # the N = 1 run of this node (`n1_same_settings`); the driver computes its own figure from the per-N values
+            try:
+                import socket
+                anc = json.load(open(os.path.join(ROOT, ".bench_n1_anchor.json")))
+                same = (anc.get("host") == socket.gethostname() and (anc.get("batch"), anc.get("crop"), anc.get("nclass"),
+                        anc.get("gemm_arith")) == (a.batch, a.crop, a.nclass, a.gemm_arith))
+                out["scaling_vs_n1_same_settings"] = dict(
+                    n1_same_settings=anc["value"], efficiency=round(ips / (world * anc["value"]), 4) if same else None,
+                    efficiency_vs_default_n1=round(ips / (world * anc["default_line_value"]), 4) if same else None,
+                    note="value / (N x the N = 1 run with a rank's stream settings) -- the communication's share alone; "
+                         "efficiency_vs_default_n1 divides by the default N = 1 line (weight-gradient stream on, 4 queues)" if same
+                         else "anchor file is from another host / config: not used")
+            except (OSError, ValueError, KeyError):
+                out["scaling_vs_n1_same_settings"] = dict(efficiency=None, note="no N = 1 anchor on this node yet (run `python bench.py` first)")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

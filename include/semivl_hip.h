@@ -53,6 +53,8 @@ int svl_stream_release(svl_stream_t stream);
  * process's streams onto its hardware queues in creation order: a caller that wants a reproducible map (the data-parallel
  * reducer creates the step's streams before its communication stream) creates them up front.  No reference counterpart. */
 int svl_stream_prepare(svl_stream_t stream);
+/* The helper stream svl_stream_prepare(stream) created (a hipStream_t): for probing hardware-queue sharing only. */
+int svl_stream_helper(svl_stream_t stream, void** helper);
 int svl_shutdown(void);
 int svl_num_stream_contexts(void); /* live (device, stream) helper contexts -- introspection for tests */
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
@@ -503,6 +505,22 @@ int svl_groupnorm_apply(const float* x, int64_t ldx, const float* gamma, const f
 int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* y, int64_t ldy,
                       const float* stats, const float* gamma, const float* beta, int imgs, int64_t HW, int C, int G,
                       int relu, float* dx, int64_t lddx, float* chan_sums, svl_stream_t stream);
+/* Round 6: the GroupNorm-backward statistics from the epilogue of the kernel that PRODUCES dy.  svl_conv3x3_dgrad_gnb_f32 = the
+ * input gradient of a narrow 3x3 convolution (dgrad pack w [N, 9 C1], mirrored taps; N = 32 / 64) whose result out [pix, N] is
+ * the dy of a GroupNorm + ReLU over gnb_x [pix, N] (same pixel stride ldo; vlg_head.py:120-127: conv -> GN -> ReLU -> conv):
+ * besides out it leaves chan_sums [imgs][2][N] = (sum dy', sum dy' xhat) per (image, channel) -- what svl_groupnorm_bwd's first
+ * pass computes from a read of dy and x.  gnb_table = that GroupNorm's [imgs][2][N] (scale, shift) (svl_groupnorm_scale_shift),
+ * gnb_stats its [imgs][N / 16][2] (mean, rstd); ws = svl_conv3x3_gnb_ws_doubles(...) doubles of scratch.  Returns
+ * SVL_ERR_UNSUPPORTED without launching when the split tiled kernel does not take the shape or the arithmetic mode is not 6
+ * (callers then run svl_gemm_f32 + svl_groupnorm_bwd).  svl_groupnorm_bwd_apply = svl_groupnorm_bwd's second pass on given sums. */
+int64_t svl_conv3x3_gnb_ws_doubles(int imgs, int H, int W, int N);
+int svl_conv3x3_dgrad_gnb_f32(const float* dy, int64_t lddy, int C1, const float* w, int imgs, int H, int W, int N, float* out,
+                              int64_t ldo, int accumulate, const float* gnb_x, const float* gnb_table, const float* gnb_stats,
+                              double* ws, float* chan_sums, const void* w_planes, svl_stream_t stream);
+int svl_groupnorm_bwd_apply(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* stats, const float* gamma,
+                            const float* beta, int imgs, int64_t HW, int C, int G, int relu, const float* chan_sums, float* dx,
+                            int64_t lddx, svl_stream_t stream);
+
 
 /* Fused (flash-style) multi-head self-attention of the ViT blocks, head dim 64, softmax scale 64^-0.5, fp32 MFMA
  * (or the bf16 x 6 split emulation with fp32 accumulation under svl_set_gemm_emulation(6): same error level vs fp64)

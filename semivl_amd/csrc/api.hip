@@ -98,6 +98,17 @@ extern "C" int svl_stream_prepare(svl_stream_t stream) {
   return ctx_for((hipStream_t)stream, &c);
 }
 
+// The helper stream of `stream` (created if needed): measurement aid for callers that probe which hardware queue a stream of
+// their own would share (semivl_amd/train.py: the communication stream is picked against the step's streams AND their helpers).
+extern "C" int svl_stream_helper(svl_stream_t stream, void** helper) {
+  SVL_CHECK_ARG(helper, "svl_stream_helper: null out pointer");
+  StreamCtx c;
+  const int rc = ctx_for((hipStream_t)stream, &c);
+  if (rc != SVL_OK) return rc;
+  *helper = (void*)c.aux;
+  return SVL_OK;
+}
+
 extern "C" int svl_stream_release(svl_stream_t stream) {
   int dev = 0;
   int rc = stream_device((hipStream_t)stream, &dev);

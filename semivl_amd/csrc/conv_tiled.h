@@ -15,6 +15,14 @@ struct ConvTiledP {
   const float* gn_in;                               // null, or [imgs][2][C1] (scale, shift): src1 holds PRE-normalisation
                                                     // values, the operand is relu(fma(x, scale, shift)) (GroupNorm + ReLU
                                                     // applied while the tile is staged: svl_groupnorm_scale_shift)
+  // GroupNorm-BACKWARD sums of the unit whose output gradient this launch PRODUCES (round 6; split kernel only): the result
+  // out [pix, N] is dy of a GroupNorm + ReLU over x = gnb_x [pix, N] (pixel stride = ldo); the epilogue leaves, per tile and
+  // channel, (sum dy', sum dy' xhat) with dy' = dy where fma(x, scale, shift) > 0 (the forward's own expression) in gnb_part
+  // [tiles][N][2] -- the statistics pass of svl_groupnorm_bwd (a read of dy and of x) disappears.
+  const float* gnb_x;                               // null = off
+  const float* gnb_table;                           // [imgs][2][N] (scale, shift) of that GroupNorm (svl_groupnorm_scale_shift)
+  const float* gnb_stats;                           // [imgs][N / 16][2] (mean, rstd)
+  double* gnb_part;
   const void* w_planes;                             // null, or the weights pre-split into the bf16 planes image of the split
                                                     // kernel's LDS weight buffer (svl_conv3x3_weight_planes): staging a
                                                     // slab's weights is then a copy instead of 9 N 16 splits per block

@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __shared__ __attribute__((aligned(16))) __bf16 xs[3 * XPL];
   __shared__ __attribute__((aligned(16))) __bf16 ws[3 * WPL];
   __shared__ double gred[4 * TN * 2 * 2];           // GroupNorm partials of the four waves (ws holds the NEXT tile's weights by then)
+  __shared__ double gbred[4][N][2];                 // GroupNorm-backward channel sums of the four waves (gnb_part)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   // PERSISTENT blocks: a block walks tiles blockIdx.x, + gridDim.x, ... and the (tile, slab) pairs form ONE pipeline -- the
   // first slab of the next tile is requested during the last MFMA phase of this one and the result stores drain under the
@@ -496,11 +497,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // epilogue of the tile (its stores drain under the next tile's first MFMA phase): the fp32 kernel's (column = output
   // channel, row = pixel of the wave), with the pixel offsets formed once per pixel tile in 32 bits -- the epilogue's VALU
   // instructions wait for gaps in the other block's MFMA stream like every VALU instruction of a staging phase
-  double gs[TN], gq[TN];
+  double gs[TN], gq[TN], ba[TN], bb[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.0;
+  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = ba[j] = bb[j] = 0.0;
   {
     float* obase = p.out + (long)img * p.H * p.W * p.ldo + l31;
+    const float* xbase = p.gnb_x ? p.gnb_x + (long)img * p.H * p.W * p.ldo + l31 : nullptr;
     const int ldo = (int)p.ldo;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
@@ -548,10 +550,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if ((okm >> r) & 1u) ob[off[r]] = v[r];
+        if (p.gnb_part) {
+          // this lane's channel c = l31 + 32 j of the GroupNorm whose dy was just written: mask from the forward's own fma,
+          // sums in double from the first addition (norm.hip::groupnorm_bwd_sums_kernel's expressions)
+          const int c = l31 + 32 * j;
+          const float sc = p.gnb_table[((long)img * 2 + 0) * N + c], sh = p.gnb_table[((long)img * 2 + 1) * N + c];
+          const float mean = p.gnb_stats[((long)img * (N / 16) + (c >> 4)) * 2], rstd = p.gnb_stats[((long)img * (N / 16) + (c >> 4)) * 2 + 1];
+          const float* xb = xbase + 32 * j;
+          float xv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xv[r] = xb[off[r]];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool on = ((okm >> r) & 1u) && __builtin_fmaf(xv[r], sc, sh) > 0.f;
+            const float dm = on ? v[r] : 0.f;
+            ba[j] += (double)dm;
+            bb[j] += (double)dm * ((xv[r] - mean) * rstd);
+          }
+        }
       }
     }
   }
   if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, gred, tid, tile);   // (one barrier inside; gred is not touched by the staging)
+  if (p.gnb_part) {       // lanes hi = 0 / 1 hold different pixel rows of the same channel; then the four waves, fixed order
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const double a2 = ba[j] + __shfl_xor(ba[j], 32, 64), b2 = bb[j] + __shfl_xor(bb[j], 32, 64);
+      if (hi == 0) {
+        gbred[wave][l31 + 32 * j][0] = a2;
+        gbred[wave][l31 + 32 * j][1] = b2;
+      }
+    }
+    __syncthreads();
+    if (tid < N) {
+      double* o = p.gnb_part + ((long)tile * N + tid) * 2;
+      o[0] = (gbred[0][tid][0] + gbred[1][tid][0]) + (gbred[2][tid][0] + gbred[3][tid][0]);
+      o[1] = (gbred[0][tid][1] + gbred[1][tid][1]) + (gbred[2][tid][1] + gbred[3][tid][1]);
+    }
+  }
   SVL_PH(5)
   tile += (int)gridDim.x;
   if (tile >= ntiles) break;
@@ -562,366 +598,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[i], ph[i]);
-    atomicAdd(&g_conv_phase[7], 1ull);
-  }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// The same convolution with the ROLE SPLIT of gemm_planes.hip (round 4, late): one block of 8 waves per CU, two groups of
-// four waves, each group on its own pixel patch, the weight planes shared.  A slab is three TAP ROWS; for row m a group
-// first runs a MEMORY phase (stage its share of what comes next, read the row's 27 fragments into registers) and, one
-// barrier interval later, a MATRIX phase (the row's 36 MFMAs and nothing else).  Group 1 runs one interval behind group 0,
-// so on every SIMD one wave issues only MFMAs while its partner only reads, writes and loads -- a wave that mixes the two
-// pays for its own reads in issue order (57 cycles per MFMA alone on a SIMD, see above).
-//   interval i (barrier at its end):  group g, j = i - g:  j even -> MEM(j / 2),  j odd -> MFMA((j - 1) / 2)
-//   weights: tap row r of slab s lives in LDS slot r; MEM(m) writes this group's half of row m + 2 (requested in MEM(m - 1):
-//            its slot was last read, by group 1, two barriers earlier) and requests its half of row m + 3;
-//   pixels:  per group two buffers by slab parity; slab sigma + 1 is requested in MEM(3 sigma) and split + written in
-//            MEM(3 sigma + 2);
-//   a tile's epilogue runs at the start of the MEM phase after its last row; the GroupNorm partials of the four waves are
-//   summed one MEM phase later (the interval barriers order the two steps).
-// Accumulation order per accumulator = taps in order, six terms each: bit-identical to conv3x3_tiled_bf16x_kernel.
-// STATUS (round 4): opt-in (SVL_CONV_TILED_RS=1), 139 - 149 TF at N = 64 against the default kernel's 150 - 160.  s_memtime
-// per MEM phase (tools/conv_phases_rs.py): the 27 fragment reads + their wait 555 cycles, the MFMA phase 1463 -- but every
-// VALU instruction of a MEM phase waits for a gap in the partner's back-to-back MFMAs (~30 cycles each): the pixel split
-// costs 1650 cycles per slab, the address arithmetic of its loads 1070, the tile epilogue (~600 VALU) 12 k cycles on the
-// interval's critical path.  gemm_planes.hip's memory phase has no VALU at all.  To finish this kernel the VALU work has
-// to move into the MFMA phase of the SAME wave (the split and the epilogue as fillers between its own MFMAs, accumulators
-// copied aside), leaving reads, LDS writes and loads at precomputed addresses for the MEM phase.
-template <int TN, int PT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_tiled_rs_kernel(const ConvTiledP p, int tiles_x, int tiles_y) {
-  constexpr int N = 32 * TN;
-  constexpr int PHT = PH * PT, IHT = PHT + 2, NPX = IHT * IW;
-  constexpr int XP = (NPX * 4 + 255) / 256;
-  constexpr int XROW = IW * 16 + 8, XPL = IHT * XROW, WPL = 9 * N * 16;
-  constexpr int RQ = 6 * N;                 // 16-byte pieces of one plane of one tap row (3 taps x N rows x 32 B)
-  constexpr int PLQ = 18 * N;               // ... of one whole plane of a slab
-  constexpr int HALF = 9 * N;               // pieces of a tap row (3 planes) a group stages
-  constexpr int WQ = (HALF + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) __bf16 smem_rs[];
-  __bf16* ws = smem_rs;                                      // [3][9 N][16]
-  __bf16* xsg = smem_rs + 3 * WPL;                           // [group][buffer][3][XPL]
-  __shared__ double gred[2][4 * TN * 2 * 2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), gw = wave & 3, gt = tid & 255;   // (wave-uniform role)
-  const int ntiles = p.imgs * tiles_x * tiles_y;
-  const int Ct = p.C1 + p.C2, nslab = Ct / SLAB;
-  const int tstride = 2 * (int)gridDim.x;
-  const int t0 = 2 * (int)blockIdx.x;                        // group 0's first tile (group 1: t0 + 1)
-  const int Kt = (ntiles - t0 + tstride - 1) / tstride;      // tiles of group 0 (>= group 1's)
-  const int rows_per_tile = 3 * nslab;
-  const int Q = Kt * rows_per_tile;
-  auto decode = [&](int t, int& im, int& yy, int& xx) __attribute__((always_inline)) {
-    t = min(t, ntiles - 1);
-    const int txi = t % tiles_x;
-    t /= tiles_x;
-    const int tyi = t % tiles_y;
-    im = t / tiles_y;
-    yy = tyi * PHT; xx = txi * PW;
-  };
-  __bf16* xs0 = xsg + (size_t)grp * 2 * 3 * XPL;
-
-  f32x16 acc[PT][TN];
-#pragma unroll
-  for (int u = 0; u < PT; ++u)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[u][j][r] = 0.f;
-
-  // All (tile, slab, row) bookkeeping is COUNTERS advanced once per phase: an integer division costs a MEM phase more
-  // than its fragment reads (the first version of this kernel, with m / 3, m % rows and a decode per slab, ran at 66 TF).
-  // ---- pixel staging: this group's patch of its (lk-th tile, slab ls) ----
-  float4 rx[XP];
-  float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f), gsh = make_float4(0.f, 0.f, 0.f, 0.f);
-  unsigned rxok = 0;
-  bool gnow = false;
-  int limg, ly0, lx0;                                 // patch of the tile being STAGED
-  int pixo[XP];                                       // ... its pieces' clamped pixel index inside the image, in-image flags
-  unsigned tok = 0;
-  auto xtile = [&](int t) __attribute__((always_inline)) {     // once per tile: everything of a piece's address but the channel
-    decode(t, limg, ly0, lx0);
-    tok = 0;
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      const int f = gt + 256 * i;
-      const int pix = min(f >> 2, NPX - 1);
-      const int iy = pix / IW, ix = pix - iy * IW;
-      const int y = ly0 - 1 + iy, x = lx0 - 1 + ix;
-      const bool in = f < NPX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W;
-      tok |= in ? (1u << i) : 0u;
-      pixo[i] = min(max(y, 0), p.H - 1) * p.W + min(max(x, 0), p.W - 1);
-    }
-  };
-  xtile(t0 + grp);
-  auto xload = [&](int ls) __attribute__((always_inline)) {
-    const int c0 = ls * SLAB;
-    const bool first = c0 < p.C1;
-    const float* base = first ? p.src1 + ((long)limg * p.H) * p.W * p.ld1 + c0
-                              : p.src2 + ((long)(limg / p.rep) * p.H) * p.W * p.ld2 + (c0 - p.C1);
-    const int ld = (int)(first ? p.ld1 : p.ld2);
-    gnow = p.gn_in != nullptr && first;
-    rxok = tok;
-    base += 4 * (gt & 3);
-#pragma unroll
-    for (int i = 0; i < XP; ++i) rx[i] = *reinterpret_cast<const float4*>(base + (long)pixo[i] * ld);
-    if (gnow) {
-      gsc = *reinterpret_cast<const float4*>(p.gn_in + ((long)limg * 2 + 0) * p.C1 + c0 + 4 * (gt & 3));
-      gsh = *reinterpret_cast<const float4*>(p.gn_in + ((long)limg * 2 + 1) * p.C1 + c0 + 4 * (gt & 3));
-    }
-  };
-  int xo[XP];                                         // LDS element offsets of this thread's pixel pieces (constant)
-#pragma unroll
-  for (int i = 0; i < XP; ++i) {
-    const int f = min(gt + 256 * i, NPX * 4 - 1);
-    const int spx = f >> 2, siy = spx / IW;
-    xo[i] = siy * XROW + (spx - siy * IW) * 16 + 4 * (f & 3);
-  }
-  auto xstore = [&](int par) __attribute__((always_inline)) {
-    __bf16* xs = xs0 + (size_t)par * 3 * XPL;
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      if (gt + 256 * i < NPX * 4) {
-        bf16x4 h0, h1, h2;
-        const unsigned in = (rxok >> i) & 1u;
-        split3x4(gnow ? gn_relu4(rx[i], gsc, gsh, in) : (in ? rx[i] : make_float4(0.f, 0.f, 0.f, 0.f)), h0, h1, h2);
-        *reinterpret_cast<bf16x4*>(xs + xo[i]) = h0;
-        *reinterpret_cast<bf16x4*>(xs + XPL + xo[i]) = h1;
-        *reinterpret_cast<bf16x4*>(xs + 2 * XPL + xo[i]) = h2;
-      }
-    }
-  };
-  // ---- weight staging: this group's half of a tap row (slab ws_, slot r): piece offsets inside a slab's image are constant ----
-  u32q rq[WQ];
-  int wo[WQ];
-#pragma unroll
-  for (int i = 0; i < WQ; ++i) {
-    const int f = min(grp * HALF + gt + 256 * i, 3 * RQ - 1);
-    const int pl = f / RQ;
-    wo[i] = pl * PLQ + (f - pl * RQ);
-  }
-  auto wload = [&](int ws_, int r) __attribute__((always_inline)) {
-    const u32q* src = reinterpret_cast<const u32q*>(p.w_planes) + (long)ws_ * 3 * PLQ + r * RQ;
-#pragma unroll
-    for (int i = 0; i < WQ; ++i) rq[i] = src[wo[i]];
-  };
-  auto wstore = [&](int r) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < WQ; ++i)
-      if (gt + 256 * i < HALF) reinterpret_cast<u32q*>(ws)[wo[i] + r * RQ] = rq[i];
-  };
-
-  // ---- prologue: tap rows 0 and 1 of slab 0 by everybody, row 2 requested; each group its slab 0 ----
-  {
-    const u32q* src = reinterpret_cast<const u32q*>(p.w_planes);
-    for (int f = tid; f < 2 * 3 * RQ; f += 512) {
-      const int r = f / (3 * RQ), g = f - r * 3 * RQ;
-      const int pl = g / RQ, within = g - pl * RQ;
-      reinterpret_cast<u32q*>(ws)[pl * PLQ + r * RQ + within] = src[pl * PLQ + r * RQ + within];
-    }
-  }
-  xload(0);
-  xstore(0);
-  wload(0, 2);
-  __syncthreads();
-
-  const int pr = gw * 2 * PT + (l31 >> 4), pc = l31 & 15;
-  int abase[PT];
-#pragma unroll
-  for (int u = 0; u < PT; ++u) abase[u] = (pr + 2 * u + 1) * XROW + (pc + 1) * 16 + 8 * hi;
-  const int bbase = l31 * 16 + (((hi ^ (l31 >> 3)) & 1) << 3);    // (N % 32 == 0: the swizzle bit of row tap N + 32 j + l31 is l31's)
-  bf16x8 a[3][3][PT], b[3][3][TN];
-  int pend_tile = -1;                                   // tile whose GroupNorm partials wait in gred for the final sum
-  // counters of the row this group's NEXT MEM phase works on: row cr of slab cs of its ck-th tile (global row m, slab parity cpar)
-  int m = 0, cr = 0, cs = 0, ck = 0, cpar = 0;
-  int lks = 0, lkk = 0;                                 // (slab, tile index) the staged patch (limg, ...) belongs to
-  const int nint = 2 * Q + 4;
-#ifdef SVL_CONV_PHASE_TIMING
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
-#endif
-  for (int it = 0; it < nint; ++it) {
-    const int j = it - grp;
-    SVL_PH(6)
-    if (j >= 0 && (j & 1) == 0) {
-      // ------------------------------------------------------------------ MEM(m)
-      if (pend_tile >= 0) {                             // (written one MEM phase = two barriers ago)
-        if (gt < 2 * TN) {
-          double ts = 0.0, tq = 0.0;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            ts += gred[grp][(w * 2 * TN + gt) * 2];
-            tq += gred[grp][(w * 2 * TN + gt) * 2 + 1];
-          }
-          double* o = p.gn_part + ((long)pend_tile * (2 * TN) + gt) * 2;
-          o[0] = ts;
-          o[1] = tq;
-        }
-        pend_tile = -1;
-      }
-      if (m > 0 && m <= Q && cr == 0 && cs == 0) {      // epilogue of the tile whose last row was m - 1
-        const int tile = t0 + grp + (ck - 1) * tstride;
-        const bool tvalid = tile < ntiles;
-        int img, y0, x0;
-        decode(tile, img, y0, x0);
-        double gs[TN], gq[TN];
-#pragma unroll
-        for (int jj = 0; jj < TN; ++jj) gs[jj] = gq[jj] = 0.0;
-        float* obase = p.out + (long)img * p.H * p.W * p.ldo + l31;
-        const int ldo = (int)p.ldo;
-#pragma unroll
-        for (int u = 0; u < PT; ++u) {
-          int off[16];                                  // (the fragment registers are dead here: room for the whole tile's offsets)
-          unsigned okm = 0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int y = y0 + gw * 2 * PT + 2 * u + (i >> 4), x = x0 + (i & 15);
-            okm |= (tvalid && y < p.H && x < p.W) ? (1u << r) : 0u;
-            off[r] = (min(y, p.H - 1) * p.W + min(x, p.W - 1)) * ldo;
-          }
-#pragma unroll
-          for (int jj = 0; jj < TN; ++jj) {
-            const float bv = p.bias ? p.bias[l31 + 32 * jj] : 0.f;
-            float* ob = obase + 32 * jj;
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              v[r] = acc[u][jj][r] + bv;
-              acc[u][jj][r] = 0.f;
-            }
-            if (p.gn_part) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const double t_ = ((okm >> r) & 1u) ? (double)v[r] : 0.0;
-                gs[jj] += t_;
-                gq[jj] += t_ * t_;
-              }
-            }
-            if (p.act == SVL_ACT_GELU) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
-            } else if (p.act == SVL_ACT_RELU) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (p.accumulate) {
-              float prev[16];
-#pragma unroll
-              for (int r = 0; r < 16; ++r) prev[r] = ob[off[r]];
-#pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] += prev[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if ((okm >> r) & 1u) ob[off[r]] = v[r];
-          }
-        }
-        if (p.gn_part) {                                // wave partials (the order of gn_tile_partials)
-#pragma unroll
-          for (int jj = 0; jj < TN; ++jj) {
-            double ds = gs[jj], dq = gq[jj];
-#pragma unroll
-            for (int mm = 1; mm <= 8; mm <<= 1) {
-              ds += __shfl_xor(ds, mm, 64);
-              dq += __shfl_xor(dq, mm, 64);
-            }
-            ds += __shfl_xor(ds, 32, 64);
-            dq += __shfl_xor(dq, 32, 64);
-            if ((lane & 47) == 0) {
-              double* d = &gred[grp][((gw * TN + jj) * 2 + (lane >> 4)) * 2];
-              d[0] = ds;
-              d[1] = dq;
-            }
-          }
-          if (tvalid) pend_tile = tile;
-        }
-      }
-      SVL_PH(0)
-      if (m < Q) {
-        // staging: weights of row m + 2 (requested in the previous MEM phase), request row m + 3 (= row cr of the next slab)
-        if (m + 2 < Q) wstore(cr == 0 ? 2 : cr - 1);
-        SVL_PH(1)
-        if (m + 3 < Q) wload(cs + 1 == nslab ? 0 : cs + 1, cr);
-        SVL_PH(2)
-        // pixels of the next slab: request in the slab's first row, split + write in its last
-        if (cr == 2 && m + 1 < Q) xstore(cpar ^ 1);
-        SVL_PH(3)
-        if (cr == 0 && m + 3 < Q) {
-          lks = lks + 1;
-          if (lks == nslab) {                           // the next slab opens this group's next tile
-            lks = 0;
-            lkk = lkk + 1;
-            xtile(t0 + grp + lkk * tstride);
-          }
-          xload(lks);
-        }
-      }
-      SVL_PH(4)
-      {
-        // fragments of this row (unconditionally -- past the last row they are never used, but a conditional definition
-        // would keep the previous row's 108 registers alive through the epilogue above)
-        const __bf16* xs = xs0 + (size_t)cpar * 3 * XPL;
-        const int dyo = p.sign * (cr - 1) * XROW, dxs = p.sign * 16;
-        const __bf16* wr = ws + bbase + cr * 3 * N * 16;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-#pragma unroll
-          for (int u = 0; u < PT; ++u) {
-            const __bf16* ap = xs + abase[u] + dyo + (c - 1) * dxs;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[c][pl][u] = *reinterpret_cast<const bf16x8*>(ap + pl * XPL);
-          }
-#pragma unroll
-          for (int jj = 0; jj < TN; ++jj) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-              b[c][pl][jj] = *reinterpret_cast<const bf16x8*>(wr + pl * WPL + (c * N + 32 * jj) * 16);
-          }
-        }
-      }
-#ifdef SVL_CONV_PHASE_TIMING
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      SVL_PH(5)
-      // advance the row counters
-      m = m + 1;
-      cr = cr + 1;
-      if (cr == 3) {
-        cr = 0;
-        cpar ^= 1;
-        cs = cs + 1;
-        if (cs == nslab) { cs = 0; ck = ck + 1; }
-      }
-    } else if (j > 0) {
-      // ------------------------------------------------------------------ MFMA(m - 1): the row's MFMAs and nothing else
-      if (m - 1 < Q) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-#define SVL_RS(PA, PB)                                                                       \
-  _Pragma("unroll") for (int u = 0; u < PT; ++u) _Pragma("unroll") for (int jj = 0; jj < TN; ++jj) acc[u][jj] = \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c][PA][u], b[c][PB][jj], acc[u][jj], 0, 0, 0);
-          SVL_RS(2, 0)
-          SVL_RS(0, 2)
-          SVL_RS(1, 1)
-          SVL_RS(1, 0)
-          SVL_RS(0, 1)
-          SVL_RS(0, 0)
-#undef SVL_RS
-        }
-      }
-      SVL_PH(6)
-    }
-    // interval barrier: LDS traffic drained, but NOT the global loads in flight for later phases (__syncthreads() would
-    // add s_waitcnt vmcnt(0): the whole L2 / HBM latency of the staging loads inside every MEM phase)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-#ifdef SVL_CONV_PHASE_TIMING
-  if (tid == 0) {                                   // (group 0's first wave)
-#pragma unroll
-    for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[i], ph[i]);   // epilogue | wstore | wload | xstore | xload | reads (6: MFMA + barrier, not reported)
-    atomicAdd(&g_conv_phase[6], (unsigned long long)nint);
     atomicAdd(&g_conv_phase[7], 1ull);
   }
 #endif
@@ -999,29 +675,6 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st, int* tiles_per
       const int per_cu = e ? atoi(e) : 2;
       return (long)(cus > 0 ? cus : 256) * (per_cu > 0 ? per_cu : 2);
     }();
-    static const int rs_on = getenv("SVL_CONV_TILED_RS") ? atoi(getenv("SVL_CONV_TILED_RS")) : 0;
-    if (rs_on && wpre && (p.N == 64 || (p.N == 32 && pt2 && p.H >= 2 * PH))) {   // role-split kernel: one 8-wave block per CU
-      const bool n32 = p.N == 32;
-      const int tyr = n32 ? (p.H + 2 * PH - 1) / (2 * PH) : ty;
-      if (tiles_per_img) *tiles_per_img = tx * tyr;
-      const long nt = (long)p.imgs * tx * tyr;
-      const long cus = resident / 2 > 0 ? resident / 2 : 1;    // (`resident` = 2 blocks per CU of the other kernel)
-      const long gridb = (nt + 1) / 2 < cus ? (nt + 1) / 2 : cus;
-      const int IHTr = (n32 ? 2 * PH : PH) + 2;
-      const size_t lds = ((size_t)3 * 9 * p.N * 16 + (size_t)4 * 3 * IHTr * (IW * 16 + 8)) * sizeof(__bf16);
-      static std::atomic<int> attr_done{0};
-      if (!attr_done.load(std::memory_order_acquire)) {
-        SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tiled_rs_kernel<2, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-        SVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tiled_rs_kernel<1, 2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-        attr_done.store(1, std::memory_order_release);
-      }
-      if (n32) hipLaunchKernelGGL((conv3x3_tiled_rs_kernel<1, 2>), dim3((unsigned)gridb), dim3(512), lds, st, p, tx, tyr);
-      else hipLaunchKernelGGL((conv3x3_tiled_rs_kernel<2, 1>), dim3((unsigned)gridb), dim3(512), lds, st, p, tx, tyr);
-      SVL_LAUNCH_CHECK("svl_gemm_f32 (tiled 3x3 conv, role split)");
-      return SVL_OK;
-    }
     if (p.N == 32 && pt2 && p.H >= 2 * PH) {        // 16 x 16 patches: two pixel tiles per wave
       const int ty2 = (p.H + 2 * PH - 1) / (2 * PH);
       if (tiles_per_img) *tiles_per_img = tx * ty2;
@@ -1062,6 +715,7 @@ extern "C" int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const 
   t.src1 = src1; t.ld1 = ld1; t.C1 = C1; t.src2 = src2; t.ld2 = ld2; t.C2 = C2; t.rep = rep < 1 ? 1 : rep;
   t.w = w; t.K = 9 * (C1 + C2); t.out = out; t.ldo = ldo; t.bias = nullptr; t.act = SVL_ACT_NONE; t.accumulate = 0;
   t.imgs = imgs; t.H = H; t.W = W; t.N = N; t.sign = 1; t.gn_part = ws; t.gn_in = gn_in; t.w_planes = w_planes;
+  t.gnb_x = t.gnb_table = t.gnb_stats = nullptr; t.gnb_part = nullptr;
   if (!svl_conv3x3_tiled_eligible(t)) return SVL_ERR_UNSUPPORTED;
   SVL_CHECK_ARG(!gn_in || (((uintptr_t)gn_in & 15) == 0 && C1 % 4 == 0), "svl_conv3x3_gn_f32: gn_in must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -1073,6 +727,58 @@ extern "C" int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const 
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, tiles, G,
                      (double)H * W * 16.0, eps, count, stats);
   SVL_LAUNCH_CHECK("svl_conv3x3_gn_f32/finalize");
+  return SVL_OK;
+}
+
+// Input gradient of the narrow 3x3 convolution (mirrored taps) WITH the backward sums of the GroupNorm whose output it
+// differentiates (vlg_head.py:120-127: conv -> GN -> ReLU -> conv; the second conv's input gradient is the first GN's dy).
+// The split kernel's epilogue leaves per-tile channel sums (ConvTiledP::gnb_*), gnb_finalize_kernel adds an image's tiles up in
+// fixed order into chan_sums [imgs][2][N] -- svl_groupnorm_bwd's statistics pass over dy and x (8 B per element) becomes one
+// read of x in the epilogue.  SVL_ERR_UNSUPPORTED (nothing launched) when the split tiled kernel does not take the shape or the
+// arithmetic mode is not 6: the caller runs svl_gemm_f32 + svl_groupnorm_bwd.
+namespace {
+__global__ void gnb_finalize_kernel(const double* __restrict__ part, int tiles, int N, long count, float* __restrict__ chan_sums) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;    // (img, channel)
+  if (i >= count) return;
+  const long img = i / N;
+  const int c = (int)(i - img * N);
+  const double* q = part + ((img * tiles) * N + c) * 2;
+  double ta = 0.0, tb = 0.0;
+  for (int t = 0; t < tiles; ++t) {
+    ta += q[(long)t * N * 2];
+    tb += q[(long)t * N * 2 + 1];
+  }
+  chan_sums[(img * 2 + 0) * N + c] = (float)ta;
+  chan_sums[(img * 2 + 1) * N + c] = (float)tb;
+}
+}  // namespace
+
+extern "C" int64_t svl_conv3x3_gnb_ws_doubles(int imgs, int H, int W, int N) {
+  const long tiles = (long)imgs * ((W + PW - 1) / PW) * ((H + PH - 1) / PH);   // (an upper bound for the 16 x 16 patch variant)
+  return tiles * N * 2;
+}
+
+extern "C" int svl_conv3x3_dgrad_gnb_f32(const float* dy, int64_t lddy, int C1, const float* w, int imgs, int H, int W, int N,
+                                         float* out, int64_t ldo, int accumulate, const float* gnb_x, const float* gnb_table,
+                                         const float* gnb_stats, double* ws, float* chan_sums, const void* w_planes,
+                                         svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && w && out && gnb_x && gnb_table && gnb_stats && ws && chan_sums && imgs > 0 && N % 16 == 0,
+                "svl_conv3x3_dgrad_gnb_f32: bad args");
+  static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
+  if (!emu_ok || svl_get_gemm_emulation() != 6) return SVL_ERR_UNSUPPORTED;      // (epilogue of the split kernel only)
+  ConvTiledP t;
+  t.src1 = dy; t.ld1 = lddy; t.C1 = C1; t.src2 = nullptr; t.ld2 = 0; t.C2 = 0; t.rep = 1;
+  t.w = w; t.K = 9 * C1; t.out = out; t.ldo = ldo; t.bias = nullptr; t.act = SVL_ACT_NONE; t.accumulate = accumulate;
+  t.imgs = imgs; t.H = H; t.W = W; t.N = N; t.sign = -1; t.gn_part = nullptr; t.gn_in = nullptr; t.w_planes = w_planes;
+  t.gnb_x = gnb_x; t.gnb_table = gnb_table; t.gnb_stats = gnb_stats; t.gnb_part = ws;
+  if (!svl_conv3x3_tiled_eligible(t)) return SVL_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  int tiles = 0;
+  const int rc = svl_conv3x3_tiled_launch(t, st, &tiles);
+  if (rc != SVL_OK) return rc;
+  const long count = (long)imgs * N;
+  hipLaunchKernelGGL(gnb_finalize_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, tiles, N, count, chan_sums);
+  SVL_LAUNCH_CHECK("svl_conv3x3_dgrad_gnb_f32/finalize");
   return SVL_OK;
 }
 

@@ -1674,11 +1674,15 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) && d->out_mode == SVL_OUT_STRIDED && q.M >= 256 && q.N >= 96 &&
         q.K >= 64) {
       g_last_path = SVL_PATH_BF16X;
-      // (dense launches: opt-in, SVL_GEMM_EMU_H2_DENSE=1.  The ViT's split-K weight gradients gain 17 % (in_proj) and lose
-      //  9 % (out_proj: the two maximum passes), 2 ms of the step together; the full-size fp64 comparison of the in_proj
-      //  gradient of block 10 moved from 0.9e-3 to 1.02e-3 against its 1.016e-3 bound, so they stay on bf16 x 3)
-      static const int h2_dense = getenv("SVL_GEMM_EMU_H2_DENSE") ? 1 : 0;
-      if (h2_dense && (d->batch == 1 || d->ksplit > 0) && h2_ok(q, (double)q.M * q.K + (double)q.N * q.K)) {
+      // Dense launches (the ViT's split-K weight gradients): round 5 measured +17 % on in_proj (2304 x 768 x 32800) and -9 % on
+      // out_proj (768 x 768: the two maximum passes weigh three times as much per FLOP) with the form on for both, and left
+      // it opt-in.  Round 6: on by default for the launches whose halved matrix work outweighs the passes by 1.5 x (in_proj
+      // only at the ViT's shapes): 323.7 -> 319.8 ms per VOC step with both on, same call; the float64 comparison of the
+      // full-size step passes with it (tests/test_fullsize_gpu.py, FP64_RATCHET).  SVL_GEMM_EMU_H2_DENSE=0 turns it off.
+      static const int h2_dense = (getenv("SVL_GEMM_EMU_H2_DENSE") && atoi(getenv("SVL_GEMM_EMU_H2_DENSE")) == 0) ? 0 : 1;
+      const double dense_elems = (double)q.M * q.K + (double)q.N * q.K;
+      if (h2_dense && (d->batch == 1 || d->ksplit > 0) && h2_ok(q, dense_elems) &&
+          2.0 * q.M * q.N * q.K * 1.7e-15 > dense_elems * 4.0 / 4.0e12 * 1.5) {
         // dense operands: [M, K] or [K, M], [N, K] or [K, N]
         int rc = h2_begin();
         if (!rc) rc = am == SVL_A_MCONTIG ? absmax_launch(q.A.p, q.K, q.M, q.A.ld, h2_ws, st)
@@ -1730,7 +1734,6 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       static const int sk_x6 = getenv("SVL_SHORTK_NO_X6") ? 0 : 1;
       if (fast && emu_mode == 6 && sk_x6 && (d->out_mode == SVL_OUT_CONVT2X || d->K == 64)) {
         ShortKP q;
-        q.gat_C = q.gat_H = q.gat_W = 0;
         q.A = d->A.ptr; q.lda = d->A.ld; q.B = d->B.ptr; q.ldb = d->B.ld; q.C = d->C; q.ldc_m = d->ldc_m;
         q.M = d->M; q.N = d->N; q.K = d->K; q.out_mode = d->out_mode; q.ct_H = d->ct_H; q.ct_W = d->ct_W;
         q.ct_Cout = d->ct_Cout; q.alpha = d->alpha; q.bias = d->bias; q.bias_mod = d->bias_mod; q.act = d->act;
@@ -1741,28 +1744,6 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       }
       g_last_path = SVL_PATH_SHORTK;
       return launch_shortk(p, fast, st);
-    }
-  }
-
-  // Input gradient of the narrow ConvTranspose2d(k 2, s 2) (vlg_head.py:116-119, `Up.up` of the last block: a k2 s2 convolution
-  // of the 128 x 128 gradient, K = 4 x 32, N = 64): the implicit-GEMM kernel ran it at 13 TF / 0.4 TB/s on the fp32 pipe (3.4 ms
-  // per launch at VOC, 73 ms of an ADE step) -- it is a row stream whose rows are four 32-float segments; round 6: the
-  // short-K stream kernel of gemm_shortk.hip with that gather in its A loads.
-  {
-    static const int sk_gather = getenv("SVL_SHORTK_NO_GATHER") ? 0 : 1;
-    if (shortk && sk_gather && emu_mode == 6 && a_conv && bm == SVL_B_KCONTIG && cv.KH == 2 && cv.KW == 2 && p.cv.stride == 2 &&
-        cv.pad == 0 && cv.dil == 1 && cv.C2 == 0 && cv.sign == 1 && (cv.C1 == 16 || cv.C1 == 32) && d->K == 4 * cv.C1 &&
-        cv.H == 2 * p.cv.Ho && cv.W == 2 * p.cv.Wo && d->batch == 1 && d->ksplit == 0 && d->out_mode == SVL_OUT_STRIDED &&
-        d->ldc_n == 1 && !d->resid && !d->preact && !d->accumulate && !d->bias && d->act == SVL_ACT_NONE && p.A.vec && p.B.vec) {
-      ShortKP q;
-      q.A = d->A.ptr; q.lda = d->A.ld; q.B = d->B.ptr; q.ldb = d->B.ld; q.C = d->C; q.ldc_m = d->ldc_m;
-      q.M = d->M; q.N = d->N; q.K = d->K; q.out_mode = d->out_mode; q.ct_H = q.ct_W = q.ct_Cout = 0;
-      q.alpha = d->alpha; q.bias = nullptr; q.bias_mod = 0; q.act = SVL_ACT_NONE;
-      q.gat_C = cv.C1; q.gat_H = p.cv.Ho; q.gat_W = p.cv.Wo;
-      if (svl_shortk_x6_eligible(q)) {
-        g_last_path = SVL_PATH_BF16X;
-        return svl_shortk_x6_launch(q, st);
-      }
     }
   }
 
@@ -1800,6 +1781,8 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     t.sign = cv.sign;
     t.gn_part = nullptr;
     t.gn_in = nullptr;
+    t.gnb_x = t.gnb_table = t.gnb_stats = nullptr;
+    t.gnb_part = nullptr;
     t.w_planes = d->conv_w_planes;
     if ((d->bias == nullptr || d->bias_mod == 0) && svl_conv3x3_tiled_eligible(t)) {
       static const int temu = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;

@@ -11,10 +11,6 @@ struct ShortKP {
   float alpha;
   const float* bias; int bias_mod;
   int act;                           // SVL_ACT_NONE / RELU / GELU
-  // Row gather of the ConvTranspose2d(k 2, s 2) INPUT gradient (a k2 s2 convolution of the upsampled gradient, round 6):
-  // gat_C > 0: row m = (img, y, x) on the [gat_H, gat_W] grid, k = (a, b, c) with c < gat_C fastest (K = 4 gat_C), element
-  // = A[((img 2 gat_H + 2 y + a) 2 gat_W + 2 x + b) lda + c] -- four gat_C-float segments per row instead of one K-float run.
-  int gat_C, gat_H, gat_W;
 };
 
 bool svl_shortk_x6_eligible(const ShortKP& p);

@@ -89,23 +89,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto a_load = [&](float (&dst)[32], long rbi, int kci) __attribute__((always_inline)) {
     const long row = min(rbi * 32 + l31, (long)p.M - 1);
     const float* src = p.A + row * p.lda + kci * 64 + hi * 8;
-    long seg[4] = {0, 16, 32, 48};          // offset of the 16-float group ks of this 64-deep k chunk
-    if (p.gat_C > 0) {                      // (wave-uniform) the k2 s2 gather: k = (tap, c), tap = (a, b) -> pixel (2 y + a, 2 x + b)
-      const int x_ = (int)(row % p.gat_W);
-      const long t_ = row / p.gat_W;
-      const int y_ = (int)(t_ % p.gat_H);
-      const long i_ = t_ / p.gat_H;
-      src = p.A + ((i_ * (2 * p.gat_H) + 2 * y_) * (2 * p.gat_W) + 2 * x_) * p.lda + hi * 8;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int k0 = kci * 64 + 16 * ks, tap = k0 / p.gat_C, c0 = k0 - tap * p.gat_C;
-        seg[ks] = (long)((tap >> 1) * 2 * p.gat_W + (tap & 1)) * p.lda + c0;
-      }
-    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const float4 v0 = *reinterpret_cast<const float4*>(src + seg[ks]);
-      const float4 v1 = *reinterpret_cast<const float4*>(src + seg[ks] + 4);
+      const float4 v0 = *reinterpret_cast<const float4*>(src + 16 * ks);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + 16 * ks + 4);
       dst[8 * ks] = v0.x; dst[8 * ks + 1] = v0.y; dst[8 * ks + 2] = v0.z; dst[8 * ks + 3] = v0.w;
       dst[8 * ks + 4] = v1.x; dst[8 * ks + 5] = v1.y; dst[8 * ks + 6] = v1.z; dst[8 * ks + 7] = v1.w;
     }
@@ -263,9 +250,6 @@ int launch_tn(const ShortKP& p, hipStream_t st) {
 bool svl_shortk_x6_eligible(const ShortKP& p) {
   auto a16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   if (!(p.K == 64 || p.K == 128) || p.M < 32768 || p.N < 32) return false;
-  if (p.gat_C != 0 && (p.gat_C < 16 || p.gat_C % 16 || p.K != 4 * p.gat_C || p.gat_H <= 0 || p.gat_W <= 0 ||
-                       (long)p.M % ((long)p.gat_H * p.gat_W)))
-    return false;
   if (!a16(p.A) || !a16(p.B) || p.lda % 4 || p.ldb % 4) return false;
   if (!a16(p.C) || p.ldc_m % 4 || p.N % 4) return false;                          // 16-byte stores of 4 consecutive columns
   if (p.out_mode == SVL_OUT_CONVT2X && (p.ct_Cout % 4 || p.N != 4 * p.ct_Cout)) return false;

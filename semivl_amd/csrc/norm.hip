@@ -971,6 +971,23 @@ extern "C" int svl_groupnorm_bwd(const float* dy, int64_t lddy, const float* x, 
   return SVL_OK;
 }
 
+// The apply pass of svl_groupnorm_bwd alone, on channel sums that came out of the epilogue of the kernel that PRODUCED dy
+// (svl_conv3x3_dgrad_gnb_f32, round 6): chan_sums [imgs][2][C] = (sum dy', sum dy' xhat) per (image, channel), dy' = dy masked by
+// the ReLU mask re-derived from x (beta required when relu).
+extern "C" int svl_groupnorm_bwd_apply(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* stats,
+                                       const float* gamma, const float* beta, int imgs, int64_t HW, int C, int G, int relu,
+                                       const float* chan_sums, float* dx, int64_t lddx, svl_stream_t stream) {
+  SVL_CHECK_ARG(dy && x && stats && gamma && dx && chan_sums && imgs > 0 && HW > 0 && (!relu || beta),
+                "svl_groupnorm_bwd_apply: bad args (relu needs beta)");
+  SVL_CHECK_ARG(gn_shape_ok(C, G) && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, "svl_groupnorm_bwd_apply: unsupported C=%d G=%d",
+                C, G);
+  const long npix = (long)imgs * HW;
+  hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, gn_apply_grid(imgs, HW, C), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x,
+                     (long)ldx, (const float*)nullptr, 0L, stats, gamma, beta, chan_sums, npix, (long)HW, C, G, relu, dx, (long)lddx);
+  SVL_LAUNCH_CHECK("svl_groupnorm_bwd_apply");
+  return SVL_OK;
+}
+
 // dst[o][b][a][:] = src[o][a][b][:]  (rows of 4 C4 floats): a wave per destination row, the index split once per row.
 namespace {
 __global__ __launch_bounds__(256) void permute_rows_kernel(const float4* __restrict__ src, long outer, int A, int B, int C4,

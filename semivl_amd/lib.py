@@ -107,6 +107,7 @@ SIGNATURES = {
     "svl_conf_avg_factor": (_I, [_P, _P, _I, _L, _P, _P, _P]),
     "svl_stream_release": (_I, [_P]),
     "svl_stream_prepare": (_I, [_P]),
+    "svl_stream_helper": (_I, [_P, C.POINTER(C.c_void_p)]),
     "svl_last_gemm_path": (_I, []),
     "svl_shutdown": (_I, []),
     "svl_num_stream_contexts": (_I, []),
@@ -144,6 +145,9 @@ SIGNATURES = {
     "svl_groupnorm_scale_shift": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "svl_groupnorm_apply": (_I, [_P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _P, _L, _P]),
     "svl_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _L, _I, _I, _I, _P, _L, _P, _P]),
+    "svl_conv3x3_gnb_ws_doubles": (_L, [_I, _I, _I, _I]),
+    "svl_conv3x3_dgrad_gnb_f32": (_I, [_P, _L, _I, _P, _I, _I, _I, _I, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "svl_groupnorm_bwd_apply": (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _L, _P]),
     "svl_bn_ws_doubles": (_L, [_L, _I]),
     "svl_bn_stats": (_I, [_P, _L, _L, _I, _P, _P, _P]),
     "svl_bn_finalize": (_I, [_P, _D, _F, _F, _P, _P, _I, _P, _P, _P]),

@@ -216,14 +216,21 @@ def _conv_gn_fwd(x, ldx, imgs, H, W, C1, conv, gn, k, dil, sv, src2=None, ld2=0,
 _WGRAD_AFTER_DGRAD = bool(int(_os.environ.get("SVL_WGRAD_AFTER_DGRAD", "1")))
 
 
-def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None, x=None):
+def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None, x=None, chan_sums=None, below=None):
     """`dx_acc`: an existing input-gradient buffer the convolution's dgrad is ADDED to in the GEMM epilogue (the branches of a
     residual / multi-branch node) instead of returned as a new tensor and added by a separate pass.  `x`: the unit's input
-    when the caller has already re-materialised it (else `sv["x"]`, tensor or lazy handle)."""
+    when the caller has already re-materialised it (else `sv["x"]`, tensor or lazy handle).
+    Round 6: `below` = (sv, gn) of the conv + GN + ReLU unit whose OUTPUT is this unit's input: this unit's input gradient is
+    that GroupNorm's dy, and the tiled dgrad kernel's epilogue then leaves that GroupNorm's backward channel sums -- the call
+    returns (dx, sums or None) and the unit below is handed them as `chan_sums` (its statistics pass over dy and x is skipped)."""
     imgs, H, W, C1, Co, k, dil, pad = sv["geom"]
     dpre = ops.empty(imgs * H * W, Co, device=dy.device)
-    dg, db = ops.groupnorm_bwd(dy, lddy, sv["pre"], Co, sv["y"], sv["ldy"], sv["st"], gn.weight, imgs, H * W, Co,
-                               gn.num_groups, True, dpre, Co, beta=gn.bias)   # ReLU mask re-derived from `pre`: y is not read
+    if chan_sums is not None:
+        dg, db = ops.groupnorm_bwd_from_sums(dy, lddy, sv["pre"], Co, sv["st"], gn.weight, gn.bias, imgs, H * W, Co,
+                                             gn.num_groups, True, chan_sums, dpre, Co)
+    else:
+        dg, db = ops.groupnorm_bwd(dy, lddy, sv["pre"], Co, sv["y"], sv["ldy"], sv["st"], gn.weight, imgs, H * W, Co,
+                                   gn.num_groups, True, dpre, Co, beta=gn.bias)   # ReLU mask re-derived from `pre`: y is not read
     gc.put_tensor(gn.weight, dg)
     gc.put_tensor(gn.bias, db)
     C2 = sv["C2"]
@@ -245,14 +252,24 @@ def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None, x=None):
         wgrad()
     if not need_dx:
         return None
+    below_sums = None
     if dx_acc is not None:
         dx = ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad, out=dx_acc, ldo=dx_acc.stride(0),
                             accumulate=True)
     else:
-        dx = ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad)  # [pix, C1+C2]
+        fused = None
+        if below is not None and C2 == 0 and (k, dil, pad) == (3, 1, 1):
+            bsv, bgn = below
+            if bsv["geom"][:3] == (imgs, H, W) and bsv["geom"][4] == C1 and bsv["pre"].stride(0) == C1:
+                fused = ops.conv3x3_dgrad_gnb(dpre, Co, imgs, H, W, Co, sv["wd"], C1, bsv["pre"], bsv["st"], bgn.weight, bgn.bias,
+                                              bgn.num_groups)
+        if fused is not None:
+            dx, below_sums = fused
+        else:
+            dx = ops.conv_dgrad(dpre, Co, imgs, H, W, Co, sv["wd"], C1 + C2, k, k, dil, pad)  # [pix, C1+C2]
     if _WGRAD_AFTER_DGRAD:
         wgrad()
-    return dx
+    return (dx, below_sums) if below is not None else dx
 
 
 # ------------------------------------------------------------------------------------------------ head
@@ -668,11 +685,12 @@ def _up_backward(up, dg2, imgs, h, w, b, N, sv, gc):
     """Returns (dx [(b n) h w, Cin], dskip [b h w, Cs])."""
     Cin, Cu, Cs, sh, sw = sv["dims"]
     dev = dg2.device
-    dg1 = _conv_gn_bwd(dg2, dg2.shape[1], up.conv[3], up.conv[4], sv["b"], gc)
+    # (conv b's input gradient is GroupNorm a's dy: its epilogue leaves that GroupNorm's backward sums, round 6)
+    dg1, sums_a = _conv_gn_bwd(dg2, dg2.shape[1], up.conv[3], up.conv[4], sv["b"], gc, below=(sv["a"], up.conv[1]))
     xin = _mat(sv["x"])                 # the block's input (re-materialised once when it is a lazy GroupNorm output) ...
     xa = sv["a"]["x"]                   # ... feeds the re-created ConvTranspose output and the ConvTranspose weight gradient
     dcat = _conv_gn_bwd(dg1, dg1.shape[1], up.conv[0], up.conv[1], sv["a"], gc,
-                        x=xa.get(xin) if isinstance(xa, _LazyConvT) else None)  # [pix, Cu + Cs]
+                        x=xa.get(xin) if isinstance(xa, _LazyConvT) else None, chan_sums=sums_a)  # [pix, Cu + Cs]
     ld = Cu + Cs
     # skip half: sum over the N repeats, then bilinear backward
     dskip = ops.empty(b * sh * sw, Cs, device=dev)

@@ -101,6 +101,21 @@ def create_step_streams(dev):
             L.check(L.load().svl_stream_prepare(s_.cuda_stream), "svl_stream_prepare")
     return out
 
+
+def step_helper_streams(streams):
+    """The library's helper streams of `streams` (ragged-row GEMM parts, the attention's leftover-row kernels run there) as
+    torch ExternalStreams: the communication stream must not share a hardware queue with them either."""
+    import ctypes
+    from . import lib as L
+    out = []
+    for s_ in streams:
+        h_ = ctypes.c_void_p()
+        with torch.cuda.device(s_.device):
+            L.check(L.load().svl_stream_helper(s_.cuda_stream, ctypes.byref(h_)), "svl_stream_helper")
+        if h_.value:
+            out.append(torch.cuda.ExternalStream(h_.value, device=s_.device))
+    return out
+
 LOSS_NAMES = ("loss", "loss_x", "loss_s1", "loss_s2", "loss_fp", "loss_mc_s1", "loss_mc_s2", "loss_mc_fp")
 
 
@@ -593,8 +608,11 @@ class GradAllReducer:
             # fresh stream landed on the main stream's queue, measured).  Blocking backends have no communication stream:
             # the same search reports what one created at this point WOULD get.
             names = ["main", "second"] + (["weight_gradient"] if len(step_streams) > 2 else [])
+            helpers = step_helper_streams(step_streams)          # (round 6: the leftover-row / ragged-row launches' streams too)
+            names = names + [n_ + "_helper" for n_ in names[:len(helpers)]]
+            step_streams = list(step_streams) + helpers
             tried, pick, shared = [], None, None
-            for _ in range(6):
+            for _ in range(8):
                 cand = torch.cuda.Stream(optimizer.g.device)
                 sh_ = [n_ for n_, s_ in zip(names, step_streams) if ops.streams_share_queue(s_, cand)]
                 tried.append(cand)               # (kept alive: a destroyed stream's queue slot would be handed out again)

@@ -336,7 +336,7 @@ def test_fullsize_step_large_class_counts(dev, nclass, dataset):
     hip.decode_head.chunk_class_images = 1344
 
 
-BF16X3_GRAD_REL_L2 = 3e-2      # (measured: printed as `BF16X3 measured`; 16-bit products, ~4e-6 per GEMM)
+BF16X3_GRAD_REL_L2 = 1e-2      # (measured 3.4e-3 on skip_proj.1.0.weight, median 6e-4: printed as `BF16X3 measured`)
 
 
 def reduced_precision_mode_check(dev, cfg, hip, batch, masks, loss, aux, og):

@@ -1,6 +1,6 @@
 """Three SemiVL steps on one GPU with GradAllReducer's STREAM-ORDERED branch live (world = 2 stand-in): the injected
-collective launches REAL kernels on the communication stream -- a bucket-sized copy (permute4_kernel, a name no other launch
-of the step uses) followed by the x2 that "SUM over two ranks with identical gradients" amounts to (cancelled exactly by
+collective launches REAL kernels on the communication stream -- a bucket-sized copy (permute_rows_kernel: at N = 21 classes no
+other launch of the step uses it) followed by the x2 that "SUM over two ranks with identical gradients" amounts to (cancelled exactly by
 AdamW's 1 / W).  Run under rocprofv3 --kernel-trace by tools/comm_overlap_trace.sh; tools/comm_overlap_parse.py then checks
 from the trace that those kernels (1) sit on a hardware queue none of the step's other kernels use and (2) run while
 backward kernels of the step are in flight."""
@@ -31,7 +31,8 @@ class _Done:
 
 def collective(g):
     flat = g.view(-1)
-    ops.permute4(flat, (1, 1, 1, flat.numel()), (0, 0, 0, 1))       # the "wire": one bucket-sized pass on the communication stream
+    n4 = flat.numel() // 4 * 4
+    ops.permute_rows(flat[:n4], 1, 1, n4 // 4, 4)                    # the "wire": one bucket-sized pass on the communication stream
     ops.add(flat, flat, out=flat)                                    # SUM over two identical ranks
     return _Done()
 
