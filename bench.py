@@ -631,11 +631,6 @@ def main():
                     launches=dom[2], avg_ms=round(dom[0] * 1e3 / dom[2], 4),
                     **in_step_fields(dom_tag, 2.0 * Md * 3072 * 768, PEAK_F32_MFMA_TF), flops_per_launch=2.0 * Md * 3072 * 768,
                     algorithmic_bytes=513.0e6 * a.batch / 16, traffic_note=tnote)
-        if os.environ.get("SVL_BENCH_DUMP_SHAPES"):
-            allsh = sorted(by.items(), key=lambda kv: -kv[1][0])
-            with open(os.environ["SVL_BENCH_DUMP_SHAPES"], "w") as f:
-                for k, v in allsh:
-                    f.write(f"{v[0] * 1e3:9.3f} ms  n={v[2]:3d}  {v[1] / v[0] / 1e12:7.1f} TF  {k}\n")
         c = prof.get("ce_fused", [])
         cu = prof.get("ce_up_fused", [])
         if cu and not c:

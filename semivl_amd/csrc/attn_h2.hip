@@ -455,18 +455,6 @@ __global__ __launch_bounds__(512) void attn_fwd_h2_kernel(const AttnP p, const H
             make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
       }
     }
-    if (p.planes) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          x[e] = (kk < 2 ? o0[8 * (kk & 1) + e] : o1[8 * (kk & 1) + e]) * inv;
-          asm volatile("" : "+v"(x[e]));   // the split must see the ROUNDED product (the fp32 copy's value)
-        }
-        emit_planes8(p.planes, p.planes_ks, 4 * h + kk, (long)b * p.T + qi, hi, x);
-      }
-    }
     if (p.lse && hi == 0) p.lse[(long)z * p.T + qi] = (m2s + __log2f(lt)) * LN2;    // log2 sum P = log2 sum P' - 7
   } else if (wave_active) {
     (void)__shfl_xor(l, 32, 64);
@@ -583,15 +571,6 @@ __global__ __launch_bounds__(512) void attn_dq_h2_kernel(const AttnP p, const H2
       const int d0 = 8 * g + 4 * hi;
       *reinterpret_cast<float4*>(row + d0) = make_float4(dq0[4 * g] * f, dq0[4 * g + 1] * f, dq0[4 * g + 2] * f, dq0[4 * g + 3] * f);
       *reinterpret_cast<float4*>(row + 32 + d0) = make_float4(dq1[4 * g] * f, dq1[4 * g + 1] * f, dq1[4 * g + 2] * f, dq1[4 * g + 3] * f);
-    }
-    if (p.planes) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (kk < 2 ? dq0[8 * (kk & 1) + e] : dq1[8 * (kk & 1) + e]) * f;
-        emit_planes8(p.planes, p.planes_ks, 4 * h + kk, (long)b * p.T + qi, hi, x);
-      }
     }
   }
 }
@@ -718,32 +697,6 @@ __global__ __launch_bounds__(512) void attn_dkv_h2_kernel(const AttnP p, const H
         row[p.E + 32 + l31] = dk1[r];
         row[2 * p.E + l31] = dv0[r];
         row[2 * p.E + 32 + l31] = dv1[r];
-      }
-    }
-    if (p.planes) {
-      // the dK | dV columns of the planes: a planes lane is (key, 8 d) where a C register is (d, key) -- the wave's
-      // [32 keys][64 d] tile goes through its own 9 KB of the (now idle) staging LDS (attention.hip::attn_bwd_dkv_x6_kernel)
-      float* tr = reinterpret_cast<float*>(sm) + wave * (32 * 72);
-#pragma unroll
-      for (int which = 0; which < 2; ++which) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          tr[crow(r, hi) * 72 + l31] = which ? dv0[r] : dk0[r];
-          tr[crow(r, hi) * 72 + 32 + l31] = which ? dv1[r] : dk1[r];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (k0 + l31 < p.T) {
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const float4 u = *reinterpret_cast<const float4*>(tr + l31 * 72 + 16 * kk + 4 * hi);
-            const float4 v = *reinterpret_cast<const float4*>(tr + l31 * 72 + 16 * kk + 4 * hi + 8);
-            const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-            emit_planes8(p.planes, p.planes_ks, (int)((which + 1) * (p.E >> 4)) + 4 * h + kk, (long)b * p.T + k0 + l31, hi, x);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
   }
@@ -888,18 +841,6 @@ __global__ __launch_bounds__(64 * TAILW) __attribute__((amdgpu_waves_per_eu(4, 4
             make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
       }
     }
-    if (p.planes) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          x[e] = (kk < 2 ? o0[8 * (kk & 1) + e] : o1[8 * (kk & 1) + e]) * inv;
-          asm volatile("" : "+v"(x[e]));
-        }
-        emit_planes8(p.planes, p.planes_ks, 4 * h + kk, (long)b * p.T + qi, hi, x);
-      }
-    }
     if (p.lse && hi == 0) p.lse[(long)z * p.T + qi] = (m2s + __log2f(lt)) * LN2;
   }
 }
@@ -1006,21 +947,11 @@ __global__ __launch_bounds__(64 * TAILW) __attribute__((amdgpu_waves_per_eu(4, 4
       *reinterpret_cast<float4*>(row + d0) = make_float4(dq0[4 * g] * f, dq0[4 * g + 1] * f, dq0[4 * g + 2] * f, dq0[4 * g + 3] * f);
       *reinterpret_cast<float4*>(row + 32 + d0) = make_float4(dq1[4 * g] * f, dq1[4 * g + 1] * f, dq1[4 * g + 2] * f, dq1[4 * g + 3] * f);
     }
-    if (p.planes) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (kk < 2 ? dq0[8 * (kk & 1) + e] : dq1[8 * (kk & 1) + e]) * f;
-        emit_planes8(p.planes, p.planes_ks, 4 * h + kk, (long)b * p.T + qi, hi, x);
-      }
-    }
   }
 }
 
 template <bool MIX>
 __global__ __launch_bounds__(64 * TAILW) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_dkv_tail_h2_kernel(const AttnP p, const H2W w, int row0) {
-  __shared__ __attribute__((aligned(16))) float tr[32 * 72];
   const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int z = blockIdx.x, b = z / p.H, h = z - b * p.H;
@@ -1139,29 +1070,6 @@ __global__ __launch_bounds__(64 * TAILW) __attribute__((amdgpu_waves_per_eu(4, 4
       row[2 * p.E + 32 + l31] = dv1[r];
     }
   }
-  if (p.planes) {
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        tr[crow(r, hi) * 72 + l31] = which ? dv0[r] : dk0[r];
-        tr[crow(r, hi) * 72 + 32 + l31] = which ? dv1[r] : dk1[r];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (k0 + l31 < p.T) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const float4 u = *reinterpret_cast<const float4*>(tr + l31 * 72 + 16 * kk + 4 * hi);
-          const float4 v = *reinterpret_cast<const float4*>(tr + l31 * 72 + 16 * kk + 4 * hi + 8);
-          const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-          emit_planes8(p.planes, p.planes_ks, (int)((which + 1) * (p.E >> 4)) + 4 * h + kk, (long)b * p.T + k0 + l31, hi, x);
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -1182,10 +1090,8 @@ Layout layout(int B, int T, int H, int backward) {
   return l;
 }
 
-int variant() {   // SVL_ATTN_H2_VARIANT: bit 0 = v_fma_mix split, bit 1 = forward without the half-tile skew (A/B runs)
-  static const int v = getenv("SVL_ATTN_H2_VARIANT") ? atoi(getenv("SVL_ATTN_H2_VARIANT")) & 3 : 3;
-  return v;
-}
+// (rounds 5's A/B variants -- the split without v_fma_mix, the forward with a half-tile skew between its wave groups -- measured
+//  slower and were retired in round 6: one instantiation per kernel, V = 3)
 template <typename K>
 int set_lds(K kernel, std::atomic<uint64_t>& mask, int bytes) {   // per device, the bit set only after the call succeeded
   int dev = 0;
@@ -1255,13 +1161,10 @@ int fwd_pack(const AttnP& p, void* ws_, long wsb, hipStream_t st) {
   return SVL_OK;
 }
 
-#define SVL_LAUNCH_V(KERN, LDS)                                                    \
-    switch (variant()) {                                                            \
-      case 0: rc = set_lds(KERN<0>, mask[0], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<0>, grid, dim3(512), LDS, st, p, w); break; \
-      case 1: rc = set_lds(KERN<1>, mask[1], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<1>, grid, dim3(512), LDS, st, p, w); break; \
-      case 2: rc = set_lds(KERN<2>, mask[2], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<2>, grid, dim3(512), LDS, st, p, w); break; \
-      default: rc = set_lds(KERN<3>, mask[3], LDS); if (rc) return rc; hipLaunchKernelGGL(KERN<3>, grid, dim3(512), LDS, st, p, w); break; \
-    }
+#define SVL_LAUNCH_V(KERN, LDS)                                       \
+    rc = set_lds(KERN<3>, mask, LDS);                                   \
+    if (rc) return rc;                                                  \
+    hipLaunchKernelGGL(KERN<3>, grid, dim3(512), LDS, st, p, w);
 
 int fwd(const AttnP& p, int nb, void* ws_, long wsb, hipStream_t st) {   // the MFMA grid over `nb` blocks per (image, head)
   (void)wsb;
@@ -1269,7 +1172,7 @@ int fwd(const AttnP& p, int nb, void* ws_, long wsb, hipStream_t st) {   // the 
   const Layout l = layout(p.B, p.T, p.H, 0);
   const H2W w = views(l, static_cast<char*>(ws_), 0);
   int rc = SVL_OK;
-  static std::atomic<uint64_t> mask[4];
+  static std::atomic<uint64_t> mask;
   const dim3 grid(nb * p.B * p.H);
   SVL_LAUNCH_V(attn_fwd_h2_kernel, 3 * STG_F)
   SVL_LAUNCH_CHECK("svl_attention_fwd_h2");
@@ -1315,8 +1218,7 @@ int fwd_tail(const AttnP& p, int row0, void* ws_, hipStream_t aux) {
   const Layout l = layout(p.B, p.T, p.H, 0);
   const H2W w = views(l, static_cast<char*>(ws_), 0);
   const dim3 grid(p.B * p.H, (p.T - row0 + 31) / 32);
-  if (variant() & 1) hipLaunchKernelGGL(attn_fwd_tail_h2_kernel<true>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
-  else hipLaunchKernelGGL(attn_fwd_tail_h2_kernel<false>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
+  hipLaunchKernelGGL(attn_fwd_tail_h2_kernel<true>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
   SVL_LAUNCH_CHECK("svl_attention_fwd_h2/tail");
   return SVL_OK;
 }
@@ -1325,13 +1227,8 @@ int bwd_tail(const AttnP& p, int row0, void* ws_, hipStream_t aux) {
   const Layout l = layout(p.B, p.T, p.H, 1);
   const H2W w = views(l, static_cast<char*>(ws_), 1);
   const dim3 grid(p.B * p.H, (p.T - row0 + 31) / 32);
-  if (variant() & 1) {
-    hipLaunchKernelGGL(attn_dkv_tail_h2_kernel<true>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
-    hipLaunchKernelGGL(attn_dq_tail_h2_kernel<true>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
-  } else {
-    hipLaunchKernelGGL(attn_dkv_tail_h2_kernel<false>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
-    hipLaunchKernelGGL(attn_dq_tail_h2_kernel<false>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
-  }
+  hipLaunchKernelGGL(attn_dkv_tail_h2_kernel<true>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
+  hipLaunchKernelGGL(attn_dq_tail_h2_kernel<true>, grid, dim3(64 * TAILW), 0, aux, p, w, row0);
   SVL_LAUNCH_CHECK("svl_attention_bwd_h2/tail");
   return SVL_OK;
 }
@@ -1343,12 +1240,12 @@ int bwd_main(const AttnP& p, int nb, void* ws_, hipStream_t st) {
   int rc = SVL_OK;
   const dim3 grid(nb * p.B * p.H);
   {
-    static std::atomic<uint64_t> mask[4];
+    static std::atomic<uint64_t> mask;
     SVL_LAUNCH_V(attn_dkv_h2_kernel, 3 * STG_K)
     SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dkv");
   }
   {
-    static std::atomic<uint64_t> mask[4];
+    static std::atomic<uint64_t> mask;
     SVL_LAUNCH_V(attn_dq_h2_kernel, 3 * STG_Q)
     SVL_LAUNCH_CHECK("svl_attention_bwd_h2/dq");
   }

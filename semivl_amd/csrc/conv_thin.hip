@@ -217,8 +217,7 @@ extern "C" int svl_conv_cout1_fwd(const float* x, int64_t ldx, int imgs, int H, 
                     KH > 0 && KW > 0 && (long)KH * KW * C * 4 <= 64 * 1024,
                 "svl_conv_cout1_fwd: bad args (C must be a power of two in [4, 256])");
   // the LDS-tiled kernel: 3x3 / pad 1 / no dilation, C = 16 / 32 / 64, 16-byte aligned rows (the only form that takes gn_in)
-  static const int tiled_ok = getenv("SVL_COUT1_NO_TILED") ? 0 : 1;
-  const bool tiled = tiled_ok && KH == 3 && KW == 3 && dil == 1 && pad == 1 && (C == 16 || C == 32 || C == 64) &&
+  const bool tiled = KH == 3 && KW == 3 && dil == 1 && pad == 1 && (C == 16 || C == 32 || C == 64) &&
                      (((uintptr_t)x | (uintptr_t)gn_in) & 15) == 0 && H >= 8 && W >= 16;
   SVL_CHECK_ARG(!gn_in || tiled, "svl_conv_cout1_fwd: gn_in needs the tiled form (3x3, pad 1, C = 16 / 32 / 64, H >= 8, W >= 16)");
   if (tiled) {

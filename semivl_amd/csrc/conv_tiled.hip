@@ -663,19 +663,15 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st, int* tiles_per
   const long blocks = (long)p.imgs * tx * ty;
   SVL_CHECK_ARG(blocks < (1L << 31), "svl_conv3x3_tiled: grid too large");
   static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
-  static const int pt2 = getenv("SVL_CONV_TILED_PT1") ? 0 : 1;
   if (emu_ok && svl_get_gemm_emulation() == 6) {   // the split emulation covers the narrow convolutions too
-    static const int wpre_ok = getenv("SVL_CONV_TILED_NO_WPLANES") ? 0 : 1;
-    const bool wpre = wpre_ok && p.w_planes != nullptr;
+    const bool wpre = p.w_planes != nullptr;
     // persistent blocks: two per CU (the LDS image allows two), each walking tiles b, b + grid, ...
     static const long resident = [] {
       int dev = 0, cus = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      const char* e = getenv("SVL_CONV_TILED_BLOCKS_PER_CU");
-      const int per_cu = e ? atoi(e) : 2;
-      return (long)(cus > 0 ? cus : 256) * (per_cu > 0 ? per_cu : 2);
+      return (long)(cus > 0 ? cus : 256) * 2;
     }();
-    if (p.N == 32 && pt2 && p.H >= 2 * PH) {        // 16 x 16 patches: two pixel tiles per wave
+    if (p.N == 32 && p.H >= 2 * PH) {        // 16 x 16 patches: two pixel tiles per wave
       const int ty2 = (p.H + 2 * PH - 1) / (2 * PH);
       if (tiles_per_img) *tiles_per_img = tx * ty2;
       const long nt2 = (long)p.imgs * tx * ty2;

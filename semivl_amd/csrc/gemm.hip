@@ -1377,7 +1377,7 @@ static std::atomic<int> g_band{-1};
 static int svl_band_n(int tiles_n) {
   int band = g_band.load(std::memory_order_relaxed);
   if (band < 0) {
-    band = env_int("SVL_GEMM_BAND", 8);
+    band = 8;
     if (band < 0) band = 0;
     g_band.store(band, std::memory_order_relaxed);
   }
@@ -1602,8 +1602,6 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     emu_mode = env_int("SVL_GEMM_EMU", 0);
     g_emu_mode.store(emu_mode, std::memory_order_relaxed);
   }
-  static const int emu_conv = getenv("SVL_GEMM_EMU_NO_CONV") ? 0 : 1;
-  static const int sk_emu_maxk_g = env_int("SVL_SHORTK_EMU_MAXK", 64);   // (see the short-K dispatch below)
   g_last_path = SVL_PATH_F32;
   // fp16 x 2 form of the in-register split kernel (round 5): three products instead of six, one power-of-two scale per operand
   // TENSOR found by a maximum pass over exactly the elements the launch reads (d->emu_ws: 8 bytes of device scratch private to
@@ -1626,8 +1624,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     // implicit-GEMM convolutions (NHWC im2col on the fly, forward and mirrored-tap input gradient) join the split
     // emulation when every 4-k piece stays inside one tap (channels % 4) and K is a whole number of 16-deep steps
     if ((emu_mode == 3 || emu_mode == 6) && am == SVL_A_CONV && bm == SVL_B_KCONTIG && d->out_mode == SVL_OUT_STRIDED &&
-        d->batch == 1 && d->ksplit == 0 && q.M >= 256 && q.N >= 96 && q.K >= 64 && (q.K % 16) == 0 && q.A.vec && q.B.vec &&
-        emu_conv) {
+        d->batch == 1 && d->ksplit == 0 && q.M >= 256 && q.N >= 96 && q.K >= 64 && (q.K % 16) == 0 && q.A.vec && q.B.vec) {
       g_last_path = SVL_PATH_BF16X;
       const long px = (long)(q.M / (q.cv.Ho * q.cv.Wo)) * q.cv.H * q.cv.W;
       if (h2_ok(q, (double)px * q.cv.C1 + (q.cv.C2 > 0 ? (double)(px / q.cv.rep) * q.cv.C2 : 0.0) + (double)q.N * q.K)) {
@@ -1647,10 +1644,9 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     // weight gradients of the implicit-GEMM convolutions (A = dy^T, B = im2col(x)^T, split-K over the pixels): the
     // dilated / 1x1 / transposed-conv layers of the decoder.  One 128-row tile holds all of Cout = 128 (Cout = 64 wastes half of
     // every tile: measured slower than the fp32 kernel's 64-row tiles, 46 vs 53 TF, and left there); a thread's 8 consecutive k must be pixels of one image row.
-    static const int emu_convw = getenv("SVL_GEMM_EMU_NO_CONVW") ? 0 : 1;
     if ((emu_mode == 3 || emu_mode == 6) && am == SVL_A_MCONTIG && bm == SVL_B_CONVW && d->out_mode == SVL_OUT_STRIDED &&
         q.M >= 96 && q.N >= 96 && q.K >= 1024 && (q.K % 16) == 0 && (d->ksplit % 16) == 0 && (q.cv.Wo % 8) == 0 &&
-        q.A.vec && q.B.vec && emu_convw) {
+        q.A.vec && q.B.vec) {
       g_last_path = SVL_PATH_BF16X;
       const long px = (long)(q.K / (q.cv.Ho * q.cv.Wo)) * q.cv.H * q.cv.W;
       if ((d->batch == 1 || d->ksplit > 0) &&
@@ -1721,9 +1717,8 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
     // In the split-emulation modes the row-major K = 128 launches (ASPP 1x1 convolution and its input gradient, the
     // projection's input gradient N = 640: 2 N FLOP per operand byte, more matrix- than store-bound) go to the bf16-pipe
     // kernel instead: 94 -> 109 TF and 80 -> 87 TF solo, ADE 24.86 -> 25.40 img/s, VOC 77.50 -> 77.84 in the step (same
-    // box, round 4).  K = 64 (ConvTranspose of up2) and the pixel-shuffle stores stay here.  SVL_SHORTK_EMU_MAXK=128 undoes it.
-    const int sk_emu_maxk = sk_emu_maxk_g;
-    const bool sk_to_emu = (emu_mode == 3 || emu_mode == 6) && d->K > sk_emu_maxk && d->out_mode == SVL_OUT_STRIDED;
+    // box, round 4).  K = 64 (ConvTranspose of up2) and the pixel-shuffle stores stay here.
+    const bool sk_to_emu = (emu_mode == 3 || emu_mode == 6) && d->K > 64 && d->out_mode == SVL_OUT_STRIDED;
     if (shortk && !sk_to_emu && a_dense && bm == SVL_B_KCONTIG && d->batch == 1 && d->ksplit == 0 && d->K % 64 == 0 && d->K >= 64 &&
         d->K <= 128 && d->M >= 32768 && d->N >= 96 && p.A.vec && p.B.vec &&
         (d->out_mode == SVL_OUT_STRIDED || d->out_mode == SVL_OUT_CONVT2X)) {
@@ -1731,8 +1726,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
                         (d->act == SVL_ACT_NONE || d->act == SVL_ACT_RELU || d->act == SVL_ACT_GELU);
       // the ConvTranspose2d(k 2, s 2) layers (and any K = 64 stream) in emulation mode 6: the same stream structure on
       // the split pipe (gemm_shortk.hip) -- these were the largest launches left on the fp32 matrix pipe
-      static const int sk_x6 = getenv("SVL_SHORTK_NO_X6") ? 0 : 1;
-      if (fast && emu_mode == 6 && sk_x6 && (d->out_mode == SVL_OUT_CONVT2X || d->K == 64)) {
+      if (fast && emu_mode == 6 && (d->out_mode == SVL_OUT_CONVT2X || d->K == 64)) {
         ShortKP q;
         q.A = d->A.ptr; q.lda = d->A.ld; q.B = d->B.ptr; q.ldb = d->B.ld; q.C = d->C; q.ldc_m = d->ldc_m;
         q.M = d->M; q.N = d->N; q.K = d->K; q.out_mode = d->out_mode; q.ct_H = d->ct_H; q.ct_W = d->ct_W;
@@ -1797,7 +1791,7 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   // run as a second, thin-tile launch on a helper stream, concurrent with the 128-row-aligned part.
   int ragged_fork = g_ragged_fork.load(std::memory_order_relaxed);
   if (ragged_fork < 0) {
-    ragged_fork = getenv("SVL_GEMM_NO_FORK") ? 0 : 1;
+    ragged_fork = 1;
     g_ragged_fork.store(ragged_fork, std::memory_order_relaxed);
   }
   if (ragged_fork && am == SVL_A_KCONTIG && (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG) &&

@@ -104,8 +104,7 @@ extern "C" int svl_gemm_planes_f32(const svl_pgemm_desc* d, svl_stream_t stream)
   p.a_se = d->a_sexp ? d->a_sexp + mo : nullptr; p.b_se = d->b_sexp;
   p.a_rn = d->a_rnorm ? d->a_rnorm + mo : nullptr; p.b_bd = d->b_bound;
   p.p_se = d->p_sexp ? d->p_sexp + mo : nullptr; p.p_np = pnp;
-  static const int no_fast = getenv("SVL_PLANES_NO_FAST_EPI") ? atoi(getenv("SVL_PLANES_NO_FAST_EPI")) : 0;
-  p.epi_fast = !no_fast;
+  p.epi_fast = 1;
   p.b_rb = (int)(d->b_rows / 32);
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.C = d->C ? d->C + mo * d->ldc : nullptr; p.ldc = d->ldc;

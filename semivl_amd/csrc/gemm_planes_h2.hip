@@ -125,8 +125,7 @@ extern "C" int svl_split_planes_f16x2(const float* x, int64_t ld, int64_t k_stri
                 "svl_split_planes_f16x2: bad args (K %% 16, planes_rows %% 256, row_off %% 32 must be 0; sexp required)");
   const long blocks = (rows + 31) / 32;
   int ysplit = 1;
-  static const bool no_ysplit = getenv("SVL_PACK_NO_YSPLIT") != nullptr;      // (A/B switch)
-  if (blocks < 256 && !no_ysplit) {
+  if (blocks < 256) {
     ysplit = (int)(512 / blocks);
     if (ysplit > 8) ysplit = 8;
     if (ysplit > (K >> 6)) ysplit = K >> 6;      // at least four k-groups per slice

@@ -793,10 +793,9 @@ int launch_tile(PlanesP q, hipStream_t st) {
     svl_set_error("svl_gemm_planes_f32: bad tile count %ld", total);
     return SVL_ERR_INVALID_ARG;
   }
-  static const int panel_env = getenv("SVL_PLANES_PANEL") ? atoi(getenv("SVL_PLANES_PANEL")) : 0;
   // 6 columns per panel: FETCH x 2 of FFN-1 (12 column tiles) 1.035 -> 0.82 GB at unchanged time; 2 / 3 are worse than
   // row-major (A bands re-read per panel), shapes with <= 6 column tiles are row-major anyway (tools/micro/run12.sh)
-  const int pw = panel_env > 0 ? panel_env : 6;
+  const int pw = 6;
   q.panel = pw < q.tiles_n ? pw : q.tiles_n;
   long fs = 0;
   for (int x = 0; x < 8; ++x) {   // XCD x runs the blocks with id % 8 == x
@@ -815,14 +814,13 @@ int launch_tile(PlanesP q, hipStream_t st) {
 // rounds at M = 32 x 1025.
 template <int NP>
 int launch(const PlanesP& q, hipStream_t st) {
-  static const int force = getenv("SVL_PLANES_TILE") ? atoi(getenv("SVL_PLANES_TILE")) : 0;
   auto cost = [&](int bn) {
     const long tiles = (long)(q.M / BM) * ((q.N + bn - 1) / bn);
     const long rounds = tiles > 0 ? (tiles + 255) / 256 : 1;
     return (double)rounds * bn * (bn == 128 ? 1.15 : bn == 192 ? 1.04 : 1.0);   // time ~ rounds x tile width (x the narrower tiles' overhead)
   };
-  int bn = force;
-  if (!bn) {
+  int bn = 0;
+  {
     bn = 256;
     if (q.N <= 128) bn = 128;
     else {

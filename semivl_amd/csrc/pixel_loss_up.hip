@@ -457,10 +457,6 @@ extern "C" int svl_ce_up_fused_f32(const svl_ce_up_desc* d, svl_stream_t stream)
   (void)up_axis_ok(d->h, d->H, p.align != 0, &my);
   (void)up_axis_ok(d->w, d->W, p.align != 0, &mx);
   p.pstr = ((my * mx + 31) / 32) * 32;
-  {
-    static const char* force = getenv("SVL_CE_UP_PSTR");      // (A/B: "max" = RMAX^2 for every launch)
-    if (force && force[0] == 'm') p.pstr = RMAX * RMAX;
-  }
   static std::atomic<uint64_t> mask{0};
   {
     const int rc = lds_attr_once(mask, ce_up_kernel, 158 * 1024);

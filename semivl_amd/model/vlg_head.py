@@ -213,7 +213,7 @@ def _conv_gn_fwd(x, ldx, imgs, H, W, C1, conv, gn, k, dil, sv, src2=None, ld2=0,
     return deferred if deferred is not None else y
 
 
-_WGRAD_AFTER_DGRAD = bool(int(_os.environ.get("SVL_WGRAD_AFTER_DGRAD", "1")))
+_WGRAD_AFTER_DGRAD = True     # (launched beside the input gradient instead: two matrix-bound kernels share one pipe, measured slower)
 
 
 def _conv_gn_bwd(dy, lddy, conv, gn, sv, gc, need_dx=True, dx_acc=None, x=None, chan_sums=None, below=None):

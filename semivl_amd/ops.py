@@ -110,9 +110,6 @@ class Op:
 # In-register split kernel on fp16 x 2 terms with per-tensor scales (svl_gemm_desc.emu_ws; round 5): SVL_GEMM_EMU_NO_H2=1 keeps
 # the bf16 x 3 form for every launch (A/B runs).
 EMU_H2 = not os.environ.get("SVL_GEMM_EMU_NO_H2")
-EMU_H2_WGRAD = not os.environ.get("SVL_GEMM_EMU_H2_NO_WGRAD")     # (split-K launches: the weight gradients)
-EMU_H2_FWD = not os.environ.get("SVL_GEMM_EMU_H2_NO_FWD")         # (forward / input-gradient launches)
-EMU_H2_DGRAD = not os.environ.get("SVL_GEMM_EMU_H2_NO_DGRAD")     # (conv_dgrad launches: the decoder's input gradients)
 # conv_fwd launches (the dilated ASPP convolutions' forward).  Round 5 ended with them OFF: together with the fp16 x 2 attention
 # they pushed tests/test_fullsize_gpu.py::test_fullsize_gradient_error_against_fp64 past its 4 x bound (ViT tensors 4.0 - 4.4 x).
 # Round 6: the split-K slab sums run in double (csrc/gemm.hip::reduce_slabs_kernel) and the test always compares under the
@@ -148,7 +145,7 @@ def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batc
         d.ldr_n, d.r_bs_outer, d.r_bs_inner = ldr_n, r_bso, r_bsi
     d.accumulate = 1 if accumulate else 0
     ws = None
-    if (EMU_H2 and emu_h2 and (EMU_H2_WGRAD if ksplit > 0 else EMU_H2_FWD) and 2.0 * M * N * K >= 4.0e9 and (batch == 1 or ksplit > 0)
+    if (EMU_H2 and emu_h2 and 2.0 * M * N * K >= 4.0e9 and (batch == 1 or ksplit > 0)
             and Cout.is_cuda and get_gemm_emulation() == 6):
         ws = torch.empty(2, dtype=torch.int32, device=Cout.device)      # scratch of the operand-maximum passes (fp16 x 2 form)
         d.emu_ws = _p(ws)
@@ -206,7 +203,7 @@ def _env_flag(name):
 
 WGRAD_STREAM = (_env_flag("SVL_WGRAD_STREAM") or int(os.environ.get("WORLD_SIZE", "1")) <= 1) \
     and not _env_flag("SVL_NO_WGRAD_STREAM")
-WGRAD_DEPTH = int(os.environ.get("SVL_WGRAD_DEPTH", "2"))
+WGRAD_DEPTH = 2          # blocks the weight-gradient stream may lag behind the chain
 _WG = {}
 _WG_KEEP = {}   # device index -> deque of (event on the side stream, tensors read before it, block number)
 _WG_SEQ = 0     # blocks closed so far
@@ -703,7 +700,6 @@ def chanmask(x, mask, scale, rows_per_img, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ normalisation
-LN_FUSED_H2 = not os.environ.get("SVL_LN_NO_FUSED_H2")      # A/B: LayerNorm -> fp16 x 2 planes in one kernel (planes-only calls)
 
 
 def layernorm_fwd(x, gamma, beta, eps, planes=False, want_y=True):
@@ -716,7 +712,7 @@ def layernorm_fwd(x, gamma, beta, eps, planes=False, want_y=True):
         L.check(L.load().svl_layernorm_fwd(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(y), _p(stats), _st()),
                 "svl_layernorm_fwd")
         return y, stats
-    if PLANES_FMT == "h2" and not want_y and LN_FUSED_H2:    # planes only: one kernel (row statistics, exponents, planes)
+    if PLANES_FMT == "h2" and not want_y:    # planes only: one kernel (row statistics, exponents, planes)
         pl = Planes(rows, Cc, device=x.device, fmt="h2")
         pl.rnorm = torch.empty(pl.prow, dtype=torch.float32, device=x.device)
         L.check(L.load().svl_layernorm_fwd_planes_f16x2(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, None, _p(stats),
@@ -784,9 +780,8 @@ def groupnorm_fwd(x, ldx, gamma, beta, eps, imgs, HW, Cc, G, relu, y, ldy):
     return stats
 
 
-CONV_GN_FUSED = not os.environ.get("SVL_NO_CONV_GN_FUSED")
 UP_LOSS = not os.environ.get("SVL_NO_UP_LOSS")      # A/B: the logits' resize evaluated inside the pixel-loss kernels (train.py)
-GN_DEFER = not os.environ.get("SVL_NO_GN_DEFER")     # GroupNorm + ReLU applied by the consuming convolution (model/vlg_head.py)
+GN_DEFER = True     # GroupNorm + ReLU applied by the consuming convolution (model/vlg_head.py; tests flip it for bit-identity checks)
 
 
 def groupnorm_scale_shift(stats, gamma, beta, imgs, Cc, G):
@@ -801,7 +796,7 @@ def conv3x3_gn(x, ldx, imgs, H, W, C1, wf, Co, eps, src2=None, ld2=0, C2=0, rep=
     """3x3 / pad 1 convolution fused with the statistics of the following GroupNorm (groups of 16 channels): returns
     (pre [imgs*H*W, Co], stats [imgs, Co/16, 2]), or None when the tiled kernel does not take the shape (the caller then
     runs conv_fwd + groupnorm_fwd)."""
-    if not (CONV_GN_FUSED and CONV_TILED and Co % 16 == 0):
+    if not (CONV_TILED and Co % 16 == 0):
         return None
     lib = L.load()
     ws = torch.empty(max(1, lib.svl_conv3x3_gn_ws_doubles(imgs, H, W, Co)), dtype=torch.float64, device=x.device)
@@ -874,30 +869,21 @@ def groupnorm_bwd_from_sums(dy, lddy, x, ldx, stats, gamma, beta, imgs, HW, Cc, 
 
 
 # ------------------------------------------------------------------------------------------------ ViT attention (fused, D = 64)
+def attention_h2():
+    """The fused attention runs on the fp16 x 2 kernels of csrc/attn_h2.hip (pre-packed operands, three products per term):
+    emulation mode 6, unless SVL_ATTN_NO_EMU keeps the exact fp32 kernels (A/B runs).  (The bf16 x 6 family of rounds 2-5
+    and its own planes outputs were retired in round 6.)"""
+    return get_gemm_emulation() == 6 and not os.environ.get("SVL_ATTN_NO_EMU")
+
+
 def _attn_family():
-    """Profile family of the attention launches: the bf16 x 6 kernels serve them in emulation mode 6 (attention.hip)."""
-    if PROFILE is None:
-        return "attention"
-    return "attention_bf16x" if (get_gemm_emulation() == 6 and not os.environ.get("SVL_ATTN_NO_EMU")) else "attention"
+    """Profile family of the attention launches (bench.py)."""
+    return "attention_bf16x" if (PROFILE is not None and attention_h2()) else "attention"
 
 
 def attention_planes_ok():
-    """The fused attention kernels can emit their results as packed planes (bf16x6 path only)."""
-    return (get_gemm_emulation() == 6 and PLANES_PATH and not os.environ.get("SVL_ATTN_NO_EMU")
-            and not os.environ.get("SVL_ATTN_NO_PLANES"))
-
-
-# fp16 x 2 attention kernels on pre-packed operands (csrc/attn_h2.hip; round 5) serve emulation mode 6 by default;
-# SVL_ATTN_FMT=b3 keeps the bf16 x 6 kernels (A/B runs), SVL_ATTN_NO_EMU=1 the exact fp32 ones.
-ATTN_FMT = os.environ.get("SVL_ATTN_FMT", "h2")
-assert ATTN_FMT in ("h2", "b3")
-
-
-ATTN_OUT_REPACK = not os.environ.get("SVL_ATTN_NO_REPACK")     # A/B: keep the kernels' own bf16 x 3 planes outputs
-
-
-def attention_h2():
-    return get_gemm_emulation() == 6 and ATTN_FMT == "h2" and not os.environ.get("SVL_ATTN_NO_EMU")
+    """The attention results can be handed on as packed planes (the fp32 result through the generic pack pass)."""
+    return attention_h2() and PLANES_PATH
 
 
 def _attn_ws(Bn, T, H, backward, dev):
@@ -911,52 +897,44 @@ def _ws_ptr(ws):
 
 def attention_fwd(qkv, Bn, T, H, want_lse=True, planes=False, want_out=True):
     """Flash-style fused attention: qkv [Bn*T, 3E] -> (out [Bn*T, E] or None, lse [Bn*H*T] or None[, out as Planes]).
-    planes=True (attention_planes_ok()) additionally returns the output as packed planes, written by the kernel's own
-    epilogue; want_out=False then skips the fp32 copy (gradient-free passes)."""
+    planes=True (attention_planes_ok()) additionally returns the output as packed planes -- 38 us at [32800, 768] for the
+    pack pass, less than what the out-projection saves on fp16 x 2 operands; want_out=False then drops the fp32 copy
+    (gradient-free passes)."""
     E = H * 64
-    # h2 consumers (PLANES_FMT): the fp32 result is packed by the generic pass -- 38 us at [32800, 768], less than what the
-    # out-projection saves on fp16 x 2 operands (three products instead of the six of the kernels' own bf16 x 3 planes)
-    repack = planes and attention_h2() and PLANES_FMT == "h2" and ATTN_OUT_REPACK
-    out = empty(Bn * T, E, device=qkv.device) if (want_out or not planes or repack) else None
+    if planes and not attention_planes_ok():
+        raise RuntimeError("attention_fwd: planes outputs need emulation mode 6 (attention_planes_ok())")
+    out = empty(Bn * T, E, device=qkv.device)
     lse = empty(Bn * H * T, device=qkv.device) if want_lse else None
-    op = Planes(Bn * T, E, device=qkv.device, fmt="b3") if (planes and not repack) else None
     e0 = _prof_begin()
     if attention_h2():
         ws, n = _attn_ws(Bn, T, H, False, qkv.device)
-        L.check(L.load().svl_attention_fwd_h2(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if op is not None else None,
-                                              op.prow if op is not None else 0, _ws_ptr(ws), n, _st()), "svl_attention_fwd_h2")
-        if repack:
-            op = split_planes(out)
-            if not want_out:
-                out = None
+        L.check(L.load().svl_attention_fwd_h2(_p(qkv), Bn, T, H, _p(out), _p(lse), None, 0, _ws_ptr(ws), n, _st()),
+                "svl_attention_fwd_h2")
     else:
-        L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), _p(op.buf) if planes else None,
-                                           op.prow if planes else 0, _st()), "svl_attention_fwd")
+        L.check(L.load().svl_attention_fwd(_p(qkv), Bn, T, H, _p(out), _p(lse), None, 0, _st()), "svl_attention_fwd")
     _prof_end(_attn_family(), e0, 4.0 * Bn * H * T * T * 64, ("fwd_h2" if attention_h2() else "fwd", Bn, T, H))
-    return (out, lse, op) if planes else (out, lse)
+    if not planes:
+        return out, lse
+    op = split_planes(out)
+    return (out if want_out else None), lse, op
 
 
 def attention_bwd(dout, qkv, out, lse, Bn, T, H, planes=False):
-    """-> dqkv [Bn*T, 3E] (and, with planes=True, the same as Planes, written by the kernels' epilogues)."""
+    """-> dqkv [Bn*T, 3E] (and, with planes=True, the same as Planes through the generic pack pass)."""
+    if planes and not attention_planes_ok():
+        raise RuntimeError("attention_bwd: planes outputs need emulation mode 6 (attention_planes_ok())")
     dqkv = torch.empty_like(qkv)
     ws = empty(Bn * H * T, device=qkv.device)
-    E = H * 64
-    repack = planes and attention_h2() and PLANES_FMT == "h2" and ATTN_OUT_REPACK
-    dp = Planes(Bn * T, 3 * E, device=qkv.device, fmt="b3") if (planes and not repack) else None
     e0 = _prof_begin()
     if attention_h2():
         wsb, n = _attn_ws(Bn, T, H, True, qkv.device)
-        L.check(L.load().svl_attention_bwd_h2(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
-                                              _p(dp.buf) if dp is not None else None, dp.prow if dp is not None else 0,
+        L.check(L.load().svl_attention_bwd_h2(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv), None, 0,
                                               _ws_ptr(wsb), n, _st()), "svl_attention_bwd_h2")
-        if repack:
-            dp = split_planes(dqkv)
     else:
-        L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv),
-                                           _p(dp.buf) if planes else None, dp.prow if planes else 0, _st()),
+        L.check(L.load().svl_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), Bn, T, H, _p(ws), _p(dqkv), None, 0, _st()),
                 "svl_attention_bwd")
     _prof_end(_attn_family(), e0, 14.0 * Bn * H * T * T * 64, ("bwd_h2" if attention_h2() else "bwd", Bn, T, H))
-    return (dqkv, dp) if planes else dqkv
+    return (dqkv, split_planes(dqkv)) if planes else dqkv
 
 
 # ------------------------------------------------------------------------------------------------ ViT attention (materialised probabilities; head dims != 64)
@@ -1056,13 +1034,10 @@ def cached_pack(W, tag, fn):
     return out
 
 
-CONV_W_PLANES = not os.environ.get("SVL_CONV_TILED_NO_WPLANES")
-
-
 def conv3x3_weight_planes(pack, N, Ct):
     """bf16 x 3 planes of a narrow 3x3 convolution's packed weights [N, 9 Ct] in the tiled kernel's LDS image
     (svl_conv3x3_weight_planes), or None when the tiled split kernel cannot use one."""
-    if not (CONV_W_PLANES and pack.is_cuda and N in (32, 64) and Ct % 16 == 0):
+    if not (pack.is_cuda and N in (32, 64) and Ct % 16 == 0):
         return None
     lib = L.load()
     pl = torch.empty(lib.svl_conv3x3_weight_planes_bytes(N, Ct), dtype=torch.uint8, device=pack.device)
@@ -1132,7 +1107,7 @@ def conv_dgrad(dy, lddy, imgs, H, W, Co, wd, Ci, KH, KW, dil, pad, out=None, ldo
         ldo = Ci
     g = conv_geom(H, W, Co, KH, KW, dil, pad, -1)
     gemm(A_CONV, B_KC, M, Ci, K, Op(dy, lddy), Op(wd, K), out, ldc_m=ldo, conv=g, accumulate=accumulate,
-         w_planes=w_planes_of(wd) if (KH, dil, pad) == (3, 1, 1) else None, emu_h2=EMU_H2_DGRAD)
+         w_planes=w_planes_of(wd) if (KH, dil, pad) == (3, 1, 1) else None, emu_h2=True)
     return out
 
 
@@ -1170,8 +1145,7 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
     g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
     # (the split-emulation kernel serves this launch when Cout >= 96, N >= 96 and the output rows are whole 8-pixel groups:
     # 128-row tiles, two resident blocks per CU)
-    x6 = (get_gemm_emulation() in (3, 6) and Co >= 96 and N >= 96 and Wo % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0 and
-          not os.environ.get("SVL_GEMM_EMU_NO_CONVW"))
+    x6 = (get_gemm_emulation() in (3, 6) and Co >= 96 and N >= 96 and Wo % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0)
     s, ks = _ksplit_plan(Co, N, Kpix, emu_tiles=x6)
     out = empty(Co, N, device=dy.device)
     if s == 1:
@@ -1185,8 +1159,7 @@ def conv_wgrad(dy, lddy, x, ldx, imgs, H, W, C1, Co, KH, KW, dil, pad, src2=None
 
 def conv_cout1_gn_ok(H, W, Cc, KH=3, KW=3, dil=1, pad=1):
     """The LDS-tiled Conv2d(C -> 1) kernel takes this layer (the form that accepts `gn_in`)."""
-    return (KH == 3 and KW == 3 and dil == 1 and pad == 1 and Cc in (16, 32, 64) and H >= 8 and W >= 16 and
-            not os.environ.get("SVL_COUT1_NO_TILED"))
+    return KH == 3 and KW == 3 and dil == 1 and pad == 1 and Cc in (16, 32, 64) and H >= 8 and W >= 16
 
 
 def conv_cout1_fwd(x, ldx, imgs, H, W, Cc, wf, KH, KW, dil, pad, bias=None, out=None, gn_in=None):
@@ -1244,8 +1217,7 @@ def convT2x_wgrad(x, ldx, du, lddu, imgs, H, W, Ci, Co):
     Kpix = imgs * H * W
     N = 4 * Co
     g = conv_geom(2 * H, 2 * W, Co, 2, 2, 1, 0, 1, stride=2, Ho=H, Wo=W)
-    x6 = (get_gemm_emulation() in (3, 6) and Ci >= 96 and N >= 96 and W % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0 and
-          not os.environ.get("SVL_GEMM_EMU_NO_CONVW"))
+    x6 = (get_gemm_emulation() in (3, 6) and Ci >= 96 and N >= 96 and W % 8 == 0 and Kpix >= 1024 and Kpix % 16 == 0)
     s, ks = _ksplit_plan(Ci, N, Kpix, emu_tiles=x6)
     out = empty(Ci, N, device=x.device)
     if s == 1:
