@@ -72,9 +72,13 @@ MCLIP_TIE = 1e-5                # MaskCLIP label ties: top-2 probability gap / d
 # Mode 6 re-measured when the fused attention moved to fp16 x 2 operands (round 5, csrc/attn_h2.hip; the exact-mode rows did
 # not move): pascal (14, 2.1e-3, 4.3e-3) -> (13, 2.0e-3, 4.2e-3), coco (2, 4.8e-4, 7.4e-4) -> (3, 3.0e-4, 6.7e-4),
 # ade (5, 5.4e-4, 8.9e-4) -> (6, 6.4e-4, 1.27e-3) -- on coco / ade still less than half of the exact fp32 mode's distance.
-RATCHET = {("pascal", 0): (21, 1.3e-3, 2.7e-3), ("pascal", 6): (13, 2.1e-3, 4.3e-3),
-           ("coco", 0): (1, 8.2e-4, 1.1e-3), ("coco", 6): (3, 3.1e-4, 6.8e-4),
-           ("ade", 0): (6, 1.4e-3, 2.8e-3), ("ade", 6): (6, 6.5e-4, 1.3e-3)}
+# Round 6 (slab sums in double, fp16 x 2 ASPP forward + in_proj weight gradient, MFMA tail kernels for the leftover attention
+# rows, GroupNorm-backward sums from the dgrad epilogue): mode 6 re-measured -- pascal (13, 2.0e-3, 4.2e-3) -> (21, 2.0e-3, 4.2e-3)
+# (the flip count is now the exact mode's: WHICH near-ties flip is a draw per rounding pattern), coco (3, 3.0e-4, 6.7e-4) ->
+# (2, 4.0e-4, 7.2e-4), ade (6, 6.4e-4, 1.27e-3) -> (5, 5.7e-4, 8.2e-4); the exact-mode rows did not move.
+RATCHET = {("pascal", 0): (21, 1.3e-3, 2.7e-3), ("pascal", 6): (21, 2.1e-3, 4.3e-3),
+           ("coco", 0): (1, 8.2e-4, 1.1e-3), ("coco", 6): (2, 4.0e-4, 7.2e-4),
+           ("ade", 0): (6, 1.4e-3, 2.8e-3), ("ade", 6): (5, 5.7e-4, 8.3e-4)}
 
 
 def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stack=(), after_bn=(), after_bn_tol=None,
@@ -212,7 +216,7 @@ def test_fullsize_step_matches_oracle(dev, fullsize_case, gemm_mode):
 # EXACT fp32 mode: the decoder's ASPP weight gradients, a k-ordered fp32 chain per split-K slab against the host library's
 # blocked summation -- summation order, not operand precision; the split-product modes sit at or below it on those tensors.
 FP64_FAMILIES = (("vit", "backbone."), ("aspp", "decode_head.aspp"), ("up", "decode_head.up"), ("head_other", "decode_head."))
-FP64_RATCHET = {0: dict(vit=None, aspp=None, up=None, head_other=None), 6: dict(vit=None, aspp=None, up=None, head_other=None)}
+FP64_RATCHET = {0: dict(vit=1.83, aspp=3.65, up=1.43, head_other=2.63), 6: dict(vit=1.71, aspp=1.20, up=2.43, head_other=1.70)}
 
 
 def _fp64_family(name):
