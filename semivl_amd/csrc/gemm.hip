@@ -19,12 +19,18 @@
 #include "svl_common.h"
 #include "conv_tiled.h"
 #include "gemm_shortk.h"
+#include "convt_tiled.h"
 #include <atomic>
 #include <type_traits>
 #include <stdlib.h>
 
-namespace {
-
+// This file is compiled FIVE times (Makefile: gemm.o + gemm_part1..4.o, -DSVL_GEMM_PART=k): the kernel templates below have ~55
+// instantiations and one translation unit took 260 s of the library's 350 s build.  Part 0 holds the C-ABI entry points and the
+// small kernels; parts 1 / 2 the exact fp32 kernel's tile shapes for the dense / the convolution operand modes; parts 3 / 4 the
+// in-register split kernel with three bf16 / two (bf16 or fp16) terms.  The parts meet at four plain functions.
+#ifndef SVL_GEMM_PART
+#define SVL_GEMM_PART 0
+#endif
 
 struct OperandP {
   const float* p;
@@ -52,6 +58,14 @@ struct GemmP {
   int tiles_n, tiles_m, band_n;
   const unsigned* amax;   // fp16 x 2 form of the split kernel: device {bits of max |A|, bits of max |B|} over the operands' elements
 };
+
+int svl_gemm_part_mode_dense(int am, int bm, const GemmP& p, int batch, hipStream_t st);   // part 1
+int svl_gemm_part_mode_conv(int am, int bm, const GemmP& p, int batch, hipStream_t st);    // part 2
+int svl_gemm_part_emu3(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st);      // part 3: bf16 x 3, six products
+int svl_gemm_part_emu2(int h2, const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st);   // part 4: two terms (bf16 | fp16 + scales)
+
+namespace {
+
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
@@ -1417,6 +1431,7 @@ int launch_emu(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
   return SVL_OK;
 }
 
+#if SVL_GEMM_PART == 0
 // (eight slab loads in flight per thread, added in slab order -- the same sum, bit for bit, as one load at a time, which left
 //  the 50-to-500-slab reductions of the decoder's weight gradients at the pace of one HBM round trip per slab: 14 ms of
 //  exposed time per ADE step)
@@ -1441,6 +1456,7 @@ __global__ void reduce_slabs_kernel(float* out, const float* slabs, int nslab, l
   }
 }
 
+#endif
 template <int BM, int BN, int WR, int WC, int AMODE, int BMODE, int BK = 16>
 int launch_cfg(const GemmP& p, int batch, hipStream_t st) {
   GemmP q = p;
@@ -1473,6 +1489,7 @@ int launch_mode(const GemmP& p, int batch, hipStream_t st) {
   return launch_cfg<128, 128, 2, 2, AMODE, BMODE>(p, batch, st);
 }
 
+#if SVL_GEMM_PART == 0
 // Short-K stream kernel launch: column chunk width 32 * TN chosen to waste the fewest MFMA columns with the B chunk
 // (all of K) inside 80 KB of LDS (two blocks per CU); the grid is one resident set of blocks, persistent over rows.
 template <int TN>
@@ -1527,7 +1544,30 @@ int absmax_launch(const float* x, long rows, long cols, long ld, unsigned* out, 
   return SVL_OK;
 }
 
+#endif
 }  // namespace
+
+#if SVL_GEMM_PART == 1
+int svl_gemm_part_mode_dense(int am, int bm, const GemmP& p, int batch, hipStream_t st) {
+  if (am == SVL_A_KCONTIG && bm == SVL_B_KCONTIG) return launch_mode<SVL_A_KCONTIG, SVL_B_KCONTIG>(p, batch, st);
+  if (am == SVL_A_KCONTIG && bm == SVL_B_NCONTIG) return launch_mode<SVL_A_KCONTIG, SVL_B_NCONTIG>(p, batch, st);
+  if (am == SVL_A_MCONTIG && bm == SVL_B_NCONTIG) return launch_mode<SVL_A_MCONTIG, SVL_B_NCONTIG>(p, batch, st);
+  return launch_mode<SVL_A_MCONTIG, SVL_B_KCONTIG>(p, batch, st);
+}
+#elif SVL_GEMM_PART == 2
+int svl_gemm_part_mode_conv(int am, int bm, const GemmP& p, int batch, hipStream_t st) {
+  if (am == SVL_A_CONV) return launch_mode<SVL_A_CONV, SVL_B_KCONTIG>(p, batch, st);
+  if (am == SVL_A_MCONTIG) return launch_mode<SVL_A_MCONTIG, SVL_B_CONVW>(p, batch, st);
+  (void)bm;
+  return launch_mode<SVL_A_PATCH, SVL_B_KCONTIG>(p, batch, st);
+}
+#elif SVL_GEMM_PART == 3
+int svl_gemm_part_emu3(const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) { return launch_emu<3>(p, a_rm, b_rm, batch, st); }
+#elif SVL_GEMM_PART == 4
+int svl_gemm_part_emu2(int h2, const GemmP& p, int a_rm, int b_rm, int batch, hipStream_t st) {
+  return h2 ? launch_emu<2, true>(p, a_rm, b_rm, batch, st) : launch_emu<2>(p, a_rm, b_rm, batch, st);
+}
+#else   // part 0: the C-ABI
 
 extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
   SVL_CHECK_ARG(d != nullptr, "svl_gemm_f32: null desc");
@@ -1637,9 +1677,9 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         GemmP q2 = q;
         q2.amax = h2_ws;
         g_last_path = SVL_PATH_H2X;
-        return launch_emu<2, true>(q2, 2, 0, 1, st);
+        return svl_gemm_part_emu2(1, q2, 2, 0, 1, st);
       }
-      return emu_mode == 6 ? launch_emu<3>(q, 2, 0, 1, st) : launch_emu<2>(q, 2, 0, 1, st);
+      return emu_mode == 6 ? svl_gemm_part_emu3(q, 2, 0, 1, st) : svl_gemm_part_emu2(0, q, 2, 0, 1, st);
     }
     // weight gradients of the implicit-GEMM convolutions (A = dy^T, B = im2col(x)^T, split-K over the pixels): the
     // dilated / 1x1 / transposed-conv layers of the decoder.  One 128-row tile holds all of Cout = 128 (Cout = 64 wastes half of
@@ -1660,9 +1700,9 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         GemmP q2 = q;
         q2.amax = h2_ws;
         g_last_path = SVL_PATH_H2X;
-        return launch_emu<2, true>(q2, 1, 2, d->batch, st);
+        return svl_gemm_part_emu2(1, q2, 1, 2, d->batch, st);
       }
-      return emu_mode == 6 ? launch_emu<3>(q, 1, 2, d->batch, st) : launch_emu<2>(q, 1, 2, d->batch, st);
+      return emu_mode == 6 ? svl_gemm_part_emu3(q, 1, 2, d->batch, st) : svl_gemm_part_emu2(0, q, 1, 2, d->batch, st);
     }
     // (the pixel-shuffle store of ConvTranspose2d(k 2, s 2) stays with the short-K stream kernel, whose epilogue writes
     //  whole rows: through this kernel's 32 x 32 accumulator layout the K = 128 ConvTranspose of up1 ran at 31 TF, 88 there)
@@ -1689,21 +1729,16 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
         GemmP q2 = q;
         q2.amax = h2_ws;
         g_last_path = SVL_PATH_H2X;
-        return launch_emu<2, true>(q2, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
+        return svl_gemm_part_emu2(1, q2, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
       }
-      return emu_mode == 6 ? launch_emu<3>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
-                             : launch_emu<2>(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
+      return emu_mode == 6 ? svl_gemm_part_emu3(q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st)
+                             : svl_gemm_part_emu2(0, q, am == SVL_A_MCONTIG, bm == SVL_B_NCONTIG, d->batch, st);
     }
-#define SVL_MODE(AM, BM_) \
-  if (am == AM && bm == BM_) return launch_mode<AM, BM_>(q, d->batch, st);
-    SVL_MODE(SVL_A_KCONTIG, SVL_B_KCONTIG)
-    SVL_MODE(SVL_A_KCONTIG, SVL_B_NCONTIG)
-    SVL_MODE(SVL_A_MCONTIG, SVL_B_NCONTIG)
-    SVL_MODE(SVL_A_MCONTIG, SVL_B_KCONTIG)
-    SVL_MODE(SVL_A_CONV, SVL_B_KCONTIG)
-    SVL_MODE(SVL_A_MCONTIG, SVL_B_CONVW)
-    SVL_MODE(SVL_A_PATCH, SVL_B_KCONTIG)
-#undef SVL_MODE
+    if ((am == SVL_A_KCONTIG || am == SVL_A_MCONTIG) && (bm == SVL_B_KCONTIG || bm == SVL_B_NCONTIG))
+      return svl_gemm_part_mode_dense(am, bm, q, d->batch, st);
+    if ((am == SVL_A_CONV && bm == SVL_B_KCONTIG) || (am == SVL_A_MCONTIG && bm == SVL_B_CONVW) ||
+        (am == SVL_A_PATCH && bm == SVL_B_KCONTIG))
+      return svl_gemm_part_mode_conv(am, bm, q, d->batch, st);
     svl_set_error("svl_gemm_f32: unsupported mode combination a=%d b=%d", am, bm);
     return SVL_ERR_UNSUPPORTED;
   };
@@ -1738,6 +1773,25 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       }
       g_last_path = SVL_PATH_SHORTK;
       return launch_shortk(p, fast, st);
+    }
+  }
+
+  // Input gradient of the narrow ConvTranspose2d(k 2, s 2) (a k2 s2 convolution of the upsampled gradient): spatially tiled
+  // kernel with coalesced staging (convt_tiled.hip) instead of the implicit GEMM's 512-byte-strided gathers
+  {
+    static const int ct_tiled = getenv("SVL_CONVT_NO_TILED") ? 0 : 1;
+    if (ct_tiled && emu_mode == 6 && a_conv && bm == SVL_B_KCONTIG && cv.KH == 2 && cv.KW == 2 && p.cv.stride == 2 && cv.pad == 0 &&
+        cv.dil == 1 && cv.C2 == 0 && cv.sign == 1 && d->K == 4 * cv.C1 && cv.H == 2 * p.cv.Ho && cv.W == 2 * p.cv.Wo &&
+        d->batch == 1 && d->ksplit == 0 && d->out_mode == SVL_OUT_STRIDED && d->ldc_n == 1 && !d->resid && !d->preact &&
+        !d->accumulate && !d->bias && d->act == SVL_ACT_NONE && d->alpha == 1.0f && d->B.ld == d->K &&
+        (long)d->M == (long)(d->M / ((long)p.cv.Ho * p.cv.Wo)) * p.cv.Ho * p.cv.Wo) {
+      ConvTDgradP t;
+      t.du = d->A.ptr; t.ld = d->A.ld; t.wb = d->B.ptr; t.dx = d->C; t.ldo = d->ldc_m;
+      t.imgs = (int)(d->M / ((long)p.cv.Ho * p.cv.Wo)); t.H = p.cv.Ho; t.W = p.cv.Wo; t.Co = cv.C1; t.Ci = d->N;
+      if (svl_convt_dgrad_tiled_eligible(t)) {
+        g_last_path = SVL_PATH_BF16X;
+        return svl_convt_dgrad_tiled_launch(t, st);
+      }
     }
   }
 
@@ -1849,3 +1903,4 @@ extern "C" int svl_reduce_slabs_f32(float* out, const float* slabs, int nslab, i
   SVL_LAUNCH_CHECK("svl_reduce_slabs_f32");
   return SVL_OK;
 }
+#endif   // SVL_GEMM_PART
