@@ -19,7 +19,6 @@
 #include "svl_common.h"
 #include "conv_tiled.h"
 #include "gemm_shortk.h"
-#include "convt_tiled.h"
 #include <atomic>
 #include <type_traits>
 #include <stdlib.h>
@@ -1773,25 +1772,6 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       }
       g_last_path = SVL_PATH_SHORTK;
       return launch_shortk(p, fast, st);
-    }
-  }
-
-  // Input gradient of the narrow ConvTranspose2d(k 2, s 2) (a k2 s2 convolution of the upsampled gradient): spatially tiled
-  // kernel with coalesced staging (convt_tiled.hip) instead of the implicit GEMM's 512-byte-strided gathers
-  {
-    static const int ct_tiled = getenv("SVL_CONVT_NO_TILED") ? 0 : 1;
-    if (ct_tiled && emu_mode == 6 && a_conv && bm == SVL_B_KCONTIG && cv.KH == 2 && cv.KW == 2 && p.cv.stride == 2 && cv.pad == 0 &&
-        cv.dil == 1 && cv.C2 == 0 && cv.sign == 1 && d->K == 4 * cv.C1 && cv.H == 2 * p.cv.Ho && cv.W == 2 * p.cv.Wo &&
-        d->batch == 1 && d->ksplit == 0 && d->out_mode == SVL_OUT_STRIDED && d->ldc_n == 1 && !d->resid && !d->preact &&
-        !d->accumulate && !d->bias && d->act == SVL_ACT_NONE && d->alpha == 1.0f && d->B.ld == d->K &&
-        (long)d->M == (long)(d->M / ((long)p.cv.Ho * p.cv.Wo)) * p.cv.Ho * p.cv.Wo) {
-      ConvTDgradP t;
-      t.du = d->A.ptr; t.ld = d->A.ld; t.wb = d->B.ptr; t.dx = d->C; t.ldo = d->ldc_m;
-      t.imgs = (int)(d->M / ((long)p.cv.Ho * p.cv.Wo)); t.H = p.cv.Ho; t.W = p.cv.Wo; t.Co = cv.C1; t.Ci = d->N;
-      if (svl_convt_dgrad_tiled_eligible(t)) {
-        g_last_path = SVL_PATH_BF16X;
-        return svl_convt_dgrad_tiled_launch(t, st);
-      }
     }
   }
 

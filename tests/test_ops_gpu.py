@@ -1088,13 +1088,12 @@ def test_convT_split_stream(dev, emu_mode, n, Ci, Co, H, W, extra):
     assert err[6] < 5e-7, err
 
 
-@pytest.mark.parametrize("n,H,W,extra", [(10, 64, 64, 16), (9, 33, 128, 0), (3, 128, 96, 16)])
-def test_convT_input_gradient_tiled(dev, emu_mode, n, H, W, extra):
-    """Input gradient of the narrow ConvTranspose2d(k 2, s 2) (48 upsampled channels -> 64, `Up.up` of the last block) in
-    emulation mode 6: the spatially tiled kernel of convt_tiled.hip (coalesced staging of two gradient rows, fragment-ordered
-    LDS images, bf16 x 3 split).  Error vs float64 at the level of the exact implicit GEMM's on the same data, channels past Co
-    of the gradient's pixel stride are not read, odd tile counts, deterministic; the library reports the split pipe."""
-    from semivl_amd import ops, lib as L
+@pytest.mark.parametrize("n,H,W,extra", [(10, 64, 64, 16), (9, 33, 128, 0)])
+def test_convT_input_gradient(dev, emu_mode, n, H, W, extra):
+    """Input gradient of the narrow ConvTranspose2d(k 2, s 2) (48 upsampled channels -> 64, `Up.up` of the last block: a k2 s2
+    convolution of the gradient through the implicit-GEMM kernel) at a row count of the training step's order: against float64,
+    channels past Co of the gradient's pixel stride never enter, deterministic."""
+    from semivl_amd import ops
     Ci, Co = 64, 48
     w = rnd(Ci, Co, 2, 2, dev=dev, scale=0.1, seed=81)                     # ConvTranspose2d weight [in, out, kh, kw]
     du = rnd(n * 4 * H * W, Co + extra, dev=dev, seed=82)                  # gradient at the upsampled resolution (+ concat slice)
@@ -1102,17 +1101,12 @@ def test_convT_input_gradient_tiled(dev, emu_mode, n, H, W, extra):
         du[:, Co:] = 1e30                                                  # must never enter
     wb = w.permute(0, 2, 3, 1).reshape(Ci, 4 * Co).contiguous()            # [Ci, (a, b, co)]
     g64 = du[:, :Co].double().view(n, 2 * H, 2 * W, Co).permute(0, 3, 1, 2)
-    ref = F.conv2d(g64, w.double().permute(0, 1, 2, 3), stride=2)          # [n, Ci, H, W]: dx = conv(du, W[ci, co, a, b])
-    err, path = {}, {}
+    ref = F.conv2d(g64, w.double(), stride=2)                              # [n, Ci, H, W]
     for mode in (0, 6):
         emu_mode(mode)
         dx = ops.convT2x_dgrad(du, Co + extra, n, H, W, Co, wb, Ci)
-        path[mode] = L.load().svl_last_gemm_path()
-        err[mode] = _relerr(nchw(dx, n, H, W), ref)
+        assert _relerr(nchw(dx, n, H, W), ref) < 5e-7
         assert torch.equal(dx, ops.convT2x_dgrad(du, Co + extra, n, H, W, Co, wb, Ci))
-    print("CONVT_DGRAD rel err vs fp64: exact", err[0], "tiled split", err[6], "paths", path)
-    assert path[6] == 1 and path[0] == 0, path
-    assert err[6] <= EMU6_ERR_FACTOR * err[0] + 1e-9 and err[6] < 5e-7, err
 
 
 def test_patch_embed(dev):
