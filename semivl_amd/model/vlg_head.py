@@ -419,8 +419,9 @@ def _head_forward(m, hw, fp_masks, fp_cfg, out_size, text, feats, chunks_out):
     b0 = emb.shape[0]
     dev = emb.device
     N = text.shape[0]
-    if N != m.num_classes:
-        raise NotImplementedError("concept-level text embeddings inside VLGHead are off the BASELINE configs")
+    # (the reference asserts the same, vlg_head.py:212: `list(text_feats.shape) == [B, self.num_classes, C]` -- its concept
+    #  aggregation behind the decoder, vlg_head.py:242-244, is therefore unreachable; concepts enter through MaskCLIP's guidance)
+    assert N == m.num_classes, f"VLGHead: {N} text embeddings for num_classes = {m.num_classes} (vlg_head.py:212)"
     Ce, Cv, C0 = emb.shape[2], v4.shape[2], v0.shape[2]
     # ---- feature perturbation: cat(f, dropout2d(f)) ------------------------------------------------------
     if fp_masks is not None:
