@@ -603,10 +603,369 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 }
 
-// The weight planes image of conv3x3_tiled_bf16x_kernel<.., WPRE = true>: for slab s (16 input channels) the three planes
-// [pl][tap * N + co][16 channels, halves swapped by swz] exactly as the kernel lays a slab's weights out in LDS -- the same
-// split3x4 on the same values, so both forms of the kernel compute identical bits.
-__global__ __launch_bounds__(256) void conv_w_planes_kernel(const float* __restrict__ w, int N, int Ct, __bf16* __restrict__ out) {
+// ------------------------------------------------------------------------------------------------------------------
+// Round 6: the same kernel on fp16 x 2 terms -- THREE products per fp32 MAC instead of six, two planes instead of three in LDS
+// (per tap 2 + 2 TN fragment reads for 3 TN MFMAs where the bf16 x 3 form reads 3 + 3 TN for 6 TN).  fp16 has 5 exponent bits,
+// so every operand needs a power-of-two scale, and a convolution's sum runs over taps (pixels) and slabs (channels): everything
+// ONE accumulator adds up must share its scale.  The weights take one exponent per OUTPUT CHANNEL (a row scale of the B operand
+// factors out of the sum; svl_conv3x3_weight_planes writes them behind the planes image).  The pixel operand takes a RUNNING
+// exponent per tile, in the manner of an online softmax: the block finds the largest |value| of the slab it is about to stage
+// (after GroupNorm + ReLU when gn_in is set; a wave reduction + four floats exchanged at a barrier the loop has anyway), stages
+// it with max(exponent of that maximum, exponent the accumulators are at), and when the exponent rises the accumulators are
+// multiplied by the (exact) power of two <= 1 before the slab's MFMAs.  No maximum pass over the tensor, no exponents from the
+// producer; an element 2^-17 below the largest value its tile has seen so far keeps an absolute error of 2^-39 of that value.
+// Only with pre-split weights (w_planes); without them the bf16 x 3 kernel above serves the launch.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int TN, int PT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_tiled_h2_kernel(const ConvTiledP p, int tiles_x, int tiles_y) {
+  constexpr int N = 32 * TN;
+  constexpr int PHT = PH * PT, IHT = PHT + 2, NPX = IHT * IW;   // patch rows, halo rows, staged pixels
+  constexpr int XP = (NPX * 4 + 255) / 256;         // input float4 pieces per thread (3 / 6)
+  // x tile in LDS: 32-byte pixels, patch rows IW * 32 + 16 bytes apart and NO swizzle.  A ds_read_b128 serves lanes
+  // {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (and the same + 32) together -- 8 pixels of patch row r and the 8 OTHER
+  // columns of row r + 1: within a row the 8 pixels cover the 8 residues (mod 8) once = banks 8 k + [0, 4) for the lanes'
+  // 16-byte half, and the odd number of 16-byte units per row puts row r + 1 on banks 8 k + [4, 8): all 64 banks once,
+  // for every tap shift.  (The round-3 layout, rows 18 pixels apart with the halves swapped on bit 3 of the pixel index,
+  // was conflict-free for 16 CONSECUTIVE lanes only: 19 % of the LDS cycles of this kernel were conflict cycles.)
+  constexpr int XROW = IW * 16 + 8;                 // 16-bit elements per staged patch row
+  constexpr int XPL = IHT * XROW, WPL = 9 * N * 16; // plane strides (16-bit elements)
+  constexpr int NWQ = 2 * WPL / 8;                  // 16-byte pieces of a slab's weight planes image (36 N)
+  constexpr int WQ = (NWQ + 255) / 256;             // of those per thread (5 / 9)
+  __shared__ __attribute__((aligned(16))) _Float16 xs[2 * XPL];
+  __shared__ __attribute__((aligned(16))) _Float16 ws[2 * WPL];
+  __shared__ float smax[4];                         // per-wave maxima of the slab being staged (exchanged at the loop's first barrier)
+  __shared__ double gred[4 * TN * 2 * 2];           // GroupNorm partials of the four waves (ws holds the NEXT tile's weights by then)
+  __shared__ double gbred[4][N][2];                 // GroupNorm-backward channel sums of the four waves (gnb_part)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  // PERSISTENT blocks: a block walks tiles blockIdx.x, + gridDim.x, ... and the (tile, slab) pairs form ONE pipeline -- the
+  // first slab of the next tile is requested during the last MFMA phase of this one and the result stores drain under the
+  // next tile's work.  One tile per block cost 14 % (128 -> 64 channels) to 57 % (32 -> 32) of a block's cycles in the
+  // exposed first fetch and the store tail (s_memtime phases, round 4).
+  const int ntiles = p.imgs * tiles_x * tiles_y;
+  int tile = blockIdx.x;                             // the tile being computed
+  int img, y0, x0;                                   // ... and its image / origin
+  int limg, ly0, lx0;                                // the same of the tile whose slab is being STAGED
+  auto decode = [&](int t, int& im, int& yy, int& xx) __attribute__((always_inline)) {
+    const int txi = t % tiles_x;
+    t /= tiles_x;
+    const int tyi = t % tiles_y;
+    im = t / tiles_y;
+    yy = tyi * PHT; xx = txi * PW;
+  };
+  decode(tile, img, y0, x0);
+  limg = img; ly0 = y0; lx0 = x0;
+  // per-output-channel exponents of the weight planes (behind the planes image: svl_conv3x3_weight_planes)
+  const int* wexp = reinterpret_cast<const int*>(reinterpret_cast<const char*>(p.w_planes) + (long)((p.C1 + p.C2) / SLAB) * NWQ * 16);
+  const int Ct = p.C1 + p.C2, nslab = Ct / SLAB;
+
+  f32x16 acc[PT][TN];
+#pragma unroll
+  for (int u = 0; u < PT; ++u)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][j][r] = 0.f;
+
+  float4 rx[XP];
+  u32q rq[WQ];
+  float4 gsc = make_float4(1.f, 1.f, 1.f, 1.f), gsh = make_float4(0.f, 0.f, 0.f, 0.f);   // gn_in: this thread's channel quad
+  unsigned rxok = 0;                                                                      // in-image flags of rx[]
+  bool gnow = false;                                                                      // the staged slab is normalised
+  auto gload = [&](int s) __attribute__((always_inline)) {
+    const int c0 = s * SLAB;
+    const bool first = c0 < p.C1;
+    const float* base = first ? p.src1 + ((long)limg * p.H) * p.W * p.ld1 + c0
+                              : p.src2 + ((long)(limg / p.rep) * p.H) * p.W * p.ld2 + (c0 - p.C1);
+    const long ld = first ? p.ld1 : p.ld2;
+    gnow = p.gn_in != nullptr && first;
+    rxok = 0;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int f = tid + 256 * i;
+      const int pix = min(f >> 2, NPX - 1), q = f & 3;
+      const int iy = pix / IW, ix = pix - iy * IW;
+      const int y = ly0 - 1 + iy, x = lx0 - 1 + ix;
+      const bool in = f < NPX * 4 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      rxok |= in ? (1u << i) : 0u;
+      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.W - 1);   // (unconditional: see the fp32 kernel)
+      rx[i] = *reinterpret_cast<const float4*>(base + ((long)yc * p.W + xc) * ld + 4 * q);
+    }
+    {
+      const u32q* wq = reinterpret_cast<const u32q*>(p.w_planes) + (long)s * NWQ;
+#pragma unroll
+      for (int i = 0; i < WQ; ++i) {
+        const int f = tid + 256 * i;
+        rq[i] = wq[f < NWQ ? f : NWQ - 1];         // (clamped, not conditional: the loads stay batched)
+      }
+    }
+    if (gnow) {   // (last: the wait that protects the table registers then sits behind the issue of the big loads)
+      gsc = *reinterpret_cast<const float4*>(p.gn_in + ((long)limg * 2 + 0) * p.C1 + c0 + 4 * (tid & 3));
+      gsh = *reinterpret_cast<const float4*>(p.gn_in + ((long)limg * 2 + 1) * p.C1 + c0 + 4 * (tid & 3));
+    }
+  };
+  // The loaded pieces become the OPERAND values (GroupNorm + ReLU applied, out-of-image pixels zero) in place; returns this
+  // thread's largest |value|: the slab's scale exponent is the block-wide maximum's (exchanged through smax at a barrier the
+  // loop has anyway).
+  auto xform = [&]() __attribute__((always_inline)) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const unsigned in = (rxok >> i) & 1u;
+      rx[i] = gnow ? gn_relu4(rx[i], gsc, gsh, in) : (in ? rx[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+      if (tid + 256 * i < NPX * 4)
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(rx[i].x), fabsf(rx[i].y)), fmaxf(fabsf(rx[i].z), fabsf(rx[i].w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) smax[wave] = m;
+  };
+  auto exp_of = [](float mx) {      // mx 2^-e in [2^14, 2^15)  (fp16 overflows at 65504); an all-zero slab takes the floor
+    const int e = mx > 0.f ? __builtin_amdgcn_frexp_expf(mx) - 15 : -100;
+    return e < -100 ? -100 : (e > 100 ? 100 : e);
+  };
+  // x 2^-e = h0 + h1, two round-to-nearest fp16 terms (23 significand bits for every element within 2^-17 of the slab maximum)
+  auto sstore = [&](int e) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int f = tid + 256 * i;
+      if (f < NPX * 4) {
+        const float v[4] = {__builtin_amdgcn_ldexpf(rx[i].x, -e), __builtin_amdgcn_ldexpf(rx[i].y, -e),
+                            __builtin_amdgcn_ldexpf(rx[i].z, -e), __builtin_amdgcn_ldexpf(rx[i].w, -e)};
+        f16x4 h0, h1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          h0[j] = (_Float16)v[j];
+          h1[j] = (_Float16)(v[j] - (float)h0[j]);
+        }
+        const int spx = f >> 2, siy = spx / IW;
+        const int o = siy * XROW + (spx - siy * IW) * 16 + 4 * (f & 3);
+        *reinterpret_cast<f16x4*>(xs + o) = h0;
+        *reinterpret_cast<f16x4*>(xs + XPL + o) = h1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+      const int f = tid + 256 * i;
+      if (f < NWQ) reinterpret_cast<u32q*>(ws)[f] = rq[i];
+    }
+  };
+
+  const int pr = wave * 2 * PT + (l31 >> 4), pc = l31 & 15;   // this lane's A-operand pixel of its first tile
+#ifdef SVL_CONV_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
+  // Scale bookkeeping (every thread holds the same values): e_st = exponent the STAGED slab was scaled with, e_acc = exponent of
+  // the accumulators.  A slab is staged with max(e_acc, its own exponent) -- never below what the tile has accumulated at, so
+  // the only rescale ever needed is acc *= 2^(e_acc - e_st) <= 1 (exact); a later slab of smaller magnitude keeps an ABSOLUTE
+  // error of 2^-39 of the running maximum, far below the fp32 accumulation noise.  The first slab of a tile starts afresh.
+  int e_st, e_acc = 0;
+  bool fresh = true;                                  // the staged slab is the first of its tile
+  gload(0);
+  xform();
+  __syncthreads();
+  e_st = exp_of(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+  sstore(e_st);
+  __syncthreads();
+  SVL_PH(0)
+  // The fragments of tap t + 1 are requested BEFORE the MFMAs of tap t and the two groups are fenced: left alone the
+  // scheduler sinks every ds_read to just above its first use (register pressure), and the wave sits in s_waitcnt for
+  // the LDS latency once per MFMA pair (round 4 counters: matrix pipe 52 % busy, a quarter of the wave cycles parked).
+  f16x8 a[2][2][PT], b[2][2][TN];
+  auto lfrag = [&](int tap, int fb) __attribute__((always_inline)) {
+    const int dy = p.sign * (tap / 3 - 1), dx = p.sign * (tap % 3 - 1);
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      const int oa = (pr + 2 * u + 1 + dy) * XROW + (pc + 1 + dx) * 16 + 8 * hi;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) a[fb][pl][u] = *reinterpret_cast<const f16x8*>(xs + pl * XPL + oa);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int rb = tap * N + 32 * j + l31;
+      const int ob = rb * 16 + (((hi ^ (rb >> 3)) & 1) << 3);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) b[fb][pl][j] = *reinterpret_cast<const f16x8*>(ws + pl * WPL + ob);
+    }
+  };
+  for (;;) {
+  for (int s = 0; s < nslab; ++s) {
+    // the next piece of the pipeline: this tile's next slab, or slab 0 of the block's next tile
+    const bool last = s + 1 == nslab;
+    const bool more = !last || tile + (int)gridDim.x < ntiles;
+    if (last && more) decode(tile + (int)gridDim.x, limg, ly0, lx0);
+    if (more) gload(last ? 0 : s + 1);
+    // the staged slab joins the accumulators at e_st
+    if (fresh) e_acc = e_st;
+    else if (e_st > e_acc) {
+      const float f_ = __builtin_amdgcn_ldexpf(1.f, e_acc - e_st);
+#pragma unroll
+      for (int u = 0; u < PT; ++u)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[u][j][r] *= f_;
+      e_acc = e_st;
+    }
+    lfrag(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int fb = tap & 1;
+      if (tap + 1 < 9) lfrag(tap + 1, fb ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // three products, smallest first: (1,0) (0,1) (0,0) -- fp16 x fp16 is exact in the fp32 accumulator
+#define SVL_CT(PA, PB)                                                                     \
+  _Pragma("unroll") for (int u = 0; u < PT; ++u) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[u][j] = \
+      __builtin_amdgcn_mfma_f32_32x32x16_f16(a[fb][PA][u], b[fb][PB][j], acc[u][j], 0, 0, 0);
+      SVL_CT(1, 0)
+      SVL_CT(0, 1)
+      SVL_CT(0, 0)
+#undef SVL_CT
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    SVL_PH(1)
+    if (more) xform();                               // (the next slab's loads have landed under the MFMA phase)
+    __syncthreads();
+    SVL_PH(2)
+    if (more) {
+      const int e_own = exp_of(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+      fresh = last;                                  // slab 0 of the block's next tile
+      e_st = fresh ? e_own : (e_own > e_acc ? e_own : e_acc);
+      sstore(e_st);
+    }
+    SVL_PH(3)
+    if (!last) {
+      __syncthreads();
+      SVL_PH(4)
+    }
+  }
+  // epilogue of the tile (its stores drain under the next tile's first MFMA phase): the fp32 kernel's (column = output
+  // channel, row = pixel of the wave), with the pixel offsets formed once per pixel tile in 32 bits -- the epilogue's VALU
+  // instructions wait for gaps in the other block's MFMA stream like every VALU instruction of a staging phase
+  double gs[TN], gq[TN], ba[TN], bb[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = ba[j] = bb[j] = 0.0;
+  {
+    float* obase = p.out + (long)img * p.H * p.W * p.ldo + l31;
+    const float* xbase = p.gnb_x ? p.gnb_x + (long)img * p.H * p.W * p.ldo + l31 : nullptr;
+    const int ldo = (int)p.ldo;
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+      int off[16];
+      unsigned okm = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int y = y0 + wave * 2 * PT + 2 * u + (i >> 4), x = x0 + (i & 15);
+        okm |= (y < p.H && x < p.W) ? (1u << r) : 0u;
+        off[r] = (min(y, p.H - 1) * p.W + min(x, p.W - 1)) * ldo;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float bv = p.bias ? p.bias[l31 + 32 * j] : 0.f;
+        const int es = e_acc + wexp[l31 + 32 * j];     // undo the slab scale and this output channel's weight scale (exact)
+        float* ob = obase + 32 * j;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = __builtin_amdgcn_ldexpf(acc[u][j][r], es) + bv;
+          acc[u][j][r] = 0.f;
+        }
+        if (p.gn_part) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const double t = ((okm >> r) & 1u) ? (double)v[r] : 0.0;
+            gs[j] += t;
+            gq[j] += t * t;
+          }
+        }
+        if (p.act == SVL_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+        } else if (p.act == SVL_ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.accumulate) {
+          float prev[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) prev[r] = ob[off[r]];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += prev[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if ((okm >> r) & 1u) ob[off[r]] = v[r];
+        if (p.gnb_part) {
+          // this lane's channel c = l31 + 32 j of the GroupNorm whose dy was just written: mask from the forward's own fma,
+          // sums in double from the first addition (norm.hip::groupnorm_bwd_sums_kernel's expressions)
+          const int c = l31 + 32 * j;
+          const float sc = p.gnb_table[((long)img * 2 + 0) * N + c], sh = p.gnb_table[((long)img * 2 + 1) * N + c];
+          const float mean = p.gnb_stats[((long)img * (N / 16) + (c >> 4)) * 2], rstd = p.gnb_stats[((long)img * (N / 16) + (c >> 4)) * 2 + 1];
+          const float* xb = xbase + 32 * j;
+          float xv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xv[r] = xb[off[r]];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool on = ((okm >> r) & 1u) && __builtin_fmaf(xv[r], sc, sh) > 0.f;
+            const float dm = on ? v[r] : 0.f;
+            ba[j] += (double)dm;
+            bb[j] += (double)dm * ((xv[r] - mean) * rstd);
+          }
+        }
+      }
+    }
+  }
+  if (p.gn_part) gn_tile_partials<TN>(p, gs, gq, gred, tid, tile);   // (one barrier inside; gred is not touched by the staging)
+  if (p.gnb_part) {       // lanes hi = 0 / 1 hold different pixel rows of the same channel; then the four waves, fixed order
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const double a2 = ba[j] + __shfl_xor(ba[j], 32, 64), b2 = bb[j] + __shfl_xor(bb[j], 32, 64);
+      if (hi == 0) {
+        gbred[wave][l31 + 32 * j][0] = a2;
+        gbred[wave][l31 + 32 * j][1] = b2;
+      }
+    }
+    __syncthreads();
+    if (tid < N) {
+      double* o = p.gnb_part + ((long)tile * N + tid) * 2;
+      o[0] = (gbred[0][tid][0] + gbred[1][tid][0]) + (gbred[2][tid][0] + gbred[3][tid][0]);
+      o[1] = (gbred[0][tid][1] + gbred[1][tid][1]) + (gbred[2][tid][1] + gbred[3][tid][1]);
+    }
+  }
+  SVL_PH(5)
+  tile += (int)gridDim.x;
+  if (tile >= ntiles) break;
+  img = limg; y0 = ly0; x0 = lx0;
+  __syncthreads();                                   // the staged slab 0 of the next tile is complete
+  }
+#ifdef SVL_CONV_PHASE_TIMING
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_conv_phase[i], ph[i]);
+    atomicAdd(&g_conv_phase[7], 1ull);
+  }
+#endif
+}
+
+// The weight planes image of conv3x3_tiled_h2_kernel: per output channel co one scale exponent e[co] (largest |w| of its 9 Ct
+// weights 2^-e in [2^14, 2^15)), and for slab s (16 input channels) the two fp16 planes [pl][tap * N + co][16 channels, halves
+// swapped by swz] of w 2^-e[co] exactly as the kernel lays a slab's weights out in LDS; the exponents follow the planes.
+__global__ __launch_bounds__(256) void conv_w_exps_kernel(const float* __restrict__ w, int N, int Ct, int* __restrict__ exps) {
+  __shared__ float red[4];
+  const int co = blockIdx.x;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < 9 * Ct; i += 256) m = fmaxf(m, fabsf(w[(long)co * (9 * Ct) + i]));
+  m = block_max_256(m, red);
+  if (threadIdx.x == 0) {
+    const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) - 15 : 0;
+    exps[co] = e < -100 ? -100 : (e > 100 ? 100 : e);
+  }
+}
+__global__ __launch_bounds__(256) void conv_w_planes_kernel(const float* __restrict__ w, int N, int Ct, const int* __restrict__ exps,
+                                                            _Float16* __restrict__ out) {
   const int nslab = Ct / SLAB;
   const long total = (long)nslab * 9 * N * 4;
   const long f = (long)blockIdx.x * 256 + threadIdx.x;
@@ -616,14 +975,20 @@ __global__ __launch_bounds__(256) void conv_w_planes_kernel(const float* __restr
   const int co = (int)(rest % N);
   rest /= N;
   const int tap = (int)(rest % 9), s = (int)(rest / 9);
-  const float4 v = *reinterpret_cast<const float4*>(w + (long)co * (9 * Ct) + tap * Ct + s * SLAB + 4 * q);
-  bf16x4 h0, h1, h2;
-  split3x4(v, h0, h1, h2);
+  const float4 v4 = *reinterpret_cast<const float4*>(w + (long)co * (9 * Ct) + tap * Ct + s * SLAB + 4 * q);
+  const int e = exps[co];
+  const float v[4] = {__builtin_amdgcn_ldexpf(v4.x, -e), __builtin_amdgcn_ldexpf(v4.y, -e), __builtin_amdgcn_ldexpf(v4.z, -e),
+                      __builtin_amdgcn_ldexpf(v4.w, -e)};
+  f16x4 h0, h1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h0[j] = (_Float16)v[j];
+    h1[j] = (_Float16)(v[j] - (float)h0[j]);
+  }
   const int WPL = 9 * N * 16;
-  __bf16* o = out + (long)s * 3 * WPL + swz(tap * N + co, q);
-  *reinterpret_cast<bf16x4*>(o) = h0;
-  *reinterpret_cast<bf16x4*>(o + WPL) = h1;
-  *reinterpret_cast<bf16x4*>(o + 2 * WPL) = h2;
+  _Float16* o = out + (long)s * 2 * WPL + swz(tap * N + co, q);
+  *reinterpret_cast<f16x4*>(o) = h0;
+  *reinterpret_cast<f16x4*>(o + WPL) = h1;
 }
 
 }  // namespace
@@ -635,14 +1000,17 @@ extern "C" int svl_debug_conv_phases(unsigned long long* out8, int reset) {
   return SVL_OK;
 }
 #endif
-extern "C" int64_t svl_conv3x3_weight_planes_bytes(int N, int Ct) { return (int64_t)3 * 9 * N * Ct * 2; }
+extern "C" int64_t svl_conv3x3_weight_planes_bytes(int N, int Ct) { return (int64_t)2 * 9 * N * Ct * 2 + (int64_t)N * 4; }
 
 extern "C" int svl_conv3x3_weight_planes(const float* w, int N, int Ct, void* planes, svl_stream_t stream) {
   SVL_CHECK_ARG(w && planes && (N == 32 || N == 64) && Ct > 0 && Ct % SLAB == 0, "svl_conv3x3_weight_planes: N must be 32 / 64, Ct a multiple of 16");
   SVL_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)planes & 15) == 0, "svl_conv3x3_weight_planes: 16-byte aligned pointers");
+  int* exps = reinterpret_cast<int*>(static_cast<char*>(planes) + (size_t)2 * 9 * N * Ct * 2);
+  hipLaunchKernelGGL(conv_w_exps_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, w, N, Ct, exps);
+  SVL_LAUNCH_CHECK("svl_conv3x3_weight_planes/exponents");
   const long total = (long)(Ct / SLAB) * 9 * N * 4;
-  hipLaunchKernelGGL(conv_w_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, Ct,
-                     reinterpret_cast<__bf16*>(planes));
+  hipLaunchKernelGGL(conv_w_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, Ct, exps,
+                     reinterpret_cast<_Float16*>(planes));
   SVL_LAUNCH_CHECK("svl_conv3x3_weight_planes");
   return SVL_OK;
 }
@@ -664,7 +1032,8 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st, int* tiles_per
   SVL_CHECK_ARG(blocks < (1L << 31), "svl_conv3x3_tiled: grid too large");
   static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
   if (emu_ok && svl_get_gemm_emulation() == 6) {   // the split emulation covers the narrow convolutions too
-    const bool wpre = p.w_planes != nullptr;
+    static const int h2_ok = getenv("SVL_CONV_TILED_NO_H2") ? 0 : 1;     // (A/B: the bf16 x 3 kernel for every launch)
+    const bool wpre = h2_ok && p.w_planes != nullptr;
     // persistent blocks: two per CU (the LDS image allows two), each walking tiles b, b + grid, ...
     static const long resident = [] {
       int dev = 0, cus = 256;
@@ -676,15 +1045,15 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st, int* tiles_per
       if (tiles_per_img) *tiles_per_img = tx * ty2;
       const long nt2 = (long)p.imgs * tx * ty2;
       const dim3 grid2((unsigned)(nt2 < resident ? nt2 : resident));
-      if (wpre) hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 2, true>), grid2, dim3(256), 0, st, p, tx, ty2);
+      if (wpre) hipLaunchKernelGGL((conv3x3_tiled_h2_kernel<1, 2>), grid2, dim3(256), 0, st, p, tx, ty2);
       else hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 2, false>), grid2, dim3(256), 0, st, p, tx, ty2);
     } else {
       const dim3 grid1((unsigned)(blocks < resident ? blocks : resident));
       if (p.N == 32) {
-        if (wpre) hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 1, true>), grid1, dim3(256), 0, st, p, tx, ty);
+        if (wpre) hipLaunchKernelGGL((conv3x3_tiled_h2_kernel<1, 1>), grid1, dim3(256), 0, st, p, tx, ty);
         else hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<1, 1, false>), grid1, dim3(256), 0, st, p, tx, ty);
       } else {
-        if (wpre) hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<2, 1, true>), grid1, dim3(256), 0, st, p, tx, ty);
+        if (wpre) hipLaunchKernelGGL((conv3x3_tiled_h2_kernel<2, 1>), grid1, dim3(256), 0, st, p, tx, ty);
         else hipLaunchKernelGGL((conv3x3_tiled_bf16x_kernel<2, 1, false>), grid1, dim3(256), 0, st, p, tx, ty);
       }
     }

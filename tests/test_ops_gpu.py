@@ -679,9 +679,11 @@ def test_conv3x3_dgrad_with_groupnorm_backward_sums(dev, emu_mode, Cm, Co, H, W,
 @pytest.mark.parametrize("C1,C2,Co,H,W,n,rep", [(64, 0, 64, 32, 32, 16, 1), (96, 32, 64, 16, 48, 24, 3), (64, 0, 32, 40, 24, 18, 1),
                                                 (32, 0, 32, 19, 37, 24, 1), (48, 16, 32, 16, 16, 66, 2)])
 def test_conv3x3_presplit_weight_planes(dev, emu_mode, C1, C2, Co, H, W, n, rep):
-    """svl_conv3x3_weight_planes: the packed weights of a narrow 3x3 convolution split once into the tiled kernel's LDS
-    image.  Forward, forward + GroupNorm statistics and the input gradient compute the same bits with the planes (a copy
-    per slab) as with the fp32 weights (a split per block and slab); the planes travel with the cached pack."""
+    """svl_conv3x3_weight_planes (round 6: fp16 x 2 planes + one exponent per output channel): with the planes a narrow 3x3
+    convolution runs the THREE-product kernel (running per-tile exponent for the pixel operand), without them the bf16 x 3
+    kernel.  Forward, forward + GroupNorm statistics and the input gradient: error vs float64 at the level of the exact fp32
+    kernel's in both forms, the statistics variant bit-identical to the plain launch, operand magnitudes 2^40 apart between
+    the two concat sources / small integers exact; the planes travel with the cached pack."""
     from semivl_amd import ops, lib as L
     a, b2 = rnd(n, C1, H, W, dev=dev, seed=91), (rnd(n // rep, C2, H, W, dev=dev) if C2 else None)
     w = rnd(Co, C1 + C2, 3, 3, dev=dev, scale=0.1)
@@ -692,22 +694,42 @@ def test_conv3x3_presplit_weight_planes(dev, emu_mode, C1, C2, Co, H, W, n, rep)
     bare_f, bare_d = wf.clone(), wd.clone()                # the same values without a planes image
     assert ops.w_planes_of(bare_f) is None
     kw = dict(src2=nhwc(b2), ld2=C2, C2=C2, rep=rep) if C2 else {}
+    xcat = torch.cat([a, b2.repeat_interleave(rep, 0)], 1) if C2 else a
+    ref = F.conv2d(xcat.double(), w.double(), padding=1)
+    emu_mode(0)
+    e_exact = _relerr(nchw(ops.conv_fwd(nhwc(a), C1, n, H, W, C1, wf, Co, 3, 3, 1, 1, **kw), n, H, W), ref)
     emu_mode(6)
     y1 = ops.conv_fwd(nhwc(a), C1, n, H, W, C1, wf, Co, 3, 3, 1, 1, **kw)
     assert L.load().svl_last_gemm_path() == 1
     y0 = ops.conv_fwd(nhwc(a), C1, n, H, W, C1, bare_f, Co, 3, 3, 1, 1, **kw)
-    assert torch.equal(y0, y1)
+    e1, e0 = _relerr(nchw(y1, n, H, W), ref), _relerr(nchw(y0, n, H, W), ref)
+    print(f"TILED_H2 fwd rel err vs fp64: exact {e_exact:.2e}  fp16 x 2 (planes) {e1:.2e}  bf16 x 3 (no planes) {e0:.2e}")
+    assert e1 <= EMU6_ERR_FACTOR * e_exact + 1e-9 and e0 <= EMU6_ERR_FACTOR * e_exact + 1e-9, (e_exact, e1, e0)
+    assert torch.equal(y1, ops.conv_fwd(nhwc(a), C1, n, H, W, C1, wf, Co, 3, 3, 1, 1, **kw)), "deterministic"
     g1 = ops.conv3x3_gn(nhwc(a), C1, n, H, W, C1, wf, Co, 1e-5, **kw)
-    g0 = ops.conv3x3_gn(nhwc(a), C1, n, H, W, C1, bare_f, Co, 1e-5, **kw)
-    assert torch.equal(g0[0], g1[0]) and torch.equal(g0[1], g1[1]) and torch.equal(g1[0], y1)
+    assert torch.equal(g1[0], y1)
+    # scales are exact powers of two: operands 2^20 up / weights 2^-20 down give the same bits; small integers are exact
+    ys = ops.conv_fwd(nhwc(a) * 2.0 ** 20, C1, n, H, W, C1, ops.pack_conv_w(w * 2.0 ** -20)[0], Co, 3, 3, 1, 1,
+                      **(dict(kw, src2=kw["src2"] * 2.0 ** 20) if C2 else {}))
+    assert torch.equal(ys, y1)
+    if not C2:
+        xi = torch.randint(-8, 8, (n * H * W, C1), device=dev).float()
+        xi[: H * W] *= 2.0 ** -30                          # one image 2^30 below the others: its own tiles, its own exponents
+        wi = torch.randint(-8, 8, (Co, C1, 3, 3), device=dev).float()
+        yi = ops.conv_fwd(xi, C1, n, H, W, C1, ops.pack_conv_w(wi)[0], Co, 3, 3, 1, 1)
+        refi = F.conv2d(xi.view(n, H, W, C1).permute(0, 3, 1, 2).double(), wi.double(), padding=1)
+        assert torch.equal(nchw(yi, n, H, W), refi.float())
     if (C1 + C2) in (32, 64):                              # the input gradient of this layer is a narrow convolution too
         assert ops.w_planes_of(wd) is not None
         d1 = ops.conv_dgrad(dy, Co, n, H, W, Co, wd, C1 + C2, 3, 3, 1, 1)
         d0 = ops.conv_dgrad(dy, Co, n, H, W, Co, bare_d, C1 + C2, 3, 3, 1, 1)
-        assert torch.equal(d0, d1)
-        xg = torch.cat([a, b2.repeat_interleave(rep, 0)], 1).requires_grad_(True) if C2 else a.clone().requires_grad_(True)
-        F.conv2d(xg, w, padding=1).backward(nchw(dy, n, H, W))
-        close(nchw(d1, n, H, W), xg.grad, atol=3e-5 * math.sqrt(9 * Co) + 1e-5, what="dgrad with planes")
+        xg = (torch.cat([a, b2.repeat_interleave(rep, 0)], 1) if C2 else a.clone()).double().requires_grad_(True)
+        F.conv2d(xg, w.double(), padding=1).backward(nchw(dy, n, H, W).double())
+        emu_mode(0)
+        ed_exact = _relerr(nchw(ops.conv_dgrad(dy, Co, n, H, W, Co, wd, C1 + C2, 3, 3, 1, 1), n, H, W), xg.grad)
+        emu_mode(6)
+        ed1, ed0 = _relerr(nchw(d1, n, H, W), xg.grad), _relerr(nchw(d0, n, H, W), xg.grad)
+        assert ed1 <= EMU6_ERR_FACTOR * ed_exact + 1e-9 and ed0 <= EMU6_ERR_FACTOR * ed_exact + 1e-9, (ed_exact, ed1, ed0)
     else:
         assert ops.w_planes_of(wd) is None
     # a parameter's planes are rebuilt with its pack when the weights change
