@@ -481,11 +481,14 @@ int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const float* src2
                        const float* w, int imgs, int H, int W, int N, float* out, int64_t ldo, float eps, double* ws,
                        float* stats, const float* gn_in, const void* w_planes, svl_stream_t stream);
 /* The weights of a narrow 3x3 convolution (forward pack [N, 9 Ct], or the input-gradient pack [Cin, 9 Cout]; N = 32 / 64,
- * Ct % 16 == 0) split ONCE into the three bf16 planes of emulation mode 6, in the LDS image of the tiled kernel (per slab of
- * 16 input channels: [plane][tap N + n][16]) -- svl_conv3x3_weight_planes_bytes(N, Ct) = 6 bytes per weight.  Optional
- * operand `w_planes` of svl_conv3x3_gn_f32 and `conv_w_planes` of svl_gemm_desc (null = the kernel splits the fp32 weights
- * in every block: same bits, ~20 % slower).  Build it once per weight version (the reference has no counterpart: cuDNN
- * re-lays its filters out internally).  Replaces nothing of the reference by itself: vlg_head.py:120-127's Conv2d weights. */
+ * Ct % 16 == 0) split ONCE into two fp16 planes scaled by a power of two per OUTPUT channel (w = 2^e[n] (h0 + h1), e[n] from
+ * the channel's largest |w|), in the LDS image of the tiled kernel (per slab of 16 input channels: [plane][tap N + n][16]),
+ * followed by the N int32 exponents -- svl_conv3x3_weight_planes_bytes(N, Ct) = 4 bytes per weight + 4 N.  Optional operand
+ * `w_planes` of svl_conv3x3_gn_f32 / svl_conv3x3_dgrad_gnb_f32 and `conv_w_planes` of svl_gemm_desc: with it the tiled kernel
+ * runs three fp16 MFMA products per term with a running per-tile exponent on the pixel operand (error below the exact fp32
+ * kernel's on the step's shapes); null = the kernel splits the fp32 weights into three bf16 planes in every block (six
+ * products, ~25 % slower).  Build it once per weight version (the reference has no counterpart: cuDNN re-lays its filters out
+ * internally).  Replaces nothing of the reference by itself: vlg_head.py:120-127's Conv2d weights. */
 int64_t svl_conv3x3_weight_planes_bytes(int N, int Ct);
 int svl_conv3x3_weight_planes(const float* w, int N, int Ct, void* planes, svl_stream_t stream);
 /* scsh [imgs][2][C]: the per-(image, channel) affine form of GroupNorm, y = fma(x, scsh[img][0][c], scsh[img][1][c]), from
