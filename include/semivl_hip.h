@@ -145,10 +145,13 @@ typedef struct svl_gemm_desc {
   const float* resid; /* addressed like C for SVL_OUT_STRIDED (own strides below); see SVL_OUT_PATCH */
   int64_t ldr_m, ldr_n, r_bs_outer, r_bs_inner;
   int accumulate;
-  const void* conv_w_planes; /* optional, SVL_A_CONV with a 3x3 / pad 1 / dilation 1 / stride 1 geometry and N = 32 / 64 only: the
-                              * weights B once more as svl_conv3x3_weight_planes(B, N, C1 + C2) wrote them.  Used when the
-                              * spatially tiled kernel serves the launch in emulation mode 6 (identical results, the
-                              * kernel copies the planes instead of splitting the weights in every block); ignored otherwise. */
+  const void* conv_w_planes; /* optional, SVL_A_CONV with a 3x3 / stride 1 geometry: the weights B once more as
+                              * svl_conv3x3_weight_planes(B, N, C1 + C2) wrote them (two fp16 planes + per-output-channel
+                              * exponents).  Used in emulation mode 6 by (a) the spatially tiled kernel (pad 1, dilation 1,
+                              * N = 32 / 64: three fp16 products per term instead of six bf16 ones) and (b) the whole-image
+                              * kernel of the DILATED convolutions (pad = dilation > 1 on 32 x 32 maps, one source, N % 64 == 0,
+                              * no bias / activation: the ASPP branches of vlg_head.py:38-50 and their input gradients);
+                              * ignored otherwise. */
   void* emu_ws;              /* optional (round 5): 8 bytes of device scratch private to this call.  With it, emulation mode 6
                               * serves a large launch of the in-register split kernel (implicit-GEMM convolutions, their weight
                               * gradients, dense GEMMs outside the packed-planes path; >= 4 GFLOP) on fp16 x 2 terms -- three
@@ -480,11 +483,12 @@ int64_t svl_conv3x3_gn_ws_doubles(int imgs, int H, int W, int N);
 int svl_conv3x3_gn_f32(const float* src1, int64_t ld1, int C1, const float* src2, int64_t ld2, int C2, int rep,
                        const float* w, int imgs, int H, int W, int N, float* out, int64_t ldo, float eps, double* ws,
                        float* stats, const float* gn_in, const void* w_planes, svl_stream_t stream);
-/* The weights of a narrow 3x3 convolution (forward pack [N, 9 Ct], or the input-gradient pack [Cin, 9 Cout]; N = 32 / 64,
+/* The weights of a 3x3 convolution (forward pack [N, 9 Ct], or the input-gradient pack [Cin, 9 Cout]; N % 32 == 0,
  * Ct % 16 == 0) split ONCE into two fp16 planes scaled by a power of two per OUTPUT channel (w = 2^e[n] (h0 + h1), e[n] from
  * the channel's largest |w|), in the LDS image of the tiled kernel (per slab of 16 input channels: [plane][tap N + n][16]),
  * followed by the N int32 exponents -- svl_conv3x3_weight_planes_bytes(N, Ct) = 4 bytes per weight + 4 N.  Optional operand
- * `w_planes` of svl_conv3x3_gn_f32 / svl_conv3x3_dgrad_gnb_f32 and `conv_w_planes` of svl_gemm_desc: with it the tiled kernel
+ * `w_planes` of svl_conv3x3_gn_f32 / svl_conv3x3_dgrad_gnb_f32 and `conv_w_planes` of svl_gemm_desc (N a multiple of 32; the
+ * dilated whole-image kernel takes N % 64 == 0): with it the tiled kernel
  * runs three fp16 MFMA products per term with a running per-tile exponent on the pixel operand (error below the exact fp32
  * kernel's on the step's shapes); null = the kernel splits the fp32 weights into three bf16 planes in every block (six
  * products, ~25 % slower).  Build it once per weight version (the reference has no counterpart: cuDNN re-lays its filters out

@@ -1003,7 +1003,7 @@ extern "C" int svl_debug_conv_phases(unsigned long long* out8, int reset) {
 extern "C" int64_t svl_conv3x3_weight_planes_bytes(int N, int Ct) { return (int64_t)2 * 9 * N * Ct * 2 + (int64_t)N * 4; }
 
 extern "C" int svl_conv3x3_weight_planes(const float* w, int N, int Ct, void* planes, svl_stream_t stream) {
-  SVL_CHECK_ARG(w && planes && (N == 32 || N == 64) && Ct > 0 && Ct % SLAB == 0, "svl_conv3x3_weight_planes: N must be 32 / 64, Ct a multiple of 16");
+  SVL_CHECK_ARG(w && planes && N > 0 && N % 32 == 0 && Ct > 0 && Ct % SLAB == 0, "svl_conv3x3_weight_planes: N must be a multiple of 32, Ct a multiple of 16");
   SVL_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)planes & 15) == 0, "svl_conv3x3_weight_planes: 16-byte aligned pointers");
   int* exps = reinterpret_cast<int*>(static_cast<char*>(planes) + (size_t)2 * 9 * N * Ct * 2);
   hipLaunchKernelGGL(conv_w_exps_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, w, N, Ct, exps);

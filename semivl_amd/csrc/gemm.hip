@@ -18,6 +18,7 @@
 // optional second concatenated source), the patch-embedding gather, conv wgrad (im2col^T) and split-K.
 #include "svl_common.h"
 #include "conv_tiled.h"
+#include "conv_dil.h"
 #include "gemm_shortk.h"
 #include <atomic>
 #include <type_traits>
@@ -1816,6 +1817,25 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       static const int temu = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
       g_last_path = (temu && emu_mode == 6) ? SVL_PATH_BF16X : SVL_PATH_F32;
       return svl_conv3x3_tiled_launch(t, st);
+    }
+  }
+
+  // Dilated 3x3 convolutions on 32 x 32 maps (the ASPP branches and their input gradients) with pre-split weight planes, in the
+  // split-product mode: whole-image tiles on fp16 x 2 terms (conv_dil.hip) instead of the implicit GEMM
+  if (conv_tiled && emu_mode == 6 && d->conv_w_planes && am == SVL_A_CONV && bm == SVL_B_KCONTIG && d->out_mode == SVL_OUT_STRIDED &&
+      d->batch == 1 && d->ksplit == 0 && cv.KH == 3 && cv.KW == 3 && cv.dil > 1 && cv.pad == cv.dil && p.cv.stride == 1 &&
+      cv.C2 == 0 && d->alpha == 1.0f && !d->preact && !d->resid && !d->bias && d->act == SVL_ACT_NONE && d->B.ld == d->K &&
+      d->ldc_n == 1 && (long)d->M % ((long)cv.H * cv.W) == 0) {
+    static const int dil_on = getenv("SVL_CONV_NO_DIL") ? 0 : 1;
+    ConvDilP t;
+    t.src = d->A.ptr; t.ld = d->A.ld; t.C = cv.C1;
+    t.out = d->C; t.ldo = d->ldc_m;
+    t.imgs = (int)((long)d->M / ((long)cv.H * cv.W)); t.H = cv.H; t.W = cv.W; t.N = d->N;
+    t.dil = cv.dil; t.sign = cv.sign; t.accumulate = d->accumulate;
+    t.w_planes = d->conv_w_planes;
+    if (dil_on && d->K == 9 * cv.C1 && svl_conv3x3_dil_eligible(t)) {
+      g_last_path = SVL_PATH_H2X;
+      return svl_conv3x3_dil_launch(t, st);
     }
   }
 

@@ -1037,7 +1037,7 @@ def cached_pack(W, tag, fn):
 def conv3x3_weight_planes(pack, N, Ct):
     """bf16 x 3 planes of a narrow 3x3 convolution's packed weights [N, 9 Ct] in the tiled kernel's LDS image
     (svl_conv3x3_weight_planes), or None when the tiled split kernel cannot use one."""
-    if not (pack.is_cuda and N in (32, 64) and Ct % 16 == 0):
+    if not (pack.is_cuda and N in (32, 64, 128) and Ct % 16 == 0):     # (128: the dilated ASPP convolutions, conv_dil.hip)
         return None
     lib = L.load()
     pl = torch.empty(lib.svl_conv3x3_weight_planes_bytes(N, Ct), dtype=torch.uint8, device=pack.device)
@@ -1094,7 +1094,7 @@ def conv_fwd(x, ldx, imgs, H, W, C1, wf, Co, KH, KW, dil, pad, bias=None, act=AC
         ldo = Co
     g = conv_geom(H, W, C1, KH, KW, dil, pad, 1, C2, rep, src2, ld2, stride=stride, Ho=Ho, Wo=Wo)
     gemm(A_CONV, B_KC, M, Co, K, Op(x, ldx), Op(wf, K), out, ldc_m=ldo, bias=bias, act=act, conv=g, resid=resid,
-         ldr_m=ldr, w_planes=w_planes_of(wf) if (KH, dil, pad, stride) == (3, 1, 1, 1) else None, emu_h2=EMU_H2_CONVFWD)
+         ldr_m=ldr, w_planes=w_planes_of(wf) if (KH, KW, pad, stride) == (3, 3, dil, 1) else None, emu_h2=EMU_H2_CONVFWD)
     return out
 
 
@@ -1107,7 +1107,7 @@ def conv_dgrad(dy, lddy, imgs, H, W, Co, wd, Ci, KH, KW, dil, pad, out=None, ldo
         ldo = Ci
     g = conv_geom(H, W, Co, KH, KW, dil, pad, -1)
     gemm(A_CONV, B_KC, M, Ci, K, Op(dy, lddy), Op(wd, K), out, ldc_m=ldo, conv=g, accumulate=accumulate,
-         w_planes=w_planes_of(wd) if (KH, dil, pad) == (3, 1, 1) else None, emu_h2=True)
+         w_planes=w_planes_of(wd) if (KH, KW, pad) == (3, 3, dil) else None, emu_h2=True)
     return out
 
 

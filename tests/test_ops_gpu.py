@@ -745,6 +745,66 @@ def test_conv3x3_presplit_weight_planes(dev, emu_mode, C1, C2, Co, H, W, n, rep)
     close(y2, 2.0 * y1, atol=1e-5 * (1 + y1.abs().max().item()), what="planes of the updated weights")
 
 
+@pytest.mark.parametrize("C,Co,n,dil", [(128, 128, 9, 6), (128, 128, 17, 12), (128, 128, 8, 18), (64, 64, 5, 3), (64, 128, 3, 31)])
+def test_dilated_conv3x3_whole_image_tiles(dev, emu_mode, C, Co, n, dil):
+    """conv_dil.hip: the ASPP module's dilated 3x3 convolutions (vlg_head.py:38-50) and their input gradients on 32 x 32 maps,
+    whole-image tiles on fp16 x 2 terms with pre-split weight planes (mode 6).  Error vs float64 at the level of the exact fp32
+    kernel's; a strided output (the concat buffer's column block) and the accumulate form (a branch's input gradient added
+    to the running one); power-of-two scalings give the same bits, small integers are exact -- also when a later channel slab
+    is 2^10 larger than the first (the tile's exponent is outgrown: the partial sums are flushed and the tile continues);
+    image counts that are not a multiple of eight (padding work items)."""
+    from semivl_amd import ops, lib as L
+    H = W = 32
+    x = rnd(n, C, H, W, dev=dev, seed=55)
+    w = rnd(Co, C, 3, 3, dev=dev, scale=0.1)
+    wf, wd = ops.pack_conv_w(w)
+    assert ops.w_planes_of(wf) is not None and ops.w_planes_of(wd) is not None
+    bare_f = wf.clone()
+    ref = F.conv2d(x.double(), w.double(), padding=dil, dilation=dil)
+    emu_mode(0)
+    e_exact = _relerr(nchw(ops.conv_fwd(nhwc(x), C, n, H, W, C, wf, Co, 3, 3, dil, dil), n, H, W), ref)
+    emu_mode(6)
+    y1 = ops.conv_fwd(nhwc(x), C, n, H, W, C, wf, Co, 3, 3, dil, dil)
+    assert L.load().svl_last_gemm_path() == 4, "the whole-image kernel took the launch"
+    y0 = ops.conv_fwd(nhwc(x), C, n, H, W, C, bare_f, Co, 3, 3, dil, dil)       # without planes: the implicit GEMM
+    e1, e0 = _relerr(nchw(y1, n, H, W), ref), _relerr(nchw(y0, n, H, W), ref)
+    print(f"DIL_H2 d={dil} fwd rel err vs fp64: exact {e_exact:.2e}  whole-image fp16 x 2 {e1:.2e}  implicit GEMM {e0:.2e}")
+    assert e1 <= EMU6_ERR_FACTOR * e_exact + 1e-9, (e_exact, e1, e0)
+    assert torch.equal(y1, ops.conv_fwd(nhwc(x), C, n, H, W, C, wf, Co, 3, 3, dil, dil)), "deterministic"
+    # a column block of a wider buffer (the ASPP concat), untouched outside
+    buf = torch.full((n * H * W, Co + 48), 7.0, device=dev)
+    ops.conv_fwd(nhwc(x), C, n, H, W, C, wf, Co, 3, 3, dil, dil, out=buf[:, 16:], ldo=Co + 48)
+    assert torch.equal(buf[:, 16:16 + Co], y1) and bool((buf[:, :16] == 7.0).all()) and bool((buf[:, 16 + Co:] == 7.0).all())
+    # exact powers of two move between operand and weights without changing a bit
+    ys = ops.conv_fwd(nhwc(x) * 2.0 ** 20, C, n, H, W, C, ops.pack_conv_w(w * 2.0 ** -20)[0], Co, 3, 3, dil, dil)
+    assert torch.equal(ys, y1)
+    # small integers: exact, one image 2^30 below the others, and channels 16.. 2^10 above the first slab (flush path)
+    xi = torch.randint(-2, 3, (n, C, H, W), device=dev).float()
+    xi[0] *= 2.0 ** -30
+    xi[:, 16:] *= 2.0 ** 10
+    wi = torch.randint(-2, 3, (Co, C, 3, 3), device=dev).float()
+    yi = ops.conv_fwd(nhwc(xi), C, n, H, W, C, ops.pack_conv_w(wi)[0], Co, 3, 3, dil, dil)
+    assert L.load().svl_last_gemm_path() == 4
+    refi = F.conv2d(xi.double(), wi.double(), padding=dil, dilation=dil)
+    assert torch.equal(nchw(yi, n, H, W), refi.float())
+    # input gradient (mirrored taps), plain and added onto an existing gradient
+    dy = rnd(n * H * W, Co, dev=dev, seed=56)
+    xg = x.double().requires_grad_(True)
+    F.conv2d(xg, w.double(), padding=dil, dilation=dil).backward(nchw(dy, n, H, W).double())
+    emu_mode(0)
+    ed_exact = _relerr(nchw(ops.conv_dgrad(dy, Co, n, H, W, Co, wd, C, 3, 3, dil, dil), n, H, W), xg.grad)
+    emu_mode(6)
+    d1 = ops.conv_dgrad(dy, Co, n, H, W, Co, wd, C, 3, 3, dil, dil)
+    assert L.load().svl_last_gemm_path() == 4
+    ed1 = _relerr(nchw(d1, n, H, W), xg.grad)
+    print(f"DIL_H2 d={dil} dgrad rel err vs fp64: exact {ed_exact:.2e}  whole-image fp16 x 2 {ed1:.2e}")
+    assert ed1 <= EMU6_ERR_FACTOR * ed_exact + 1e-9, (ed_exact, ed1)
+    base = rnd(n * H * W, C, dev=dev, seed=57)
+    acc = base.clone()
+    ops.conv_dgrad(dy, Co, n, H, W, Co, wd, C, 3, 3, dil, dil, out=acc, ldo=C, accumulate=True)
+    assert torch.equal(acc, base + d1)
+
+
 @pytest.mark.parametrize("C,Co,H,W,n", [(64, 64, 32, 32, 16), (32, 32, 40, 24, 18), (64, 32, 64, 64, 5), (32, 32, 19, 37, 24)])
 def test_groupnorm_applied_by_the_consuming_conv(dev, emu_mode, C, Co, H, W, n):
     """`gn_in`: a tiled 3x3 convolution (forward + GroupNorm statistics, and the weight gradient) whose operand is the
