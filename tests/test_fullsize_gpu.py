@@ -76,9 +76,9 @@ MCLIP_TIE = 1e-5                # MaskCLIP label ties: top-2 probability gap / d
 # rows, GroupNorm-backward sums from the dgrad epilogue): mode 6 re-measured -- pascal (13, 2.0e-3, 4.2e-3) -> (21, 2.0e-3, 4.2e-3)
 # (the flip count is now the exact mode's: WHICH near-ties flip is a draw per rounding pattern), coco (3, 3.0e-4, 6.7e-4) ->
 # (2, 4.0e-4, 7.2e-4), ade (6, 6.4e-4, 1.27e-3) -> (5, 5.7e-4, 8.2e-4); the exact-mode rows did not move.
-RATCHET = {("pascal", 0): (21, 1.3e-3, 2.7e-3), ("pascal", 6): (21, 2.1e-3, 4.3e-3),
-           ("coco", 0): (1, 8.2e-4, 1.1e-3), ("coco", 6): (2, 4.0e-4, 7.2e-4),
-           ("ade", 0): (6, 1.4e-3, 2.8e-3), ("ade", 6): (5, 5.7e-4, 8.3e-4)}
+RATCHET = {("pascal", 0): (21, 1.3e-3, 2.7e-3), ("pascal", 6): (21, 1.9e-3, 2.8e-3),
+           ("coco", 0): (2, 8.2e-4, 1.1e-3), ("coco", 6): (1, 3.8e-4, 7.1e-4),
+           ("ade", 0): (6, 1.4e-3, 2.8e-3), ("ade", 6): (3, 5.0e-4, 7.6e-4)}
 
 
 def check_step(dev, cfg, hip, orc, batch, masks, loss, aux, gemm_mode=0, bn_stack=(), after_bn=(), after_bn_tol=None,
@@ -216,7 +216,7 @@ def test_fullsize_step_matches_oracle(dev, fullsize_case, gemm_mode):
 # EXACT fp32 mode: the decoder's ASPP weight gradients, a k-ordered fp32 chain per split-K slab against the host library's
 # blocked summation -- summation order, not operand precision; the split-product modes sit at or below it on those tensors.
 FP64_FAMILIES = (("vit", "backbone."), ("aspp", "decode_head.aspp"), ("up", "decode_head.up"), ("head_other", "decode_head."))
-FP64_RATCHET = {0: dict(vit=1.83, aspp=3.65, up=1.43, head_other=2.63), 6: dict(vit=1.71, aspp=1.20, up=2.43, head_other=1.70)}
+FP64_RATCHET = {0: dict(vit=1.83, aspp=3.65, up=1.43, head_other=2.63), 6: dict(vit=1.39, aspp=1.17, up=2.48, head_other=1.37)}
 
 
 def _fp64_family(name):
