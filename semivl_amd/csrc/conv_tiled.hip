@@ -1568,6 +1568,309 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// The same kernel on fp16 x 2 terms (round 6): three products per fp32 MAC, two planes in LDS.  Both operands are activations, so
+// both take a power-of-two scale per PATCH: exponent of the patch's largest |value| (dy; x after GroupNorm + ReLU and zero
+// padding), never below the largest exponent the block has used so far -- the consumers' accumulators, which sum over all of
+// the block's patches, are then only ever scaled DOWN (by an exact power of two, when a patch raises an exponent; uniform and
+// rare) and the slabs leave multiplied by 2^(e_dy + e_x).  The maxima have to be known before a patch is split, so the
+// producers run one patch further ahead than in the bf16 x 3 kernel: loads three patches ahead of the consumers, values +
+// wave maxima two ahead (exchanged through LDS across the loop's one barrier), split + store one ahead.
+__device__ __forceinline__ void split2w(const float (&v)[8], int e, u32x4_t (&h)[2]) {
+#pragma unroll
+  for (int jp = 0; jp < 4; ++jp) {
+    const float x0 = __builtin_amdgcn_ldexpf(v[2 * jp], -e), x1 = __builtin_amdgcn_ldexpf(v[2 * jp + 1], -e);
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f16x2_t t0 = {(_Float16)x0, (_Float16)x1};
+    const f16x2_t t1 = {(_Float16)(x0 - (float)t0[0]), (_Float16)(x1 - (float)t0[1])};
+    h[0][jp] = __builtin_bit_cast(unsigned, t0);
+    h[1][jp] = __builtin_bit_cast(unsigned, t1);
+  }
+}
+
+template <int MT, int NT, int PR = 1>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_wgrad_tiled_h2_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
+  static_assert(MT * NT * PR == 2, "six consumer waves = two tiles x three tap rows");
+  constexpr int Co = 32 * MT, SL = 32 * NT;
+  constexpr int WPHT = WPH * PR, WIHT = WPHT + 2;          // patch rows / halo rows staged per iteration
+  constexpr int DCH = 2 * WPHT, DRS = (DCH + 1) * 8;       // dy^T: 8 (16) slots per row, row stride an odd number of slots
+  constexpr int XCH = 3 * WIHT, XRS = (XCH + 1) * 8;       // x^T: 18 (30) slots per row
+  constexpr int DPL = Co * DRS, XPL = SL * XRS;          // plane strides (elements)
+  constexpr int NDC = DCH * Co, NXC = XCH * SL;           // thread-chunks per patch
+  constexpr int ND = (NDC + 383) / 384, NX = (NXC + 383) / 384;
+  constexpr int BUFE = 2 * (DPL + XPL);                   // one buffer: dy^T planes, then x^T planes
+  __shared__ __attribute__((aligned(16))) _Float16 smw[2 * BUFE];
+  __shared__ int sexp[2][2];                              // (e_dy, e_x) the patch in buffer b was staged with
+  __shared__ float smx[2][6][2];                          // producer waves' maxima (dy, x) of the patch staged next into buffer b
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool producer = wave_all >= 6;
+  const int tid = threadIdx.x - (producer ? 384 : 0), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = producer ? wave_all - 6 : wave_all;
+  const int g = blockIdx.x, slab = blockIdx.y, ngrp = gridDim.x;
+  const int cz = Co * blockIdx.z;                         // Co = 128 layers: two launches' worth of 64 output channels
+  const int c0 = slab * SL, Ct = p.C1 + p.C2;
+  const int npatch = p.imgs * tiles_x * tiles_y;
+  const int mt = MT == 2 ? (wave & 1) : 0, nt = NT == 2 ? (wave & 1) : 0, ty = wave >> 1;
+  const int pt = PR == 2 ? (wave & 1) : 0;                 // which 4-row half of the staged patch this consumer wave owns
+
+  // The two roles run SEPARATE loops with the same number of barriers (one before the first patch, one per patch), so that
+  // neither role's registers are live in the other's loop.
+  if (producer) {
+  // staging assignment (fixed per thread): ND dy chunks (channel dco, slot dch) and NX x chunks (channel xci, slot xch).
+  // Addressing is the expensive part of a transposed staging (one dword per lane and load), so everything that does not
+  // change from patch to patch is hoisted: byte offset inside the IMAGE = thread constant + (y0 W + x0) ld (+ j ld),
+  // clamped into the image (reads past an edge land on a neighbouring pixel and are zeroed in sstore), added to the
+  // image's base pointer.
+  float rd[ND][8], rx[NX][8];     // the patch to be staged next: operand VALUES (masked, normalised)
+  float nd[ND][8], nx[NX][8];     // the patch after it: raw loads in flight
+  int dco[ND], dch[ND], xci[NX], xch[NX], xdiv[NX];
+  bool dok[ND], xok[NX];
+  int dtc[ND], dmax[ND], xtp[NX], xch4[NX], xmax[NX], xld4[NX];
+  const char* xsrc[NX];   // (channel 0 of) this thread's concat source -- selected ONCE: a per-lane choice of source inside
+                          // the loop would turn every load into a branch
+  long ximg[NX];          // bytes per image of that source
+  bool xgn[NX];           // gn_in: this thread's channel belongs to the pre-normalisation source (scale / shift per patch image)
+  float rsc[NX], rsh[NX];         // gn_in scale / shift of the patch in nd / nx
+  const int dld4 = (int)p.lddy * 4;
+#pragma unroll
+  for (int z = 0; z < ND; ++z) {
+    const int f = tid + 384 * z;
+    dok[z] = f < NDC;
+    dco[z] = f % Co; dch[z] = dok[z] ? f / Co : 0;
+    dtc[z] = ((dch[z] >> 1) * p.W + 8 * (dch[z] & 1)) * dld4 + dco[z] * 4;
+    dmax[z] = (p.H * p.W - 1) * dld4 + dco[z] * 4;
+  }
+#pragma unroll
+  for (int z = 0; z < NX; ++z) {
+    const int f = tid + 384 * z;
+    xok[z] = f < NXC;
+    xci[z] = f % SL; xch[z] = xok[z] ? f / SL : 0;
+    const bool second = c0 + xci[z] >= p.C1;
+    xsrc[z] = reinterpret_cast<const char*>(second ? p.src2 : p.src1);
+    xld4[z] = (int)(second ? p.ld2 : p.ld1) * 4;
+    xdiv[z] = second ? p.rep : 1;
+    ximg[z] = (long)p.H * p.W * xld4[z];
+    xch4[z] = (second ? c0 + xci[z] - p.C1 : c0 + xci[z]) * 4;
+    xgn[z] = p.gn_in != nullptr && !second;
+    rsc[z] = 1.f; rsh[z] = 0.f;
+    const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
+    xtp[z] = (hr - 1) * p.W + 8 * cg - 1;                      // pixel offset of element 0 from the patch origin
+    xmax[z] = (p.H * p.W - 1) * xld4[z] + xch4[z];
+  }
+  // gload = unconditional loads at clamped addresses, nothing else: the zeroing of out-of-image pixels happens in
+  // sstore, on the far side of the compute phase and its barrier (a select next to the load makes the compiler sink the
+  // load under the condition -- one exec-masked branch and one s_waitcnt per element).
+  auto coords = [&](int pi, int& img, int& y0, int& x0) {
+    int t = pi;
+    const int txi = t % tiles_x;
+    t /= tiles_x;
+    const int tyi = t % tiles_y;
+    img = t / tiles_y;
+    y0 = tyi * WPHT; x0 = txi * PW;
+  };
+  auto gload = [&](int pi) {
+    int img, y0, x0;
+    coords(pi, img, y0, x0);
+    const int spix = y0 * p.W + x0;
+    const char* dimg = reinterpret_cast<const char*>(p.dy + cz) + (long)img * p.H * p.W * dld4;
+#pragma unroll
+    for (int z = 0; z < ND; ++z) {
+      const int o0 = dtc[z] + spix * dld4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nd[z][j] = *reinterpret_cast<const float*>(dimg + (unsigned)min(o0 + j * dld4, dmax[z]));
+    }
+#pragma unroll
+    for (int z = 0; z < NX; ++z) {
+      if (xgn[z]) {
+        rsc[z] = p.gn_in[((long)img * 2 + 0) * p.C1 + (xch4[z] >> 2)];
+        rsh[z] = p.gn_in[((long)img * 2 + 1) * p.C1 + (xch4[z] >> 2)];
+      }
+      const char* ximgp = xsrc[z] + (long)(img / xdiv[z]) * ximg[z];
+      int o = (spix + xtp[z]) * xld4[z] + xch4[z];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        nx[z][j] = *reinterpret_cast<const float*>(ximgp + (unsigned)min(max(o, xch4[z]), xmax[z]));
+        o += xld4[z];
+      }
+    }
+  };
+  // nd / nx (raw loads of patch pi) -> rd / rx as operand VALUES (GroupNorm + ReLU applied, out-of-image pixels zero), and this
+  // wave's largest |dy| and |x| of the patch into smx[par]: the block-wide maxima fix the patch's scale exponents one barrier
+  // later, before anything is split.
+  auto xform = [&](int pi, int par) {
+    int img, y0, x0;
+    coords(pi, img, y0, x0);
+    const bool inner = y0 >= 1 && y0 + WPHT + 1 <= p.H && x0 >= 1 && x0 + PW + 1 <= p.W;
+    float md = 0.f, mx = 0.f;
+#pragma unroll
+    for (int z = 0; z < ND; ++z) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rd[z][j] = nd[z][j];
+      if (!inner) {
+        const int y = y0 + (dch[z] >> 1), xb = x0 + 8 * (dch[z] & 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rd[z][j] = (y < p.H && xb + j < p.W) ? rd[z][j] : 0.f;
+      }
+      if (dok[z]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) md = fmaxf(md, fabsf(rd[z][j]));
+      }
+    }
+#pragma unroll
+    for (int z = 0; z < NX; ++z) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rx[z][j] = nx[z][j];
+      if (xgn[z]) {         // GroupNorm + ReLU of the pre-normalisation operand (before the zero padding below)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rx[z][j] = fmaxf(__builtin_fmaf(rx[z][j], rsc[z], rsh[z]), 0.f);
+      }
+      if (!inner) {
+        const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
+        const int y = y0 - 1 + hr, xb = x0 - 1 + 8 * cg;
+        const bool rowok = y >= 0 && y < p.H;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rx[z][j] = (rowok && xb + j >= 0 && xb + j < p.W) ? rx[z][j] : 0.f;
+      }
+      if (xok[z]) {         // (halo columns 18..23 of a row are staged but never read: finite neighbours, they only widen the scale)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(rx[z][j]));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      md = fmaxf(md, __shfl_xor(md, o, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
+    if (lane == 0) { smx[par][wave][0] = md; smx[par][wave][1] = mx; }
+  };
+  auto exp_of = [](float m) {      // m 2^-e in [2^14, 2^15); an all-zero patch takes the floor
+    const int e = m > 0.f ? __builtin_amdgcn_frexp_expf(m) - 15 : -100;
+    return e < -100 ? -100 : (e > 100 ? 100 : e);
+  };
+  // Running exponents (identical in every producer thread): a patch is staged with max(its own exponent, the largest one used
+  // so far) -- never below what the accumulators hold, so the consumers only ever scale them DOWN (conv3x3_tiled_h2_kernel).
+  int e_rd = -100, e_rx = -100;
+  auto sstore = [&](int buf) {
+    _Float16* dsT = smw + buf * BUFE;
+    _Float16* xsT = dsT + 2 * DPL;
+    float md = smx[buf][0][0], mx = smx[buf][0][1];
+#pragma unroll
+    for (int w = 1; w < 6; ++w) { md = fmaxf(md, smx[buf][w][0]); mx = fmaxf(mx, smx[buf][w][1]); }
+    const int ed = exp_of(md), ex = exp_of(mx);
+    e_rd = ed > e_rd ? ed : e_rd;
+    e_rx = ex > e_rx ? ex : e_rx;
+    if (tid == 0) { sexp[buf][0] = e_rd; sexp[buf][1] = e_rx; }
+#pragma unroll
+    for (int z = 0; z < ND; ++z) {
+      u32x4_t h[2];
+      split2w(rd[z], e_rd, h);
+      if (dok[z]) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4_t*>(dsT + pl * DPL + dco[z] * DRS + dch[z] * 8) = h[pl];
+      }
+    }
+#pragma unroll
+    for (int z = 0; z < NX; ++z) {
+      u32x4_t h[2];
+      split2w(rx[z], e_rx, h);
+      if (xok[z]) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<u32x4_t*>(xsT + pl * XPL + xci[z] * XRS + xch[z] * 8) = h[pl];
+      }
+    }
+  };
+
+    // Pipeline (q_k = g + k ngrp): in the interval in which the consumers run patch q_it out of buffer it & 1 the producers
+    // stage q_{it+1} (its maxima were exchanged one barrier earlier), turn the landed loads of q_{it+2} into values + maxima
+    // and request q_{it+3}.  One barrier per patch as in the bf16 x 3 kernel, plus one in the prologue (both roles).
+    int pi = g;
+    if (pi < npatch) {
+      gload(pi);
+      xform(pi, 0);
+    }
+    __syncthreads();
+    if (pi < npatch) {
+      sstore(0);
+      if (pi + ngrp < npatch) {
+        gload(pi + ngrp);
+        xform(pi + ngrp, 1);
+      }
+      if (pi + 2 * ngrp < npatch) gload(pi + 2 * ngrp);
+    }
+    __syncthreads();
+    for (int it = 0; pi < npatch; pi += ngrp, ++it) {
+      if (pi + ngrp < npatch) sstore((it + 1) & 1);
+      if (pi + 2 * ngrp < npatch) xform(pi + 2 * ngrp, it & 1);       // (loaded during the previous patch)
+      if (pi + 3 * ngrp < npatch) gload(pi + 3 * ngrp);
+      __syncthreads();
+    }
+    return;
+  }
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int fa = (l31 + 32 * mt) * DRS + (2 * WPH * pt + hi) * 8, fb = 2 * DPL + (l31 + 32 * nt) * XRS + (3 * WPH * pt + ty * 3 + hi) * 8;
+  int e_acc = 0;
+  __syncthreads();
+  __syncthreads();
+  for (int it = 0, pi = g; pi < npatch; pi += ngrp, ++it) {
+    {
+      // this patch's scale: never below the accumulators' (the producers' exponents only grow)
+      const int e_new = sexp[it & 1][0] + sexp[it & 1][1];
+      if (it == 0) e_acc = e_new;
+      else if (e_new > e_acc) {
+        const float f_ = __builtin_amdgcn_ldexpf(1.f, e_acc - e_new);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] *= f_;
+        e_acc = e_new;
+      }
+      const _Float16* da = smw + (it & 1) * BUFE + fa;
+      const _Float16* xb_ = smw + (it & 1) * BUFE + fb;
+#pragma unroll
+      for (int r = 0; r < WPH; ++r) {
+        f16x8 a[2], b0[2], b1[2], b2[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          a[pl] = *reinterpret_cast<const f16x8*>(da + pl * DPL + 2 * r * 8);
+          const _Float16* q = xb_ + pl * XPL + 3 * r * 8;
+          // two whole 16 B slots, made opaque: left alone the compiler re-reads the shifted words one dword at a time, and
+          // dword reads of 32 rows whose stride is a multiple of 16 B are 4-way bank conflicts (PMC: 56 % of the LDS cycles)
+          u32x4_t w = *reinterpret_cast<const u32x4_t*>(q), wn = *reinterpret_cast<const u32x4_t*>(q + 8);
+          asm("" : "+v"(w), "+v"(wn));
+          const unsigned w4 = wn[0];
+          b0[pl] = __builtin_bit_cast(f16x8, w);
+          const u32x4_t s1 = {__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                              __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};
+          const u32x4_t s2 = {w[1], w[2], w[3], w4};
+          b1[pl] = __builtin_bit_cast(f16x8, s1);
+          b2[pl] = __builtin_bit_cast(f16x8, s2);
+        }
+        // three products, smallest first: (lo, hi) (hi, lo) (hi, hi); the three tx accumulators alternate
+#define SVL_W6(PA, PB)                                                                               \
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA], b0[PB], acc[0], 0, 0, 0);                      \
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA], b1[PB], acc[1], 0, 0, 0);                      \
+  acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA], b2[PB], acc[2], 0, 0, 0);
+        SVL_W6(1, 0) SVL_W6(0, 1) SVL_W6(0, 0)
+#undef SVL_W6
+      }
+    }
+    __syncthreads();
+  }
+  // C layout: row i = co (within the tile), column = lane = ci; tap = 3 ty + tx
+  float* out = p.slabs + ((long)(g * PR + pt) * Co * gridDim.z + cz) * 9 * Ct;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      out[(long)co * 9 * Ct + (3 * ty + t) * Ct + c0 + 32 * nt + l31] = __builtin_amdgcn_ldexpf(acc[t][r], e_acc);
+    }
+}
+
 }  // namespace
 
 extern "C" int svl_conv3x3_wgrad_tiled_groups(int imgs, int H, int W, int Ct, int Co) {
@@ -1610,12 +1913,17 @@ extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, co
   const int tx = (W + PW - 1) / PW, ty = (H + PH - 1) / PH;
   dim3 grid((unsigned)groups, (unsigned)(Ct / 32));
   hipStream_t st = (hipStream_t)stream;
+  static const int wg_h2 = getenv("SVL_CONV_WGRAD_NO_H2") ? 0 : 1;     // (A/B: the bf16 x 3 kernel for every launch)
   if (emu6 && Co == 32 && Ct == 32 && groups >= 2 && groups % 2 == 0 && H >= 2 * WPH) {
     const int ty8 = (H + 2 * WPH - 1) / (2 * WPH);
-    hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 1, 2>), dim3((unsigned)(groups / 2), 1u), dim3(768), 0, st, p, tx, ty8);
+    if (wg_h2) hipLaunchKernelGGL((conv3x3_wgrad_tiled_h2_kernel<1, 1, 2>), dim3((unsigned)(groups / 2), 1u), dim3(768), 0, st, p, tx, ty8);
+    else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 1, 2>), dim3((unsigned)(groups / 2), 1u), dim3(768), 0, st, p, tx, ty8);
   } else if (emu6 && (Co >= 64 || Ct % 64 == 0)) {   // the split emulation covers the weight gradient too
     const int ty4 = (H + WPH - 1) / WPH;
-    if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(768), 0, st, p, tx, ty4);
+    if (wg_h2) {
+      if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_h2_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(768), 0, st, p, tx, ty4);
+      else hipLaunchKernelGGL((conv3x3_wgrad_tiled_h2_kernel<2, 1>), dim3((unsigned)groups, (unsigned)(Ct / 32), (unsigned)(Co / 64)), dim3(768), 0, st, p, tx, ty4);
+    } else if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(768), 0, st, p, tx, ty4);
     else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<2, 1>), dim3((unsigned)groups, (unsigned)(Ct / 32), (unsigned)(Co / 64)), dim3(768), 0, st, p, tx, ty4);
   } else if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<1, 32>), grid, dim3(256), 0, st, p, tx, ty);
   else hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<2, 32>), grid, dim3(256), 0, st, p, tx, ty);

@@ -731,7 +731,7 @@ def test_conv3x3_presplit_weight_planes(dev, emu_mode, C1, C2, Co, H, W, n, rep)
         ed1, ed0 = _relerr(nchw(d1, n, H, W), xg.grad), _relerr(nchw(d0, n, H, W), xg.grad)
         assert ed1 <= EMU6_ERR_FACTOR * ed_exact + 1e-9 and ed0 <= EMU6_ERR_FACTOR * ed_exact + 1e-9, (ed_exact, ed1, ed0)
     else:
-        assert ops.w_planes_of(wd) is None
+        assert (ops.w_planes_of(wd) is None) == ((C1 + C2) != 128)       # (128: planes for the dilated whole-image kernel)
     # a parameter's planes are rebuilt with its pack when the weights change
     par = torch.nn.Parameter(w.clone())
     p1, _ = ops.pack_conv_w(par)
@@ -1633,7 +1633,7 @@ def test_tiled_narrow_conv3x3_split_emulation(dev, emu_mode, b, N, H, W, C1, C2,
         assert torch.equal(dwf, ops.conv_wgrad(dy.view(-1, Co), Co, x1.view(-1, C1), C1, imgs, H, W, C1, Co, 3, 3, 1, 1, **kw))
         err[mode] = (_relerr(y.view(imgs, H, W, Co), ref), _relerr(dx.view(imgs, H, W, C1 + C2), gx), _relerr(dw, gw))
     assert err[6][0] <= EMU6_ERR_FACTOR * err[0][0] + 1e-8 and err[6][1] <= EMU6_ERR_FACTOR * err[0][1] + 1e-8, err
-    assert err[6][2] <= EMU6_ERR_FACTOR * err[0][2] + 1e-8, err      # weight gradient (conv3x3_wgrad_tiled_bf16x_kernel)
+    assert err[6][2] <= EMU6_ERR_FACTOR * err[0][2] + 1e-8, err      # weight gradient (conv3x3_wgrad_tiled_h2_kernel)
     emu_mode(6)
     bias = rnd(Co, dev=dev)
     y = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, bias=bias, act=ops.ACT_RELU, **kw)
@@ -1644,6 +1644,44 @@ def test_tiled_narrow_conv3x3_split_emulation(dev, emu_mode, b, N, H, W, C1, C2,
     close(acc, want, atol=2e-4, what="accumulate")
     y2 = ops.conv_fwd(x1.view(-1, C1), C1, imgs, H, W, C1, wf, Co, 3, 3, 1, 1, bias=bias, act=ops.ACT_RELU, **kw)
     assert torch.equal(y, y2), "deterministic"
+
+
+@pytest.mark.parametrize("C,Co,H,W,n", [(32, 64, 32, 32, 16), (64, 32, 32, 32, 16), (32, 32, 32, 64, 8), (64, 128, 24, 40, 18)])
+def test_tiled_wgrad_running_exponents(dev, emu_mode, C, Co, H, W, n):
+    """conv3x3_wgrad_tiled_h2_kernel (mode 6): both operands of the narrow 3x3 weight gradient are activations and take a
+    power-of-two scale per PATCH that never falls below the largest one the block has used (the accumulators are only scaled
+    down).  Small integers with the images' x growing by 2^3 per image and dy shrinking by the same factor (every product has
+    the same scale: the exact sum is an integer), in both orders: bit-exact against float64; random data with magnitudes
+    2^20 apart between images: error vs float64 at the level of the exact fp32 kernel's; all-zero leading images."""
+    from semivl_amd import ops
+    emu_mode(6)
+    assert ops.conv_wgrad_tiled_ok(n, H, W, C, 0, Co, Co, C)
+    def wgrad(x, dy):
+        return ops.unpack_conv_wgrad(ops.conv_wgrad(nhwc(dy), Co, nhwc(x), C, n, H, W, C, Co, 3, 3, 1, 1), Co, C, 3, 3)
+    def ref64(x, dy):
+        wz = torch.zeros(Co, C, 3, 3, device=dev, dtype=torch.float64, requires_grad=True)
+        return torch.autograd.grad(F.conv2d(x.double(), wz, padding=1), wz, dy.double())[0]
+    emu_mode(6)
+    xi = torch.randint(-2, 3, (n, C, H, W), device=dev).float()
+    di = torch.randint(-2, 3, (n, Co, H, W), device=dev).float()
+    for order in (1, -1):
+        up = torch.tensor([2.0 ** (order * i) for i in range(n)], device=dev).view(n, 1, 1, 1)     # (exact powers of two)
+        xs, ds = xi * up, di / up
+        assert torch.equal(wgrad(xs, ds), ref64(xs, ds).float()), order
+    xz, dz = xi.clone(), di.clone()
+    xz[:3] = 0.0                                            # the first patches of every block are all-zero in x
+    dz[1] = 0.0
+    assert torch.equal(wgrad(xz, dz), ref64(xz, dz).float())
+    x, dy = rnd(n, C, H, W, dev=dev, seed=77), rnd(n, Co, H, W, dev=dev, seed=78)
+    x[n // 2:] *= 2.0 ** 20
+    dy[::2] *= 2.0 ** -20
+    ref = ref64(x, dy)
+    emu_mode(0)
+    e0 = _relerr(wgrad(x, dy), ref)
+    emu_mode(6)
+    e6 = _relerr(wgrad(x, dy), ref)
+    print(f"WGRAD_H2 rel err vs fp64: exact {e0:.2e}  fp16 x 2 {e6:.2e}")
+    assert e6 <= EMU6_ERR_FACTOR * e0 + 1e-9, (e0, e6)
 
 
 @pytest.mark.parametrize("b,N,G,heads", [(2, 81, 16, 4), (1, 150, 9, 4), (3, 64, 4, 2)])
