@@ -321,9 +321,10 @@ def main():
                "f32 storage and accumulation; the large GEMMs' products from TWO bf16 terms per operand (three 16-bit products per "
                "fp32 MAC, ~4e-6 relative per GEMM): a reduced-precision build-only mode, see mode_label" if a.gemm_arith == "bf16x3" else
                f"f32 (fp32 in / out / accumulate everywhere; the MFMA products as split 16-bit terms with fp32 accumulation: the ViT's "
-               f"linears, in_proj weight gradients and fused attention and the decoder's dilated convolutions on fp16 x 2 operands with "
-               f"power-of-two scales (3 products per fp32 MAC), the decoder's tiled 3x3 convolutions, the other weight gradients and narrow "
-               f"GEMMs on bf16 x 3 terms (6 products: --gemm-arith {a.gemm_arith}), the remaining MFMA kernels on the fp32 pipe.  Accuracy: "
+               f"linears, in_proj weight gradients and fused attention and the decoder's 3x3 convolutions (tiled: forward, input and "
+               f"weight gradient; dilated: forward, input gradient) on fp16 x 2 operands with power-of-two scales (3 products per fp32 "
+               f"MAC), the other weight gradients, the ConvTranspose streams and narrow GEMMs on bf16 x 3 terms (6 products: --gemm-arith "
+               f"{a.gemm_arith}), the remaining MFMA kernels on the fp32 pipe.  Accuracy: "
                f"per kernel error vs fp64 <= 1.2 x the exact fp32 MFMA chain's (tests/test_ops_gpu.py); full-size step vs a FLOAT64 oracle "
                f"(`numerics`): every tensor family <= 2.5 x the fp32 oracle's own distance, while the EXACT fp32 mode's worst family sits at "
                f"3.65 x -- summation order of its split-K chains, not operand precision)",
