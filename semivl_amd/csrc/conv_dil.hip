@@ -208,9 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   f16x8 a[2][2], b[2][2][2];
   const int ntl = ntiles;
-  // column parts of the A-fragment addresses (16-bit elements) for kx = 0, 1, 2 and the lanes' in-image flags
-  const bool ok0 = (unsigned)(l31 - sd) < (unsigned)DW, ok2 = (unsigned)(l31 + sd) < (unsigned)DW;
-  const int cp0 = (l31 - sd) * 16 + 8 * hi, cp1 = l31 * 16 + 8 * hi, cp2 = (l31 + sd) * 16 + 8 * hi;
+
   int s0 = 0;                                          // first slab of the segment (> 0 after a flush)
   for (;;) {
     int s = s0;
@@ -232,22 +230,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         wdma(last ? 0 : s + 1, cur ^ 1);
         gload(last ? 0 : s + 1);
       }
+      // A fragment of group g = (tap, output row u): the lane's source pixel = column part (per kx, lane-dependent) + row part
+      // (wave-uniform); lanes whose source column lies outside the image read the zero block.  The column parts are formed HERE,
+      // per slab, from the lane id read inside an asm: kept live across the persistent loop they were spilled, and their
+      // reload at the loop head put an s_waitcnt vmcnt(0) -- a wait for the next slab's sixteen loads and nine DMAs, issued just
+      // above -- in front of every MFMA phase; left visible to the optimizer the 72 addresses are hoisted into 72 registers.
+      int lz;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lz));
+      const int l31z = lz & 31, hiz = lz >> 5;
+      const int cq0 = (l31z - sd) * 16 + 8 * hiz, cq1 = l31z * 16 + 8 * hiz, cq2 = (l31z + sd) * 16 + 8 * hiz;
+      const bool ok0 = (unsigned)(l31z - sd) < (unsigned)DW, ok2 = (unsigned)(l31z + sd) < (unsigned)DW;
       const _Float16* wb = ws + cur * D_WBUF;
       auto lfragB = [&](int tap, int fb) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int rb = tap * DNB + 32 * j + l31;
-          const int ob = rb * 16 + (((hi ^ (rb >> 3)) & 1) << 3);
+          const int rb = tap * DNB + 32 * j + l31z;
+          const int ob = rb * 16 + (((hiz ^ (rb >> 3)) & 1) << 3);
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) b[fb][pl][j] = *reinterpret_cast<const f16x8*>(wb + pl * D_WPL + ob);
         }
       };
-      // A fragment of group g = (tap, output row u): the lane's source pixel = column part (per kx: lane-dependent, formed once)
-      // + row part (wave-uniform); lanes whose source column lies outside the image read the zero block.  The column parts
-      // pass through an empty asm per slab so that the 36 addresses are formed where they are used (2 VALU each) instead of
-      // being hoisted out of the slab loop into 36 live registers.
-      int cq0 = cp0, cq2 = cp2, cq1 = cp1;
-      asm volatile("" : "+v"(cq0), "+v"(cq1), "+v"(cq2));
       auto lfragA = [&](int g, int fa) __attribute__((always_inline)) {
         const int tap = g >> 3, u = g & 7, kx = tap % 3;
         const int sy = wave + 4 * u + sd * (tap / 3 - 1);
