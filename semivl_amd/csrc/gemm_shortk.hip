@@ -82,10 +82,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   long rb = (long)grp * 4 + wave;
   int kc = 0;
   // this lane's fragment of a work item (row block, 64-deep k chunk): k = kc 64 + ks 16 + hi 8 + [0, 8) for ks = 0 .. 3
-  // loads run two work items ahead (the store bursts of the epilogues delay them); ONE ahead where the accumulators of
-  // >= 4 column tiles leave no room for a third register set (an item's 96+ MFMAs cover the latency there)
-  constexpr bool TWO_AHEAD = TN <= 3;
-  float a[32], an[32], an2[TWO_AHEAD ? 32 : 1];
+  // loads run TWO work items ahead: vmcnt counts loads and stores in order, so a load requested behind an item's 24 stores is
+  // waited for together with those stores; with two sets in flight the set a wave waits for was requested before the
+  // previous item's stores (round 6: the one-ahead form of the wide tiles, with its store offsets spilled, ran 8 % slower)
+  float a[32], an[32], an2[32];
   auto a_load = [&](float (&dst)[32], long rbi, int kci) __attribute__((always_inline)) {
     const long row = min(rbi * 32 + l31, (long)p.M - 1);
     const float* src = p.A + row * p.lda + kci * 64 + hi * 8;
@@ -114,9 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     long rbn2;
     int kcn2;
     next_item(rbn, kcn, rbn2, kcn2);
-    if constexpr (TWO_AHEAD) {
-      if (rbn2 < nrb) a_load(an2, rbn2, kcn2);
-    }
+    if (rbn2 < nrb) a_load(an2, rbn2, kcn2);
     if (kc == 0) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
@@ -185,18 +183,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const long i_ = t / p.ct_H;
         rowoff = (((i_ * (2 * p.ct_H) + 2 * h_) * (2 * p.ct_W)) + 2 * w_) * p.ldc_m;
       }
-      float* rowp = p.C + rowoff;
+      // A store's address = this lane's row pointer (+ its 4-column half) + a WAVE-UNIFORM column offset, formed from scalars at
+      // the store: the 24 lane-dependent 64-bit offsets of the first version were hoisted out of the persistent loop, nine of
+      // them spilled, and every reload in front of a store carried an s_waitcnt vmcnt(0) -- a wait for ALL earlier stores and
+      // for the prefetched rows, eight times per 32-row block of a store-bound kernel.  (ConvTranspose: Cout % 8 == 0, so that the two
+      // 4-column halves of an 8-column step share their tap -- svl_shortk_x6_eligible.)
+      float* rowp = p.C + rowoff + 4 * hi;
       const bool mok = m < p.M;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int nl = 32 * j + 8 * q + 4 * hi, nb = n0 + nl;
-          long coloff = nb;
+          const int nl0 = 32 * j + 8 * q, nb0 = n0 + nl0, nl = nl0 + 4 * hi, nb = nb0 + 4 * hi;
+          long coloff = nb0;                                   // (wave-uniform)
           if (ct) {
-            const int ab = (nb >= p.ct_Cout) + (nb >= 2 * p.ct_Cout) + (nb >= 3 * p.ct_Cout);
-            coloff = (long)((ab >> 1) * 2 * p.ct_W + (ab & 1)) * p.ldc_m + (nb - ab * p.ct_Cout);
+            const int ab = (nb0 >= p.ct_Cout) + (nb0 >= 2 * p.ct_Cout) + (nb0 >= 3 * p.ct_Cout);
+            coloff = (long)((ab >> 1) * 2 * p.ct_W + (ab & 1)) * p.ldc_m + (nb0 - ab * p.ct_Cout);
           }
+          float* dst = rowp + coloff;
           const float4 bq = *reinterpret_cast<const float4*>(bsh + nl);
           float v[4] = {acc[j][4 * q] * p.alpha + bq.x, acc[j][4 * q + 1] * p.alpha + bq.y,
                         acc[j][4 * q + 2] * p.alpha + bq.z, acc[j][4 * q + 3] * p.alpha + bq.w};
@@ -207,18 +211,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
-          if (mok && nb < p.N) *reinterpret_cast<float4*>(rowp + coloff) = make_float4(v[0], v[1], v[2], v[3]);
+          if (mok && nb < p.N) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
-    if constexpr (TWO_AHEAD) {
 #pragma unroll
-      for (int s = 0; s < 32; ++s) { a[s] = an[s]; an[s] = an2[s]; }
-    } else {
-#pragma unroll
-      for (int s = 0; s < 32; ++s) a[s] = an[s];
-      if (rbn2 < nrb) a_load(an, rbn2, kcn2);     // (a's old values were consumed by this item's splits)
-    }
+    for (int s = 0; s < 32; ++s) { a[s] = an[s]; an[s] = an2[s]; }
     rb = rbn;
     kc = kcn;
     rbn = rbn2;
@@ -252,7 +250,7 @@ bool svl_shortk_x6_eligible(const ShortKP& p) {
   if (!(p.K == 64 || p.K == 128) || p.M < 32768 || p.N < 32) return false;
   if (!a16(p.A) || !a16(p.B) || p.lda % 4 || p.ldb % 4) return false;
   if (!a16(p.C) || p.ldc_m % 4 || p.N % 4) return false;                          // 16-byte stores of 4 consecutive columns
-  if (p.out_mode == SVL_OUT_CONVT2X && (p.ct_Cout % 4 || p.N != 4 * p.ct_Cout)) return false;
+  if (p.out_mode == SVL_OUT_CONVT2X && (p.ct_Cout % 8 || p.N != 4 * p.ct_Cout)) return false;   // (% 8: the epilogue's uniform column offsets)
   if (p.act != SVL_ACT_NONE && p.act != SVL_ACT_RELU && p.act != SVL_ACT_GELU) return false;
   return p.out_mode == SVL_OUT_STRIDED || p.out_mode == SVL_OUT_CONVT2X;
 }
