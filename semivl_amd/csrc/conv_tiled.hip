@@ -1032,8 +1032,7 @@ int svl_conv3x3_tiled_launch(const ConvTiledP& p, hipStream_t st, int* tiles_per
   SVL_CHECK_ARG(blocks < (1L << 31), "svl_conv3x3_tiled: grid too large");
   static const int emu_ok = getenv("SVL_CONV_TILED_NO_EMU") ? 0 : 1;
   if (emu_ok && svl_get_gemm_emulation() == 6) {   // the split emulation covers the narrow convolutions too
-    static const int h2_ok = getenv("SVL_CONV_TILED_NO_H2") ? 0 : 1;     // (A/B: the bf16 x 3 kernel for every launch)
-    const bool wpre = h2_ok && p.w_planes != nullptr;
+    const bool wpre = p.w_planes != nullptr;     // planes given: the fp16 x 2 kernel; else the bf16 x 3 kernel splits the fp32 weights per block
     // persistent blocks: two per CU (the LDS image allows two), each walking tiles b, b + grid, ...
     static const long resident = [] {
       int dev = 0, cus = 256;
@@ -1318,26 +1317,7 @@ constexpr int WPH = 4, WIH = WPH + 2;
 // (per kernel shape: DCH = 2 rows' halves, DRS = (DCH + 1) * 8 elements: dy^T row stride, 9 or 17 slots; XCH = 3 x halo rows,
 //  XRS = (XCH + 1) * 8: x^T row stride, 19 or 31 slots -- odd strides: conflict-free 16 B accesses)
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3w(const float (&v)[8], u32x4_t (&h)[3]) {   // 5.5 VALU per element, pairs packed
-  float x[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = v[j];
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp) {
-      const f32x2_t pr = {x[2 * jp], x[2 * jp + 1]};
-      const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_t));
-      h[pl][jp] = u;
-      if (pl < 2) {
-        x[2 * jp] -= __builtin_bit_cast(float, u << 16);
-        x[2 * jp + 1] -= __builtin_bit_cast(float, u & 0xffff0000u);
-      }
-    }
-}
 
 // <MT, NT> = (2, 1): Co = 64, slab of 32 input channels, wave = (co tile, ty); (1, 2): Co = 32, slab of 64 input
 // channels, wave = (ci tile, ty).  Either way a block issues 4 k-steps x 18 tiles x 6 products per patch.
@@ -1349,231 +1329,13 @@ __device__ __forceinline__ void split3w(const float (&v)[8], u32x4_t (&h)[3]) { 
 // patch (PR = 2): the producers stage 8 + 2 halo rows, consumer wave (half, ty) runs the half's four k-steps, and the two
 // halves' accumulators -- partial sums over different pixels -- leave as two slabs (the block writes slabs 2 g and 2 g + 1).
 // Same MFMA count per wave and barrier as the other two shapes; this layer ran on the fp32 kernel at 79-82 TF.
-template <int MT, int NT, int PR = 1>
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_wgrad_tiled_bf16x_kernel(const WgradTiledP p, int tiles_x, int tiles_y) {
-  static_assert(MT * NT * PR == 2, "six consumer waves = two tiles x three tap rows");
-  constexpr int Co = 32 * MT, SL = 32 * NT;
-  constexpr int WPHT = WPH * PR, WIHT = WPHT + 2;          // patch rows / halo rows staged per iteration
-  constexpr int DCH = 2 * WPHT, DRS = (DCH + 1) * 8;       // dy^T: 8 (16) slots per row, row stride an odd number of slots
-  constexpr int XCH = 3 * WIHT, XRS = (XCH + 1) * 8;       // x^T: 18 (30) slots per row
-  constexpr int DPL = Co * DRS, XPL = SL * XRS;          // plane strides (elements)
-  constexpr int NDC = DCH * Co, NXC = XCH * SL;           // thread-chunks per patch
-  constexpr int ND = (NDC + 383) / 384, NX = (NXC + 383) / 384;
-  constexpr int BUFE = 3 * (DPL + XPL);                   // one buffer: dy^T planes, then x^T planes
-  __shared__ __attribute__((aligned(16))) __bf16 smw[2 * BUFE];
-  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool producer = wave_all >= 6;
-  const int tid = threadIdx.x - (producer ? 384 : 0), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-  const int wave = producer ? wave_all - 6 : wave_all;
-  const int g = blockIdx.x, slab = blockIdx.y, ngrp = gridDim.x;
-  const int cz = Co * blockIdx.z;                         // Co = 128 layers: two launches' worth of 64 output channels
-  const int c0 = slab * SL, Ct = p.C1 + p.C2;
-  const int npatch = p.imgs * tiles_x * tiles_y;
-  const int mt = MT == 2 ? (wave & 1) : 0, nt = NT == 2 ? (wave & 1) : 0, ty = wave >> 1;
-  const int pt = PR == 2 ? (wave & 1) : 0;                 // which 4-row half of the staged patch this consumer wave owns
-
-  // The two roles run SEPARATE loops with the same number of barriers (one before the first patch, one per patch), so that
-  // neither role's registers are live in the other's loop.
-  if (producer) {
-  // staging assignment (fixed per thread): ND dy chunks (channel dco, slot dch) and NX x chunks (channel xci, slot xch).
-  // Addressing is the expensive part of a transposed staging (one dword per lane and load), so everything that does not
-  // change from patch to patch is hoisted: byte offset inside the IMAGE = thread constant + (y0 W + x0) ld (+ j ld),
-  // clamped into the image (reads past an edge land on a neighbouring pixel and are zeroed in sstore), added to the
-  // image's base pointer.
-  float rd[ND][8], rx[NX][8];
-  int dco[ND], dch[ND], xci[NX], xch[NX], xdiv[NX];
-  bool dok[ND], xok[NX];
-  int dtc[ND], dmax[ND], xtp[NX], xch4[NX], xmax[NX], xld4[NX];
-  const char* xsrc[NX];   // (channel 0 of) this thread's concat source -- selected ONCE: a per-lane choice of source inside
-                          // the loop would turn every load into a branch
-  long ximg[NX];          // bytes per image of that source
-  bool xgn[NX];           // gn_in: this thread's channel belongs to the pre-normalisation source (scale / shift per patch image)
-  float rsc[NX], rsh[NX];
-  const int dld4 = (int)p.lddy * 4;
-#pragma unroll
-  for (int z = 0; z < ND; ++z) {
-    const int f = tid + 384 * z;
-    dok[z] = f < NDC;
-    dco[z] = f % Co; dch[z] = dok[z] ? f / Co : 0;
-    dtc[z] = ((dch[z] >> 1) * p.W + 8 * (dch[z] & 1)) * dld4 + dco[z] * 4;
-    dmax[z] = (p.H * p.W - 1) * dld4 + dco[z] * 4;
-  }
-#pragma unroll
-  for (int z = 0; z < NX; ++z) {
-    const int f = tid + 384 * z;
-    xok[z] = f < NXC;
-    xci[z] = f % SL; xch[z] = xok[z] ? f / SL : 0;
-    const bool second = c0 + xci[z] >= p.C1;
-    xsrc[z] = reinterpret_cast<const char*>(second ? p.src2 : p.src1);
-    xld4[z] = (int)(second ? p.ld2 : p.ld1) * 4;
-    xdiv[z] = second ? p.rep : 1;
-    ximg[z] = (long)p.H * p.W * xld4[z];
-    xch4[z] = (second ? c0 + xci[z] - p.C1 : c0 + xci[z]) * 4;
-    xgn[z] = p.gn_in != nullptr && !second;
-    rsc[z] = 1.f; rsh[z] = 0.f;
-    const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
-    xtp[z] = (hr - 1) * p.W + 8 * cg - 1;                      // pixel offset of element 0 from the patch origin
-    xmax[z] = (p.H * p.W - 1) * xld4[z] + xch4[z];
-  }
-  // gload = unconditional loads at clamped addresses, nothing else: the zeroing of out-of-image pixels happens in
-  // sstore, on the far side of the compute phase and its barrier (a select next to the load makes the compiler sink the
-  // load under the condition -- one exec-masked branch and one s_waitcnt per element).
-  auto coords = [&](int pi, int& img, int& y0, int& x0) {
-    int t = pi;
-    const int txi = t % tiles_x;
-    t /= tiles_x;
-    const int tyi = t % tiles_y;
-    img = t / tiles_y;
-    y0 = tyi * WPHT; x0 = txi * PW;
-  };
-  auto gload = [&](int pi) {
-    int img, y0, x0;
-    coords(pi, img, y0, x0);
-    const int spix = y0 * p.W + x0;
-    const char* dimg = reinterpret_cast<const char*>(p.dy + cz) + (long)img * p.H * p.W * dld4;
-#pragma unroll
-    for (int z = 0; z < ND; ++z) {
-      const int o0 = dtc[z] + spix * dld4;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rd[z][j] = *reinterpret_cast<const float*>(dimg + (unsigned)min(o0 + j * dld4, dmax[z]));
-    }
-#pragma unroll
-    for (int z = 0; z < NX; ++z) {
-      if (xgn[z]) {
-        rsc[z] = p.gn_in[((long)img * 2 + 0) * p.C1 + (xch4[z] >> 2)];
-        rsh[z] = p.gn_in[((long)img * 2 + 1) * p.C1 + (xch4[z] >> 2)];
-      }
-      const char* ximgp = xsrc[z] + (long)(img / xdiv[z]) * ximg[z];
-      int o = (spix + xtp[z]) * xld4[z] + xch4[z];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        rx[z][j] = *reinterpret_cast<const float*>(ximgp + (unsigned)min(max(o, xch4[z]), xmax[z]));
-        o += xld4[z];
-      }
-    }
-  };
-  auto sstore = [&](int pi, int buf) {
-    __bf16* dsT = smw + buf * BUFE;
-    __bf16* xsT = dsT + 3 * DPL;
-    int img, y0, x0;
-    coords(pi, img, y0, x0);
-    // patches whose halo lies inside the image need no zeroing at all (uniform branch)
-    const bool inner = y0 >= 1 && y0 + WPHT + 1 <= p.H && x0 >= 1 && x0 + PW + 1 <= p.W;
-#pragma unroll
-    for (int z = 0; z < ND; ++z) {
-      u32x4_t h[3];
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = rd[z][j];
-      if (!inner) {
-        const int y = y0 + (dch[z] >> 1), xb = x0 + 8 * (dch[z] & 1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (y < p.H && xb + j < p.W) ? v[j] : 0.f;
-      }
-      split3w(v, h);
-      if (dok[z]) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4_t*>(dsT + pl * DPL + dco[z] * DRS + dch[z] * 8) = h[pl];
-      }
-    }
-#pragma unroll
-    for (int z = 0; z < NX; ++z) {
-      u32x4_t h[3];
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = rx[z][j];
-      if (xgn[z]) {         // GroupNorm + ReLU of the pre-normalisation operand (before the zero padding of y below)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(__builtin_fmaf(v[j], rsc[z], rsh[z]), 0.f);
-      }
-      if (!inner) {
-        const int hr = xch[z] / 3, cg = xch[z] - 3 * hr;
-        const int y = y0 - 1 + hr, xb = x0 - 1 + 8 * cg;
-        const bool rowok = y >= 0 && y < p.H;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (rowok && xb + j >= 0 && xb + j < p.W) ? v[j] : 0.f;
-      }
-      split3w(v, h);     // (halo columns 18..23 of a row are staged but never read: finite neighbours, no mask needed)
-      if (xok[z]) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4_t*>(xsT + pl * XPL + xci[z] * XRS + xch[z] * 8) = h[pl];
-      }
-    }
-  };
-
-    int pi = g;
-    if (pi < npatch) {
-      gload(pi);
-      sstore(pi, 0);
-      if (pi + ngrp < npatch) gload(pi + ngrp);
-    }
-    __syncthreads();
-    for (int it = 0; pi < npatch; pi += ngrp, ++it) {
-      if (pi + ngrp < npatch) sstore(pi + ngrp, (it + 1) & 1);       // (loaded during the previous patch)
-      if (pi + 2 * ngrp < npatch) gload(pi + 2 * ngrp);
-      __syncthreads();
-    }
-    return;
-  }
-
-  f32x16 acc[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const int fa = (l31 + 32 * mt) * DRS + (2 * WPH * pt + hi) * 8, fb = 3 * DPL + (l31 + 32 * nt) * XRS + (3 * WPH * pt + ty * 3 + hi) * 8;
-  __syncthreads();
-  for (int it = 0, pi = g; pi < npatch; pi += ngrp, ++it) {
-    {
-      const __bf16* da = smw + (it & 1) * BUFE + fa;
-      const __bf16* xb_ = smw + (it & 1) * BUFE + fb;
-#pragma unroll
-      for (int r = 0; r < WPH; ++r) {
-        bf16x8 a[3], b0[3], b1[3], b2[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          a[pl] = *reinterpret_cast<const bf16x8*>(da + pl * DPL + 2 * r * 8);
-          const __bf16* q = xb_ + pl * XPL + 3 * r * 8;
-          // two whole 16 B slots, made opaque: left alone the compiler re-reads the shifted words one dword at a time, and
-          // dword reads of 32 rows whose stride is a multiple of 16 B are 4-way bank conflicts (PMC: 56 % of the LDS cycles)
-          u32x4_t w = *reinterpret_cast<const u32x4_t*>(q), wn = *reinterpret_cast<const u32x4_t*>(q + 8);
-          asm("" : "+v"(w), "+v"(wn));
-          const unsigned w4 = wn[0];
-          b0[pl] = __builtin_bit_cast(bf16x8, w);
-          const u32x4_t s1 = {__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
-                              __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w4, w[3], 16)};
-          const u32x4_t s2 = {w[1], w[2], w[3], w4};
-          b1[pl] = __builtin_bit_cast(bf16x8, s1);
-          b2[pl] = __builtin_bit_cast(bf16x8, s2);
-        }
-        // smallest cross terms first; the three tx accumulators alternate (dependent MFMAs are 3 apart)
-#define SVL_W6(PA, PB)                                                                               \
-  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b0[PB], acc[0], 0, 0, 0);                      \
-  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b1[PB], acc[1], 0, 0, 0);                      \
-  acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b2[PB], acc[2], 0, 0, 0);
-        SVL_W6(2, 0) SVL_W6(0, 2) SVL_W6(1, 1) SVL_W6(1, 0) SVL_W6(0, 1) SVL_W6(0, 0)
-#undef SVL_W6
-      }
-    }
-    __syncthreads();
-  }
-  // C layout: row i = co (within the tile), column = lane = ci; tap = 3 ty + tx
-  float* out = p.slabs + ((long)(g * PR + pt) * Co * gridDim.z + cz) * 9 * Ct;
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      out[(long)co * 9 * Ct + (3 * ty + t) * Ct + c0 + 32 * nt + l31] = acc[t][r];
-    }
-}
-
-// The same kernel on fp16 x 2 terms (round 6): three products per fp32 MAC, two planes in LDS.  Both operands are activations, so
+// Round 6: the kernel runs on fp16 x 2 terms -- three products per fp32 MAC, two planes in LDS (the bf16 x 3 form of rounds 4 - 5,
+// six products, measured 308.5 vs 306.0 - 307.1 ms per VOC step and 1000 vs 985 ms on ADE, is gone).  Both operands are activations, so
 // both take a power-of-two scale per PATCH: exponent of the patch's largest |value| (dy; x after GroupNorm + ReLU and zero
 // padding), never below the largest exponent the block has used so far -- the consumers' accumulators, which sum over all of
 // the block's patches, are then only ever scaled DOWN (by an exact power of two, when a patch raises an exponent; uniform and
 // rare) and the slabs leave multiplied by 2^(e_dy + e_x).  The maxima have to be known before a patch is split, so the
-// producers run one patch further ahead than in the bf16 x 3 kernel: loads three patches ahead of the consumers, values +
+// producers run one patch further ahead than a plain double buffer needs: loads three patches ahead of the consumers, values +
 // wave maxima two ahead (exchanged through LDS across the loop's one barrier), split + store one ahead.
 __device__ __forceinline__ void split2w(const float (&v)[8], int e, u32x4_t (&h)[2]) {
 #pragma unroll
@@ -1913,18 +1675,13 @@ extern "C" int svl_conv3x3_wgrad_tiled(const float* dy, int64_t lddy, int Co, co
   const int tx = (W + PW - 1) / PW, ty = (H + PH - 1) / PH;
   dim3 grid((unsigned)groups, (unsigned)(Ct / 32));
   hipStream_t st = (hipStream_t)stream;
-  static const int wg_h2 = getenv("SVL_CONV_WGRAD_NO_H2") ? 0 : 1;     // (A/B: the bf16 x 3 kernel for every launch)
   if (emu6 && Co == 32 && Ct == 32 && groups >= 2 && groups % 2 == 0 && H >= 2 * WPH) {
     const int ty8 = (H + 2 * WPH - 1) / (2 * WPH);
-    if (wg_h2) hipLaunchKernelGGL((conv3x3_wgrad_tiled_h2_kernel<1, 1, 2>), dim3((unsigned)(groups / 2), 1u), dim3(768), 0, st, p, tx, ty8);
-    else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 1, 2>), dim3((unsigned)(groups / 2), 1u), dim3(768), 0, st, p, tx, ty8);
+    hipLaunchKernelGGL((conv3x3_wgrad_tiled_h2_kernel<1, 1, 2>), dim3((unsigned)(groups / 2), 1u), dim3(768), 0, st, p, tx, ty8);
   } else if (emu6 && (Co >= 64 || Ct % 64 == 0)) {   // the split emulation covers the weight gradient too
     const int ty4 = (H + WPH - 1) / WPH;
-    if (wg_h2) {
-      if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_h2_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(768), 0, st, p, tx, ty4);
-      else hipLaunchKernelGGL((conv3x3_wgrad_tiled_h2_kernel<2, 1>), dim3((unsigned)groups, (unsigned)(Ct / 32), (unsigned)(Co / 64)), dim3(768), 0, st, p, tx, ty4);
-    } else if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(768), 0, st, p, tx, ty4);
-    else hipLaunchKernelGGL((conv3x3_wgrad_tiled_bf16x_kernel<2, 1>), dim3((unsigned)groups, (unsigned)(Ct / 32), (unsigned)(Co / 64)), dim3(768), 0, st, p, tx, ty4);
+    if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_h2_kernel<1, 2>), dim3((unsigned)groups, (unsigned)(Ct / 64)), dim3(768), 0, st, p, tx, ty4);
+    else hipLaunchKernelGGL((conv3x3_wgrad_tiled_h2_kernel<2, 1>), dim3((unsigned)groups, (unsigned)(Ct / 32), (unsigned)(Co / 64)), dim3(768), 0, st, p, tx, ty4);
   } else if (Co == 32) hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<1, 32>), grid, dim3(256), 0, st, p, tx, ty);
   else hipLaunchKernelGGL((conv3x3_wgrad_tiled_kernel<2, 32>), grid, dim3(256), 0, st, p, tx, ty);
   SVL_LAUNCH_CHECK("svl_conv3x3_wgrad_tiled");

@@ -1714,10 +1714,9 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       // out_proj (768 x 768: the two maximum passes weigh three times as much per FLOP) with the form on for both, and left
       // it opt-in.  Round 6: on by default for the launches whose halved matrix work outweighs the passes by 1.5 x (in_proj
       // only at the ViT's shapes): 323.7 -> 319.8 ms per VOC step with both on, same call; the float64 comparison of the
-      // full-size step passes with it (tests/test_fullsize_gpu.py, FP64_RATCHET).  SVL_GEMM_EMU_H2_DENSE=0 turns it off.
-      static const int h2_dense = (getenv("SVL_GEMM_EMU_H2_DENSE") && atoi(getenv("SVL_GEMM_EMU_H2_DENSE")) == 0) ? 0 : 1;
+      // full-size step passes with it (tests/test_fullsize_gpu.py, FP64_RATCHET).
       const double dense_elems = (double)q.M * q.K + (double)q.N * q.K;
-      if (h2_dense && (d->batch == 1 || d->ksplit > 0) && h2_ok(q, dense_elems) &&
+      if ((d->batch == 1 || d->ksplit > 0) && h2_ok(q, dense_elems) &&
           2.0 * q.M * q.N * q.K * 1.7e-15 > dense_elems * 4.0 / 4.0e12 * 1.5) {
         // dense operands: [M, K] or [K, M], [N, K] or [K, N]
         int rc = h2_begin();
@@ -1826,14 +1825,13 @@ extern "C" int svl_gemm_f32(const svl_gemm_desc* d, svl_stream_t stream) {
       d->batch == 1 && d->ksplit == 0 && cv.KH == 3 && cv.KW == 3 && cv.dil > 1 && cv.pad == cv.dil && p.cv.stride == 1 &&
       cv.C2 == 0 && d->alpha == 1.0f && !d->preact && !d->resid && !d->bias && d->act == SVL_ACT_NONE && d->B.ld == d->K &&
       d->ldc_n == 1 && (long)d->M % ((long)cv.H * cv.W) == 0) {
-    static const int dil_on = getenv("SVL_CONV_NO_DIL") ? 0 : 1;
     ConvDilP t;
     t.src = d->A.ptr; t.ld = d->A.ld; t.C = cv.C1;
     t.out = d->C; t.ldo = d->ldc_m;
     t.imgs = (int)((long)d->M / ((long)cv.H * cv.W)); t.H = cv.H; t.W = cv.W; t.N = d->N;
     t.dil = cv.dil; t.sign = cv.sign; t.accumulate = d->accumulate;
     t.w_planes = d->conv_w_planes;
-    if (dil_on && d->K == 9 * cv.C1 && svl_conv3x3_dil_eligible(t)) {
+    if (d->K == 9 * cv.C1 && svl_conv3x3_dil_eligible(t)) {
       g_last_path = SVL_PATH_H2X;
       return svl_conv3x3_dil_launch(t, st);
     }

@@ -110,13 +110,10 @@ class Op:
 # In-register split kernel on fp16 x 2 terms with per-tensor scales (svl_gemm_desc.emu_ws; round 5): SVL_GEMM_EMU_NO_H2=1 keeps
 # the bf16 x 3 form for every launch (A/B runs).
 EMU_H2 = not os.environ.get("SVL_GEMM_EMU_NO_H2")
-# conv_fwd launches (the dilated ASPP convolutions' forward).  Round 5 ended with them OFF: together with the fp16 x 2 attention
-# they pushed tests/test_fullsize_gpu.py::test_fullsize_gradient_error_against_fp64 past its 4 x bound (ViT tensors 4.0 - 4.4 x).
-# Round 6: the split-K slab sums run in double (csrc/gemm.hip::reduce_slabs_kernel) and the test always compares under the
-# product's own tie decisions; with the launches ON the worst mode-6 ratios are vit 1.71 / head 1.70 / aspp 1.20 / up 2.43 x
-# (exact fp32 mode: aspp 3.65 x) -- back ON: VOC 326.5 -> 324.7 ms, ADE 1114 -> 1101 ms per step (same call).
-# SVL_GEMM_EMU_H2_CONVFWD=0 turns them off (A/B).
-EMU_H2_CONVFWD = bool(int(os.environ.get("SVL_GEMM_EMU_H2_CONVFWD", "1")))
+# conv_fwd launches on the in-register fp16 x 2 form (implicit-GEMM convolutions the tiled / whole-image kernels do not take).
+# Round 5 ended with them OFF (the float64 gate of tests/test_fullsize_gpu.py at 4.0 - 4.4 x); since the split-K slab sums run in
+# double and the gate compares under the product's own tie decisions they are ON (mode-6 families <= 2.5 x).
+EMU_H2_CONVFWD = True
 
 
 def gemm(a_mode, b_mode, M, N, K, A, B, Cout, c_off=0, ldc_m=None, ldc_n=1, batch=1, batch_inner=1, ksplit=0,
@@ -834,7 +831,7 @@ def groupnorm_bwd(dy, lddy, x, ldx, y, ldy, stats, gamma, imgs, HW, Cc, G, relu,
     return dgamma, dbeta
 
 
-GN_BWD_FUSED = not os.environ.get("SVL_NO_GN_BWD_FUSED")     # A/B: GroupNorm-backward sums from the producing dgrad's epilogue
+GN_BWD_FUSED = True      # GroupNorm-backward sums from the producing dgrad's epilogue (round 6: 327.4 -> 326.5 ms VOC, 1121 -> 1114 ms ADE)
 
 
 def conv3x3_dgrad_gnb(dy, lddy, imgs, H, W, Co, wd, Ci, gn_x, gn_stats, gn_gamma, gn_beta, G):

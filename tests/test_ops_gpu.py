@@ -932,9 +932,7 @@ def test_split_kernel_fp16x2_form(dev, emu_mode, monkeypatch):
     SVL_GEMM_EMU_NO_H2 / small launches keep the bf16 x 3 form."""
     from semivl_amd import lib as L, ops
     lib = L.load()
-    # (the training path leaves conv_fwd launches on bf16 x 3 since the end of round 5 -- ops.EMU_H2_CONVFWD; the form itself
-    #  stays tested on all three launch kinds)
-    monkeypatch.setattr(ops, "EMU_H2_CONVFWD", True)
+    monkeypatch.setattr(ops, "EMU_H2_CONVFWD", True)     # (the default since round 6; pinned for this test)
     n, Ci, Co, k, dil, H = 4, 128, 128, 3, 6, 96
     W, pad = H, dil
     x, w = rnd(n, Ci, H, W, dev=dev, seed=71), rnd(Co, Ci, k, k, dev=dev, scale=0.1)
@@ -973,7 +971,7 @@ def test_split_kernel_fp16x2_form(dev, emu_mode, monkeypatch):
     refi = F.conv2d(xi.view(n, H, W, Ci).permute(0, 3, 1, 2).double(), wi.double(), padding=pad, dilation=dil)
     assert torch.equal(nchw(yi, n, H, W), refi.float())
     # (dense launches -- the ViT's split-K weight gradients -- take the form where the halved matrix work outweighs the two
-    #  maximum passes 1.5 x: in_proj at the ViT's shapes; SVL_GEMM_EMU_H2_DENSE=0 turns that off: csrc/gemm.hip)
+    #  maximum passes 1.5 x: in_proj at the ViT's shapes: csrc/gemm.hip)
     # a small launch stays on the bf16 x 3 form (the two maximum passes would cost more than the halved matrix work)
     ops.conv_fwd(xs[:2 * 16 * 16], Ci, 2, 16, 16, Ci, wf, Co, k, k, 1, 1)
     assert lib.svl_last_gemm_path() == 1
