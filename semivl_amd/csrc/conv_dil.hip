@@ -14,8 +14,9 @@
 //   * the slab's weights (two fp16 planes pre-split by svl_conv3x3_weight_planes, per-output-channel exponents) are copied
 //     global -> LDS by the DMA path (global_load_lds_dwordx4: the planes image IS the LDS image), double-buffered, no registers;
 //     per tap a wave reads 4 weight fragments and 2 x 8 pixel fragments for 48 MFMAs (13 B of LDS per cycle and SIMD);
-//   * the pixel operand takes the RUNNING per-tile exponent of conv3x3_tiled_h2_kernel (maximum of the slab being staged, found
-//     while the previous slab's MFMAs run; accumulators rescaled by a power of two <= 1 when it rises);
+//   * the pixel operand takes a per-tile exponent in the manner of conv3x3_tiled_h2_kernel (maximum of the slab being staged,
+//     found while the previous slab's MFMAs run) -- but AGPR accumulators cannot be rescaled, so the tile's exponent carries
+//     four bits of headroom and a slab that outgrows it flushes the partial sums through the epilogue (see the slab loop);
 //   * persistent blocks: the next work item's first slab is requested during the last MFMA phase of this one; the two 64-channel
 //     halves of an image are 8 blocks apart so that they land on the same XCD and share the image in its L2.
 // MFMA layout as in conv_tiled.hip: A = 32 pixels (one image row) x 16 channels, B = 16 channels x 32 outputs; an accumulator's
@@ -321,7 +322,7 @@ bool svl_conv3x3_dil_eligible(const ConvDilP& p) {
   if (p.H != DH || p.W != DW || p.dil < 1 || p.dil > 31) return false;
   if (p.C <= 0 || p.C % DSLAB || p.N <= 0 || p.N % DNB || !p.w_planes) return false;
   if (p.ld % 4 || !a16(p.src) || !a16(p.w_planes) || p.imgs < 1) return false;
-  return (long)p.imgs * DPX * p.ldo < (1L << 31);                        // (32-bit pixel offsets in the epilogue)
+  return p.out != nullptr && p.ldo >= p.N;                               // (all pixel offsets are formed in 64 bits)
 }
 
 int svl_conv3x3_dil_launch(const ConvDilP& p, hipStream_t st) {
