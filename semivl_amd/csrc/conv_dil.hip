@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   sstore(e_st);
   __syncthreads();
 
-  f16x8 a[2][2], b[2][2][2];
+  f16x8 a[3][2], b[2][2][2];
   const int ntl = ntiles;
 
   int s0 = 0;                                          // first slab of the segment (> 0 after a flush)
@@ -261,27 +261,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) a[fa][pl] = *reinterpret_cast<const f16x8*>(xs + pl * D_XPL + oa);
       };
+      // One wave per SIMD issues everything in order, so the fragment reads sit INSIDE the MFMA runs (in the shadow of a running
+      // MFMA) instead of between them: group g's six MFMAs are split 2 + 4 and the reads of group g + 2 (pixel fragments, three
+      // register sets) -- in the tap's second group also the next tap's weight fragments -- go into the gap: -1 ... -4 % solo (the size of the pool's box-to-box spread).
+      // (Tried: two output rows per run, so that the MFMAs on one accumulator are four issues apart instead of two, a pair with
+      // one row outside the image running that row on the zero block -- the extra MFMAs cost more: +4 ... +8 %.)
       lfragB(0, 0);
       lfragA(0, 0);
+      lfragA(1, 1);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int fb = tap & 1;
-        if (tap + 1 < 9) lfragB(tap + 1, fb ^ 1);
 #pragma unroll
         for (int u = 0; u < DPT; ++u) {
-          const int g = tap * DPT + u, fa = g & 1;
-          if (g + 1 < 9 * DPT) lfragA(g + 1, fa ^ 1);
+          const int g = tap * DPT + u, fa = g % 3;
           __builtin_amdgcn_sched_barrier(0);
           const int sy = wave + 4 * u + sd * (tap / 3 - 1);               // wave-uniform: the source row of this output row
-          if ((unsigned)sy < (unsigned)DH) {
-            // three products, smallest first: (1,0) (0,1) (0,0)
-#define SVL_CD(PA, PB) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[u][j] = \
-    __builtin_amdgcn_mfma_f32_32x32x16_f16(a[fa][PA], b[fb][PB][j], acc[u][j], 0, 0, 0);
-            SVL_CD(1, 0)
-            SVL_CD(0, 1)
-            SVL_CD(0, 0)
-#undef SVL_CD
+          const bool rowok = (unsigned)sy < (unsigned)DH;
+          // three products, smallest first: (1,0) (0,1) (0,0)
+#define SVL_CD(PA, PB, J) acc[u][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[fa][PA], b[fb][PB][J], acc[u][J], 0, 0, 0);
+          if (rowok) {
+            SVL_CD(1, 0, 0)
+            SVL_CD(1, 0, 1)
           }
+          __builtin_amdgcn_sched_barrier(0);
+          if (g + 2 < 9 * DPT) lfragA(g + 2, (g + 2) % 3);
+          if (u == 1 && tap + 1 < 9) lfragB(tap + 1, fb ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (rowok) {
+            SVL_CD(0, 1, 0)
+            SVL_CD(0, 1, 1)
+            SVL_CD(0, 0, 0)
+            SVL_CD(0, 0, 1)
+          }
+#undef SVL_CD
           __builtin_amdgcn_sched_barrier(0);
         }
       }
